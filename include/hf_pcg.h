@@ -1,0 +1,168 @@
+/*
+ * hf_pcg.h -- C ABI of the MI355X-native Hessian-free Newton-step solver.
+ *
+ * This is the drop-in boundary for ONE hot path of ltatzel/PyTorchHessianFree:
+ * the preconditioned-CG loop (reference hessianfree/cg.py:9-231) and the vector
+ * algebra around the curvature matvec (hessianfree/optimizer.py:266, :288-294,
+ * :349-350, :462; hessianfree/preconditioners.py:98, :124-125).  The reference
+ * is pure Python and has no FFI; every entry point below names the reference
+ * lines whose work it replaces.  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch types.
+ *   - every `void*` vector is a DEVICE pointer to `n` contiguous elements of
+ *     the handle's dtype (HF_F32 / HF_F64), 16-byte aligned unless stated.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - the library BORROWS vectors for the duration of the enqueue; it owns only
+ *     its scalar block, partial-sum scratch and a pinned host mirror, all
+ *     created in hf_pcg_create.  No allocation, free or synchronisation happens
+ *     in any per-iteration entry point (they are hipGraph-capturable).
+ *   - return value: 0 (HF_OK) or a negative HF_ERR_* / a positive hipError_t.
+ */
+#ifndef HF_PCG_H
+#define HF_PCG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HF_ABI_VERSION 1
+
+enum hf_dtype { HF_F32 = 0, HF_F64 = 1 };
+
+/* Termination reasons, in the order the reference tests them (cg.py:95-115). */
+enum hf_reason {
+  HF_RUNNING = 0,
+  HF_REASON_MARTENS = 1,  /* "Convergence (Martens)"     cg.py:103 */
+  HF_REASON_MAXITER = 2,  /* "Number of iterations"      cg.py:107 */
+  HF_REASON_DIVERGED = 3, /* "Divergence"                cg.py:111 */
+  HF_REASON_TOL = 4       /* "Convergence (tolerances)"  cg.py:115 */
+};
+
+/* How y = M(r) is obtained (cg.py:190, :220). */
+enum hf_precond {
+  HF_M_NONE = 0,    /* y = r                                   (M is None)            */
+  HF_M_DIAG = 1,    /* y = minv * r, minv = (diag+lambda)^-a   preconditioners.py:124 */
+  HF_M_EXTERNAL = 2 /* y supplied by the caller after every residual update          */
+};
+
+enum hf_error {
+  HF_OK = 0,
+  HF_ERR_ARG = -1,      /* null / negative / inconsistent argument */
+  HF_ERR_ALIGN = -2,    /* a vector pointer is not 16-byte aligned */
+  HF_ERR_STATE = -3,    /* call order violated (e.g. iterate before begin) */
+  HF_ERR_NOSYMBOL = -4, /* RCCL symbol not resolvable in this process */
+  HF_ERR_CAPACITY = -5  /* too many tensors / snapshots for one call */
+};
+
+typedef struct hf_pcg hf_pcg_t; /* opaque solver handle */
+
+typedef struct hf_pcg_status {
+  int32_t done;          /* 0 while running, else an hf_reason              */
+  int32_t reason;        /* same as done                                    */
+  int64_t n_iters;       /* iterations performed (len(x_iters)-1, optimizer.py:276) */
+  int64_t iter_next;     /* next iteration the device would run             */
+  int64_t nonpos_count;  /* how often pAp <= 0 was seen (cg.py:133-139)     */
+  double last_alpha, last_beta, last_pAp, last_res_norm, res_bound;
+  int64_t n_stored;      /* snapshot slots written so far                   */
+} hf_pcg_status;
+
+int hf_abi_version(void);
+const char* hf_error_string(int code);
+
+/* ---- solver lifetime ------------------------------------------------------ */
+/* max_blocks: grid size of the vector kernels (0 = default: 4 per CU). */
+int hf_pcg_create(hf_pcg_t** out, int64_t n, int dtype, int max_blocks);
+int hf_pcg_destroy(hf_pcg_t* h);
+
+/*
+ * Begin a solve (cg.py:75-76, :177-192).  On entry `x` holds x0 (zeros when the
+ * reference would be called with x0=None).  `store_iters` is a DEVICE int64
+ * array, sorted ascending, of the iterations whose iterate must be copied into
+ * `slab + slot*slab_stride` (slot = position in the array); may be NULL/0.
+ * `store_x0` must be 1 iff store_iters[0] == 0 (x0 itself is a snapshot).
+ * `m_hist` is a DEVICE array of max_iter+1 elements (NULL iff !martens).
+ * atol < 0 means "no atol" (cg.py:76).
+ */
+int hf_pcg_begin(hf_pcg_t* h, void* x, void* r, void* p, const void* b,
+                 const void* minv, int precond, int64_t max_iter, double tol,
+                 double atol, int martens, const int64_t* store_iters,
+                 int64_t n_store, int store_x0, void* slab, int64_t slab_stride,
+                 void* m_hist);
+
+/* r = A x0 - b, snapshot of x0, partial sums for m_0 and ||b|| (cg.py:187-189).
+ * For HF_M_NONE / HF_M_DIAG this also sets p = -M r and ry (cg.py:190-192). */
+int hf_pcg_init(hf_pcg_t* h, const void* Ax0, void* stream);
+/* HF_M_EXTERNAL only: p = -y, ry = r.y with the caller's y = M(r). */
+int hf_pcg_init_external(hf_pcg_t* h, const void* y, void* stream);
+
+/*
+ * One PCG iteration for HF_M_NONE / HF_M_DIAG (cg.py:205-224), three kernels:
+ *   K1 curvature  : pAp = p.(Bp + damping*p)                (optimizer.py:266, cg.py:206)
+ *   K2 update_xr  : alpha, x += alpha p, r += alpha Ap, snapshot,
+ *                   partials of r.y, r.r, (r-b).x           (cg.py:207-211, :93, :97, :221)
+ *   K3 update_p   : ||r||, m_i, Martens / max-iter / NaN / tol tests on device,
+ *                   beta, p = -y + beta p                   (cg.py:95-115, :222-224)
+ * `Bp` is the UNDAMPED curvature product B p (damping is added in-kernel); pass
+ * damping = 0 when `Bp` already is A p.  After termination the kernels are
+ * no-ops, so a host that enqueued speculative iterations still gets the
+ * reference's final iterate.
+ */
+int hf_pcg_iterate(hf_pcg_t* h, const void* Bp, double damping, void* stream);
+
+/* The same three phases individually (HF_M_EXTERNAL needs y = M(r) between the
+ * residual update and the direction update). */
+int hf_pcg_curvature(hf_pcg_t* h, const void* Bp, double damping, void* stream);
+int hf_pcg_update_xr(hf_pcg_t* h, const void* Bp, double damping, void* stream);
+int hf_pcg_update_p(hf_pcg_t* h, const void* y_external, void* stream);
+
+/* Non-blocking: reads the pinned host mirror the device writes at termination. */
+int hf_pcg_poll(hf_pcg_t* h, hf_pcg_status* out);
+/* Synchronises `stream`, copies the scalar block back, fills `out`. */
+int hf_pcg_finish(hf_pcg_t* h, hf_pcg_status* out, void* stream);
+/* After finish: the first `cap` non-positive-curvature events (cg.py:136-139). */
+int hf_pcg_read_nonpos(hf_pcg_t* h, int64_t* iters, double* values, int cap);
+
+/* Per-kernel HIP-event timing of hf_pcg_iterate (for bench.py's roofline). */
+int hf_pcg_timing_enable(hf_pcg_t* h, int enable);
+/* After finish: mean duration in ms of K1,K2,K3 over the recorded iterations. */
+int hf_pcg_timing_read(hf_pcg_t* h, double* ms_k1, double* ms_k2, double* ms_k3,
+                       int64_t* n_recorded);
+
+/* ---- vector helpers around the matvec -------------------------------------- */
+/*
+ * Multi-tensor gather: dst[off_t + i] = scale * src_t[i] for t < n_tensors
+ * (replaces parameters_to_vector's torch.cat, optimizer.py:234, :455, :462).
+ * `srcs` / `numels` are HOST arrays; pointers are passed to the kernel by value.
+ * src tensors must be contiguous; only 4-byte (8 for f64) alignment is needed.
+ * mode 0: dst = scale*src ; mode 1: dst += (scale*src)^2 (preconditioners.py:98).
+ */
+int hf_pack(void* dst, const void* const* srcs, const int64_t* numels,
+            int n_tensors, double scale, int mode, int dtype, void* stream);
+
+/* minv = (diag + damping)^(-exponent)   (preconditioners.py:124, hoisted out of
+ * the CG loop). */
+int hf_precond_build(void* minv, const void* diag, double damping,
+                     double exponent, int64_t n, int dtype, void* stream);
+
+/* out = a + alpha*s  (params_vec + step / params_vec + lr*step_vec,
+ * optimizer.py:293, :349); out may alias a.  No alignment requirement. */
+int hf_axpy_out(void* out, const void* a, const void* s, double alpha, int64_t n,
+                int dtype, void* stream);
+
+/* ---- RCCL (resolved at run time from the already-loaded librccl) ----------- */
+typedef struct hf_comm hf_comm_t;
+int hf_comm_unique_id(char* out128);                        /* ncclGetUniqueId */
+int hf_comm_create(hf_comm_t** out, const char* id128, int nranks, int rank);
+int hf_comm_destroy(hf_comm_t* c);
+/* In-place sum all-reduce of the GGN.v partial (the `+=` of optimizer.py:677-684
+ * across ranks), enqueued on `stream`. */
+int hf_allreduce_sum(hf_comm_t* c, void* buf, int64_t n, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HF_PCG_H */

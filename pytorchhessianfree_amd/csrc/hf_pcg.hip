@@ -1,0 +1,1127 @@
+// hf_pcg.hip -- hand-written gfx950 (CDNA4, wave64) kernels + C ABI of the
+// Hessian-free Newton-step solver.  See include/hf_pcg.h for the boundary and
+// DESIGN.md for the data layout / roofline of every kernel.
+//
+// Design in one paragraph.  The solver state is a set of persistent, contiguous
+// HBM vectors (x, r, p, b, minv and the caller's B.p) plus one small device
+// scalar block.  One PCG iteration is THREE streaming kernels, separated by the
+// two global scalars alpha and beta that the algorithm forces:
+//     K1 curvature  reads Bp,p                       -> G partial sums of p.(Bp+lambda p)
+//     K2 update_xr  reads x,r,p,Bp,b(,minv) writes x,r -> partials of r.y, r.r, (r-b).x
+//     K3 update_p   reads r,p(,minv)        writes p   (+ all termination tests)
+// A kernel never reduces its own partial sums: each block of the NEXT kernel
+// re-reduces the <=1024 fp64 partials (same order in every block -> bitwise
+// identical scalars everywhere, no atomics, no extra launch, no host sync).
+// Scalar fields are split so that no kernel reads a field that the same launch
+// writes (blocks of one launch are not ordered).  After termination every
+// kernel is a no-op, so speculative launches by the host are harmless.
+//
+// Arithmetic mirrors the reference's elementwise rounding (separate mul and add,
+// no FMA contraction: this file is compiled with -ffp-contract=off); only the
+// reduction ORDER of the dot products differs (fp64 accumulation here).
+//
+// Target: gfx950 only.  No CUDA paths, no hipify, no portability macros.
+
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdint.h>
+#include <string.h>
+#include <new>
+
+#include "hf_pcg.h"
+
+namespace {
+
+constexpr int BLOCK = 256;          // 4 waves of 64
+constexpr int WAVES = BLOCK / 64;
+constexpr int NP_CAP = 32;          // recorded non-positive-curvature events
+constexpr int TIMING_CAP = 1024;    // iterations with per-kernel events
+
+// ---------------------------------------------------------------------------
+// device scalar block
+// ---------------------------------------------------------------------------
+struct DevState {
+  // written by init_finalize / K3, read by K1/K2
+  double ry_next;
+  long long iter_next;
+  long long slot_next;
+  // written by K2 (block 0), read by K3
+  double ry_cur;
+  long long iter_cur;
+  long long slot_cur;
+  long long stored_cur;
+  // written by init_finalize only
+  double res_bound;
+  // termination (written by K3 block 0)
+  long long n_iters;
+  int done;
+  int pad0;
+  // diagnostics
+  double last_alpha, last_beta, last_pAp, last_res_norm;
+  long long nonpos_count;
+  long long nonpos_iter[NP_CAP];
+  double nonpos_val[NP_CAP];
+};
+
+template <typename T> struct VecOf;
+template <> struct VecOf<float>  { typedef float4  type; static constexpr int W = 4; };
+template <> struct VecOf<double> { typedef double2 type; static constexpr int W = 2; };
+
+template <typename T> union VU {
+  typename VecOf<T>::type v;
+  T e[VecOf<T>::W];
+};
+
+// ---------------------------------------------------------------------------
+// reductions: 64-lane __shfl_down tree -> LDS partial per wave -> fixed-order sum
+// ---------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void block_allreduce(double (&v)[K], double* lds /*K*WAVES*/) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) lds[k * WAVES + wave] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double s = lds[k * WAVES];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) s += lds[k * WAVES + w];
+    v[k] = s;
+  }
+  __syncthreads();
+}
+
+// Every block re-reduces the previous kernel's per-block partials (layout
+// part[k*stride + block]) in the same order.
+template <int K>
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ part, int nparts,
+                                                int stride, double (&out)[K], double* lds) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) out[k] = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += BLOCK) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] += part[k * stride + i];
+  }
+  block_allreduce<K>(out, lds);
+}
+
+template <int K>
+__device__ __forceinline__ void write_partials(double* __restrict__ part, int stride,
+                                               double (&v)[K], double* lds) {
+  block_allreduce<K>(v, lds);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) part[k * stride + blockIdx.x] = v[k];
+  }
+}
+
+template <typename T> __device__ __forceinline__ T apply_damping(T bp, T p, T lam, bool damped) {
+  // reference: mvp(x) + damping * x  (optimizer.py:266) -- two roundings
+  return damped ? (T)(bp + (T)(lam * p)) : bp;
+}
+
+// ---------------------------------------------------------------------------
+// init:  r = A x0 - b ; (optional) p = -M r ; partial sums
+//   part[0] r.y   part[1] b.b   part[2] (r-b).x0
+// ---------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_init(double* __restrict__ part, int stride,
+                                                const T* __restrict__ x, T* __restrict__ r,
+                                                T* __restrict__ p, const T* __restrict__ Ax0,
+                                                const T* __restrict__ b,
+                                                const T* __restrict__ minv, T* __restrict__ slot0,
+                                                long long n) {
+  constexpr int W = VecOf<T>::W;
+  typedef typename VecOf<T>::type V;
+  __shared__ double lds[3 * WAVES];
+  double acc[3] = {0.0, 0.0, 0.0};
+  const long long nvec = n / W;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * BLOCK) {
+    VU<T> vx, va, vb, vm, vr, vp;
+    vx.v = reinterpret_cast<const V*>(x)[i];
+    va.v = reinterpret_cast<const V*>(Ax0)[i];
+    vb.v = reinterpret_cast<const V*>(b)[i];
+    if (MODE == HF_M_DIAG) vm.v = reinterpret_cast<const V*>(minv)[i];
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      const T rr = va.e[c] - vb.e[c];
+      vr.e[c] = rr;
+      acc[1] += (double)vb.e[c] * (double)vb.e[c];
+      acc[2] += (double)(T)(rr - vb.e[c]) * (double)vx.e[c];
+      if (MODE != HF_M_EXTERNAL) {
+        const T y = (MODE == HF_M_DIAG) ? (T)(vm.e[c] * rr) : rr;
+        acc[0] += (double)rr * (double)y;
+        vp.e[c] = -y;
+      }
+    }
+    reinterpret_cast<V*>(r)[i] = vr.v;
+    if (MODE != HF_M_EXTERNAL) reinterpret_cast<V*>(p)[i] = vp.v;
+    if (slot0) reinterpret_cast<V*>(slot0)[i] = vx.v;
+  }
+  if (blockIdx.x == 0) {
+    const long long j = nvec * W + threadIdx.x;
+    if (j < n) {
+      const T rr = Ax0[j] - b[j];
+      r[j] = rr;
+      acc[1] += (double)b[j] * (double)b[j];
+      acc[2] += (double)(T)(rr - b[j]) * (double)x[j];
+      if (MODE != HF_M_EXTERNAL) {
+        const T y = (MODE == HF_M_DIAG) ? (T)(minv[j] * rr) : rr;
+        acc[0] += (double)rr * (double)y;
+        p[j] = -y;
+      }
+      if (slot0) slot0[j] = x[j];
+    }
+  }
+  write_partials<3>(part, stride, acc, lds);
+}
+
+// HF_M_EXTERNAL: p = -y, part[0] = r.y
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_init_external(double* __restrict__ part, int stride,
+                                                         const T* __restrict__ r,
+                                                         T* __restrict__ p,
+                                                         const T* __restrict__ y, long long n) {
+  __shared__ double lds[WAVES];
+  double acc[1] = {0.0};
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n;
+       i += (long long)gridDim.x * BLOCK) {
+    const T yy = y[i];
+    acc[0] += (double)r[i] * (double)yy;
+    p[i] = -yy;
+  }
+  write_partials<1>(part, stride, acc, lds);
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_init_finalize(DevState* __restrict__ st,
+                                                         const double* __restrict__ part,
+                                                         int nparts, int stride, double tol,
+                                                         double atol, T* __restrict__ m_hist,
+                                                         const long long* __restrict__ store_iters,
+                                                         long long n_store, int* host_flag) {
+  __shared__ double lds[3 * WAVES];
+  double s[3];
+  reduce_partials<3>(part, nparts, stride, s, lds);
+  if (threadIdx.x == 0) {
+    const T ry = (T)s[0];
+    const T bnorm = (T)sqrt(s[1]);            // torch.linalg.norm(b)          cg.py:75
+    double bound = tol * (double)bnorm;       // python float arithmetic       cg.py:75
+    if (atol >= 0.0) bound = bound > atol ? bound : atol;  // cg.py:76
+    if (m_hist) m_hist[0] = (T)0.5 * (T)s[2]; // 0.5*dot(r-b, x0)              cg.py:189
+    st->ry_next = (double)ry;
+    st->iter_next = 1;
+    st->slot_next = (n_store > 0 && store_iters[0] == 0) ? 1 : 0;
+    st->ry_cur = 0.0;
+    st->iter_cur = 0;
+    st->slot_cur = 0;
+    st->stored_cur = 0;
+    st->res_bound = bound;
+    st->n_iters = 0;
+    st->done = 0;
+    st->last_alpha = st->last_beta = st->last_pAp = st->last_res_norm = 0.0;
+    st->nonpos_count = 0;
+    __hip_atomic_store(host_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K1: partial sums of p.(Bp + lambda p)                         8N bytes
+// ---------------------------------------------------------------------------
+template <typename T, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void k_curvature(const DevState* __restrict__ st,
+                                                     double* __restrict__ part1, int stride,
+                                                     const T* __restrict__ p,
+                                                     const T* __restrict__ Bp, T lam, int damped,
+                                                     long long n) {
+  if (st->done) return;
+  constexpr int W = VecOf<T>::W;
+  typedef typename VecOf<T>::type V;
+  __shared__ double lds[WAVES];
+  double acc[1] = {0.0};
+  const long long nvec = n / W;
+  const long long tile = (long long)BLOCK * UNROLL;
+  for (long long base = (long long)blockIdx.x * tile; base < nvec;
+       base += (long long)gridDim.x * tile) {
+    VU<T> vp[UNROLL], vg[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const long long i = base + u * BLOCK + threadIdx.x;
+      if (i < nvec) {
+        vp[u].v = reinterpret_cast<const V*>(p)[i];
+        vg[u].v = reinterpret_cast<const V*>(Bp)[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const long long i = base + u * BLOCK + threadIdx.x;
+      if (i < nvec) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          const T ap = apply_damping<T>(vg[u].e[c], vp[u].e[c], lam, damped);
+          acc[0] += (double)vp[u].e[c] * (double)ap;
+        }
+      }
+    }
+  }
+  if (blockIdx.x == 0) {
+    const long long j = nvec * W + threadIdx.x;
+    if (j < n) acc[0] += (double)p[j] * (double)apply_damping<T>(Bp[j], p[j], lam, damped);
+  }
+  write_partials<1>(part1, stride, acc, lds);
+}
+
+// ---------------------------------------------------------------------------
+// K2: alpha; x += alpha p; r += alpha (Bp + lambda p); snapshot; partials
+//   part2[0] r.y   part2[1] r.r   part2[2] (r-b).x         28N (32N with minv)
+// ---------------------------------------------------------------------------
+template <typename T, int MODE, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void k_update_xr(
+    DevState* __restrict__ st, const double* __restrict__ part1, double* __restrict__ part2,
+    int nparts, int stride, T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p,
+    const T* __restrict__ Bp, const T* __restrict__ b, const T* __restrict__ minv, T lam,
+    int damped, const long long* __restrict__ store_iters, long long n_store,
+    T* __restrict__ slab, long long slab_stride, long long n) {
+  if (st->done) return;
+  constexpr int W = VecOf<T>::W;
+  typedef typename VecOf<T>::type V;
+  __shared__ double lds[3 * WAVES];
+
+  double s[1];
+  reduce_partials<1>(part1, nparts, stride, s, lds);
+  const T pAp = (T)s[0];                       // torch.dot(p, Ap)             cg.py:206
+  const T ry = (T)st->ry_next;
+  const T alpha = ry / pAp;                    //                              cg.py:207
+  const long long iter = st->iter_next;
+  const long long slot = st->slot_next;
+  const bool store = (slot < n_store) && (store_iters[slot] == iter);  // cg.py:209
+  T* __restrict__ snap = store ? slab + slot * slab_stride : nullptr;
+
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->ry_cur = (double)ry;
+    st->iter_cur = iter;
+    st->slot_cur = slot;
+    st->stored_cur = store ? 1 : 0;
+    st->last_pAp = (double)pAp;
+    st->last_alpha = (double)alpha;
+    if (!(pAp > (T)0)) {                       // _postprocess_pAp             cg.py:133-139
+      const long long c = st->nonpos_count;
+      if (c < NP_CAP) { st->nonpos_iter[c] = iter; st->nonpos_val[c] = (double)pAp; }
+      st->nonpos_count = c + 1;
+    }
+  }
+
+  double acc[3] = {0.0, 0.0, 0.0};
+  const long long nvec = n / W;
+  const long long tile = (long long)BLOCK * UNROLL;
+  for (long long base = (long long)blockIdx.x * tile; base < nvec;
+       base += (long long)gridDim.x * tile) {
+    VU<T> vx[UNROLL], vr[UNROLL], vp[UNROLL], vg[UNROLL], vb[UNROLL], vm[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const long long i = base + u * BLOCK + threadIdx.x;
+      if (i < nvec) {
+        vx[u].v = reinterpret_cast<const V*>(x)[i];
+        vr[u].v = reinterpret_cast<const V*>(r)[i];
+        vp[u].v = reinterpret_cast<const V*>(p)[i];
+        vg[u].v = reinterpret_cast<const V*>(Bp)[i];
+        vb[u].v = reinterpret_cast<const V*>(b)[i];
+        if (MODE == HF_M_DIAG) vm[u].v = reinterpret_cast<const V*>(minv)[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const long long i = base + u * BLOCK + threadIdx.x;
+      if (i < nvec) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          const T pp = vp[u].e[c];
+          const T ap = apply_damping<T>(vg[u].e[c], pp, lam, damped);
+          const T xn = vx[u].e[c] + (T)(alpha * pp);   // x = x + alpha*p   cg.py:208
+          const T rn = vr[u].e[c] + (T)(alpha * ap);   // r = r + alpha*Ap  cg.py:211
+          vx[u].e[c] = xn;
+          vr[u].e[c] = rn;
+          if (MODE == HF_M_DIAG) acc[0] += (double)rn * (double)(T)(vm[u].e[c] * rn);
+          acc[1] += (double)rn * (double)rn;
+          acc[2] += (double)(T)(rn - vb[u].e[c]) * (double)xn;  // dot(r-b, x)  cg.py:97
+        }
+        reinterpret_cast<V*>(x)[i] = vx[u].v;
+        reinterpret_cast<V*>(r)[i] = vr[u].v;
+        if (snap) reinterpret_cast<V*>(snap)[i] = vx[u].v;
+      }
+    }
+  }
+  if (blockIdx.x == 0) {
+    const long long j = nvec * W + threadIdx.x;
+    if (j < n) {
+      const T pp = p[j];
+      const T ap = apply_damping<T>(Bp[j], pp, lam, damped);
+      const T xn = x[j] + (T)(alpha * pp);
+      const T rn = r[j] + (T)(alpha * ap);
+      x[j] = xn;
+      r[j] = rn;
+      if (snap) snap[j] = xn;
+      if (MODE == HF_M_DIAG) acc[0] += (double)rn * (double)(T)(minv[j] * rn);
+      acc[1] += (double)rn * (double)rn;
+      acc[2] += (double)(T)(rn - b[j]) * (double)xn;
+    }
+  }
+  if (MODE == HF_M_NONE) acc[0] = acc[1];
+  write_partials<3>(part2, stride, acc, lds);
+}
+
+// K3a (HF_M_EXTERNAL only): part3 = r.y
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_dot_ry(const DevState* __restrict__ st,
+                                                  double* __restrict__ part3, int stride,
+                                                  const T* __restrict__ r,
+                                                  const T* __restrict__ y, long long n) {
+  if (st->done) return;
+  __shared__ double lds[WAVES];
+  double acc[1] = {0.0};
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n;
+       i += (long long)gridDim.x * BLOCK)
+    acc[0] += (double)r[i] * (double)y[i];
+  write_partials<1>(part3, stride, acc, lds);
+}
+
+// ---------------------------------------------------------------------------
+// K3: finalise ||r||, m_i; termination tests (cg.py:95-115); beta; p = -y + beta p
+//                                                           12N (16N with minv)
+// ---------------------------------------------------------------------------
+template <typename T, int MODE, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void k_update_p(
+    DevState* __restrict__ st, const double* __restrict__ part2,
+    const double* __restrict__ part3, int nparts, int stride, const T* __restrict__ r,
+    T* __restrict__ p, const T* __restrict__ minv, const T* __restrict__ yext,
+    T* __restrict__ m_hist, long long max_iter, int* host_flag, long long n) {
+  if (st->done) return;
+  constexpr int W = VecOf<T>::W;
+  typedef typename VecOf<T>::type V;
+  __shared__ double lds[3 * WAVES];
+
+  double s[3];
+  reduce_partials<3>(part2, nparts, stride, s, lds);
+  if (MODE == HF_M_EXTERNAL) {
+    double e[1];
+    reduce_partials<1>(part3, nparts, stride, e, lds);
+    s[0] = e[0];
+  }
+  const long long iter = st->iter_cur;
+  const T ry_old = (T)st->ry_cur;
+  const T ry_new = (T)s[0];                    // torch.dot(r, y)              cg.py:221
+  const T res_norm = (T)sqrt(s[1]);            // torch.linalg.norm(r)         cg.py:93
+  const T m_i = (T)0.5 * (T)s[2];              // 0.5*torch.dot(r-b, x)        cg.py:97
+
+  int reason = HF_RUNNING;
+  if (m_hist) {                                // Martens' test                cg.py:96-103
+    const long long a = iter / 10;
+    const long long k = a > 10 ? a : 10;
+    if (k < iter) {
+      const T num = m_i - m_hist[iter - k];
+      const T den = m_i - m_hist[0];
+      if ((T)(num / den) < (T)5e-4) reason = HF_REASON_MARTENS;
+    }
+  }
+  if (reason == HF_RUNNING) {
+    if (iter >= max_iter) reason = HF_REASON_MAXITER;                      // cg.py:106
+    else if (res_norm != res_norm) reason = HF_REASON_DIVERGED;            // cg.py:110
+    else if (res_norm < (T)st->res_bound) reason = HF_REASON_TOL;          // cg.py:114
+  }
+  const T beta = ry_new / ry_old;              //                              cg.py:222
+
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (m_hist) m_hist[iter] = m_i;
+    st->last_res_norm = (double)res_norm;
+    st->slot_next = st->slot_cur + st->stored_cur;
+    if (reason != HF_RUNNING) {
+      st->n_iters = iter;
+      st->done = reason;
+      __hip_atomic_store(host_flag, reason, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      st->ry_next = (double)ry_new;
+      st->iter_next = iter + 1;
+      st->last_beta = (double)beta;
+    }
+  }
+  if (reason != HF_RUNNING) return;
+
+  const long long nvec = n / W;
+  const long long tile = (long long)BLOCK * UNROLL;
+  for (long long base = (long long)blockIdx.x * tile; base < nvec;
+       base += (long long)gridDim.x * tile) {
+    VU<T> vr[UNROLL], vp[UNROLL], vm[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const long long i = base + u * BLOCK + threadIdx.x;
+      if (i < nvec) {
+        if (MODE == HF_M_EXTERNAL) vr[u].v = reinterpret_cast<const V*>(yext)[i];
+        else vr[u].v = reinterpret_cast<const V*>(r)[i];
+        vp[u].v = reinterpret_cast<const V*>(p)[i];
+        if (MODE == HF_M_DIAG) vm[u].v = reinterpret_cast<const V*>(minv)[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const long long i = base + u * BLOCK + threadIdx.x;
+      if (i < nvec) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          const T y = (MODE == HF_M_DIAG) ? (T)(vm[u].e[c] * vr[u].e[c]) : vr[u].e[c];
+          vp[u].e[c] = (-y) + (T)(beta * vp[u].e[c]);   // p = -y + beta*p   cg.py:224
+        }
+        reinterpret_cast<V*>(p)[i] = vp[u].v;
+      }
+    }
+  }
+  if (blockIdx.x == 0) {
+    const long long j = nvec * W + threadIdx.x;
+    if (j < n) {
+      const T rv = (MODE == HF_M_EXTERNAL) ? yext[j] : r[j];
+      const T y = (MODE == HF_M_DIAG) ? (T)(minv[j] * rv) : rv;
+      p[j] = (-y) + (T)(beta * p[j]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// multi-tensor gather (pointer table passed by value)
+// ---------------------------------------------------------------------------
+constexpr int PACK_MAXT = 96;
+constexpr int PACK_CHUNK = BLOCK * 16;  // elements per block
+struct PackArgs {
+  const void* src[PACK_MAXT];
+  long long dst_off[PACK_MAXT];
+  long long numel[PACK_MAXT];
+  int blk_start[PACK_MAXT + 1];
+  int nt;
+};
+
+template <typename T, int OP>
+__device__ __forceinline__ T pack_op(T d, T s, T scale) {
+  if (OP == 0) return (T)(scale * s);
+  const T g = (T)(scale * s);
+  return d + (T)(g * g);
+}
+
+template <typename T, int OP>
+__global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackArgs a, T scale) {
+  constexpr int W = VecOf<T>::W;
+  typedef typename VecOf<T>::type V;
+  // binary search: tensor t with blk_start[t] <= blockIdx.x < blk_start[t+1]
+  int lo = 0, hi = a.nt;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.blk_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const T* __restrict__ src = reinterpret_cast<const T*>(a.src[lo]);
+  const long long numel = a.numel[lo];
+  const long long j0 = (long long)(blockIdx.x - a.blk_start[lo]) * PACK_CHUNK;
+  const long long j1 = (j0 + PACK_CHUNK < numel) ? j0 + PACK_CHUNK : numel;
+  T* __restrict__ out = dst + a.dst_off[lo];
+  const bool vec_ok = ((((uintptr_t)src) | ((uintptr_t)out)) & 15) == 0;
+  if (vec_ok) {
+    const long long v0 = j0 / W, v1 = j1 / W;
+    for (long long i = v0 + threadIdx.x; i < v1; i += BLOCK) {
+      VU<T> s, d;
+      s.v = reinterpret_cast<const V*>(src)[i];
+      if (OP == 1) d.v = reinterpret_cast<const V*>(out)[i];
+#pragma unroll
+      for (int c = 0; c < W; ++c) d.e[c] = pack_op<T, OP>(d.e[c], s.e[c], scale);
+      reinterpret_cast<V*>(out)[i] = d.v;
+    }
+    for (long long j = v1 * W + threadIdx.x; j < j1; j += BLOCK)
+      out[j] = pack_op<T, OP>(out[j], src[j], scale);
+  } else {
+    for (long long j = j0 + threadIdx.x; j < j1; j += BLOCK)
+      out[j] = pack_op<T, OP>(out[j], src[j], scale);
+  }
+}
+
+// minv = (diag + damping)^(-exponent)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_precond_build(T* __restrict__ minv,
+                                                         const T* __restrict__ diag, T lam,
+                                                         T neg_exp, long long n) {
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n;
+       i += (long long)gridDim.x * BLOCK)
+    minv[i] = pow((T)(diag[i] + lam), neg_exp);
+}
+
+// out = a + alpha*s
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_axpy_out(T* out, const T* a, const T* s, T alpha,
+                                                    long long n, int vec_ok) {
+  constexpr int W = VecOf<T>::W;
+  typedef typename VecOf<T>::type V;
+  const long long nvec = vec_ok ? n / W : 0;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * BLOCK) {
+    VU<T> va, vs;
+    va.v = reinterpret_cast<const V*>(a)[i];
+    vs.v = reinterpret_cast<const V*>(s)[i];
+#pragma unroll
+    for (int c = 0; c < W; ++c) va.e[c] = va.e[c] + (T)(alpha * vs.e[c]);
+    reinterpret_cast<V*>(out)[i] = va.v;
+  }
+  for (long long j = nvec * W + (long long)blockIdx.x * BLOCK + threadIdx.x; j < n;
+       j += (long long)gridDim.x * BLOCK)
+    out[j] = a[j] + (T)(alpha * s[j]);
+}
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+// ===========================================================================
+// host side
+// ===========================================================================
+struct hf_pcg {
+  int64_t n;
+  int dtype;
+  int grid;            // blocks of the vector kernels == partials per sum
+  DevState* d_state;
+  double* d_part;      // [3 sums][3 slots][grid]
+  DevState* h_state;   // pinned
+  int* h_flag;         // pinned, device-visible
+  int* d_flag;         // device alias of h_flag
+  // borrowed for the current solve
+  void *x, *r, *p;
+  const void *b, *minv;
+  int precond;
+  int64_t max_iter;
+  double tol, atol;
+  int martens;
+  const int64_t* store_iters;
+  int64_t n_store;
+  void* slab;
+  int64_t slab_stride;
+  int store_x0;
+  void* m_hist;
+  int begun, inited, finished;
+  // timing
+  int timing;
+  int64_t t_count;
+  hipEvent_t* ev;      // 4 per iteration
+};
+
+#define HF_HIP(expr)                         \
+  do {                                       \
+    hipError_t e_ = (expr);                  \
+    if (e_ != hipSuccess) return (int)e_;    \
+  } while (0)
+
+namespace {
+inline double* part_ptr(hf_pcg* h, int which) { return h->d_part + (size_t)which * 3 * h->grid; }
+
+// blocks for a kernel whose blocks walk tiles of BLOCK*unroll 16-byte vectors
+int grid_for(const hf_pcg* h, int unroll) {
+  const int W = h->dtype == HF_F32 ? 4 : 2;
+  const int64_t nvec = h->n / W;
+  int64_t tiles = (nvec + (int64_t)BLOCK * unroll - 1) / ((int64_t)BLOCK * unroll);
+  if (tiles < 1) tiles = 1;
+  return (int)(tiles < h->grid ? tiles : h->grid);
+}
+}  // namespace
+
+// C linkage comes from the declarations in hf_pcg.h
+
+int hf_abi_version(void) { return HF_ABI_VERSION; }
+
+const char* hf_error_string(int code) {
+  switch (code) {
+    case HF_OK: return "ok";
+    case HF_ERR_ARG: return "hf: invalid argument";
+    case HF_ERR_ALIGN: return "hf: vector pointer not 16-byte aligned";
+    case HF_ERR_STATE: return "hf: call order violated";
+    case HF_ERR_NOSYMBOL: return "hf: RCCL symbol not found in this process";
+    case HF_ERR_CAPACITY: return "hf: capacity exceeded";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "hf: unknown error";
+  }
+}
+
+int hf_pcg_create(hf_pcg_t** out, int64_t n, int dtype, int max_blocks) {
+  if (!out || n <= 0 || (dtype != HF_F32 && dtype != HF_F64) || max_blocks < 0) return HF_ERR_ARG;
+  hf_pcg* h = new (std::nothrow) hf_pcg();
+  if (!h) return HF_ERR_ARG;
+  memset(h, 0, sizeof(*h));
+  h->n = n;
+  h->dtype = dtype;
+  if (max_blocks == 0) {
+    int dev = 0, cus = 256;
+    HF_HIP(hipGetDevice(&dev));
+    HF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    max_blocks = 4 * cus;
+  }
+  h->grid = max_blocks;
+  HF_HIP(hipMalloc((void**)&h->d_state, sizeof(DevState)));
+  HF_HIP(hipMemset(h->d_state, 0, sizeof(DevState)));
+  HF_HIP(hipMalloc((void**)&h->d_part, sizeof(double) * 3 * 3 * (size_t)h->grid));
+  HF_HIP(hipMemset(h->d_part, 0, sizeof(double) * 3 * 3 * (size_t)h->grid));
+  HF_HIP(hipHostMalloc((void**)&h->h_state, sizeof(DevState), hipHostMallocDefault));
+  HF_HIP(hipHostMalloc((void**)&h->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
+  h->h_flag[0] = 0;
+  HF_HIP(hipHostGetDevicePointer((void**)&h->d_flag, h->h_flag, 0));
+  *out = h;
+  return HF_OK;
+}
+
+int hf_pcg_destroy(hf_pcg_t* h) {
+  if (!h) return HF_OK;
+  if (h->ev) {
+    for (int i = 0; i < 4 * TIMING_CAP; ++i) (void)hipEventDestroy(h->ev[i]);
+    delete[] h->ev;
+  }
+  (void)hipFree(h->d_state);
+  (void)hipFree(h->d_part);
+  (void)hipHostFree(h->h_state);
+  (void)hipHostFree(h->h_flag);
+  delete h;
+  return HF_OK;
+}
+
+int hf_pcg_begin(hf_pcg_t* h, void* x, void* r, void* p, const void* b, const void* minv,
+                 int precond, int64_t max_iter, double tol, double atol, int martens,
+                 const int64_t* store_iters, int64_t n_store, int store_x0, void* slab,
+                 int64_t slab_stride, void* m_hist) {
+  if (!h || !x || !r || !p || !b || max_iter < 1) return HF_ERR_ARG;
+  if (precond < HF_M_NONE || precond > HF_M_EXTERNAL) return HF_ERR_ARG;
+  if (precond == HF_M_DIAG && !minv) return HF_ERR_ARG;
+  if (martens && !m_hist) return HF_ERR_ARG;
+  if (n_store < 0 || (n_store > 0 && (!store_iters || !slab || slab_stride < h->n)))
+    return HF_ERR_ARG;
+  if (store_x0 && n_store == 0) return HF_ERR_ARG;
+  if (!aligned16(x) || !aligned16(r) || !aligned16(p) || !aligned16(b) ||
+      (minv && !aligned16(minv)) || (slab && !aligned16(slab)))
+    return HF_ERR_ALIGN;
+  const int W = h->dtype == HF_F32 ? 4 : 2;
+  if (n_store > 0 && (slab_stride % W) != 0) return HF_ERR_ALIGN;
+  h->x = x; h->r = r; h->p = p; h->b = b; h->minv = minv;
+  h->precond = precond;
+  h->max_iter = max_iter;
+  h->tol = tol; h->atol = atol;
+  h->martens = martens;
+  h->store_iters = store_iters; h->n_store = n_store;
+  h->slab = slab; h->slab_stride = slab_stride;
+  h->store_x0 = store_x0 ? 1 : 0;
+  h->m_hist = martens ? m_hist : nullptr;
+  h->begun = 1; h->inited = 0; h->finished = 0;
+  h->t_count = 0;
+  h->h_flag[0] = 0;
+  return HF_OK;
+}
+
+template <typename T>
+static int init_impl(hf_pcg* h, const void* Ax0, int slot0, hipStream_t s) {
+  const int g = grid_for(h, 1);
+  double* part = part_ptr(h, 0);
+  T* snap = slot0 ? (T*)h->slab : nullptr;
+#define HF_LAUNCH_INIT(MODE)                                                                   \
+  hipLaunchKernelGGL((k_init<T, MODE>), dim3(g), dim3(BLOCK), 0, s, part, h->grid,             \
+                     (const T*)h->x, (T*)h->r, (T*)h->p, (const T*)Ax0, (const T*)h->b,        \
+                     (const T*)h->minv, snap, (long long)h->n)
+  switch (h->precond) {
+    case HF_M_NONE: HF_LAUNCH_INIT(HF_M_NONE); break;
+    case HF_M_DIAG: HF_LAUNCH_INIT(HF_M_DIAG); break;
+    default: HF_LAUNCH_INIT(HF_M_EXTERNAL); break;
+  }
+#undef HF_LAUNCH_INIT
+  HF_HIP(hipGetLastError());
+  if (h->precond != HF_M_EXTERNAL) {
+    hipLaunchKernelGGL((k_init_finalize<T>), dim3(1), dim3(BLOCK), 0, s, h->d_state, part, g,
+                       h->grid, h->tol, h->atol, (T*)h->m_hist,
+                       (const long long*)h->store_iters, (long long)h->n_store, h->d_flag);
+    HF_HIP(hipGetLastError());
+    h->inited = 1;
+  }
+  return HF_OK;
+}
+
+int hf_pcg_init(hf_pcg_t* h, const void* Ax0, void* stream) {
+  if (!h || !Ax0) return HF_ERR_ARG;
+  if (!h->begun) return HF_ERR_STATE;
+  if (!aligned16(Ax0)) return HF_ERR_ALIGN;
+  const int slot0 = h->store_x0;
+  return h->dtype == HF_F32 ? init_impl<float>(h, Ax0, slot0, (hipStream_t)stream)
+                            : init_impl<double>(h, Ax0, slot0, (hipStream_t)stream);
+}
+
+int hf_pcg_init_external(hf_pcg_t* h, const void* y, void* stream) {
+  if (!h || !y) return HF_ERR_ARG;
+  if (!h->begun || h->precond != HF_M_EXTERNAL) return HF_ERR_STATE;
+  hipStream_t s = (hipStream_t)stream;
+  const int g = grid_for(h, 1);
+  double* part = part_ptr(h, 0);
+  if (h->dtype == HF_F32) {
+    hipLaunchKernelGGL((k_init_external<float>), dim3(g), dim3(BLOCK), 0, s, part, h->grid,
+                       (const float*)h->r, (float*)h->p, (const float*)y, (long long)h->n);
+    hipLaunchKernelGGL((k_init_finalize<float>), dim3(1), dim3(BLOCK), 0, s, h->d_state, part, g,
+                       h->grid, h->tol, h->atol, (float*)h->m_hist,
+                       (const long long*)h->store_iters, (long long)h->n_store, h->d_flag);
+  } else {
+    hipLaunchKernelGGL((k_init_external<double>), dim3(g), dim3(BLOCK), 0, s, part, h->grid,
+                       (const double*)h->r, (double*)h->p, (const double*)y, (long long)h->n);
+    hipLaunchKernelGGL((k_init_finalize<double>), dim3(1), dim3(BLOCK), 0, s, h->d_state, part,
+                       g, h->grid, h->tol, h->atol, (double*)h->m_hist,
+                       (const long long*)h->store_iters, (long long)h->n_store, h->d_flag);
+  }
+  HF_HIP(hipGetLastError());
+  h->inited = 1;
+  return HF_OK;
+}
+
+// unroll factors: K1 streams 2 vectors, K2 6, K3 3 -> keep ~12-16 x 16 B loads in
+// flight per lane in each
+constexpr int U1 = 4, U2 = 2, U3 = 4;
+
+template <typename T>
+static int curvature_impl(hf_pcg* h, const void* Bp, double damping, hipStream_t s) {
+  const int g = grid_for(h, U1);
+  hipLaunchKernelGGL((k_curvature<T, U1>), dim3(g), dim3(BLOCK), 0, s, h->d_state,
+                     part_ptr(h, 1), h->grid, (const T*)h->p, (const T*)Bp, (T)damping,
+                     damping != 0.0 ? 1 : 0, (long long)h->n);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+template <typename T>
+static int update_xr_impl(hf_pcg* h, const void* Bp, double damping, hipStream_t s) {
+  const int g1 = grid_for(h, U1);
+  const int g = grid_for(h, U2);
+#define HF_LAUNCH_XR(MODE)                                                                     \
+  hipLaunchKernelGGL((k_update_xr<T, MODE, U2>), dim3(g), dim3(BLOCK), 0, s, h->d_state,       \
+                     part_ptr(h, 1), part_ptr(h, 2), g1, h->grid, (T*)h->x, (T*)h->r,          \
+                     (const T*)h->p, (const T*)Bp, (const T*)h->b, (const T*)h->minv,          \
+                     (T)damping, damping != 0.0 ? 1 : 0, (const long long*)h->store_iters,     \
+                     (long long)h->n_store, (T*)h->slab, (long long)h->slab_stride,            \
+                     (long long)h->n)
+  switch (h->precond) {
+    case HF_M_NONE: HF_LAUNCH_XR(HF_M_NONE); break;
+    case HF_M_DIAG: HF_LAUNCH_XR(HF_M_DIAG); break;
+    default: HF_LAUNCH_XR(HF_M_EXTERNAL); break;
+  }
+#undef HF_LAUNCH_XR
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+template <typename T>
+static int update_p_impl(hf_pcg* h, const void* yext, hipStream_t s) {
+  const int g2 = grid_for(h, U2);
+  const int g = grid_for(h, U3);
+  if (h->precond == HF_M_EXTERNAL) {
+    // same grid as K2 so that part2 and part3 hold the same number of partials
+    hipLaunchKernelGGL((k_dot_ry<T>), dim3(g2), dim3(BLOCK), 0, s, h->d_state, part_ptr(h, 0),
+                       h->grid, (const T*)h->r, (const T*)yext, (long long)h->n);
+    HF_HIP(hipGetLastError());
+  }
+#define HF_LAUNCH_P(MODE, NP3)                                                                 \
+  hipLaunchKernelGGL((k_update_p<T, MODE, U3>), dim3(g), dim3(BLOCK), 0, s, h->d_state,        \
+                     part_ptr(h, 2), part_ptr(h, 0), NP3, h->grid, (const T*)h->r, (T*)h->p,   \
+                     (const T*)h->minv, (const T*)yext, (T*)h->m_hist,                         \
+                     (long long)h->max_iter, h->d_flag, (long long)h->n)
+  switch (h->precond) {
+    case HF_M_NONE: HF_LAUNCH_P(HF_M_NONE, g2); break;
+    case HF_M_DIAG: HF_LAUNCH_P(HF_M_DIAG, g2); break;
+    default: HF_LAUNCH_P(HF_M_EXTERNAL, g2); break;
+  }
+#undef HF_LAUNCH_P
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_pcg_curvature(hf_pcg_t* h, const void* Bp, double damping, void* stream) {
+  if (!h || !Bp) return HF_ERR_ARG;
+  if (!h->inited) return HF_ERR_STATE;
+  if (!aligned16(Bp)) return HF_ERR_ALIGN;
+  return h->dtype == HF_F32 ? curvature_impl<float>(h, Bp, damping, (hipStream_t)stream)
+                            : curvature_impl<double>(h, Bp, damping, (hipStream_t)stream);
+}
+
+int hf_pcg_update_xr(hf_pcg_t* h, const void* Bp, double damping, void* stream) {
+  if (!h || !Bp) return HF_ERR_ARG;
+  if (!h->inited) return HF_ERR_STATE;
+  if (!aligned16(Bp)) return HF_ERR_ALIGN;
+  return h->dtype == HF_F32 ? update_xr_impl<float>(h, Bp, damping, (hipStream_t)stream)
+                            : update_xr_impl<double>(h, Bp, damping, (hipStream_t)stream);
+}
+
+int hf_pcg_update_p(hf_pcg_t* h, const void* y_external, void* stream) {
+  if (!h) return HF_ERR_ARG;
+  if (!h->inited) return HF_ERR_STATE;
+  if (h->precond == HF_M_EXTERNAL && (!y_external || !aligned16(y_external)))
+    return y_external ? HF_ERR_ALIGN : HF_ERR_ARG;
+  return h->dtype == HF_F32 ? update_p_impl<float>(h, y_external, (hipStream_t)stream)
+                            : update_p_impl<double>(h, y_external, (hipStream_t)stream);
+}
+
+int hf_pcg_iterate(hf_pcg_t* h, const void* Bp, double damping, void* stream) {
+  if (!h || !Bp) return HF_ERR_ARG;
+  if (!h->inited || h->precond == HF_M_EXTERNAL) return HF_ERR_STATE;
+  if (!aligned16(Bp)) return HF_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const bool t = h->timing && h->t_count < TIMING_CAP;
+  hipEvent_t* ev = t ? h->ev + 4 * h->t_count : nullptr;
+  int rc;
+  if (t) HF_HIP(hipEventRecord(ev[0], s));
+  rc = h->dtype == HF_F32 ? curvature_impl<float>(h, Bp, damping, s)
+                          : curvature_impl<double>(h, Bp, damping, s);
+  if (rc) return rc;
+  if (t) HF_HIP(hipEventRecord(ev[1], s));
+  rc = h->dtype == HF_F32 ? update_xr_impl<float>(h, Bp, damping, s)
+                          : update_xr_impl<double>(h, Bp, damping, s);
+  if (rc) return rc;
+  if (t) HF_HIP(hipEventRecord(ev[2], s));
+  rc = h->dtype == HF_F32 ? update_p_impl<float>(h, nullptr, s)
+                          : update_p_impl<double>(h, nullptr, s);
+  if (rc) return rc;
+  if (t) {
+    HF_HIP(hipEventRecord(ev[3], s));
+    h->t_count++;
+  }
+  return HF_OK;
+}
+
+static void fill_status(const hf_pcg* h, const DevState* st, hf_pcg_status* out) {
+  out->done = st->done;
+  out->reason = st->done;
+  out->n_iters = st->n_iters;
+  out->iter_next = st->iter_next;
+  out->nonpos_count = st->nonpos_count;
+  out->last_alpha = st->last_alpha;
+  out->last_beta = st->last_beta;
+  out->last_pAp = st->last_pAp;
+  out->last_res_norm = st->last_res_norm;
+  out->res_bound = st->res_bound;
+  out->n_stored = st->slot_next;
+  (void)h;
+}
+
+int hf_pcg_poll(hf_pcg_t* h, hf_pcg_status* out) {
+  if (!h || !out) return HF_ERR_ARG;
+  memset(out, 0, sizeof(*out));
+  const int f = *(volatile int*)h->h_flag;
+  out->done = f;
+  out->reason = f;
+  return HF_OK;
+}
+
+int hf_pcg_finish(hf_pcg_t* h, hf_pcg_status* out, void* stream) {
+  if (!h || !out) return HF_ERR_ARG;
+  if (!h->inited) return HF_ERR_STATE;
+  hipStream_t s = (hipStream_t)stream;
+  HF_HIP(hipMemcpyAsync(h->h_state, h->d_state, sizeof(DevState), hipMemcpyDeviceToHost, s));
+  HF_HIP(hipStreamSynchronize(s));
+  fill_status(h, h->h_state, out);
+  h->finished = 1;
+  return HF_OK;
+}
+
+int hf_pcg_read_nonpos(hf_pcg_t* h, int64_t* iters, double* values, int cap) {
+  if (!h || !iters || !values || cap < 0) return HF_ERR_ARG;
+  if (!h->finished) return HF_ERR_STATE;
+  int64_t c = h->h_state->nonpos_count;
+  if (c > NP_CAP) c = NP_CAP;
+  if (c > cap) c = cap;
+  for (int64_t i = 0; i < c; ++i) {
+    iters[i] = h->h_state->nonpos_iter[i];
+    values[i] = h->h_state->nonpos_val[i];
+  }
+  return (int)c;
+}
+
+int hf_pcg_timing_enable(hf_pcg_t* h, int enable) {
+  if (!h) return HF_ERR_ARG;
+  if (enable && !h->ev) {
+    h->ev = new (std::nothrow) hipEvent_t[4 * TIMING_CAP];
+    if (!h->ev) return HF_ERR_ARG;
+    for (int i = 0; i < 4 * TIMING_CAP; ++i) HF_HIP(hipEventCreate(&h->ev[i]));
+  }
+  h->timing = enable ? 1 : 0;
+  h->t_count = 0;
+  return HF_OK;
+}
+
+int hf_pcg_timing_read(hf_pcg_t* h, double* ms_k1, double* ms_k2, double* ms_k3,
+                       int64_t* n_recorded) {
+  if (!h || !ms_k1 || !ms_k2 || !ms_k3 || !n_recorded) return HF_ERR_ARG;
+  double a = 0, b = 0, c = 0;
+  for (int64_t i = 0; i < h->t_count; ++i) {
+    float t = 0;
+    hipEvent_t* ev = h->ev + 4 * i;
+    HF_HIP(hipEventElapsedTime(&t, ev[0], ev[1])); a += t;
+    HF_HIP(hipEventElapsedTime(&t, ev[1], ev[2])); b += t;
+    HF_HIP(hipEventElapsedTime(&t, ev[2], ev[3])); c += t;
+  }
+  const double k = h->t_count > 0 ? 1.0 / (double)h->t_count : 0.0;
+  *ms_k1 = a * k; *ms_k2 = b * k; *ms_k3 = c * k;
+  *n_recorded = h->t_count;
+  return HF_OK;
+}
+
+// ---- vector helpers -------------------------------------------------------
+template <typename T>
+static int pack_impl(void* dst, const void* const* srcs, const int64_t* numels, int nt,
+                     double scale, int mode, hipStream_t s) {
+  int t = 0;
+  long long off = 0;
+  while (t < nt) {
+    PackArgs a;
+    memset(&a, 0, sizeof(a));
+    int k = 0, blocks = 0;
+    while (t < nt && k < PACK_MAXT) {
+      if (numels[t] < 0) return HF_ERR_ARG;
+      if (numels[t] > 0) {
+        if (!srcs[t]) return HF_ERR_ARG;
+        a.src[k] = srcs[t];
+        a.dst_off[k] = off;
+        a.numel[k] = numels[t];
+        a.blk_start[k] = blocks;
+        blocks += (int)((numels[t] + PACK_CHUNK - 1) / PACK_CHUNK);
+        ++k;
+      }
+      off += numels[t];
+      ++t;
+    }
+    a.blk_start[k] = blocks;
+    a.nt = k;
+    if (blocks == 0) continue;
+    if (mode == 0)
+      hipLaunchKernelGGL((k_pack<T, 0>), dim3(blocks), dim3(BLOCK), 0, s, (T*)dst, a, (T)scale);
+    else
+      hipLaunchKernelGGL((k_pack<T, 1>), dim3(blocks), dim3(BLOCK), 0, s, (T*)dst, a, (T)scale);
+    HF_HIP(hipGetLastError());
+  }
+  return HF_OK;
+}
+
+int hf_pack(void* dst, const void* const* srcs, const int64_t* numels, int n_tensors,
+            double scale, int mode, int dtype, void* stream) {
+  if (!dst || !srcs || !numels || n_tensors < 0 || (mode != 0 && mode != 1)) return HF_ERR_ARG;
+  if (dtype == HF_F32)
+    return pack_impl<float>(dst, srcs, numels, n_tensors, scale, mode, (hipStream_t)stream);
+  if (dtype == HF_F64)
+    return pack_impl<double>(dst, srcs, numels, n_tensors, scale, mode, (hipStream_t)stream);
+  return HF_ERR_ARG;
+}
+
+static int small_grid(int64_t n) {
+  int64_t g = (n + BLOCK * 4 - 1) / (BLOCK * 4);
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;
+  return (int)g;
+}
+
+int hf_precond_build(void* minv, const void* diag, double damping, double exponent, int64_t n,
+                     int dtype, void* stream) {
+  if (!minv || !diag || n <= 0) return HF_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == HF_F32)
+    hipLaunchKernelGGL((k_precond_build<float>), dim3(small_grid(n)), dim3(BLOCK), 0, s,
+                       (float*)minv, (const float*)diag, (float)damping, (float)(-exponent),
+                       (long long)n);
+  else if (dtype == HF_F64)
+    hipLaunchKernelGGL((k_precond_build<double>), dim3(small_grid(n)), dim3(BLOCK), 0, s,
+                       (double*)minv, (const double*)diag, damping, -exponent, (long long)n);
+  else
+    return HF_ERR_ARG;
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_axpy_out(void* out, const void* a, const void* sv, double alpha, int64_t n, int dtype,
+                void* stream) {
+  if (!out || !a || !sv || n <= 0) return HF_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int vec_ok = aligned16(out) && aligned16(a) && aligned16(sv);
+  if (dtype == HF_F32)
+    hipLaunchKernelGGL((k_axpy_out<float>), dim3(small_grid(n / 4 + 1)), dim3(BLOCK), 0, s,
+                       (float*)out, (const float*)a, (const float*)sv, (float)alpha,
+                       (long long)n, vec_ok);
+  else if (dtype == HF_F64)
+    hipLaunchKernelGGL((k_axpy_out<double>), dim3(small_grid(n / 2 + 1)), dim3(BLOCK), 0, s,
+                       (double*)out, (const double*)a, (const double*)sv, alpha, (long long)n,
+                       vec_ok);
+  else
+    return HF_ERR_ARG;
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+// ---- RCCL, resolved at run time -------------------------------------------
+struct hf_comm {
+  void* comm;  // ncclComm_t
+};
+
+namespace {
+struct NcclUid { char internal[128]; };
+typedef int (*fn_get_uid)(NcclUid*);
+typedef int (*fn_init_rank)(void**, int, NcclUid, int);
+typedef int (*fn_destroy)(void*);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+
+void* rccl_sym(const char* name) {
+  void* f = dlsym(RTLD_DEFAULT, name);
+  if (f) return f;
+  // torch's extension modules are loaded RTLD_LOCAL: look the library up by its
+  // SONAME among the objects already mapped into this process (never load a
+  // second copy).
+  static void* lib = nullptr;
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW);
+  return lib ? dlsym(lib, name) : nullptr;
+}
+}  // namespace
+
+int hf_comm_unique_id(char* out128) {
+  if (!out128) return HF_ERR_ARG;
+  fn_get_uid f = (fn_get_uid)rccl_sym("ncclGetUniqueId");
+  if (!f) return HF_ERR_NOSYMBOL;
+  NcclUid id;
+  const int rc = f(&id);
+  if (rc) return 1000 + rc;
+  memcpy(out128, id.internal, 128);
+  return HF_OK;
+}
+
+int hf_comm_create(hf_comm_t** out, const char* id128, int nranks, int rank) {
+  if (!out || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return HF_ERR_ARG;
+  fn_init_rank f = (fn_init_rank)rccl_sym("ncclCommInitRank");
+  if (!f) return HF_ERR_NOSYMBOL;
+  NcclUid id;
+  memcpy(id.internal, id128, 128);
+  hf_comm* c = new (std::nothrow) hf_comm();
+  if (!c) return HF_ERR_ARG;
+  const int rc = f(&c->comm, nranks, id, rank);
+  if (rc) { delete c; return 1000 + rc; }
+  *out = c;
+  return HF_OK;
+}
+
+int hf_comm_destroy(hf_comm_t* c) {
+  if (!c) return HF_OK;
+  fn_destroy f = (fn_destroy)rccl_sym("ncclCommDestroy");
+  if (f && c->comm) (void)f(c->comm);
+  delete c;
+  return HF_OK;
+}
+
+int hf_allreduce_sum(hf_comm_t* c, void* buf, int64_t n, int dtype, void* stream) {
+  if (!c || !c->comm || !buf || n <= 0) return HF_ERR_ARG;
+  fn_allreduce f = (fn_allreduce)rccl_sym("ncclAllReduce");
+  if (!f) return HF_ERR_NOSYMBOL;
+  // ncclFloat32 = 7, ncclFloat64 = 8, ncclSum = 0 (nccl.h / rccl.h enum values)
+  const int nccl_dtype = dtype == HF_F32 ? 7 : 8;
+  const int rc = f(buf, buf, (size_t)n, nccl_dtype, 0, c->comm, (hipStream_t)stream);
+  return rc ? 1000 + rc : HF_OK;
+}
+
