@@ -46,6 +46,16 @@ def snapshot_grid(max_iter, gamma=1.3):
     return sorted(set(marks))
 
 
+def _dot64(a, b):
+    """Dot product accumulated in float64 from exact products, rounded once to
+    the operand dtype -- the arithmetic of the HIP kernels' reductions."""
+    return (a.double() * b.double()).sum().to(a.dtype)
+
+
+def _norm64(a):
+    return (a.double() * a.double()).sum().sqrt().to(a.dtype)
+
+
 class _Trace:
     """Optional per-iteration scalar trace (for debugging GPU parity)."""
 
@@ -65,13 +75,28 @@ def pcg(
     store_x_at_iters=(),
     verbose=False,
     trace=None,
+    accumulate="reference",
 ):
     """Oracle PCG.  Same signature and return value as the reference ``cg``:
     ``(x_iters, m_iters, reason)``.  ``trace`` may be a ``_Trace`` to collect the
     scalars of every iteration.
+
+    ``accumulate="reference"`` (default) uses ``torch.dot`` / ``torch.linalg.norm``
+    exactly as the reference does and is the mode pinned bit-for-bit against it.
+    ``accumulate="fp64"`` changes ONLY the precision in which the five reductions
+    are accumulated (exact products summed in float64, rounded once): that is the
+    arithmetic of the HIP kernels, so GPU iterates can be compared (nearly) bit
+    for bit even on ill-conditioned systems where any change of summation order
+    moves fp32 CG iterates by percents.
     """
+    if accumulate == "reference":
+        dot, norm = torch.dot, torch.linalg.norm
+    elif accumulate == "fp64":
+        dot, norm = _dot64, _norm64
+    else:
+        raise ValueError(accumulate)
     # ---- tolerance bound (cg.py:75-76) --------------------------------------
-    bound = tol * torch.linalg.norm(b).item()
+    bound = tol * norm(b).item()
     if atol is not None:
         bound = max([bound, atol])
 
@@ -87,9 +112,9 @@ def pcg(
     x = start
     xs = [x if 0 in keep else None]
     r = A(start) - b
-    ms = [0.5 * torch.dot(r - b, start)] if martens_conv_crit else None
+    ms = [0.5 * dot(r - b, start)] if martens_conv_crit else None
     y = r if M is None else M(r)
-    ry = torch.dot(r, y)
+    ry = dot(r, y)
     p = -y
 
     k = 0
@@ -99,7 +124,7 @@ def pcg(
         k += 1
         # ---- curvature along p (cg.py:205-207, :133-139) --------------------
         Ap = A(p).detach()
-        pAp = torch.dot(p, Ap)
+        pAp = dot(p, Ap)
         if not (pAp > 0):
             warnings.warn(
                 f"Directional curvature pAp = {pAp:.3e} <= 0 detected in cg-"
@@ -115,14 +140,14 @@ def pcg(
         r = r + alpha * Ap
 
         # ---- termination tests, in the reference's order (cg.py:93-115) -----
-        res_norm = torch.linalg.norm(r)
+        res_norm = norm(r)
         if trace is not None:
             trace.alpha.append(float(alpha))
             trace.pAp.append(float(pAp))
             trace.res_norm.append(float(res_norm))
         stop = False
         if martens_conv_crit:
-            ms.append(0.5 * torch.dot(r - b, x))
+            ms.append(0.5 * dot(r - b, x))
             lag = max(10, int(k / 10))
             if lag < k:
                 gain = ms[k] - ms[k - lag]
@@ -140,7 +165,7 @@ def pcg(
 
         # ---- new search direction (cg.py:220-224) ---------------------------
         y = r if M is None else M(r)
-        ry_next = torch.dot(r, y)
+        ry_next = dot(r, y)
         beta = ry_next / ry
         ry = ry_next
         p = -y + beta * p

@@ -1,0 +1,202 @@
+"""ctypes binding of ``libhfpcg.so`` (C ABI declared in ``include/hf_pcg.h``).
+
+The library is loaded AFTER ``import torch`` so that its ``DT_NEEDED``
+``libamdhip64.so.7`` resolves to the HIP runtime PyTorch-ROCm already mapped
+(same SONAME) -- kernels, streams and device pointers then live in ONE runtime.
+There is no fallback: if the shared object is missing or a call fails, a
+``RuntimeError`` is raised.
+"""
+
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhfpcg.so")
+
+HF_F32, HF_F64 = 0, 1
+HF_M_NONE, HF_M_DIAG, HF_M_EXTERNAL = 0, 1, 2
+REASONS = {
+    1: "Convergence (Martens)",
+    2: "Number of iterations",
+    3: "Divergence",
+    4: "Convergence (tolerances)",
+}
+
+c_void_p, c_int, c_int64, c_double = (
+    ctypes.c_void_p,
+    ctypes.c_int,
+    ctypes.c_int64,
+    ctypes.c_double,
+)
+
+
+class Status(ctypes.Structure):
+    _fields_ = [
+        ("done", ctypes.c_int32),
+        ("reason", ctypes.c_int32),
+        ("n_iters", c_int64),
+        ("iter_next", c_int64),
+        ("nonpos_count", c_int64),
+        ("last_alpha", c_double),
+        ("last_beta", c_double),
+        ("last_pAp", c_double),
+        ("last_res_norm", c_double),
+        ("res_bound", c_double),
+        ("n_stored", c_int64),
+    ]
+
+
+# name -> (restype, argtypes); must list EVERY symbol include/hf_pcg.h declares
+SIGNATURES = {
+    "hf_abi_version": (c_int, []),
+    "hf_error_string": (ctypes.c_char_p, [c_int]),
+    "hf_pcg_create": (c_int, [ctypes.POINTER(c_void_p), c_int64, c_int, c_int]),
+    "hf_pcg_destroy": (c_int, [c_void_p]),
+    "hf_pcg_begin": (
+        c_int,
+        [c_void_p] * 6
+        + [c_int, c_int64, c_double, c_double, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p],
+    ),
+    "hf_pcg_init": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "hf_pcg_init_external": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "hf_pcg_iterate": (c_int, [c_void_p, c_void_p, c_double, c_void_p]),
+    "hf_pcg_curvature": (c_int, [c_void_p, c_void_p, c_double, c_void_p]),
+    "hf_pcg_update_xr": (c_int, [c_void_p, c_void_p, c_double, c_void_p]),
+    "hf_pcg_update_p": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "hf_pcg_poll": (c_int, [c_void_p, ctypes.POINTER(Status)]),
+    "hf_pcg_finish": (c_int, [c_void_p, ctypes.POINTER(Status), c_void_p]),
+    "hf_pcg_read_nonpos": (
+        c_int,
+        [c_void_p, ctypes.POINTER(c_int64), ctypes.POINTER(c_double), c_int],
+    ),
+    "hf_pcg_timing_enable": (c_int, [c_void_p, c_int]),
+    "hf_pcg_timing_read": (
+        c_int,
+        [c_void_p] + [ctypes.POINTER(c_double)] * 3 + [ctypes.POINTER(c_int64)],
+    ),
+    "hf_pack": (
+        c_int,
+        [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), c_int, c_double, c_int, c_int, c_void_p],
+    ),
+    "hf_precond_build": (c_int, [c_void_p, c_void_p, c_double, c_double, c_int64, c_int, c_void_p]),
+    "hf_axpy_out": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int, c_void_p]),
+    "hf_comm_unique_id": (c_int, [ctypes.c_char_p]),
+    "hf_comm_create": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_char_p, c_int, c_int]),
+    "hf_comm_destroy": (c_int, [c_void_p]),
+    "hf_allreduce_sum": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and type every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is REQUIRED (there is no "
+            "CPU fallback). Build it with `python -m pytorchhessianfree_amd.csrc.build`."
+        )
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.hf_abi_version() != 1:
+        raise RuntimeError("libhfpcg.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().hf_error_string(code)
+        msg = msg.decode() if msg else "?"
+        raise RuntimeError(f"libhfpcg {what} failed with code {code}: {msg}")
+
+
+def dtype_code(dtype):
+    if dtype == torch.float32:
+        return HF_F32
+    if dtype == torch.float64:
+        return HF_F64
+    raise TypeError(f"libhfpcg supports float32/float64 vectors, not {dtype}")
+
+
+def current_stream_ptr(device):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_device_tensor(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"`{name}` should be a torch.Tensor, not {type(t)}.")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"`{name}` lives on {t.device}: the PCG solver runs only as HIP kernels "
+            "on an AMD GPU (no CPU fallback exists in this package)."
+        )
+
+
+# ---- thin helpers used by several modules -----------------------------------
+def pack(dst, tensors, scale=1.0, mode=0):
+    """dst[off_t : off_t+numel_t] = scale * tensors[t]  (mode 0)
+    dst[...] += (scale * tensors[t])**2                 (mode 1)
+    One multi-tensor gather launch instead of ``torch.cat``."""
+    lib = load()
+    require_device_tensor(dst, "dst")
+    n = len(tensors)
+    ptrs = (c_void_p * n)()
+    numels = (c_int64 * n)()
+    keep = []
+    total = 0
+    for i, t in enumerate(tensors):
+        if t.dtype != dst.dtype or t.device != dst.device:
+            raise RuntimeError("pack: dtype/device mismatch")
+        if not t.is_contiguous():
+            t = t.contiguous()
+        keep.append(t)
+        ptrs[i] = t.data_ptr()
+        numels[i] = t.numel()
+        total += t.numel()
+    if total != dst.numel():
+        raise RuntimeError(f"pack: {total} source elements for a vector of {dst.numel()}")
+    check(
+        lib.hf_pack(
+            c_void_p(dst.data_ptr()), ptrs, numels, n, float(scale), int(mode),
+            dtype_code(dst.dtype), current_stream_ptr(dst.device),
+        ),
+        "hf_pack",
+    )
+    return dst
+
+
+def axpy_out(out, a, s, alpha):
+    """out = a + alpha * s (separately rounded mul and add, like the reference)."""
+    lib = load()
+    require_device_tensor(out, "out")
+    check(
+        lib.hf_axpy_out(
+            c_void_p(out.data_ptr()), c_void_p(a.data_ptr()), c_void_p(s.data_ptr()),
+            float(alpha), out.numel(), dtype_code(out.dtype), current_stream_ptr(out.device),
+        ),
+        "hf_axpy_out",
+    )
+    return out
+
+
+def precond_build(minv, diag, damping, exponent):
+    lib = load()
+    require_device_tensor(minv, "minv")
+    check(
+        lib.hf_precond_build(
+            c_void_p(minv.data_ptr()), c_void_p(diag.data_ptr()), float(damping),
+            float(exponent), minv.numel(), dtype_code(minv.dtype),
+            current_stream_ptr(minv.device),
+        ),
+        "hf_precond_build",
+    )
+    return minv

@@ -184,19 +184,36 @@ __global__ __launch_bounds__(BLOCK) void k_init(double* __restrict__ part, int s
   write_partials<3>(part, stride, acc, lds);
 }
 
-// HF_M_EXTERNAL: p = -y, part[0] = r.y
+// HF_M_EXTERNAL: p = -y, part[0] = r.y.  Same loop nest as k_init so that an
+// identity M reproduces the HF_M_NONE sums bit for bit (tests/test_cg.py:217).
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_init_external(double* __restrict__ part, int stride,
                                                          const T* __restrict__ r,
                                                          T* __restrict__ p,
                                                          const T* __restrict__ y, long long n) {
+  constexpr int W = VecOf<T>::W;
+  typedef typename VecOf<T>::type V;
   __shared__ double lds[WAVES];
   double acc[1] = {0.0};
-  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n;
+  const long long nvec = n / W;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < nvec;
        i += (long long)gridDim.x * BLOCK) {
-    const T yy = y[i];
-    acc[0] += (double)r[i] * (double)yy;
-    p[i] = -yy;
+    VU<T> vr, vy, vp;
+    vr.v = reinterpret_cast<const V*>(r)[i];
+    vy.v = reinterpret_cast<const V*>(y)[i];
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      acc[0] += (double)vr.e[c] * (double)vy.e[c];
+      vp.e[c] = -vy.e[c];
+    }
+    reinterpret_cast<V*>(p)[i] = vp.v;
+  }
+  if (blockIdx.x == 0) {
+    const long long j = nvec * W + threadIdx.x;
+    if (j < n) {
+      acc[0] += (double)r[j] * (double)y[j];
+      p[j] = -y[j];
+    }
   }
   write_partials<1>(part, stride, acc, lds);
 }
@@ -378,18 +395,37 @@ __global__ __launch_bounds__(BLOCK) void k_update_xr(
   write_partials<3>(part2, stride, acc, lds);
 }
 
-// K3a (HF_M_EXTERNAL only): part3 = r.y
-template <typename T>
+// K3a (HF_M_EXTERNAL only): part3 = r.y.  Same tile walk as K2 (see k_init_external).
+template <typename T, int UNROLL>
 __global__ __launch_bounds__(BLOCK) void k_dot_ry(const DevState* __restrict__ st,
                                                   double* __restrict__ part3, int stride,
                                                   const T* __restrict__ r,
                                                   const T* __restrict__ y, long long n) {
   if (st->done) return;
+  constexpr int W = VecOf<T>::W;
+  typedef typename VecOf<T>::type V;
   __shared__ double lds[WAVES];
   double acc[1] = {0.0};
-  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n;
-       i += (long long)gridDim.x * BLOCK)
-    acc[0] += (double)r[i] * (double)y[i];
+  const long long nvec = n / W;
+  const long long tile = (long long)BLOCK * UNROLL;
+  for (long long base = (long long)blockIdx.x * tile; base < nvec;
+       base += (long long)gridDim.x * tile) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const long long i = base + u * BLOCK + threadIdx.x;
+      if (i < nvec) {
+        VU<T> vr, vy;
+        vr.v = reinterpret_cast<const V*>(r)[i];
+        vy.v = reinterpret_cast<const V*>(y)[i];
+#pragma unroll
+        for (int c = 0; c < W; ++c) acc[0] += (double)vr.e[c] * (double)vy.e[c];
+      }
+    }
+  }
+  if (blockIdx.x == 0) {
+    const long long j = nvec * W + threadIdx.x;
+    if (j < n) acc[0] += (double)r[j] * (double)y[j];
+  }
   write_partials<1>(part3, stride, acc, lds);
 }
 
@@ -757,6 +793,7 @@ int hf_pcg_init(hf_pcg_t* h, const void* Ax0, void* stream) {
 int hf_pcg_init_external(hf_pcg_t* h, const void* y, void* stream) {
   if (!h || !y) return HF_ERR_ARG;
   if (!h->begun || h->precond != HF_M_EXTERNAL) return HF_ERR_STATE;
+  if (!aligned16(y)) return HF_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   const int g = grid_for(h, 1);
   double* part = part_ptr(h, 0);
@@ -819,7 +856,7 @@ static int update_p_impl(hf_pcg* h, const void* yext, hipStream_t s) {
   const int g = grid_for(h, U3);
   if (h->precond == HF_M_EXTERNAL) {
     // same grid as K2 so that part2 and part3 hold the same number of partials
-    hipLaunchKernelGGL((k_dot_ry<T>), dim3(g2), dim3(BLOCK), 0, s, h->d_state, part_ptr(h, 0),
+    hipLaunchKernelGGL((k_dot_ry<T, U2>), dim3(g2), dim3(BLOCK), 0, s, h->d_state, part_ptr(h, 0),
                        h->grid, (const T*)h->r, (const T*)yext, (long long)h->n);
     HF_HIP(hipGetLastError());
   }

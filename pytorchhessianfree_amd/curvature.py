@@ -1,0 +1,139 @@
+"""Curvature-vector products ``v -> B v`` on flat parameter vectors (the ``mvp`` of
+the reference's ``optimizer.py:237-247, :450-462``) and their data-parallel sum.
+
+The reference delegates to BackPACK, which re-derives everything on every call:
+``R_op`` builds a double-backward graph through a dummy cotangent, runs it, and
+``parameters_to_vector`` concatenates the result (optimizer.py:457-462).  Here
+
+* the linear map ``u -> J^T u`` (``J = d outputs / d params``) is recorded ONCE per
+  step as an autograd graph; ``J v`` is then one backward sweep through that
+  recorded graph per matvec (MIOpen/rocBLAS kernels on PyTorch-ROCm -- this is
+  not a dense contraction, so no custom MFMA kernel);
+* the loss Hessian ``H_L`` is likewise recorded once (``d loss / d outputs`` with
+  graph) and applied with one tiny backward sweep;
+* ``J^T (H_L J v)`` is one ordinary reverse pass through the step's forward graph;
+* the per-parameter results are gathered into ONE contiguous HBM vector by the
+  multi-tensor ``hf_pack`` kernel (8 N bytes instead of ``torch.cat``), with the
+  data-parallel weight ``N_k / sum N`` folded into the same pass;
+* across ranks the partial products are summed with ONE all-reduce per matvec
+  (the ``result += N * mb_result`` of optimizer.py:677-684 turned sideways).
+
+On CPU tensors (host-logic tests, gloo tests) the gather is ``torch.cat``; on a
+GPU the HIP kernel is mandatory (``_lib`` raises if the library is missing).
+"""
+
+import torch
+
+from . import _lib
+from .utils import vector_to_parameter_list
+
+
+def flatten_into(tensors, like_params, out=None, scale=1.0):
+    """``parameters_to_vector`` replacement: gather ``tensors`` (``None`` -> zeros
+    shaped like the matching parameter) into one flat vector, times ``scale``."""
+    ref = like_params[0]
+    n = sum(p.numel() for p in like_params)
+    if out is None:
+        out = torch.empty(n, dtype=ref.dtype, device=ref.device)
+    dense = [
+        torch.zeros_like(p) if t is None else t.detach() for t, p in zip(tensors, like_params)
+    ]
+    if out.is_cuda:
+        _lib.pack(out, dense, scale=scale, mode=0)
+    else:
+        torch.cat([t.reshape(-1) for t in dense], out=out)
+        if scale != 1.0:
+            out.mul_(scale)
+    return out
+
+
+def _all_reduce_sum(t, group):
+    if group is not None:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=group)
+    return t
+
+
+class _Operator:
+    """Common part: flat-vector in, flat-vector out, optional rank weight and
+    process group.  ``group=None`` means single process (reference behaviour)."""
+
+    def __init__(self, params, weight=1.0, group=None):
+        self.params = list(params)
+        self.weight = float(weight)
+        self.group = group
+        self.n = sum(p.numel() for p in self.params)
+        self.calls = 0
+
+    def _finish(self, per_param, out):
+        out = flatten_into(per_param, self.params, out=out, scale=self.weight)
+        self.calls += 1
+        return _all_reduce_sum(out, self.group)
+
+    def __call__(self, v, out=None):
+        raise NotImplementedError
+
+
+class GGNOperator(_Operator):
+    """``v -> J^T H_L J v`` for the mini-batch behind ``(loss, outputs)``
+    (math contract of BackPACK's ``ggn_vector_product_from_plist``,
+    optimizer.py:457-462)."""
+
+    def __init__(self, loss, outputs, params, weight=1.0, group=None):
+        super().__init__(params, weight, group)
+        self.outputs = outputs
+        # u -> J^T u, recorded once (u is a dummy cotangent)
+        self._u = torch.zeros_like(outputs, requires_grad=True)
+        JTu = torch.autograd.grad(
+            outputs, self.params, grad_outputs=self._u, create_graph=True,
+            retain_graph=True, allow_unused=True,
+        )
+        self._used = [i for i, g in enumerate(JTu) if g is not None]
+        self._JTu = [JTu[i] for i in self._used]
+        # d loss / d outputs with graph -> H_L by one more sweep
+        (self._dl,) = torch.autograd.grad(loss, outputs, create_graph=True, retain_graph=True)
+
+    def __call__(self, v, out=None):
+        vs = vector_to_parameter_list(v, self.params)
+        (Jv,) = torch.autograd.grad(
+            self._JTu, self._u, grad_outputs=[vs[i] for i in self._used], retain_graph=True
+        )
+        if self._dl.requires_grad:
+            (HJv,) = torch.autograd.grad(
+                self._dl, self.outputs, grad_outputs=Jv, retain_graph=True, allow_unused=True
+            )
+            if HJv is None:
+                HJv = torch.zeros_like(Jv)
+        else:  # loss linear in the outputs: H_L = 0
+            HJv = torch.zeros_like(Jv)
+        JTHJv = torch.autograd.grad(
+            self.outputs, self.params, grad_outputs=HJv, retain_graph=True, allow_unused=True
+        )
+        return self._finish(JTHJv, out)
+
+
+class HessianOperator(_Operator):
+    """``v -> (d^2 loss / d params^2) v`` (BackPACK's ``hessian_vector_product``,
+    optimizer.py:450-455).  ``grad_with_graph`` are the per-parameter gradients
+    computed with ``create_graph=True`` (the step needs them anyway,
+    optimizer.py:231-233); H is symmetric, so one reverse sweep through that
+    graph with cotangent ``v`` is ``H v``."""
+
+    def __init__(self, loss, params, grad_with_graph=None, weight=1.0, group=None):
+        super().__init__(params, weight, group)
+        if grad_with_graph is None:
+            grad_with_graph = torch.autograd.grad(
+                loss, self.params, create_graph=True, retain_graph=True
+            )
+        self._used = [i for i, g in enumerate(grad_with_graph) if g.requires_grad]
+        self._g = [grad_with_graph[i] for i in self._used]
+
+    def __call__(self, v, out=None):
+        vs = vector_to_parameter_list(v, self.params)
+        if self._g:
+            Hv = torch.autograd.grad(
+                self._g, self.params, grad_outputs=[vs[i] for i in self._used],
+                retain_graph=True, allow_unused=True,
+            )
+        else:  # loss linear in the parameters
+            Hv = [None] * len(self.params)
+        return self._finish(Hv, out)

@@ -218,7 +218,17 @@ def make_cg_lowrank():
         store[key + "/X"] = stack_iters(out[0], b)
         store[key + "/m"] = np.array([float(m) for m in out[1]], dtype=np.float32)
         store[key + "/reason"] = np.array(out[2])
-        print(f"  {key}: {len(out[0])-1} iters, {out[2]}")
+        # the reference itself in float64 on the same inputs: the trajectory
+        # both fp32 runs (reference and HIP) approximate
+        U64, d64, b64 = U.double(), d.double(), b.double()
+        M64 = ref_d2p(diag.double(), damping) if precond else None
+        kw64 = dict(kw, x0=None if x0 is None else x0.double(), M=M64)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out64 = ref_cg(lambda v: d64 * v + U64 @ (U64.T @ v) + damping * v, b64, **kw64)
+        store[key + "/X64"] = stack_iters(out64[0], b64)
+        store[key + "/m64"] = np.array([float(m) for m in out64[1]], dtype=np.float64)
+        print(f"  {key}: {len(out[0])-1} iters, {out[2]} (fp64: {len(out64[0])-1})")
     store["index"] = np.array(index)
     save("cg_lowrank.npz", store)
 
