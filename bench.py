@@ -1,0 +1,237 @@
+"""Benchmark of the hot path: GGN-matvecs/sec (and CG-iters/sec) of the HIP PCG
+solver on a ResNet-18-sized parameter vector (BASELINE.json ``configs[1]``).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one Newton-step solve: ``--iters`` (250) PCG iterations on one
+synthetic mini-batch, i.e. 251 calls of the damped GGN operator ``A(p)`` (one for
+``A(x0)``, cg.py:188) with inputs, weights and all solver vectors resident in
+HBM.  ``value`` = damped-operator calls per second summed over ranks; with N>1
+every rank holds its own 32-sample shard (weak scaling) and each matvec ends in
+one all-reduce of the 44.7 MB partial product.
+
+Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
+``roofline`` (dominant hand-written kernel: K2 update_xr, HIP-event timed inside
+the timed region) and ``cpu_baseline`` (the oracle -- the reference's algorithm
+restated on torch-CPU -- timed on a bounded sample on this box's host cores).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=250, help="PCG iterations per step")
+    ap.add_argument("--batch", type=int, default=32, help="samples per GPU")
+    ap.add_argument("--workload", default="resnet18", choices=["resnet18", "allcnnc"])
+    ap.add_argument("--damping", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=20)
+    ap.add_argument("--graph", type=int, default=1, help="replay the matvec as a hipGraph if possible")
+    return ap.parse_args()
+
+
+def build_problem(args, device, rank):
+    from pytorchhessianfree_amd import testproblems as tp
+
+    make = tp.resnet18_mnist if args.workload == "resnet18" else tp.allcnnc_cifar100
+    # same weights on every rank (seed 0), a different data shard per rank
+    return make(batch_size=args.batch, seed=0, device=device, data_seed=1000 + rank)
+
+
+def cpu_baseline(args):
+    """The oracle (reference algorithm restated, torch CPU ops in the reference's
+    order: oracle/pcg.py + oracle/backpack_restated.py) on the same workload,
+    bounded to ``--cpu-iters`` PCG iterations."""
+    from oracle import backpack_restated as bp
+    from oracle import pcg as oracle
+    from pytorchhessianfree_amd.utils import vector_to_parameter_list
+
+    model, (x, t), lossf = build_problem(args, "cpu", 0)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    loss = lossf(out, t)
+    grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, params, retain_graph=True)])
+    calls = [0]
+
+    def mvp(v):  # optimizer.py:457-462 with BackPACK's published algorithm
+        calls[0] += 1
+        Gv = bp.ggn_vector_product_from_plist(loss, out, params, vector_to_parameter_list(v, params))
+        return torch.cat([g.reshape(-1) for g in Gv]).detach()
+
+    lam = args.damping
+    mvp(torch.randn_like(grad))  # warm-up
+    calls[0] = 0
+    t0 = time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xs, _, _ = oracle.pcg(lambda v: mvp(v) + lam * v, -grad, max_iter=args.cpu_iters, tol=0.0,
+                              martens_conv_crit=True, store_x_at_iters=None)
+    dt = time.perf_counter() - t0
+    return {
+        "value": calls[0] / dt,
+        "unit": "GGN-matvecs/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{len(xs)-1} PCG iterations ({calls[0]} matvecs) of the same {args.workload} "
+                  f"batch-{args.batch} problem, {dt:.1f} s",
+        "cg_iters_per_s": (len(xs) - 1) / dt,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+        group = dist.group.WORLD
+
+    import pytorchhessianfree_amd as hf
+    from pytorchhessianfree_amd import cg as _unused  # noqa: F401
+    from pytorchhessianfree_amd import curvature
+    from pytorchhessianfree_amd.cg import enable_kernel_timing, read_kernel_timing
+
+    model, (x, t), lossf = build_problem(args, device, rank)
+    params = [p for p in model.parameters() if p.requires_grad]
+    n = sum(p.numel() for p in params)
+    weight = 1.0 / world
+    grads = torch.autograd.grad(lossf(model(x), t), params)
+    grad = curvature.flatten_into(grads, params, scale=weight)
+    if group is not None:
+        torch.distributed.all_reduce(grad, group=group)
+    b = -grad
+
+    def builder():  # forward graph + recorded J^T / H_L maps (once per Newton step)
+        out = model(x)
+        return curvature.GGNOperator(lossf(out, t), out, params, weight=weight, group=group)
+
+    op = curvature.maybe_graphed(builder, enable=bool(args.graph))
+    A = hf.DampedCurvature(op, args.damping)
+
+    def solve(martens=False, max_iter=args.iters):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return hf.cg(A, b, max_iter=max_iter, tol=0.0, martens_conv_crit=martens,
+                         store_x_at_iters=[0])
+
+    def barrier():
+        if group is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solve()
+    ws = enable_kernel_timing(device, n, torch.float32, True)
+    calls0 = op.calls
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        xs, _, reason = solve()
+    barrier()
+    dt = time.perf_counter() - t0
+    timing = read_kernel_timing(ws)
+    enable_kernel_timing(device, n, torch.float32, False)
+    matvecs = op.calls - calls0
+    iters_done = len(xs) - 1
+
+    if group is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # CG-iters/sec to Martens' criterion (second half of BASELINE.json's metric)
+    barrier()
+    t1 = time.perf_counter()
+    xs_m, _, reason_m = solve(martens=True)
+    barrier()
+    dt_m = time.perf_counter() - t1
+
+    if rank == 0:
+        k2_s = timing["k2_ms"] * 1e-3
+        alg_bytes = 28.0 * n  # K2: reads x,r,p,Bp,b, writes x,r (fp32)  SURVEY.md 8(d)
+        achieved = alg_bytes / k2_s / 1e9 if k2_s > 0 else 0.0
+        all3 = (timing["k1_ms"] + timing["k2_ms"] + timing["k3_ms"]) * 1e-3
+        line = {
+            "metric": "GGN-matvecs/sec (damped operator calls inside the PCG loop)",
+            "value": world * matvecs / dt,
+            "unit": "matvecs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload} GGN PCG solve: N={n} fp32 parameters, "
+                            f"batch {args.batch}/GPU, {iters_done} PCG iterations/step, "
+                            f"damping {args.damping}, eval-mode BN, CE-mean, x0=0, tol=0",
+                "parallelism": f"dp{world} (batch sharded, one all-reduce of 4N bytes per matvec)",
+                "matvec": getattr(op, "mode", "eager autograd"),
+                "termination": reason,
+            },
+            "cg_iters_per_s": world * args.steps * iters_done / dt,
+            "cg_to_martens": {"iters": len(xs_m) - 1, "reason": reason_m,
+                              "iters_per_s": (len(xs_m) - 1) / dt_m},
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_update_xr (K2)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "alg_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": timing["k2_ms"],
+                "launches_timed": timing["n"],
+                "all_pcg_kernels": {
+                    "k1_ms": timing["k1_ms"], "k2_ms": timing["k2_ms"], "k3_ms": timing["k3_ms"],
+                    "alg_bytes_per_iter": 48.0 * n,
+                    "achieved_GBs": 48.0 * n / all3 / 1e9 if all3 > 0 else 0.0,
+                },
+            },
+        }
+        prof = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(prof):
+            try:
+                line["roofline"]["traffic"] = json.load(open(prof)).get(f"k_update_xr_{n}")
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if group is not None:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -4,3 +4,17 @@ curvature-matvec hot path of ltatzel/PyTorchHessianFree)."""
 from .cg import DampedCurvature, DiagonalPreconditioner, cg, storing_grid  # noqa: F401
 
 __all__ = ["cg", "DampedCurvature", "DiagonalPreconditioner", "storing_grid"]
+from .optimizer import HessianFree  # noqa: F401,E402
+from .preconditioners import (  # noqa: F401,E402
+    diag_EF_autograd,
+    diag_EF_backpack,
+    diag_EF_preconditioner,
+    diag_to_preconditioner,
+)
+from .cg_backtracking import cg_backtracking, cg_efficient_backtracking  # noqa: F401,E402
+from .linesearch import simple_linesearch  # noqa: F401,E402
+from .utils import vector_to_parameter_list, vector_to_trainparams  # noqa: F401,E402
+
+__all__ += ["HessianFree", "diag_EF_autograd", "diag_EF_backpack", "diag_EF_preconditioner",
+            "diag_to_preconditioner", "cg_backtracking", "cg_efficient_backtracking",
+            "simple_linesearch", "vector_to_parameter_list", "vector_to_trainparams"]

@@ -209,13 +209,22 @@ def cg(
         matvec, damping = A.mvp, A.damping
     else:
         matvec, damping = A, 0.0
+    # a hipGraph-captured operator reads its input from a fixed buffer: make that
+    # buffer the search direction p itself (K3 then writes straight into it)
+    p_vec = ws.p
+    ib = getattr(matvec, "input_buffer", None)
+    if (
+        isinstance(ib, torch.Tensor) and ib.shape == b.shape and ib.dtype == dtype
+        and ib.device == device and ib.is_contiguous() and ib.data_ptr() % 16 == 0
+    ):
+        p_vec = ib
 
     def ptr(t):
         return _lib.c_void_p(t.data_ptr()) if t is not None else None
 
     _lib.check(
         lib.hf_pcg_begin(
-            ws.handle, ptr(x), ptr(ws.r), ptr(ws.p), ptr(b), ptr(minv), mode, max_iter,
+            ws.handle, ptr(x), ptr(ws.r), ptr(p_vec), ptr(b), ptr(minv), mode, max_iter,
             float(tol), -1.0 if atol is None else float(atol), 1 if martens_conv_crit else 0,
             ptr(store_dev), len(store), 1 if (store and store[0] == 0) else 0, ptr(slab),
             stride, ptr(m_hist),
@@ -241,7 +250,7 @@ def cg(
     for it in range(1, max_iter + 1):
         if verbose:
             print(f"  cg-iteration {it}")
-        Bp = _as_operand(matvec(ws.p), b, "A(p)")
+        Bp = _as_operand(matvec(p_vec), b, "A(p)")
         if mode == _lib.HF_M_EXTERNAL:
             _lib.check(lib.hf_pcg_curvature(ws.handle, ptr(Bp), damping, stream), "curvature")
             _lib.check(lib.hf_pcg_update_xr(ws.handle, ptr(Bp), damping, stream), "update_xr")

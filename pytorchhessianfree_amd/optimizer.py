@@ -1,0 +1,485 @@
+"""``HessianFree`` -- drop-in for the reference's ``hessianfree/optimizer.py:18-952``
+with the Newton-step solve running on the MI355X.
+
+Public surface preserved: constructor arguments and their validation
+(optimizer.py:23-123), ``step`` (:126-363), ``acc_step`` (:519-606),
+``test_reduction`` (:817-926), ``get_preconditioner`` (:928-952) and the string-
+keyed ``state`` (``x0``, ``init_losses``, ``final_losses``, ``dampings``,
+``cg_reasons``, ``num_cg_iters``, ``best_cg_iters``, ``learning_rates``).
+
+What runs where
+  * the PCG loop: ``pytorchhessianfree_amd.cg.cg`` -> HIP kernels, damping fused
+    (``DampedCurvature``), diagonal preconditioner fused;
+  * curvature products: ``curvature.GGNOperator`` / ``HessianOperator`` (graphs
+    recorded once per step, multi-tensor gather into one HBM vector);
+  * trial parameter writes ``theta = theta0 + alpha*step`` for LM damping,
+    CG-backtracking, line search and the final update: one fused kernel on a
+    persistent flat parameter arena (the reference re-concatenates and re-binds
+    all parameters for each of them, optimizer.py:288-294, :349-350);
+  * host control (LM rule, backtracking order, Armijo rule) is restated 1:1.
+
+Extensions (keyword-only, default = reference behaviour)
+  * ``process_group`` / ``shard_weight``: data parallelism over the batch.  Every
+    rank calls ``step`` with the ``forward`` of ITS shard; loss, gradient and
+    every curvature product are summed over ranks with weight ``shard_weight``
+    (default ``1/world_size``, i.e. equal shards of a mean-reduced loss) -- the
+    single-process accumulation of optimizer.py:677-684 turned into one
+    all-reduce.  All ranks then run the identical PCG on identical data.
+  * ``graph_matvec``: replay the local curvature product as a hipGraph.
+  * ``get_preconditioner`` RETURNS the preconditioner (the reference computes it
+    and drops it, optimizer.py:943-952 -- documented deviation).
+"""
+
+from contextlib import nullcontext
+from warnings import warn
+
+import torch
+
+from . import curvature
+from .cg import DampedCurvature, cg
+from .cg_backtracking import cg_efficient_backtracking
+from .linesearch import simple_linesearch
+from .preconditioners import diag_EF_preconditioner
+from .utils import ParameterArena
+
+
+class HessianFree(torch.optim.Optimizer):
+    def __init__(
+        self,
+        params,
+        curvature_opt="ggn",
+        damping=1.0,
+        adapt_damping=True,
+        cg_max_iter=250,
+        cg_decay_x0=0.95,
+        use_cg_backtracking=True,
+        lr=1.0,
+        use_linesearch=True,
+        verbose=False,
+        *,
+        process_group=None,
+        shard_weight=None,
+        graph_matvec=False,
+    ):
+        if curvature_opt not in ["hessian", "ggn"]:
+            raise ValueError(f"Invalid curvature_opt = {curvature_opt}")
+        if damping < 0.0:
+            raise ValueError(f"Invalid damping = {damping}")
+        self.adapt_damping = adapt_damping
+        if damping == 0.0 and adapt_damping:
+            self.adapt_damping = False
+            warn("The damping is set to `0.0` and won't get adapted.")
+        if cg_max_iter is not None and cg_max_iter < 1:
+            raise ValueError(f"Invalid cg_max_iter: {cg_max_iter}")
+        if lr < 0.0:
+            raise ValueError(f"Invalid learning rate lr = {lr}")
+        self.cg_decay_x0 = cg_decay_x0
+        self.use_cg_backtracking = use_cg_backtracking
+        self.use_linesearch = use_linesearch
+
+        defaults = dict(curvature_opt=curvature_opt, damping=damping, cg_max_iter=cg_max_iter, lr=lr)
+        super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise ValueError("`HessianFree` does not support per-parameter options.")
+
+        self.verbose = verbose
+        self._group = self.param_groups[0]
+        self._params = self._group["params"]
+        self._params_list = [p for p in self._params if p.requires_grad]
+        self.device = self._params_list[0].device
+
+        # data parallelism
+        self.process_group = process_group
+        if process_group is not None:
+            world = torch.distributed.get_world_size(process_group)
+            self.shard_weight = (1.0 / world) if shard_weight is None else float(shard_weight)
+        else:
+            self.shard_weight = 1.0 if shard_weight is None else float(shard_weight)
+        self.graph_matvec = bool(graph_matvec)
+
+        self._acc_comm = process_group  # group `_acc` sums over (None: this process only)
+        self._arena = None
+        self._cg = cg  # the HIP PCG; tests swap in the CPU oracle to check host logic
+
+    # ------------------------------------------------------------------------
+    # helpers
+    # ------------------------------------------------------------------------
+    def _log(self, *a):
+        if self.verbose:
+            print(*a)
+
+    def _reduce_scalar(self, value):
+        """Weighted sum over ranks of a per-shard scalar (float in, float out)."""
+        if self.process_group is None:
+            return value
+        t = torch.tensor([value * self.shard_weight], dtype=torch.float64, device=self.device)
+        torch.distributed.all_reduce(t, group=self.process_group)
+        return float(t.item())
+
+    def _reduce_vector(self, vec):
+        if self.process_group is not None:
+            torch.distributed.all_reduce(vec, group=self.process_group)
+        return vec
+
+    def _flat(self, tensors):
+        """parameters_to_vector replacement (+ shard weight)."""
+        return curvature.flatten_into(tensors, self._params_list, scale=self.shard_weight)
+
+    def _ensure_arena(self):
+        if self._arena is None:
+            self._arena = ParameterArena(self._params)
+        else:
+            self._arena.ensure_bound()
+        return self._arena
+
+    # ------------------------------------------------------------------------
+    # step
+    # ------------------------------------------------------------------------
+    def step(self, forward, grad=None, mvp=None, M_func=None, test_deterministic=False):
+        """One Hessian-free update; arguments as optimizer.py:126-180.  ``forward()``
+        returns ``(loss, outputs)``; ``grad`` / ``mvp`` / ``M_func`` optionally
+        override the gradient vector, the curvature product ``x -> B x`` and the
+        preconditioner ``x -> M^-1 x``.  Returns the final loss (``None`` without
+        line search unless ``verbose``)."""
+        state = self.state
+        state.setdefault("x0", None)
+        for key in ("init_losses", "final_losses", "dampings", "cg_reasons", "num_cg_iters",
+                    "best_cg_iters", "learning_rates"):
+            state.setdefault(key, [])
+
+        if self.verbose:
+            print("\nInformation on parameters...")
+            print("  Total number of parameters: ", sum(p.numel() for p in self._params))
+            print("  Number of trainable parameters: ",
+                  sum(p.numel() for p in self._params if p.requires_grad))
+            print("  Device = ", self.device)
+
+        arena = self._ensure_arena()
+        if test_deterministic:
+            self._test_forward_determinisitc(forward)
+
+        # ---- loss, gradient, curvature operator (optimizer.py:216-247) ---------
+        curvature_opt = self._group["curvature_opt"]
+        user_grad, user_mvp = grad is not None, mvp is not None
+        holder = {}
+
+        def setup():
+            """Forward pass (+ gradient, + curvature operator).  Runs on the capture
+            stream when the matvec is to be replayed as a hipGraph."""
+            with torch.no_grad() if (user_grad and user_mvp) else nullcontext():
+                loss, outputs = forward()
+            holder["loss"] = loss
+            grads = None
+            if not user_grad:
+                grads = torch.autograd.grad(
+                    loss, self._params_list, create_graph=(curvature_opt == "hessian"),
+                    retain_graph=True, allow_unused=True,
+                )
+                holder["grad"] = self._reduce_vector(self._flat(grads))
+            if user_mvp:
+                return None
+            if curvature_opt == "hessian":
+                return curvature.HessianOperator(
+                    loss, self._params_list,
+                    grad_with_graph=None if (grads is None or any(g is None for g in grads)) else grads,
+                    weight=self.shard_weight, group=self.process_group)
+            return curvature.GGNOperator(loss, outputs, self._params_list,
+                                         weight=self.shard_weight, group=self.process_group)
+
+        if self.graph_matvec and not user_mvp and self.device.type == "cuda":
+            mvp = curvature.maybe_graphed(setup)
+        else:
+            op = setup()
+            mvp = mvp if user_mvp else op
+        if not user_grad:
+            grad = holder["grad"]
+        init_loss = self._reduce_scalar(holder["loss"].item())
+        self._log(f"\nInitial loss = {init_loss:.6f}")
+        state["init_losses"].append(init_loss)
+
+        if test_deterministic:
+            self._test_mvp_deterministic(mvp)
+
+        # ---- PCG (optimizer.py:256-281) -------------------------------------
+        damping = self._group["damping"]
+        state["dampings"].append(damping)
+        x_iters, m_iters, cg_reason = self._cg(
+            A=DampedCurvature(mvp, damping),
+            b=-grad,
+            x0=state["x0"],
+            M=M_func,
+            max_iter=self._group["cg_max_iter"],
+            martens_conv_crit=True,
+            store_x_at_iters=None if self.use_cg_backtracking else [0],
+            verbose=self.verbose,
+        )
+        state["cg_reasons"].append(cg_reason)
+        state["num_cg_iters"].append(len(x_iters) - 1)
+        step_vec = x_iters[-1]
+        # warm start of the next solve: decayed FINAL iterate (optimizer.py:281)
+        self._set_x0(self.cg_decay_x0 * x_iters[-1])
+
+        # ---- target function on the flat arena (optimizer.py:288-294) -----------
+        params_vec = arena.snapshot()
+
+        @torch.no_grad()
+        def trial(step, alpha):
+            if alpha == 0.0:
+                arena.theta.copy_(params_vec)
+            else:
+                arena.write(params_vec, step, alpha)
+            return self._reduce_scalar(forward()[0].item())
+
+        def tfunc(step):
+            return trial(step, 1.0)
+
+        tfunc.scaled = trial
+
+        # ---- Levenberg-Marquardt damping (optimizer.py:299-306) ----------------
+        assert x_iters[0] is not None and x_iters[-1] is not None
+        if self.adapt_damping:
+            self._adapt_damping(
+                f_0=tfunc(x_iters[0]), f_step=tfunc(x_iters[-1]),
+                m_0=m_iters[0], m_step=m_iters[-1],
+            )
+
+        # ---- CG-backtracking (optimizer.py:311-318) ----------------------------
+        if self.use_cg_backtracking:
+            best_cg_iter, _ = cg_efficient_backtracking(f=tfunc, steps_list=x_iters,
+                                                        verbose=self.verbose)
+            state["best_cg_iters"].append(best_cg_iter)
+            step_vec = x_iters[best_cg_iter]
+
+        # ---- line search (optimizer.py:323-340) ---------------------------------
+        lr = self._group["lr"]
+        if not self.use_linesearch:
+            self._log(f"\nConstant lr = {lr:.6f}")
+            final_loss = None
+        else:
+            lr, final_loss = simple_linesearch(f=tfunc, f_grad_0=grad, step=step_vec,
+                                               init_alpha=lr, verbose=self.verbose)
+        state["learning_rates"].append(lr)
+
+        # ---- parameter update (optimizer.py:349-350) ----------------------------
+        self._log(f"\nParameter update with lr = {lr:.6f}")
+        with torch.no_grad():
+            if lr == 0.0:
+                arena.theta.copy_(params_vec)
+            else:
+                arena.write(params_vec, step_vec, lr)
+
+        if self.verbose:
+            if final_loss is None:
+                final_loss = self._reduce_scalar(forward()[0].item())
+            state["final_losses"].append(final_loss)
+            print(f"Initial loss = {init_loss:.6f} --> final loss = {final_loss:.6f}")
+        return final_loss
+
+    # ------------------------------------------------------------------------
+    def _test_forward_determinisitc(self, forward):
+        """Two forward passes must agree (optimizer.py:365-412); warns otherwise."""
+        self._log("\nTest deterministic behavior of `forward`...")
+        loss_1, out_1 = forward()
+        loss_2, out_2 = forward()
+        ok = True
+        if out_1 is not None and out_2 is not None:
+            same = torch.allclose(out_1, out_2)
+            self._log("  Test outputs: " + ("passed" if same else "failed"))
+            ok = ok and same
+        same = torch.allclose(loss_1, loss_2)
+        self._log("  Test loss values: " + ("passed" if same else "failed"))
+        ok = ok and same
+        if not ok:
+            msg = "Non-determinisitc behaviour detected. Consider setting your "
+            msg += "model to evaluation mode, i.e. `model.eval()`."
+            warn(msg)
+        else:
+            self._log("  All tests passed")
+
+    def _test_mvp_deterministic(self, mvp):
+        """Two products with the same random vector must agree (optimizer.py:414-448)."""
+        self._log("\nTest deterministic behavior of `mvp`...")
+        x = torch.randn(sum(p.numel() for p in self._params_list),
+                        dtype=self._params_list[0].dtype, device=self._params_list[0].device)
+        x = x.to(self.device)
+        first = mvp(x).clone()
+        second = mvp(x)
+        if not torch.allclose(first, second):
+            self._log("  Test mvps: failed")
+            msg = "Non-determinisitc behaviour detected. Consider setting your "
+            msg += "model to evaluation mode, i.e. `model.eval()`."
+            warn(msg)
+        else:
+            self._log("  Test mvps: passed\n  All tests passed")
+
+    @staticmethod
+    def _Hv(loss, params_list, vec):
+        """``H vec`` on the flat vector (optimizer.py:450-455)."""
+        return curvature.HessianOperator(loss, params_list)(vec)
+
+    @staticmethod
+    def _Gv(loss, outputs, params_list, vec):
+        """``J^T H_L J vec`` on the flat vector (optimizer.py:457-462)."""
+        return curvature.GGNOperator(loss, outputs, params_list)(vec)
+
+    def _adapt_damping(self, f_0, f_step, m_0, m_step):
+        """Levenberg-Marquardt rule (optimizer.py:464-506): ``rho`` = actual over
+        predicted reduction; damping x3/2 if rho < 1/4, x2/3 if rho > 3/4."""
+        rho = (f_step - f_0) / (m_step - m_0)
+        if self.verbose:
+            print("\nLM-heurisitc: Adapt damping...")
+            print(f"  f_0    = {f_0:.6f}\n  f_step = {f_step:.6f}")
+            print(f"  m_0    = {m_0:.6f}\n  m_step = {m_step:.6f}")
+            print(f"  Reduction ratio rho = {rho:.6f}")
+        if rho < 0.25:
+            self._group["damping"] *= 3 / 2
+        elif rho > 0.75:
+            self._group["damping"] *= 2 / 3
+        self._log(f"  Damping is set to {self._group['damping']:.6f}")
+        if rho < 0:
+            msg = "The reduction ratio `rho` is negative. This might result in "
+            msg += "a bad cg-initialization in the next step."
+            warn(msg)
+
+    def _set_x0(self, new_x0):
+        self.state["x0"] = new_x0
+
+    # ------------------------------------------------------------------------
+    # acc_step: loss / gradient / curvature accumulated over lists of mini-batches
+    # ------------------------------------------------------------------------
+    def acc_step(self, model, loss_func, loss_datalist, grad_datalist=None, mvp_datalist=None,
+                 M_func=None, reduction="mean", test_deterministic=False):
+        """optimizer.py:519-606.  With a process group every rank passes ITS data
+        lists; ``mean`` weights are then ``N_chunk / N_total over all ranks``."""
+        grad_datalist = loss_datalist if grad_datalist is None else grad_datalist
+        mvp_datalist = loss_datalist if mvp_datalist is None else mvp_datalist
+        curvature_opt = self._group["curvature_opt"]
+
+        def forward():
+            return self._acc_loss(model, loss_func, loss_datalist, reduction), None
+
+        grad = self._acc_grad(model, loss_func, grad_datalist, reduction)
+
+        def mvp(x):
+            return self._acc_mvp(model, loss_func, mvp_datalist, curvature_opt, reduction, x)
+
+        # `step` must not re-weight what `_acc` already reduced over ranks
+        saved = (self.process_group, self.shard_weight)
+        self.process_group, self.shard_weight = None, 1.0
+        try:
+            return self.step(forward=forward, grad=grad, mvp=mvp, M_func=M_func,
+                             test_deterministic=test_deterministic)
+        finally:
+            self.process_group, self.shard_weight = saved
+
+    def _acc(self, model, loss_func, datalist, device, with_grad, init_result, eval_mb, reduction):
+        """Generic accumulator (optimizer.py:608-684): ``sum_k N_k q_k / sum_k N_k``
+        (``mean``) or ``sum_k q_k`` (``sum``) over the chunks -- and over ranks."""
+        if reduction not in ["mean", "sum"]:
+            raise ValueError(f"Invalid reduction {reduction}")
+        total, count = init_result, 0
+        for inputs, targets in datalist:
+            n_chunk = targets.shape[0]
+            count += n_chunk
+            inputs, targets = inputs.to(device), targets.to(device)
+            with nullcontext() if with_grad else torch.no_grad():
+                outputs = model(inputs)
+                loss = loss_func(outputs, targets)
+            piece = eval_mb(loss, outputs)
+            if reduction == "mean":
+                total += n_chunk * piece
+            else:
+                total += piece
+        if self._acc_comm is not None:  # the same sum, continued over the ranks
+            if not isinstance(total, torch.Tensor):
+                total = torch.tensor(float(total), device=device)
+            torch.distributed.all_reduce(total, group=self._acc_comm)
+            cnt = torch.tensor([float(count)], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(cnt, group=self._acc_comm)
+            count = cnt.item()
+        return total / count if reduction == "mean" else total
+
+    def _acc_loss(self, model, loss_func, datalist, reduction):
+        """optimizer.py:686-723."""
+        return self._acc(model, loss_func, datalist, device=self.device, with_grad=False,
+                         init_result=0.0, eval_mb=lambda loss, outputs: loss.detach(),
+                         reduction=reduction)
+
+    def _zeros_flat(self):
+        ref = self._params_list[0]
+        return torch.zeros(sum(p.numel() for p in self._params_list), dtype=ref.dtype,
+                           device=ref.device)
+
+    def _acc_grad(self, model, loss_func, datalist, reduction):
+        """optimizer.py:725-765."""
+
+        def eval_mb(loss, outputs):
+            g = torch.autograd.grad(loss, self._params_list, allow_unused=True)
+            return curvature.flatten_into(g, self._params_list)
+
+        return self._acc(model, loss_func, datalist, device=self.device, with_grad=True,
+                         init_result=self._zeros_flat(), eval_mb=eval_mb, reduction=reduction)
+
+    def _acc_mvp(self, model, loss_func, datalist, curvature_opt, reduction, x):
+        """optimizer.py:767-814."""
+
+        def eval_mb(loss, outputs):
+            if curvature_opt == "hessian":
+                return curvature.HessianOperator(loss, self._params_list)(x)
+            return curvature.GGNOperator(loss, outputs, self._params_list)(x)
+
+        return self._acc(model, loss_func, datalist, device=self.device, with_grad=True,
+                         init_result=self._zeros_flat(), eval_mb=eval_mb, reduction=reduction)
+
+    # ------------------------------------------------------------------------
+    def test_reduction(self, model, loss_func, datalist, reduction):
+        """Accumulated vs whole-batch loss / gradient / product must agree
+        (``rtol=1e-2, atol=1e-4``), else ``RuntimeError`` (optimizer.py:817-926)."""
+        self._log(f"\nTest reduction {reduction}...")
+        msg = "This test is only meaningful for a data list with at least two entries."
+        assert len(datalist) > 1, msg
+        x = torch.randn(sum(p.numel() for p in self._params_list),
+                        dtype=self._params_list[0].dtype, device=self._params_list[0].device)
+        x = x.to(self.device)
+        curvature_opt = self._group["curvature_opt"]
+        saved, self._acc_comm = self._acc_comm, None  # a local self-test: no communication
+        try:
+            acc_loss = self._acc_loss(model, loss_func, datalist, reduction)
+            acc_grad = self._acc_grad(model, loss_func, datalist, reduction)
+            acc_mvp = self._acc_mvp(model, loss_func, datalist, curvature_opt, reduction, x)
+        finally:
+            self._acc_comm = saved
+
+        ref_inputs = torch.cat([d[0] for d in datalist], dim=0).to(self.device)
+        ref_targets = torch.cat([d[1] for d in datalist], dim=0).to(self.device)
+        ref_outputs = model(ref_inputs)
+        ref_loss = loss_func(ref_outputs, ref_targets)
+        ref_grad = curvature.flatten_into(
+            torch.autograd.grad(ref_loss, self._params_list, create_graph=True, allow_unused=True),
+            self._params_list)
+        if curvature_opt == "ggn":
+            ref_mvp = self._Gv(ref_loss, ref_outputs, self._params_list, x)
+        else:
+            ref_mvp = self._Hv(ref_loss, self._params_list, x)
+
+        passed = True
+        for name, ref, acc in [("loss values", ref_loss, acc_loss), ("gradients", ref_grad, acc_grad),
+                               ("mvps", ref_mvp, acc_mvp)]:
+            acc_t = acc if isinstance(acc, torch.Tensor) else torch.tensor(acc)
+            ok = torch.allclose(acc_t.to(ref.dtype), ref.detach(), rtol=1e-2, atol=1e-4)
+            self._log(f"  Test {name}: " + ("passed" if ok else "failed"))
+            passed = passed and ok
+        if not passed:
+            error_msg = f"Inconsistent results for reduction {reduction}. "
+            error_msg += "This could also be the result of non-deterministic "
+            error_msg += "behavior or simply due to using the GPU."
+            raise RuntimeError(error_msg)
+        self._log("  All tests passed")
+
+    def get_preconditioner(self, model, loss_func, inputs, targets, reduction, exponent=None,
+                           use_backpack=True):
+        """Diagonal empirical-Fisher preconditioner at the CURRENT damping
+        (optimizer.py:928-952).  Unlike the reference, the result is returned."""
+        return diag_EF_preconditioner(model, loss_func, inputs, targets, reduction,
+                                      damping=self._group["damping"], exponent=exponent,
+                                      use_backpack=use_backpack)

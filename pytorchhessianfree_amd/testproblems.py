@@ -1,0 +1,124 @@
+"""Synthetic workloads of the shapes BASELINE.json names (random-init weights,
+random data: there is no network for datasets).  The reference builds these from
+torchvision / DeepOBS (``examples/example_utils.py:59-109``), neither of which
+is installed here, so the topologies are re-declared.
+
+* ``resnet18_mnist``  : torchvision ResNet-18 topology, conv1 1->64 7x7/2 without
+  bias, fc 512->10: 11 175 370 trainable parameters in 62 tensors
+  (example_utils.py:86-109).
+* ``allcnnc_cifar100``: DeepOBS ``cifar100_allcnnc`` topology (dropout is inert in
+  eval mode, which the reference example sets): 1 387 108 parameters
+  (example_utils.py:59-83).
+* ``mwe_mlp`` / ``small_nn``: examples/run_mwe.py:16-20, example_utils.py:23-56.
+"""
+
+import torch
+from torch import nn
+
+
+class _BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=False)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout)
+            )
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + idt)
+
+
+class ResNet18(nn.Module):
+    def __init__(self, in_channels=1, num_classes=10):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=False)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        cfg = [(64, 64, 1), (64, 64, 1), (64, 128, 2), (128, 128, 1),
+               (128, 256, 2), (256, 256, 1), (256, 512, 2), (512, 512, 1)]
+        self.layers = nn.Sequential(*[_BasicBlock(a, b, s) for a, b, s in cfg])
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512, num_classes)
+        for m in self.modules():  # torchvision's init
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.avgpool(self.layers(x))
+        return self.fc(torch.flatten(x, 1))
+
+
+class AllCNNC(nn.Module):
+    def __init__(self, num_classes=100):
+        super().__init__()
+
+        def c(i, o, k, s=1, p=0):
+            return [nn.Conv2d(i, o, k, s, p), nn.ReLU()]
+
+        self.net = nn.Sequential(
+            nn.Dropout(0.2),
+            *c(3, 96, 3, 1, 1), *c(96, 96, 3, 1, 1), *c(96, 96, 3, 2, 1),
+            nn.Dropout(0.5),
+            *c(96, 192, 3, 1, 1), *c(192, 192, 3, 1, 1), *c(192, 192, 3, 2, 1),
+            nn.Dropout(0.5),
+            *c(192, 192, 3, 1, 0), *c(192, 192, 1), *c(192, num_classes, 1),
+            nn.AdaptiveAvgPool2d((1, 1)),
+        )
+
+    def forward(self, x):
+        return torch.flatten(self.net(x), 1)
+
+
+def count_trainable(model):
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+def resnet18_mnist(batch_size=32, seed=0, device="cpu", data_seed=None):
+    """Model in eval mode (BatchNorm then uses running statistics, which makes the
+    curvature a plain sum over samples -- required for batch sharding, SURVEY.md
+    section 7), inputs U[0,1) [B,1,28,28], integer targets, CE-mean."""
+    torch.manual_seed(seed)
+    model = ResNet18(1, 10).eval()
+    g = torch.Generator().manual_seed(seed if data_seed is None else data_seed)
+    inputs = torch.rand(batch_size, 1, 28, 28, generator=g)
+    targets = torch.randint(0, 10, (batch_size,), generator=g)
+    return model.to(device), (inputs.to(device), targets.to(device)), nn.CrossEntropyLoss()
+
+
+def allcnnc_cifar100(batch_size=32, seed=0, device="cpu", data_seed=None):
+    torch.manual_seed(seed)
+    model = AllCNNC(100).eval()
+    g = torch.Generator().manual_seed(seed if data_seed is None else data_seed)
+    inputs = torch.rand(batch_size, 3, 32, 32, generator=g)
+    targets = torch.randint(0, 100, (batch_size,), generator=g)
+    return model.to(device), (inputs.to(device), targets.to(device)), nn.CrossEntropyLoss()
+
+
+def mwe_mlp(batch_size=16, dim=10, seed=0, device="cpu"):
+    torch.manual_seed(seed)
+    model = nn.Sequential(nn.Linear(dim, dim, bias=False), nn.ReLU(), nn.Linear(dim, dim))
+    inputs, targets = torch.rand(batch_size, dim), torch.rand(batch_size, dim)
+    return model.to(device), (inputs.to(device), targets.to(device)), nn.MSELoss()
+
+
+def small_nn(batch_size=32, seed=0, device="cpu", freeze_layer1=True):
+    torch.manual_seed(seed)
+    model = nn.Sequential(
+        nn.Linear(7, 5), nn.ReLU(), nn.Sequential(nn.Linear(5, 5), nn.ReLU()), nn.Linear(5, 3)
+    )
+    if freeze_layer1:
+        for p in next(model.children()).parameters():
+            p.requires_grad = False
+    inputs, targets = torch.rand(batch_size, 7), torch.rand(batch_size, 3)
+    return model.to(device), (inputs.to(device), targets.to(device)), nn.MSELoss()

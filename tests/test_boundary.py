@@ -1,0 +1,78 @@
+"""CPU: the C-ABI library loads, exports every symbol ``include/hf_pcg.h`` declares,
+and the product never imports the oracle or falls back to the CPU."""
+
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "hf_pcg.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pytorchhessianfree_amd import _lib
+
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), name
+        assert name in _lib.SIGNATURES, f"{name} is declared but not bound in _lib.py"
+    assert lib.hf_abi_version() == 1
+    assert lib.hf_error_string(-2).decode().startswith("hf:")
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    from pytorchhessianfree_amd import _lib
+
+    lib = _lib.load()
+    assert lib.hf_pcg_create(None, 10, 0, 0) == -1
+    assert lib.hf_pcg_iterate(None, None, 0.0, None) == -1
+    assert lib.hf_pack(None, None, None, 0, 1.0, 0, 0, None) == -1
+    assert lib.hf_allreduce_sum(None, None, 1, 0, None) == -1
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "pytorchhessianfree_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    # bench.py may import the oracle only inside cpu_baseline()
+    body = bench.split("def cpu_baseline")[1].split("\ndef ")[0]
+    assert bench.count("from oracle") == body.count("from oracle") > 0
+
+
+def test_cpu_tensors_are_refused_loudly():
+    import pytorchhessianfree_amd as hf
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hf.cg(lambda v: v, torch.ones(8))
+    model = torch.nn.Linear(3, 2)
+    opt = hf.HessianFree(model.parameters())
+    x, t = torch.rand(4, 3), torch.rand(4, 2)
+
+    def forward():
+        out = model(x)
+        return torch.nn.functional.mse_loss(out, t), out
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        opt.step(forward)
+
+
+def test_missing_library_is_an_error(monkeypatch):
+    from pytorchhessianfree_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libhfpcg.so")
+    with pytest.raises(RuntimeError, match="REQUIRED"):
+        _lib.load()

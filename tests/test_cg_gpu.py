@@ -164,8 +164,11 @@ def test_damped_lowrank_matches_reference_golden(key, fused):
     to 2e-1 after ~13 iterations and stops up to 15 iterations later.  Stated
     tolerance: early iterates (k <= 4) within 1e-4 of the reference; every stored
     iterate no farther from the float64 trajectory than 2x the reference's own
-    fp32 distance (+1e-5); the same for m_k (+1e-6 |m|); same reason; iteration
-    count within the reference's own fp32-vs-fp64 spread."""
+    fp32 distance (+1e-5), where the reference's distance is taken as its running
+    maximum up to the next snapshot (the separation is exponential once it starts,
+    so its onset may shift by an iteration or two); the same for m_k (+1e-6 |m|,
+    window 3 iterations); same reason; iteration count within the reference's own
+    fp32-vs-fp64 spread."""
     g = load_golden("cg_lowrank.npz")
     product = _product()
     A, B, damping = lowrank_operator(g, key, DEV)
@@ -190,17 +193,23 @@ def test_damped_lowrank_matches_reference_golden(key, fused):
     grid = product.storing_grid(250)
     for i in range(n_gpu):
         assert (gx[i] is not None) == (i in grid), i
-    for i in range(min(n_gpu, n_ref, n_64) + 1):
-        if gx[i] is None or np.isnan(X[i]).any() or np.isnan(X64[i]).any():
-            continue
+    last = min(n_gpu, n_ref, n_64)
+    common = [i for i in range(last + 1)
+              if gx[i] is not None and not np.isnan(X[i]).any() and not np.isnan(X64[i]).any()]
+    e_ref = {i: _relnorm(X[i].astype(np.float64), X64[i]) for i in common}
+    for pos, i in enumerate(common):
         xg = gx[i].cpu().numpy().astype(np.float64)
-        e_gpu, e_ref = _relnorm(xg, X64[i]), _relnorm(X[i].astype(np.float64), X64[i])
-        assert e_gpu <= 2.0 * e_ref + 1e-5, (key, i, e_gpu, e_ref)
+        e_gpu = _relnorm(xg, X64[i])
+        # the onset of the fp32/fp64 separation may come one snapshot earlier
+        window = max(e_ref[j] for j in common[: pos + 2])
+        assert e_gpu <= 2.0 * window + 1e-5, (key, i, e_gpu, window)
         if i <= 4:
             assert _relnorm(xg, X[i].astype(np.float64)) < 1e-4, (key, i)
-    for i in range(min(n_gpu, n_ref, n_64) + 1):
-        dm_gpu, dm_ref = abs(float(gm[i]) - m64[i]), abs(float(m_ref[i]) - m64[i])
-        assert dm_gpu <= 2.0 * dm_ref + 1e-6 * abs(m64[i]) + 1e-7, (key, i, dm_gpu, dm_ref)
+    dm_ref = np.abs(m_ref[: last + 1].astype(np.float64) - m64[: last + 1])
+    for i in range(last + 1):
+        dm_gpu = abs(float(gm[i]) - m64[i])
+        window = dm_ref[: min(i + 4, last + 1)].max()  # same: up to 3 iterations earlier
+        assert dm_gpu <= 2.0 * window + 1e-6 * abs(m64[i]) + 1e-7, (key, i, dm_gpu, window)
 
 
 @pytest.mark.parametrize("key", _lowrank_keys())

@@ -1,0 +1,310 @@
+"""CPU: the host layer (``HessianFree.step`` / ``acc_step`` orchestration, LM
+damping, CG-backtracking, line search, curvature operators, preconditioner
+recipe) against traces of the REAL reference (tests/golden/*.npz).
+
+The PCG loop itself has no CPU implementation in the product; these tests plug
+the CPU oracle into the optimizer's ``_cg`` hook so that everything AROUND the
+kernels is checked here, and the same traces are replayed through the HIP
+kernels in ``tests/test_optimizer_gpu.py``."""
+
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import pytorchhessianfree_amd as hf
+from conftest import load_golden
+from helpers import T, mwe_nn, small_nn, trainable_vec
+from oracle import pcg as oracle
+from pytorchhessianfree_amd import curvature
+
+
+@pytest.fixture(autouse=True)
+def _one_thread():
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    yield
+    torch.set_num_threads(n)
+
+
+def make_opt(params, **kw):
+    opt = hf.HessianFree(params, **kw)
+    opt._cg = oracle.pcg  # CPU oracle in place of the HIP kernels (tests only)
+    return opt
+
+
+def check_state(opt, g, prefix, n_steps):
+    st = opt.state
+    np.testing.assert_allclose(st["init_losses"], g[prefix + "init_losses"][:n_steps], rtol=1e-6)
+    np.testing.assert_allclose(st["dampings"], g[prefix + "dampings"][:n_steps], rtol=1e-12)
+    assert list(st["cg_reasons"]) == [str(s) for s in g[prefix + "cg_reasons"][:n_steps]]
+    assert list(st["num_cg_iters"]) == g[prefix + "num_cg_iters"][:n_steps].tolist()
+    assert [int(i) for i in st["best_cg_iters"]] == g[prefix + "best_cg_iters"][:n_steps].tolist()
+    np.testing.assert_allclose(st["learning_rates"], g[prefix + "learning_rates"][:n_steps], rtol=1e-12)
+
+
+def test_step_trace_run_mwe():
+    """examples/run_mwe.py: 5 default steps on the 10-10-10 MLP."""
+    g = load_golden("step_mwe.npz")
+    model = mwe_nn(g)
+    lossf = torch.nn.MSELoss()
+    opt = make_opt(model.parameters())
+    for s in range(5):
+        inputs, targets = T(g[f"inputs/{s}"]), T(g[f"targets/{s}"])
+
+        def forward():
+            out = model(inputs)
+            return lossf(out, targets), out
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            final = opt.step(forward=forward)
+        np.testing.assert_allclose(trainable_vec(model).numpy(), g[f"params/{s}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(opt.state["x0"].numpy(), g[f"x0/{s}"], rtol=1e-5, atol=1e-7)
+        assert abs(final - g["final_losses"][s]) < 1e-6
+    check_state(opt, g, "state/", 5)
+
+
+@pytest.mark.parametrize("curv", ["ggn", "hessian"])
+@pytest.mark.parametrize("seed", [0, 1, 42])
+def test_step_trace_small_nn(curv, seed):
+    """tests/test_optimizer.py:31-90 (frozen first layer)."""
+    g = load_golden("step_smallnn.npz")
+    key = f"{curv}_s{seed}"
+    model = small_nn(g, key)
+    lossf = torch.nn.MSELoss()
+    opt = make_opt(model.parameters(), curvature_opt=curv, damping=float(g[key + "/damping"]))
+    for s in range(3):
+        inputs, targets = T(g[f"{key}/inputs/{s}"]), T(g[f"{key}/targets/{s}"])
+
+        def forward():
+            out = model(inputs)
+            return lossf(out, targets), out
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            opt.step(forward)
+        np.testing.assert_allclose(trainable_vec(model).numpy(), g[f"{key}/params/{s}"],
+                                   rtol=1e-4, atol=1e-6)
+    check_state(opt, g, key + "/state/", 3)
+
+
+@pytest.mark.parametrize("curv", ["ggn", "hessian"])
+def test_step_trace_preconditioned(curv):
+    g = load_golden("step_precond.npz")
+    key = curv
+    model = small_nn(g, key)
+    lossf = torch.nn.MSELoss()
+    opt = make_opt(model.parameters(), curvature_opt=curv, damping=float(g[key + "/damping"]))
+    for s in range(3):
+        inputs, targets = T(g[f"{key}/inputs/{s}"]), T(g[f"{key}/targets/{s}"])
+
+        def forward():
+            out = model(inputs)
+            return lossf(out, targets), out
+
+        M = opt.get_preconditioner(model, lossf, inputs, targets, "mean", use_backpack=(s % 2 == 0))
+        assert M is not None  # documented deviation: the reference returns None here
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            opt.step(forward, M_func=M)
+        np.testing.assert_allclose(trainable_vec(model).numpy(), g[f"{key}/params/{s}"],
+                                   rtol=1e-4, atol=1e-6)
+    check_state(opt, g, key + "/state/", 3)
+
+
+@pytest.mark.parametrize("curv", ["ggn", "hessian"])
+@pytest.mark.parametrize("reduction", ["mean", "sum"])
+def test_acc_step_trace(curv, reduction):
+    """tests/test_optimizer_acc.py:116-175: step on the whole batch == acc_step on
+    [7, 8] chunks, both == the reference's parameters."""
+    g = load_golden("acc_step.npz")
+    key = f"{curv}_{reduction}"
+    m1, m2 = small_nn(g, key), small_nn(g, key)
+    lossf = torch.nn.MSELoss(reduction=reduction)
+    o1 = make_opt(m1.parameters(), curvature_opt=curv, cg_max_iter=4)
+    o2 = make_opt(m2.parameters(), curvature_opt=curv, cg_max_iter=4)
+    for s in range(3):
+        datalist = [(T(g[f"{key}/inputs/{s}/{c}"]), T(g[f"{key}/targets/{s}/{c}"])) for c in (0, 1)]
+        inputs = torch.cat([d[0] for d in datalist])
+        targets = torch.cat([d[1] for d in datalist])
+
+        def forward():
+            out = m1(inputs)
+            return lossf(out, targets), out
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            o1.step(forward=forward)
+            o2.acc_step(m2, lossf, datalist, reduction=reduction)
+        np.testing.assert_allclose(trainable_vec(m1).numpy(), g[f"{key}/params_step/{s}"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(trainable_vec(m2).numpy(), g[f"{key}/params_acc/{s}"], rtol=1e-4, atol=1e-6)
+        assert torch.allclose(trainable_vec(m1), trainable_vec(m2), atol=1e-4)  # test_optimizer_acc.py:40-57
+    check_state(o1, g, key + "/state_step/", 3)
+    check_state(o2, g, key + "/state_acc/", 3)
+
+
+@pytest.mark.parametrize("reduction", ["mean", "sum"])
+@pytest.mark.parametrize("curv", ["ggn", "hessian"])
+def test_test_reduction(curv, reduction):
+    """tests/test_optimizer_acc.py:77-109."""
+    g = load_golden("acc_step.npz")
+    model = small_nn(g, f"{curv}_{reduction}")
+    lossf = torch.nn.MSELoss(reduction=reduction)
+    gen = torch.Generator().manual_seed(1)
+    datalist = [(torch.rand(n, 7, generator=gen), torch.rand(n, 3, generator=gen)) for n in (4, 3, 7)]
+    opt = make_opt(model.parameters(), curvature_opt=curv)
+    opt.test_reduction(model, lossf, datalist, reduction)
+    with pytest.raises(RuntimeError):
+        opt.test_reduction(model, lossf, datalist, "mean" if reduction == "sum" else "sum")
+
+
+def test_quadratic_is_solved_in_one_newton_step():
+    """tests/test_optimizer.py:97-155."""
+    g = load_golden("quadratic.npz")
+    for key in [str(k) for k in g["index"]]:
+        A, b, c = T(g[key + "/A"]), T(g[key + "/b"]), T(g[key + "/c"])
+        params = T(g[key + "/init"]).clone().requires_grad_(True)
+
+        def forward():
+            return 0.5 * params.T @ A @ params + params.T @ b + c, None
+
+        opt = make_opt([params], curvature_opt="hessian", lr=1.0, use_linesearch=False, damping=0.0,
+                       adapt_damping=False, use_cg_backtracking=False)
+        opt.step(forward=forward)
+        assert torch.allclose(params.detach(), torch.linalg.solve(A, -b), atol=1e-3)
+        np.testing.assert_allclose(params.detach().numpy(), g[key + "/after"], rtol=1e-4, atol=1e-5)
+        assert opt.state["num_cg_iters"] == g[key + "/num_cg_iters"].tolist()
+        assert opt.state["cg_reasons"][0] == str(g[key + "/cg_reason"])
+
+
+def test_constructor_validation():
+    p = [torch.nn.Parameter(torch.zeros(3))]
+    for bad in (dict(curvature_opt="fisher"), dict(damping=-1.0), dict(cg_max_iter=0), dict(lr=-0.1)):
+        with pytest.raises(ValueError):
+            hf.HessianFree(p, **bad)
+    with pytest.raises(ValueError):
+        hf.HessianFree([{"params": p}, {"params": [torch.nn.Parameter(torch.zeros(2))]}])
+    with pytest.warns(UserWarning, match="won't get adapted"):
+        opt = hf.HessianFree(p, damping=0.0)
+    assert opt.adapt_damping is False
+    assert opt.defaults == dict(curvature_opt="ggn", damping=0.0, cg_max_iter=250, lr=1.0)
+
+
+# ---- curvature products ---------------------------------------------------------
+def test_curvature_products_match_reference_and_explicit_matrices():
+    """``Gv``/``Hv`` against the reference's vectors AND against explicitly
+    materialised ``J^T H_L J`` / Hessian (the reference has no independent check
+    of its GGN product)."""
+    g = load_golden("curvature.npz")
+    for key in [str(k) for k in g["index"]]:
+        model = small_nn(g, key)
+        lossf = torch.nn.MSELoss(reduction=key.split("_")[-1])
+        inputs, targets, v = T(g[key + "/inputs"]), T(g[key + "/targets"]), T(g[key + "/v"])
+        params = [p for p in model.parameters() if p.requires_grad]
+        out = model(inputs)
+        loss = lossf(out, targets)
+        Gv = hf.HessianFree._Gv(loss, out, params, v)
+        Hv = hf.HessianFree._Hv(loss, params, v)
+        np.testing.assert_allclose(Gv.numpy(), g[key + "/Gv"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(Hv.numpy(), g[key + "/Hv"], rtol=1e-5, atol=1e-6)
+        grads = torch.autograd.grad(loss, params, retain_graph=True)
+        np.testing.assert_allclose(curvature.flatten_into(grads, params).numpy(), g[key + "/grad"],
+                                   rtol=1e-6, atol=1e-7)
+
+        # explicit J (outputs x params), H_L (outputs x outputs), Hessian (params x params)
+        n, m = v.numel(), out.numel()
+        J = torch.zeros(m, n, dtype=torch.float64)
+        for i in range(m):
+            gi = torch.autograd.grad(out.reshape(-1)[i], params, retain_graph=True)
+            J[i] = torch.cat([a.reshape(-1) for a in gi]).double()
+        o = out.detach().clone().requires_grad_(True)
+        lo = lossf(o, targets)
+        (dl,) = torch.autograd.grad(lo, o, create_graph=True)
+        HL = torch.stack([torch.autograd.grad(dl.reshape(-1)[i], o, retain_graph=True)[0].reshape(-1)
+                          for i in range(m)]).double()
+        np.testing.assert_allclose(Gv.numpy(), (J.T @ (HL @ (J @ v.double()))).numpy(), rtol=1e-4, atol=1e-6)
+        gflat = torch.cat([a.reshape(-1) for a in torch.autograd.grad(loss, params, create_graph=True)])
+        H = torch.stack([torch.cat([a.reshape(-1) for a in
+                                    torch.autograd.grad(gflat[i], params, retain_graph=True)])
+                         for i in range(n)]).double()
+        np.testing.assert_allclose(Hv.numpy(), (H @ v.double()).numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_diag_empirical_fisher_and_recipe():
+    """tests/test_preconditioners.py:54-127."""
+    g = load_golden("curvature.npz")
+    for key in [str(k) for k in g["index"]]:
+        model = small_nn(g, key)
+        red = key.split("_")[-1]
+        lossf = torch.nn.MSELoss(reduction=red)
+        inputs, targets, v = T(g[key + "/inputs"]), T(g[key + "/targets"]), T(g[key + "/v"])
+        for n in (1, 16):
+            ref = g[f"{key}/diagEF_n{n}"]
+            d_ag = hf.diag_EF_autograd(model, lossf, inputs[:n], targets[:n], red)
+            d_bp = hf.diag_EF_backpack(model, lossf, inputs[:n], targets[:n], red)
+            np.testing.assert_allclose(d_ag.numpy(), ref, rtol=1e-5, atol=1e-8)
+            np.testing.assert_allclose(d_bp.numpy(), ref, rtol=1e-5, atol=1e-8)
+        M = hf.diag_to_preconditioner(T(g[f"{key}/diagEF_n16"]), 0.1, 0.75)
+        np.testing.assert_allclose(M(v).numpy(), g[key + "/Minv_v"], rtol=1e-6)
+    torch.manual_seed(0)
+    d = torch.rand(10)
+    P = torch.diag((d + 0.1) ** 0.75)
+    M = hf.diag_to_preconditioner(d, 0.1, 0.75)
+    for _ in range(5):
+        vec = torch.rand(10)
+        assert torch.allclose(P @ M(vec), vec)
+    with pytest.raises(ValueError):
+        hf.diag_EF_autograd(None, None, None, None, "max")
+
+
+# ---- back-tracking / line search / utils -----------------------------------------
+def test_backtracking_toy():
+    """tests/test_cg_backtracking.py:8-44."""
+    g = load_golden("tables.npz")
+    steps = [2.0, 1.0, None, 2.7, 2.4, None, None, 7.3]
+    bi, bf = hf.cg_backtracking(lambda s: s + 10, steps)
+    ei, ef = hf.cg_efficient_backtracking(lambda s: s + 10, steps)
+    assert int(bi) == 1 == int(g["bt/exhaustive"][0]) and bf == g["bt/exhaustive"][1]
+    assert int(ei) == 4 == int(g["bt/efficient"][0]) and ef == g["bt/efficient"][1]
+
+
+def test_linesearch_table():
+    g = load_golden("tables.npz")
+
+    def f(step):
+        return float(((1.0 + step) ** 4).sum())
+
+    for g0, st, a0, a_ref, f_ref in g["ls/rows"]:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            a, fa = hf.simple_linesearch(f, torch.tensor([g0], dtype=torch.float32),
+                                         torch.tensor([st], dtype=torch.float32), init_alpha=a0)
+        assert a == pytest.approx(a_ref, rel=1e-12) and fa == pytest.approx(f_ref, rel=1e-6)
+    with pytest.raises(ValueError):
+        hf.simple_linesearch(f, torch.ones(1), torch.ones(1), beta=1.0)
+    with pytest.warns(UserWarning, match="not a descent"):
+        hf.simple_linesearch(f, torch.tensor([4.0]), torch.tensor([1.0]))
+
+
+def test_vector_utils():
+    """hessianfree/utils.py:8-76: frozen parameters are skipped, leftovers warn,
+    non-tensors raise."""
+    lin1, lin2 = torch.nn.Linear(2, 2), torch.nn.Linear(2, 1)
+    for p in lin1.parameters():
+        p.requires_grad = False
+    params = list(lin1.parameters()) + list(lin2.parameters())
+    vec = torch.arange(3.0)
+    hf.vector_to_trainparams(vec, params)
+    assert torch.equal(lin2.weight.data.reshape(-1), vec[:2]) and lin2.bias.data_ptr() == vec[2:].data_ptr()
+    with pytest.warns(UserWarning, match="Not all entries"):
+        hf.vector_to_trainparams(torch.arange(5.0), params)
+    views = hf.vector_to_parameter_list(torch.arange(3.0), list(lin2.parameters()))
+    assert [tuple(v.shape) for v in views] == [(1, 2), (1,)]
+    with pytest.warns(UserWarning, match="Not all entries"):
+        hf.vector_to_parameter_list(torch.arange(4.0), list(lin2.parameters()))
+    with pytest.raises(TypeError):
+        hf.vector_to_parameter_list([1.0, 2.0], params)
+    with pytest.raises(TypeError):
+        hf.vector_to_trainparams([1.0], params)
