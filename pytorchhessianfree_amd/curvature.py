@@ -160,13 +160,33 @@ class GraphedOperator:
     ``builder()`` must run the forward pass and return the eager operator; it is
     executed on the capture stream because autograd issues backward kernels on
     the stream their forward ran on.
+
+    Precondition (PyTorch-ROCm 2.10 / HIP 7.0 crash the process otherwise, measured
+    in scratch/graph_repro*.py): while capturing, no autograd state that ties the
+    parameters to ANOTHER stream may be alive -- i.e. no ``.grad`` on them (stashed
+    and restored here when ``params`` is given) and no live autograd graph built
+    on another stream that reaches them (their ``AccumulateGrad`` nodes remember
+    that stream and the engine then touches it during capture).
     """
 
     mode = "hipGraph replay of autograd sweeps + hf_pack"
 
-    def __init__(self, builder, warmup=3):
+    def __init__(self, builder, warmup=3, params=None):
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedOperator needs a GPU")
+        import gc
+
+        stash = [(p, p.grad) for p in (params or []) if p.grad is not None]
+        for p, _ in stash:
+            p.grad = None
+        gc.collect()  # let dead graphs (and their AccumulateGrad nodes) go
+        try:
+            self._capture(builder, warmup)
+        finally:
+            for p, g in stash:
+                p.grad = g
+
+    def _capture(self, builder, warmup):
         cur = torch.cuda.current_stream()
         self.stream = torch.cuda.Stream()
         self.stream.wait_stream(cur)
@@ -201,12 +221,12 @@ class GraphedOperator:
         return _all_reduce_sum(self.local(v, out), self.group)
 
 
-def maybe_graphed(builder, enable=True):
+def maybe_graphed(builder, enable=True, params=None):
     """``GraphedOperator(builder)`` if capture works on this stack, else the eager
     operator (still HIP: only the launch mechanism differs)."""
     if enable and torch.cuda.is_available():
         try:
-            return GraphedOperator(builder)
+            return GraphedOperator(builder, params=params)
         except Exception as exc:  # capture not supported for some op on this stack
             import warnings
 

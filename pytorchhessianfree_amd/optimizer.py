@@ -187,7 +187,7 @@ class HessianFree(torch.optim.Optimizer):
                                          weight=self.shard_weight, group=self.process_group)
 
         if self.graph_matvec and not user_mvp and self.device.type == "cuda":
-            mvp = curvature.maybe_graphed(setup)
+            mvp = curvature.maybe_graphed(setup, params=self._params_list)
         else:
             op = setup()
             mvp = mvp if user_mvp else op

@@ -1,0 +1,299 @@
+"""GPU: the reference's ``step`` / ``acc_step`` traces (tests/golden, produced by
+the REAL reference on CPU) replayed through the full HIP path: curvature
+operators on PyTorch-ROCm, ``hf_pack``, the PCG kernels, the fused parameter
+writes.
+
+Stated fp32 tolerance: discrete trace entries (termination reason, number of CG
+iterations, learning rate, damping schedule) identical, back-tracked iterate
+identical or the adjacent snapshot (loss ties at ~1e-7);
+initial/final losses ``rtol 1e-5``; parameters after every step ``rtol 2e-4``
+(``atol 2e-6``); warm-start vector ``x0`` ``rtol 1e-3`` of its max-norm."""
+
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import pytorchhessianfree_amd as hf
+from conftest import load_golden
+from helpers import T, mwe_nn, small_nn, trainable_vec
+from pytorchhessianfree_amd import _lib, curvature
+from pytorchhessianfree_amd import testproblems as tp
+from pytorchhessianfree_amd.utils import ParameterArena
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def check_state(opt, g, prefix, n_steps):
+    st = opt.state
+    np.testing.assert_allclose(st["init_losses"], g[prefix + "init_losses"][:n_steps], rtol=1e-5)
+    np.testing.assert_allclose(st["dampings"], g[prefix + "dampings"][:n_steps], rtol=1e-12)
+    assert list(st["cg_reasons"]) == [str(s) for s in g[prefix + "cg_reasons"][:n_steps]]
+    assert list(st["num_cg_iters"]) == g[prefix + "num_cg_iters"][:n_steps].tolist()
+    # the back-tracked iterate is an argmin over losses of neighbouring snapshots that,
+    # close to CG convergence, agree to ~1e-7 relative: a tie there may fall on the
+    # adjacent snapshot (the parameters are compared separately and must still agree)
+    grid = hf.storing_grid(250)
+    for mine, ref, n_it in zip(st["best_cg_iters"], g[prefix + "best_cg_iters"][:n_steps],
+                               st["num_cg_iters"]):
+        cand = sorted(set([i for i in grid if i <= n_it] + [n_it]))
+        assert abs(cand.index(int(mine)) - cand.index(int(ref))) <= 1, (mine, ref)
+    np.testing.assert_allclose(st["learning_rates"], g[prefix + "learning_rates"][:n_steps], rtol=1e-12)
+
+
+def close(a, ref, rtol=2e-4, atol=2e-6, opt=None, g=None, prefix=None):
+    """Parameters after a step.  If the back-tracking tie (see check_state) fell on
+    the adjacent snapshot, the update differs by the distance between two nearly
+    converged CG iterates: 5e-4 of the parameter scale is allowed then."""
+    if opt is not None and opt.state["best_cg_iters"]:
+        s = len(opt.state["best_cg_iters"]) - 1
+        if int(opt.state["best_cg_iters"][s]) != int(g[prefix + "best_cg_iters"][s]):
+            atol = 5e-4 * float(np.abs(ref).max())
+    np.testing.assert_allclose(a.detach().cpu().numpy(), ref, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_step_trace_run_mwe(graph):
+    g = load_golden("step_mwe.npz")
+    model = mwe_nn(g, DEV)
+    lossf = torch.nn.MSELoss()
+    opt = hf.HessianFree(model.parameters(), graph_matvec=graph)
+    for s in range(5):
+        inputs, targets = T(g[f"inputs/{s}"], DEV), T(g[f"targets/{s}"], DEV)
+
+        def forward():
+            out = model(inputs)
+            return lossf(out, targets), out
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            final = opt.step(forward=forward)
+        close(trainable_vec(model), g[f"params/{s}"], opt=opt, g=g, prefix="state/")
+        x0_ref = g[f"x0/{s}"]
+        assert np.abs(opt.state["x0"].cpu().numpy() - x0_ref).max() <= 1e-3 * np.abs(x0_ref).max()
+        assert abs(final - g["final_losses"][s]) < 1e-5 * max(1.0, abs(g["final_losses"][s]))
+    check_state(opt, g, "state/", 5)
+
+
+@pytest.mark.parametrize("curv", ["ggn", "hessian"])
+@pytest.mark.parametrize("seed", [0, 1, 42])
+def test_step_trace_small_nn(curv, seed):
+    g = load_golden("step_smallnn.npz")
+    key = f"{curv}_s{seed}"
+    model = small_nn(g, key, DEV)
+    lossf = torch.nn.MSELoss()
+    opt = hf.HessianFree(model.parameters(), curvature_opt=curv, damping=float(g[key + "/damping"]))
+    for s in range(3):
+        inputs, targets = T(g[f"{key}/inputs/{s}"], DEV), T(g[f"{key}/targets/{s}"], DEV)
+
+        def forward():
+            out = model(inputs)
+            return lossf(out, targets), out
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            opt.step(forward, test_deterministic=(s == 0))
+        close(trainable_vec(model), g[f"{key}/params/{s}"], opt=opt, g=g, prefix=key + "/state/")
+    check_state(opt, g, key + "/state/", 3)
+
+
+@pytest.mark.parametrize("curv", ["ggn", "hessian"])
+def test_step_trace_preconditioned(curv):
+    """Fused diagonal preconditioner path (HF_M_DIAG) inside a full step."""
+    g = load_golden("step_precond.npz")
+    key = curv
+    model = small_nn(g, key, DEV)
+    lossf = torch.nn.MSELoss()
+    opt = hf.HessianFree(model.parameters(), curvature_opt=curv, damping=float(g[key + "/damping"]))
+    for s in range(3):
+        inputs, targets = T(g[f"{key}/inputs/{s}"], DEV), T(g[f"{key}/targets/{s}"], DEV)
+
+        def forward():
+            out = model(inputs)
+            return lossf(out, targets), out
+
+        M = opt.get_preconditioner(model, lossf, inputs, targets, "mean", use_backpack=(s % 2 == 0))
+        assert isinstance(M, hf.DiagonalPreconditioner)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            opt.step(forward, M_func=M)
+        close(trainable_vec(model), g[f"{key}/params/{s}"], opt=opt, g=g, prefix=key + "/state/")
+    check_state(opt, g, key + "/state/", 3)
+
+
+@pytest.mark.parametrize("curv", ["ggn", "hessian"])
+@pytest.mark.parametrize("reduction", ["mean", "sum"])
+def test_acc_step_trace(curv, reduction):
+    g = load_golden("acc_step.npz")
+    key = f"{curv}_{reduction}"
+    m1, m2 = small_nn(g, key, DEV), small_nn(g, key, DEV)
+    lossf = torch.nn.MSELoss(reduction=reduction)
+    o1 = hf.HessianFree(m1.parameters(), curvature_opt=curv, cg_max_iter=4)
+    o2 = hf.HessianFree(m2.parameters(), curvature_opt=curv, cg_max_iter=4)
+    for s in range(3):
+        # data lists stay on the host: _acc moves every chunk (optimizer.py:661)
+        datalist = [(T(g[f"{key}/inputs/{s}/{c}"]), T(g[f"{key}/targets/{s}/{c}"])) for c in (0, 1)]
+        inputs = torch.cat([d[0] for d in datalist]).to(DEV)
+        targets = torch.cat([d[1] for d in datalist]).to(DEV)
+
+        def forward():
+            out = m1(inputs)
+            return lossf(out, targets), out
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            o1.step(forward=forward)
+            o2.acc_step(m2, lossf, datalist, reduction=reduction)
+        close(trainable_vec(m1), g[f"{key}/params_step/{s}"], opt=o1, g=g, prefix=key + "/state_step/")
+        close(trainable_vec(m2), g[f"{key}/params_acc/{s}"], opt=o2, g=g, prefix=key + "/state_acc/")
+    check_state(o1, g, key + "/state_step/", 3)
+    check_state(o2, g, key + "/state_acc/", 3)
+    o2.test_reduction(m2, lossf, datalist, reduction)
+
+
+def test_quadratic_is_solved_in_one_newton_step():
+    g = load_golden("quadratic.npz")
+    for key in [str(k) for k in g["index"]]:
+        A, b, c = T(g[key + "/A"], DEV), T(g[key + "/b"], DEV), T(g[key + "/c"], DEV)
+        params = T(g[key + "/init"], DEV).clone().requires_grad_(True)
+
+        def forward():
+            return 0.5 * params.T @ A @ params + params.T @ b + c, None
+
+        opt = hf.HessianFree([params], curvature_opt="hessian", lr=1.0, use_linesearch=False,
+                             damping=0.0, adapt_damping=False, use_cg_backtracking=False)
+        opt.step(forward=forward)
+        assert torch.allclose(params.detach(), torch.linalg.solve(A, -b), atol=1e-3)
+
+
+# ---- the helper kernels -------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_pack_gathers_like_cat(dtype):
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    shapes = [(64, 1, 7, 7), (64,), (3,), (128, 64, 3, 3), (10, 512), (10,), (1,), (4097,)]
+    ts = [torch.randn(s, device=DEV, dtype=dtype, generator=gen) for s in shapes]
+    ts[3] = ts[3].transpose(0, 1)  # non-contiguous source
+    ref = torch.cat([t.reshape(-1) for t in ts])
+    out = torch.empty_like(ref)
+    _lib.pack(out, ts)
+    assert torch.equal(out, ref)
+    _lib.pack(out, ts, scale=-0.5)
+    assert torch.equal(out, -0.5 * ref)
+    acc = torch.ones_like(ref)
+    _lib.pack(acc, ts, scale=0.5, mode=1)
+    assert torch.allclose(acc, 1 + (0.5 * ref) ** 2, rtol=1e-6)
+    many = [torch.randn(5, device=DEV, dtype=dtype, generator=gen) for _ in range(300)]  # > one table
+    out = torch.empty(1500, device=DEV, dtype=dtype)
+    _lib.pack(out, many)
+    assert torch.equal(out, torch.cat(many))
+    with pytest.raises(RuntimeError):
+        _lib.pack(out, many[:-1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [1, 5, 1003, 1 << 20])
+def test_axpy_out_and_precond_build(dtype, n):
+    gen = torch.Generator(device=DEV).manual_seed(n)
+    a = torch.randn(n, device=DEV, dtype=dtype, generator=gen)
+    s = torch.randn(n, device=DEV, dtype=dtype, generator=gen)
+    out = torch.empty_like(a)
+    _lib.axpy_out(out, a, s, 0.64)
+    assert torch.equal(out, a + 0.64 * s)  # two roundings, like the reference
+    _lib.axpy_out(a[1:], a[1:], s[1:], 1.0) if n > 1 else None  # unaligned, in place
+    d = torch.rand(n, device=DEV, dtype=dtype, generator=gen)
+    minv = torch.empty_like(d)
+    _lib.precond_build(minv, d, 0.1, 0.75)
+    assert torch.allclose(minv, (d + 0.1) ** -0.75, rtol=2e-6 if dtype == torch.float32 else 1e-12)
+
+
+def test_parameter_arena_binds_views_and_writes_in_place():
+    model = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3)).to(DEV)
+    for p in model[0].parameters():
+        p.requires_grad = False
+    before = [p.detach().clone() for p in model.parameters()]
+    arena = ParameterArena(model.parameters())
+    assert arena.n == 18
+    for p, b in zip(model.parameters(), before):
+        assert torch.equal(p, b)
+    assert model[2].weight.data_ptr() == arena.theta.data_ptr()
+    base = arena.snapshot()
+    step = torch.arange(18.0, device=DEV)
+    arena.write(base, step, 0.5)
+    assert torch.equal(model[2].bias.detach(), base[15:] + 0.5 * step[15:])
+    model[2].weight.data = torch.zeros(3, 5, device=DEV)  # storage swapped behind our back
+    arena.ensure_bound()
+    assert model[2].weight.data_ptr() == arena.theta.data_ptr() and float(arena.theta[:15].abs().sum()) == 0
+
+
+# ---- BASELINE.json shapes --------------------------------------------------------------
+def _cpu_twin(make, **kw):
+    model, (x, t), lossf = make(device="cpu", **kw)
+    return model, x, t, lossf
+
+
+@pytest.mark.parametrize("workload", ["resnet18", "allcnnc"])
+def test_curvature_products_on_conv_nets_match_cpu_oracle(workload):
+    """GGN and Hessian products of the ResNet-18 / All-CNN-C shaped nets on the GPU
+    (eager and hipGraph replay) against the oracle's BackPACK restatement on CPU.
+    fp32 conv arithmetic differs between MIOpen and the CPU: rtol 2e-3 of the
+    product's max-norm."""
+    from oracle import backpack_restated as bp
+    from pytorchhessianfree_amd.utils import vector_to_parameter_list
+
+    make = tp.resnet18_mnist if workload == "resnet18" else tp.allcnnc_cifar100
+    model, x, t, lossf = _cpu_twin(make, batch_size=8)
+    params = [p for p in model.parameters()]
+    n = sum(p.numel() for p in params)
+    v = torch.randn(n, generator=torch.Generator().manual_seed(3))
+    out = model(x)
+    loss = lossf(out, t)
+    Gv_ref = torch.cat([a.reshape(-1) for a in bp.ggn_vector_product_from_plist(
+        loss, out, params, vector_to_parameter_list(v, params))])
+    Hv_ref = torch.cat([a.reshape(-1) for a in bp.hessian_vector_product(
+        loss, params, vector_to_parameter_list(v, params))])
+
+    gmodel, (gx, gt), _ = make(batch_size=8, device=DEV)
+    gparams = [p for p in gmodel.parameters()]
+
+    def builder():
+        o = gmodel(gx)
+        return curvature.GGNOperator(lossf(o, gt), o, gparams)
+
+    def rel(a, ref):
+        return float((a.cpu() - ref).abs().max() / ref.abs().max())
+
+    eager = builder()
+    Gv = eager(v.to(DEV))
+    assert rel(Gv, Gv_ref) < 2e-3
+    del eager  # GraphedOperator's precondition: no live graph from another stream
+    graphed = curvature.GraphedOperator(builder, params=gparams)
+    Gv2 = graphed(v.to(DEV)).clone()
+    assert rel(Gv2, Gv_ref) < 2e-3
+    assert rel(graphed(v.to(DEV)), Gv_ref) < 2e-3  # replay is repeatable
+    del graphed
+    o = gmodel(gx)
+    Hv = curvature.HessianOperator(lossf(o, gt), gparams)(v.to(DEV))
+    assert rel(Hv, Hv_ref) < 5e-3
+
+
+def test_resnet18_step_decreases_loss_and_graph_equals_eager():
+    torch.manual_seed(0)
+    results = {}
+    for graph in (False, True):
+        model, (x, t), lossf = tp.resnet18_mnist(batch_size=16, device=DEV)
+
+        def forward():
+            out = model(x)
+            return lossf(out, t), out
+
+        opt = hf.HessianFree(model.parameters(), cg_max_iter=20, graph_matvec=graph)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            final = opt.step(forward)
+        init = opt.state["init_losses"][0]
+        assert final < init
+        results[graph] = (init, final, opt.state["num_cg_iters"][0], opt.state["cg_reasons"][0])
+    assert results[False][2:] == results[True][2:]
+    assert abs(results[False][1] - results[True][1]) < 1e-3 * abs(results[False][1]) + 1e-6
