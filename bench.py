@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=20)
     ap.add_argument("--graph", type=int, default=1, help="replay the matvec as a hipGraph if possible")
+    ap.add_argument("--fuse-bn", type=int, default=1,
+                    help="modelprep.fuse_eval_batchnorm: eval-mode BN as one fused HIP kernel per pass")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     return ap.parse_args()
 
 
@@ -107,33 +110,44 @@ def main():
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    import pytorchhessianfree_amd as hf
+    from pytorchhessianfree_amd import curvature, modelprep
+    from pytorchhessianfree_amd.cg import enable_kernel_timing, read_kernel_timing
+
+    model, (x, t), lossf = build_problem(args, device, rank)
+    if args.fuse_bn:
+        modelprep.fuse_eval_batchnorm(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    n = sum(p.numel() for p in params)
+    weight = 1.0 / world
+
+    # local gradient first (its graph is freed again: nothing may tie the parameters
+    # to the default stream while the product is captured, see GraphedOperator)
+    grad = curvature.flatten_into(torch.autograd.grad(lossf(model(x), t), params), params,
+                                  scale=weight)
+
+    def builder():  # forward graph + recorded J^T / H_L maps (once per Newton step)
+        out = model(x)
+        return curvature.GGNOperator(lossf(out, t), out, params, weight=weight, group=None)
+
+    # The local product is captured BEFORE the process group exists: RCCL's
+    # watchdog thread must not touch the runtime while a capture is open.
+    op = curvature.maybe_graphed(builder, enable=bool(args.graph), params=params)
+
     group = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
         group = dist.group.WORLD
+    op.group = group  # one all-reduce (sum) of the 4N-byte partial product per matvec
 
-    import pytorchhessianfree_amd as hf
-    from pytorchhessianfree_amd import cg as _unused  # noqa: F401
-    from pytorchhessianfree_amd import curvature
-    from pytorchhessianfree_amd.cg import enable_kernel_timing, read_kernel_timing
-
-    model, (x, t), lossf = build_problem(args, device, rank)
-    params = [p for p in model.parameters() if p.requires_grad]
-    n = sum(p.numel() for p in params)
-    weight = 1.0 / world
-    grads = torch.autograd.grad(lossf(model(x), t), params)
-    grad = curvature.flatten_into(grads, params, scale=weight)
     if group is not None:
         torch.distributed.all_reduce(grad, group=group)
     b = -grad
-
-    def builder():  # forward graph + recorded J^T / H_L maps (once per Newton step)
-        out = model(x)
-        return curvature.GGNOperator(lossf(out, t), out, params, weight=weight, group=group)
-
-    op = curvature.maybe_graphed(builder, enable=bool(args.graph), params=params)
     A = hf.DampedCurvature(op, args.damping)
 
     def solve(martens=False, max_iter=args.iters):
@@ -197,7 +211,8 @@ def main():
                             f"batch {args.batch}/GPU, {iters_done} PCG iterations/step, "
                             f"damping {args.damping}, eval-mode BN, CE-mean, x0=0, tol=0",
                 "parallelism": f"dp{world} (batch sharded, one all-reduce of 4N bytes per matvec)",
-                "matvec": getattr(op, "mode", "eager autograd"),
+                "matvec": getattr(op, "mode", "eager autograd")
+                          + ("; eval-BN fused (hf_chan_affine)" if args.fuse_bn else ""),
                 "termination": reason,
             },
             "cg_iters_per_s": world * args.steps * iters_done / dt,

@@ -245,6 +245,11 @@ def cg(
         print(f"Starting iterations (max_iter = {max_iter})...")
 
     # ---- iterations: enqueue, never read a scalar ------------------------------
+    # If the operator ends in a collective (data-parallel matvec), every rank must
+    # leave the loop at the SAME iteration or the next all-reduce deadlocks: the
+    # opportunistic lagged poll is then replaced by a stream sync per iteration,
+    # after which the termination flag is exact on every rank.
+    lockstep = getattr(matvec, "group", None) is not None or bool(getattr(matvec, "collective", False))
     status = _lib.Status()
     events = []
     for it in range(1, max_iter + 1):
@@ -258,10 +263,14 @@ def cg(
             _lib.check(lib.hf_pcg_update_p(ws.handle, ptr(y), stream), "update_p")
         else:
             _lib.check(lib.hf_pcg_iterate(ws.handle, ptr(Bp), damping, stream), "hf_pcg_iterate")
-        # lagged, non-blocking look at the device's termination flag
+        if lockstep:
+            torch.cuda.current_stream(device).synchronize()
+        # (lagged unless lockstep) non-blocking look at the device's termination flag
         lib.hf_pcg_poll(ws.handle, ctypes.byref(status))
         if status.done:
             break
+        if lockstep:
+            continue
         ev = torch.cuda.Event()
         ev.record()
         events.append(ev)

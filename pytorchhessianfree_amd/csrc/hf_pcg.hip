@@ -613,6 +613,67 @@ __global__ __launch_bounds__(BLOCK) void k_axpy_out(T* out, const T* a, const T*
     out[j] = a[j] + (T)(alpha * s[j]);
 }
 
+// ---------------------------------------------------------------------------
+// eval-mode BatchNorm as a per-channel affine map, fused (curvature-product path)
+//   xhat = (x - mean[c]) * rstd[c]
+//   k_chan_affine     : out = a*(w[c]*rstd[c]) + xhat*q[c] + r[c]   (each term optional)
+//       forward  y = xhat*w + b          (a = null, q = w, r = b)
+//       tangent / transpose of the backward map  (a = v_gx, q = v_gw, r = v_gb)
+//   k_chan_affine_bwd : gx = gy*w[c]*rstd[c] ; gw[c] = sum gy*xhat ; gb[c] = sum gy
+// One launch each instead of the ~16 small ATen kernels autograd's generic
+// double-backward of batch_norm issues per layer and product.  NCHW-contiguous.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_chan_affine(T* __restrict__ out, const T* __restrict__ a,
+                                                       const T* __restrict__ x,
+                                                       const T* __restrict__ mean,
+                                                       const T* __restrict__ rstd,
+                                                       const T* __restrict__ w,
+                                                       const T* __restrict__ q,
+                                                       const T* __restrict__ r, long long total,
+                                                       long long C, long long HW) {
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < total;
+       i += (long long)gridDim.x * BLOCK) {
+    const long long c = (i / HW) % C;
+    const T rs = rstd[c];
+    T acc = (T)0;
+    if (a) acc = a[i] * ((w ? w[c] : (T)1) * rs);
+    if (q) acc += ((x[i] - mean[c]) * rs) * q[c];
+    if (r) acc += r[c];
+    out[i] = acc;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(T* __restrict__ gx, T* __restrict__ gw,
+                                                           T* __restrict__ gb,
+                                                           const T* __restrict__ gy,
+                                                           const T* __restrict__ x,
+                                                           const T* __restrict__ mean,
+                                                           const T* __restrict__ rstd,
+                                                           const T* __restrict__ w, long long N,
+                                                           long long C, long long HW) {
+  __shared__ double lds[2 * WAVES];
+  const long long c = blockIdx.x;
+  const T rs = rstd[c], mu = mean[c];
+  const T s = (w ? w[c] : (T)1) * rs;
+  double acc[2] = {0.0, 0.0};
+  const long long per = N * HW;
+  for (long long e = threadIdx.x; e < per; e += BLOCK) {
+    const long long n = e / HW, i = e - n * HW;
+    const long long idx = (n * C + c) * HW + i;
+    const T g = gy[idx];
+    if (gx) gx[idx] = g * s;
+    acc[0] += (double)g * (double)(T)((x[idx] - mu) * rs);
+    acc[1] += (double)g;
+  }
+  block_allreduce<2>(acc, lds);
+  if (threadIdx.x == 0) {
+    if (gw) gw[c] = (T)acc[0];
+    if (gb) gb[c] = (T)acc[1];
+  }
+}
+
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
@@ -1087,6 +1148,50 @@ int hf_axpy_out(void* out, const void* a, const void* sv, double alpha, int64_t 
     hipLaunchKernelGGL((k_axpy_out<double>), dim3(small_grid(n / 2 + 1)), dim3(BLOCK), 0, s,
                        (double*)out, (const double*)a, (const double*)sv, alpha, (long long)n,
                        vec_ok);
+  else
+    return HF_ERR_ARG;
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_chan_affine(void* out, const void* a, const void* x, const void* mean, const void* rstd,
+                   const void* w, const void* q, const void* r, int64_t n, int64_t c, int64_t hw,
+                   int dtype, void* stream) {
+  if (!out || !rstd || n <= 0 || c <= 0 || hw <= 0) return HF_ERR_ARG;
+  if (q && (!x || !mean)) return HF_ERR_ARG;
+  const long long total = (long long)n * c * hw;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == HF_F32)
+    hipLaunchKernelGGL((k_chan_affine<float>), dim3(small_grid(total)), dim3(BLOCK), 0, s,
+                       (float*)out, (const float*)a, (const float*)x, (const float*)mean,
+                       (const float*)rstd, (const float*)w, (const float*)q, (const float*)r,
+                       total, (long long)c, (long long)hw);
+  else if (dtype == HF_F64)
+    hipLaunchKernelGGL((k_chan_affine<double>), dim3(small_grid(total)), dim3(BLOCK), 0, s,
+                       (double*)out, (const double*)a, (const double*)x, (const double*)mean,
+                       (const double*)rstd, (const double*)w, (const double*)q, (const double*)r,
+                       total, (long long)c, (long long)hw);
+  else
+    return HF_ERR_ARG;
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_chan_affine_bwd(void* gx, void* gw, void* gb, const void* gy, const void* x,
+                       const void* mean, const void* rstd, const void* w, int64_t n, int64_t c,
+                       int64_t hw, int dtype, void* stream) {
+  if (!gy || !x || !mean || !rstd || n <= 0 || c <= 0 || hw <= 0) return HF_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == HF_F32)
+    hipLaunchKernelGGL((k_chan_affine_bwd<float>), dim3((unsigned)c), dim3(BLOCK), 0, s, (float*)gx,
+                       (float*)gw, (float*)gb, (const float*)gy, (const float*)x,
+                       (const float*)mean, (const float*)rstd, (const float*)w, (long long)n,
+                       (long long)c, (long long)hw);
+  else if (dtype == HF_F64)
+    hipLaunchKernelGGL((k_chan_affine_bwd<double>), dim3((unsigned)c), dim3(BLOCK), 0, s,
+                       (double*)gx, (double*)gw, (double*)gb, (const double*)gy, (const double*)x,
+                       (const double*)mean, (const double*)rstd, (const double*)w, (long long)n,
+                       (long long)c, (long long)hw);
   else
     return HF_ERR_ARG;
   HF_HIP(hipGetLastError());

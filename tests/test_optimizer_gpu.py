@@ -297,3 +297,52 @@ def test_resnet18_step_decreases_loss_and_graph_equals_eager():
         results[graph] = (init, final, opt.state["num_cg_iters"][0], opt.state["cg_reasons"][0])
     assert results[False][2:] == results[True][2:]
     assert abs(results[False][1] - results[True][1]) < 1e-3 * abs(results[False][1]) + 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_fused_eval_batchnorm_matches_stock(dtype):
+    """modelprep.fuse_eval_batchnorm: forward, gradient, GGN and Hessian products of
+    a conv-BN-ReLU net agree with PyTorch's stock eval-mode BatchNorm
+    (rtol 1e-5 fp32 / 1e-11 fp64 of the max-norm)."""
+    from pytorchhessianfree_amd import modelprep
+
+    def make():
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(
+            torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+            torch.nn.Conv2d(8, 6, 3, stride=2), torch.nn.BatchNorm2d(6), torch.nn.Tanh(),
+            torch.nn.Flatten(), torch.nn.Linear(6 * 3 * 3, 5), torch.nn.BatchNorm1d(5),
+        )
+        for m in net.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.running_mean.uniform_(-0.5, 0.5)
+                m.running_var.uniform_(0.5, 2.0)
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.uniform_(-0.3, 0.3)
+        return net.to(DEV, dtype).eval()
+
+    stock, fused = make(), make()
+    assert modelprep.fuse_eval_batchnorm(fused) == 3
+    gen = torch.Generator().manual_seed(1)
+    x = torch.rand(4, 3, 8, 8, generator=gen).to(DEV, dtype)
+    t = torch.randint(0, 5, (4,), generator=gen).to(DEV)
+    lossf = torch.nn.CrossEntropyLoss()
+    tol = 1e-5 if dtype == torch.float32 else 1e-11
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+    res = []
+    for net in (stock, fused):
+        ps = list(net.parameters())
+        out = net(x)
+        loss = lossf(out, t)
+        grads = torch.autograd.grad(loss, ps, create_graph=True)
+        v = torch.randn(sum(p.numel() for p in ps), generator=torch.Generator().manual_seed(2)).to(DEV, dtype)
+        Gv = curvature.GGNOperator(loss, out, ps)(v)
+        Hv = curvature.HessianOperator(loss, ps, grad_with_graph=grads)(v)
+        res.append((out.detach(), curvature.flatten_into(grads, ps), Gv, Hv))
+    for a, b in zip(res[1], res[0]):
+        assert rel(a, b) < tol
+    fused.train()  # training mode falls back to the stock implementation
+    assert fused(x).shape == (4, 5)
