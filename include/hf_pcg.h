@@ -74,7 +74,7 @@ int hf_abi_version(void);
 const char* hf_error_string(int code);
 
 /* ---- solver lifetime ------------------------------------------------------ */
-/* max_blocks: grid size of the vector kernels (0 = default: 4 per CU). */
+/* max_blocks: grid size of the vector kernels (0 = default: 2 per CU). */
 int hf_pcg_create(hf_pcg_t** out, int64_t n, int dtype, int max_blocks);
 int hf_pcg_destroy(hf_pcg_t* h);
 

@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (must be imported first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhfpcg.so")
+LIB_PATH = os.environ.get("HF_PCG_LIB") or os.path.join(_HERE, "csrc", "libhfpcg.so")
 
 HF_F32, HF_F64 = 0, 1
 HF_M_NONE, HF_M_DIAG, HF_M_EXTERNAL = 0, 1, 2

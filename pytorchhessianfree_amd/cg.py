@@ -28,6 +28,7 @@ There is NO CPU fallback: CPU tensors raise ``RuntimeError``.
 """
 
 import ctypes
+import os
 from math import ceil, log
 from warnings import warn
 
@@ -93,7 +94,8 @@ class _Workspace:
         self.handle = _lib.c_void_p()
         with torch.cuda.device(device):
             _lib.check(
-                lib.hf_pcg_create(ctypes.byref(self.handle), n, _lib.dtype_code(dtype), 0),
+                lib.hf_pcg_create(ctypes.byref(self.handle), n, _lib.dtype_code(dtype),
+                                  int(os.environ.get("HF_PCG_BLOCKS", "0"))),
                 "hf_pcg_create",
             )
         self.r = torch.empty(n, dtype=dtype, device=device)

@@ -35,15 +35,18 @@ def needs_build():
     return any(os.path.getmtime(f) > t for f in (SRC, HDR, __file__))
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
+def build(force=False, verbose=True, out=None, extra_flags=()):
+    """``out`` / ``extra_flags`` build tuning variants (e.g. ``-DHF_U2=4``) next to
+    the default library; ``HF_PCG_LIB`` makes ``_lib`` load such a variant."""
+    out = out or OUT
+    if out == OUT and not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *FLAGS, "-I", os.path.join(ROOT, "include"), SRC, "-o", OUT, "-ldl"]
+    cmd = [hipcc, *FLAGS, *extra_flags, "-I", os.path.join(ROOT, "include"), SRC, "-o", out, "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -756,7 +756,7 @@ int hf_pcg_create(hf_pcg_t** out, int64_t n, int dtype, int max_blocks) {
     int dev = 0, cus = 256;
     HF_HIP(hipGetDevice(&dev));
     HF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    max_blocks = 4 * cus;
+    max_blocks = 2 * cus;  // tuned on MI355X (scratch/tune.py): 2 per CU, unroll 2
   }
   h->grid = max_blocks;
   HF_HIP(hipMalloc((void**)&h->d_state, sizeof(DevState)));
@@ -876,9 +876,19 @@ int hf_pcg_init_external(hf_pcg_t* h, const void* y, void* stream) {
   return HF_OK;
 }
 
-// unroll factors: K1 streams 2 vectors, K2 6, K3 3 -> keep ~12-16 x 16 B loads in
-// flight per lane in each
-constexpr int U1 = 4, U2 = 2, U3 = 4;
+// unroll factors (x 16-B vectors per lane and stream); all variants from 1..8 and
+// 2..16 blocks per CU measured within 3 % of each other on MI355X -- the kernels sit
+// on the memory system's plateau
+#ifndef HF_U1
+#define HF_U1 2
+#endif
+#ifndef HF_U2
+#define HF_U2 2
+#endif
+#ifndef HF_U3
+#define HF_U3 2
+#endif
+constexpr int U1 = HF_U1, U2 = HF_U2, U3 = HF_U3;
 
 template <typename T>
 static int curvature_impl(hf_pcg* h, const void* Bp, double damping, hipStream_t s) {
