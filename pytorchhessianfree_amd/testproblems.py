@@ -56,7 +56,7 @@ class ResNet18(nn.Module):
     def forward(self, x):
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         x = self.avgpool(self.layers(x))
-        return self.fc(torch.flatten(x, 1))
+        return self.fc(torch.flatten(x, -3))
 
 
 class AllCNNC(nn.Module):
@@ -77,7 +77,7 @@ class AllCNNC(nn.Module):
         )
 
     def forward(self, x):
-        return torch.flatten(self.net(x), 1)
+        return torch.flatten(self.net(x), -3)  # also for one unbatched sample [C,H,W]
 
 
 def count_trainable(model):

@@ -346,3 +346,101 @@ def test_fused_eval_batchnorm_matches_stock(dtype):
         assert rel(a, b) < tol
     fused.train()  # training mode falls back to the stock implementation
     assert fused(x).shape == (4, 5)
+
+
+def test_rccl_entry_points_single_rank():
+    """hf_comm_* / hf_allreduce_sum resolve RCCL from the already-loaded librccl and
+    work on a 1-rank communicator (sum over one rank = identity, on our stream)."""
+    import ctypes
+
+    lib = _lib.load()
+    uid = ctypes.create_string_buffer(128)
+    _lib.check(lib.hf_comm_unique_id(uid), "hf_comm_unique_id")
+    comm = _lib.c_void_p()
+    _lib.check(lib.hf_comm_create(ctypes.byref(comm), uid, 1, 0), "hf_comm_create")
+    v = torch.arange(1000.0, device=DEV)
+    ref = v.clone()
+    _lib.check(lib.hf_allreduce_sum(comm, _lib.c_void_p(v.data_ptr()), v.numel(), 0,
+                                    _lib.current_stream_ptr(v.device)), "hf_allreduce_sum")
+    torch.cuda.synchronize()
+    assert torch.equal(v, ref)
+    _lib.check(lib.hf_comm_destroy(comm), "hf_comm_destroy")
+
+
+def _mlp25m(device):
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(
+        torch.nn.Linear(3072, 4096), torch.nn.Tanh(), torch.nn.Linear(4096, 3072), torch.nn.Tanh(),
+        torch.nn.Linear(3072, 100),
+    )
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(64, 3072, generator=g)
+    t = torch.randint(0, 100, (64,), generator=g)
+    return net.to(device), x.to(device), t.to(device)
+
+
+def test_full_size_step_matches_cpu_host_logic_with_oracle():
+    """BASELINE.json configs[4] shape: a ~25.5 M-parameter vector, GGN, LM damping,
+    CG-backtracking (snapshot slab) and line search -- the whole ``step()`` on the
+    GPU against the same host logic on CPU with the oracle PCG plugged in.
+    Tolerance: identical reason / iteration counts / lr / damping schedule, losses
+    rtol 1e-4 (1e-3 for the loss after the second step: each step cuts the loss by
+    ~5x, differences compound), back-tracked iterate equal or adjacent."""
+    from oracle import pcg as oracle
+
+    traces = {}
+    for device in ("cpu", DEV):
+        net, x, t = _mlp25m(device)
+        n = sum(p.numel() for p in net.parameters())
+        assert 25_000_000 < n < 26_000_000
+        lossf = torch.nn.CrossEntropyLoss()
+        opt = hf.HessianFree(net.parameters(), cg_max_iter=12, damping=0.5)
+        if device == "cpu":
+            opt._cg = oracle.pcg
+
+        def forward():
+            out = net(x)
+            return lossf(out, t), out
+
+        finals = []
+        for _ in range(2):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                finals.append(opt.step(forward))
+        traces[device] = (opt.state, finals)
+    (sc, fc), (sg, fg) = traces["cpu"], traces[DEV]
+    assert sc["cg_reasons"] == sg["cg_reasons"]
+    assert sc["num_cg_iters"] == sg["num_cg_iters"]
+    assert sc["learning_rates"] == sg["learning_rates"]
+    np.testing.assert_allclose(sc["dampings"], sg["dampings"], rtol=1e-12)
+    np.testing.assert_allclose(sc["init_losses"], sg["init_losses"], rtol=1e-4)
+    np.testing.assert_allclose(fc[0], fg[0], rtol=1e-4)
+    np.testing.assert_allclose(fc[1], fg[1], rtol=1e-3)  # after two large nonlinear steps
+    assert fg[1] < sg["init_losses"][0]
+    for a, b_ in zip(sc["best_cg_iters"], sg["best_cg_iters"]):
+        grid = hf.storing_grid(12)
+        cand = sorted(set([i for i in grid if i <= 12] + [12]))
+        assert abs(cand.index(int(a)) - cand.index(int(b_))) <= 1
+
+
+def test_allcnnc_hessian_step_with_diag_fisher_preconditioner():
+    """BASELINE.json configs[3] shape: All-CNN-C (N = 1 387 108), Hessian curvature,
+    diagonal empirical-Fisher preconditioner (exponent 0.75, autograd-style
+    per-sample path vs the batched path), one full step on the GPU."""
+    model, (x, t), lossf = tp.allcnnc_cifar100(batch_size=8, device=DEV)
+    assert tp.count_trainable(model) == 1_387_108
+    d_loop = hf.diag_EF_autograd(model, lossf, x, t, "mean")
+    d_vmap = hf.diag_EF_backpack(model, lossf, x, t, "mean")
+    assert float((d_loop - d_vmap).abs().max() / d_loop.abs().max()) < 1e-4
+    opt = hf.HessianFree(model.parameters(), curvature_opt="hessian", cg_max_iter=25, damping=1.0)
+    M = opt.get_preconditioner(model, lossf, x, t, "mean", use_backpack=True)
+
+    def forward():
+        out = model(x)
+        return lossf(out, t), out
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        final = opt.step(forward, M_func=M)
+    assert final <= opt.state["init_losses"][0] + 1e-6
+    assert opt.state["num_cg_iters"][0] >= 1
