@@ -119,7 +119,8 @@ int hf_pcg_curvature(hf_pcg_t* h, const void* Bp, double damping, void* stream);
 int hf_pcg_update_xr(hf_pcg_t* h, const void* Bp, double damping, void* stream);
 int hf_pcg_update_p(hf_pcg_t* h, const void* y_external, void* stream);
 
-/* Non-blocking: reads the pinned host mirror the device writes at termination. */
+/* Non-blocking: reads the pinned host mirror the device writes at termination
+ * (fills done/reason and, once done, n_iters = the terminating iteration). */
 int hf_pcg_poll(hf_pcg_t* h, hf_pcg_status* out);
 /* Synchronises `stream`, copies the scalar block back, fills `out`. */
 int hf_pcg_finish(hf_pcg_t* h, hf_pcg_status* out, void* stream);

@@ -248,9 +248,11 @@ def cg(
 
     # ---- iterations: enqueue, never read a scalar ------------------------------
     # If the operator ends in a collective (data-parallel matvec), every rank must
-    # leave the loop at the SAME iteration or the next all-reduce deadlocks: the
-    # opportunistic lagged poll is then replaced by a stream sync per iteration,
-    # after which the termination flag is exact on every rank.
+    # leave the loop at the SAME iteration or the next all-reduce deadlocks.  The
+    # opportunistic poll ("break as soon as the flag is seen") is then replaced by
+    # a deterministic rule: at host iteration i wait for the event of iteration
+    # i-LAG and stop iff the device terminated at an iteration <= i-LAG.  Every rank
+    # thus performs exactly n_iters+LAG operator calls, with no pipeline bubble.
     lockstep = getattr(matvec, "group", None) is not None or bool(getattr(matvec, "collective", False))
     status = _lib.Status()
     events = []
@@ -265,17 +267,20 @@ def cg(
             _lib.check(lib.hf_pcg_update_p(ws.handle, ptr(y), stream), "update_p")
         else:
             _lib.check(lib.hf_pcg_iterate(ws.handle, ptr(Bp), damping, stream), "hf_pcg_iterate")
-        if lockstep:
-            torch.cuda.current_stream(device).synchronize()
-        # (lagged unless lockstep) non-blocking look at the device's termination flag
-        lib.hf_pcg_poll(ws.handle, ctypes.byref(status))
-        if status.done:
-            break
-        if lockstep:
-            continue
         ev = torch.cuda.Event()
         ev.record()
         events.append(ev)
+        if lockstep:
+            if it > _LAG:
+                events.pop(0).synchronize()  # iteration it-_LAG has completed
+                lib.hf_pcg_poll(ws.handle, ctypes.byref(status))
+                if status.done and 0 < status.n_iters <= it - _LAG:
+                    break
+            continue
+        # lagged, non-blocking look at the device's termination flag
+        lib.hf_pcg_poll(ws.handle, ctypes.byref(status))
+        if status.done:
+            break
         if len(events) > _LAG:
             events.pop(0).synchronize()
 

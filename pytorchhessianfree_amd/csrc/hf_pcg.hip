@@ -246,6 +246,7 @@ __global__ __launch_bounds__(BLOCK) void k_init_finalize(DevState* __restrict__ 
     st->done = 0;
     st->last_alpha = st->last_beta = st->last_pAp = st->last_res_norm = 0.0;
     st->nonpos_count = 0;
+    __hip_atomic_store(host_flag + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(host_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
@@ -481,7 +482,10 @@ __global__ __launch_bounds__(BLOCK) void k_update_p(
     if (reason != HF_RUNNING) {
       st->n_iters = iter;
       st->done = reason;
-      __hip_atomic_store(host_flag, reason, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // host mirror: [1] = terminating iteration, then [0] = reason
+      __hip_atomic_store(host_flag + 1, (int)(iter > 0x7fffffff ? 0x7fffffff : iter),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(host_flag, reason, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     } else {
       st->ry_next = (double)ry_new;
       st->iter_next = iter + 1;
@@ -766,6 +770,7 @@ int hf_pcg_create(hf_pcg_t** out, int64_t n, int dtype, int max_blocks) {
   HF_HIP(hipHostMalloc((void**)&h->h_state, sizeof(DevState), hipHostMallocDefault));
   HF_HIP(hipHostMalloc((void**)&h->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
   h->h_flag[0] = 0;
+  h->h_flag[1] = 0;
   HF_HIP(hipHostGetDevicePointer((void**)&h->d_flag, h->h_flag, 0));
   *out = h;
   return HF_OK;
@@ -813,6 +818,7 @@ int hf_pcg_begin(hf_pcg_t* h, void* x, void* r, void* p, const void* b, const vo
   h->begun = 1; h->inited = 0; h->finished = 0;
   h->t_count = 0;
   h->h_flag[0] = 0;
+  h->h_flag[1] = 0;
   return HF_OK;
 }
 
@@ -1019,6 +1025,7 @@ int hf_pcg_poll(hf_pcg_t* h, hf_pcg_status* out) {
   const int f = *(volatile int*)h->h_flag;
   out->done = f;
   out->reason = f;
+  out->n_iters = f ? ((volatile int*)h->h_flag)[1] : 0;  // terminating iteration
   return HF_OK;
 }
 

@@ -25,6 +25,7 @@ GPU the HIP kernel is mandatory (``_lib`` raises if the library is missing).
 import torch
 
 from . import _lib
+from .modelprep import first_order_only
 from .utils import vector_to_parameter_list
 
 
@@ -88,10 +89,11 @@ class GGNOperator(_Operator):
         self.outputs = outputs
         # u -> J^T u, recorded once (u is a dummy cotangent)
         self._u = torch.zeros_like(outputs, requires_grad=True)
-        JTu = torch.autograd.grad(
-            outputs, self.params, grad_outputs=self._u, create_graph=True,
-            retain_graph=True, allow_unused=True,
-        )
+        with first_order_only():  # only d/du of this map is ever taken
+            JTu = torch.autograd.grad(
+                outputs, self.params, grad_outputs=self._u, create_graph=True,
+                retain_graph=True, allow_unused=True,
+            )
         self._used = [i for i, g in enumerate(JTu) if g is not None]
         self._JTu = [JTu[i] for i in self._used]
         # d loss / d outputs with graph -> H_L by one more sweep

@@ -23,6 +23,26 @@ from torch import nn
 from . import _lib
 
 
+class _Mode:
+    first_order_only = False
+
+
+class first_order_only:
+    """Context manager: inside it, the backward of the fused layers is recorded
+    WITHOUT its dependence on the layer input / weight (only on the incoming
+    cotangent).  ``GGNOperator`` records ``u -> J^T u`` under it: a GGN product only
+    ever differentiates that map with respect to ``u``, but autograd cannot know and
+    would evaluate the (discarded) second-order terms on every product."""
+
+    def __enter__(self):
+        self._old = _Mode.first_order_only
+        _Mode.first_order_only = True
+
+    def __exit__(self, *exc):
+        _Mode.first_order_only = self._old
+        return False
+
+
 def _dims(x):
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c) if x.numel() else 1
@@ -103,6 +123,8 @@ class _ChanAffine(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, w, mean, rstd = ctx.saved_tensors
+        if _Mode.first_order_only:
+            x, w = x.detach(), w.detach()
         gx, gw, gb = _ChanAffineBwd.apply(gy, x, w, mean, rstd)
         return gx, gw, gb, None, None
 

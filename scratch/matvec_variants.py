@@ -26,8 +26,11 @@ if len(sys.argv) > 1:
     r = g(g.input_buffer)
     print("RESULT", variant, "ms/matvec %.3f" % (dt * 1e3), "relerr vs eager %.2e" % float((r - ref).abs().max() / ref.abs().max()), "refnorm %.4e" % float(ref.norm()))
 else:
-    for var, envx in [("base", {}), ("bn", {})]:
-        env = dict(os.environ); env.update(envx)
+    db = os.path.join(os.getcwd(), "gpurun_out", "miopen_db2"); os.makedirs(db, exist_ok=True)
+    import shutil
+    for f in os.listdir("profiles/miopen_db"): shutil.copy(os.path.join("profiles/miopen_db", f), db)
+    for var, envx in [("bn_bench", {}), ("bn_cl_bench", {}), ("bn_cl_bench_nhwc", {"PYTORCH_MIOPEN_SUGGEST_NHWC": "1"})]:
+        env = dict(os.environ, MIOPEN_USER_DB_PATH=db); env.update(envx)
         t0 = time.time()
         p = subprocess.run([sys.executable, __file__, var], capture_output=True, text=True, env=env)
         print(var, "rc", p.returncode, "%.0fs" % (time.time() - t0), [l for l in p.stdout.splitlines() if "RESULT" in l], flush=True)

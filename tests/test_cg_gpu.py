@@ -393,3 +393,38 @@ def test_full_size_vectors_properties(n):
     xs2, _, _ = product.cg(op, 2.0 * b, M=M, max_iter=len(xs) - 1, tol=0.0)
     rel = torch.linalg.norm(xs2[-1] - 2.0 * xs[-1]) / torch.linalg.norm(xs2[-1])
     assert rel < 1e-5
+
+
+def test_lockstep_termination_rule_gives_identical_results():
+    """Operators that end in a collective switch cg() to the deterministic lagged
+    stop rule (every rank performs n_iters + LAG operator calls); results must be
+    those of the opportunistic poll."""
+    product = _product()
+    n = 5003
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    d = torch.rand(n, device=DEV, generator=gen) * 20 + 0.1
+    b = torch.randn(n, device=DEV, generator=gen)
+
+    class Op:
+        def __init__(self, collective):
+            self.collective = collective
+            self.calls = 0
+
+        def __call__(self, v):
+            self.calls += 1
+            return d * v
+
+    outs = []
+    for coll in (False, True):
+        op = Op(coll)
+        xs, ms, reason = product.cg(product.DampedCurvature(op, 0.1), b, max_iter=250,
+                                    martens_conv_crit=True, store_x_at_iters=None)
+        outs.append((xs, ms, reason, op.calls))
+    (x0, m0, r0, c0), (x1, m1, r1, c1) = outs
+    assert r0 == r1 == "Convergence (Martens)" and len(x0) == len(x1)
+    for a, c in zip(x0, x1):
+        assert (a is None) == (c is None)
+        if a is not None:
+            assert torch.equal(a, c)
+    assert torch.equal(torch.stack(m0), torch.stack(m1))
+    assert c1 == 1 + (len(x1) - 1) + 2  # A(x0) + n_iters + LAG speculative (no-op) iterations
