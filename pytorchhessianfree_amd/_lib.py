@@ -98,6 +98,16 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and not os.environ.get("HF_PCG_LIB"):
+        # in-tree build on first use (hipcc cross-compiles in ~20 s); still an error
+        # if the toolchain is missing -- there is no other implementation to fall back to
+        try:
+            from .csrc import build as _build
+
+            if os.path.abspath(LIB_PATH) == os.path.abspath(_build.OUT):
+                _build.build(force=True, verbose=False)
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension is REQUIRED (there is no "

@@ -208,7 +208,7 @@ def cg(
         mode, minv = _lib.HF_M_EXTERNAL, None
 
     if isinstance(A, DampedCurvature):
-        matvec, damping = A.mvp, A.damping
+        matvec, damping = A.mvp, A.damping  # (attributes `group` / `collective` of the mvp are honoured)
     else:
         matvec, damping = A, 0.0
     # a hipGraph-captured operator reads its input from a fixed buffer: make that

@@ -60,6 +60,7 @@ class HessianFree(torch.optim.Optimizer):
         process_group=None,
         shard_weight=None,
         graph_matvec=False,
+        cache_acc_graphs=True,
     ):
         if curvature_opt not in ["hessian", "ggn"]:
             raise ValueError(f"Invalid curvature_opt = {curvature_opt}")
@@ -96,6 +97,7 @@ class HessianFree(torch.optim.Optimizer):
         else:
             self.shard_weight = 1.0 if shard_weight is None else float(shard_weight)
         self.graph_matvec = bool(graph_matvec)
+        self.cache_acc_graphs = bool(cache_acc_graphs)
 
         self._acc_comm = process_group  # group `_acc` sums over (None: this process only)
         self._arena = None
@@ -360,8 +362,15 @@ class HessianFree(torch.optim.Optimizer):
 
         grad = self._acc_grad(model, loss_func, grad_datalist, reduction)
 
-        def mvp(x):
-            return self._acc_mvp(model, loss_func, mvp_datalist, curvature_opt, reduction, x)
+        if self.cache_acc_graphs:
+            mvp = self._acc_mvp_cached(model, loss_func, mvp_datalist, curvature_opt, reduction)
+        else:
+
+            def mvp(x):
+                return self._acc_mvp(model, loss_func, mvp_datalist, curvature_opt, reduction, x)
+
+            if self._acc_comm is not None:
+                mvp.collective = True
 
         # `step` must not re-weight what `_acc` already reduced over ranks
         saved = (self.process_group, self.shard_weight)
@@ -430,6 +439,45 @@ class HessianFree(torch.optim.Optimizer):
 
         return self._acc(model, loss_func, datalist, device=self.device, with_grad=True,
                          init_result=self._zeros_flat(), eval_mb=eval_mb, reduction=reduction)
+
+    def _acc_mvp_cached(self, model, loss_func, datalist, curvature_opt, reduction):
+        """``_acc_mvp`` with the per-chunk forward graphs built ONCE per step instead
+        of once per chunk per product (the reference rebuilds them on every call and
+        says so, optimizer.py:537-540).  Same weighted sum
+        in the same order.  Costs the memory of all chunk graphs; disable with
+        ``cache_acc_graphs=False`` for batches that only fit chunk by chunk."""
+        if reduction not in ["mean", "sum"]:
+            raise ValueError(f"Invalid reduction {reduction}")
+        chunks = []
+        for inputs, targets in datalist:
+            inputs, targets = inputs.to(self.device), targets.to(self.device)
+            outputs = model(inputs)
+            loss = loss_func(outputs, targets)
+            if curvature_opt == "hessian":
+                op = curvature.HessianOperator(loss, self._params_list)
+            else:
+                op = curvature.GGNOperator(loss, outputs, self._params_list)
+            chunks.append((targets.shape[0], op))
+
+        def mvp(x):
+            total, count = self._zeros_flat(), 0
+            for n_chunk, op in chunks:
+                count += n_chunk
+                piece = op(x)
+                if reduction == "mean":
+                    total += n_chunk * piece
+                else:
+                    total += piece
+            if self._acc_comm is not None:
+                torch.distributed.all_reduce(total, group=self._acc_comm)
+                cnt = torch.tensor([float(count)], dtype=torch.float64, device=self.device)
+                torch.distributed.all_reduce(cnt, group=self._acc_comm)
+                count = cnt.item()
+            return total / count if reduction == "mean" else total
+
+        if self._acc_comm is not None:
+            mvp.collective = True  # cg() must use its lockstep stop rule
+        return mvp
 
     # ------------------------------------------------------------------------
     def test_reduction(self, model, loss_func, datalist, reduction):

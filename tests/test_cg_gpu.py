@@ -428,3 +428,33 @@ def test_lockstep_termination_rule_gives_identical_results():
             assert torch.equal(a, c)
     assert torch.equal(torch.stack(m0), torch.stack(m1))
     assert c1 == 1 + (len(x1) - 1) + 2  # A(x0) + n_iters + LAG speculative (no-op) iterations
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 255, 256, 257, 1023])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_tiny_and_ragged_lengths(n, dtype):
+    """Vector lengths below / across the 16-byte vector width and the block tile
+    (tail handling in every kernel), incl. max_iter = 1 and out-of-range snapshot
+    requests, against the oracle in the kernels' arithmetic."""
+    product, oracle = _product(), _oracle()
+    g = torch.Generator().manual_seed(n)
+    d = (torch.rand(n, generator=g) * 3 + 0.5).to(dtype)
+    b = torch.randn(n, generator=g).to(dtype)
+    diag = torch.rand(n, generator=g).to(dtype)
+    dd, bd = d.to(DEV), b.to(DEV)
+    Mg = product.DiagonalPreconditioner(diag.to(DEV), 0.3)
+    minv = Mg.minv.cpu()
+    for max_iter in (1, 7):
+        kw = dict(max_iter=max_iter, tol=1e-6, martens_conv_crit=True, store_x_at_iters=[0, 1, 5, 99])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ox, om, oreason = oracle.pcg(lambda v: d * v + 0.3 * v, b, M=lambda v: minv * v,
+                                         accumulate="fp64", **kw)
+            gx, gm, greason = product.cg(product.DampedCurvature(lambda v: dd * v, 0.3), bd, M=Mg, **kw)
+        assert greason == oreason and len(gx) == len(ox)
+        tol = 1e-5 if dtype == torch.float32 else 1e-12
+        for a, o in zip(gx, ox):
+            assert (a is None) == (o is None)
+            if a is not None:
+                assert _maxrel(a.cpu().numpy(), o.numpy()) < tol
+        assert len(gm) == len(om)

@@ -114,9 +114,10 @@ def test_step_trace_preconditioned(curv):
     check_state(opt, g, key + "/state/", 3)
 
 
+@pytest.mark.parametrize("cache", [True, False])
 @pytest.mark.parametrize("curv", ["ggn", "hessian"])
 @pytest.mark.parametrize("reduction", ["mean", "sum"])
-def test_acc_step_trace(curv, reduction):
+def test_acc_step_trace(curv, reduction, cache):
     """tests/test_optimizer_acc.py:116-175: step on the whole batch == acc_step on
     [7, 8] chunks, both == the reference's parameters."""
     g = load_golden("acc_step.npz")
@@ -124,7 +125,7 @@ def test_acc_step_trace(curv, reduction):
     m1, m2 = small_nn(g, key), small_nn(g, key)
     lossf = torch.nn.MSELoss(reduction=reduction)
     o1 = make_opt(m1.parameters(), curvature_opt=curv, cg_max_iter=4)
-    o2 = make_opt(m2.parameters(), curvature_opt=curv, cg_max_iter=4)
+    o2 = make_opt(m2.parameters(), curvature_opt=curv, cg_max_iter=4, cache_acc_graphs=cache)
     for s in range(3):
         datalist = [(T(g[f"{key}/inputs/{s}/{c}"]), T(g[f"{key}/targets/{s}/{c}"])) for c in (0, 1)]
         inputs = torch.cat([d[0] for d in datalist])
