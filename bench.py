@@ -45,10 +45,12 @@ def parse():
                     help="Tikhonov damping; 1e-3 keeps all 250 iterations numerically alive "
                          "(with 1.0 this random-init problem converges to fp32 round-off in ~15)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=20)
+    ap.add_argument("--cpu-iters", type=int, default=120)
     ap.add_argument("--graph", type=int, default=1, help="replay the matvec as a hipGraph if possible")
     ap.add_argument("--fuse-bn", type=int, default=1,
                     help="modelprep.fuse_eval_batchnorm: eval-mode BN as one fused HIP kernel per pass")
+    ap.add_argument("--fuse-conv", type=int, default=1,
+                    help="modelprep.fuse_conv_tangent: a conv layer's tangent map as ONE convolution")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--miopen-find", type=int, default=1,
                     help="let MIOpen measure its convolution solvers once (cudnn.benchmark); the "
@@ -143,6 +145,8 @@ def main():
     model, (x, t), lossf = build_problem(args, device, rank)
     if args.fuse_bn:
         modelprep.fuse_eval_batchnorm(model)
+    if args.fuse_conv:
+        modelprep.fuse_conv_tangent(model)
     params = [p for p in model.parameters() if p.requires_grad]
     n = sum(p.numel() for p in params)
     weight = 1.0 / world
@@ -238,7 +242,8 @@ def main():
                             f"damping {args.damping}, eval-mode BN, CE-mean, x0=0, tol=0",
                 "parallelism": f"dp{world} (batch sharded, one all-reduce of 4N bytes per matvec)",
                 "matvec": getattr(op, "mode", "eager autograd")
-                          + ("; eval-BN fused (hf_chan_affine)" if args.fuse_bn else ""),
+                          + ("; eval-BN fused (hf_chan_affine)" if args.fuse_bn else "")
+                          + ("; conv tangent fused" if args.fuse_conv else ""),
                 "termination": reason,
             },
             "cg_iters_per_s": world * args.steps * iters_done / dt,

@@ -173,7 +173,12 @@ class GraphedOperator:
 
     mode = "hipGraph replay of autograd sweeps + hf_pack"
 
-    def __init__(self, builder, warmup=3, params=None):
+    _captured_before = False  # later captures in a process need a single warm-up run
+
+    def __init__(self, builder, warmup=None, params=None):
+        if warmup is None:
+            warmup = 1 if GraphedOperator._captured_before else 3
+        GraphedOperator._captured_before = True
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedOperator needs a GPU")
         import gc

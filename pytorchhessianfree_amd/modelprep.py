@@ -141,6 +141,97 @@ def _fused_forward(self, x):
     return _ChanAffine.apply(x, self.weight, self.bias, self.running_mean, rstd)
 
 
+# ------------------------------------------------------------------------------------
+# convolution: one launch for the tangent map
+# ------------------------------------------------------------------------------------
+class _ConvBwd(torch.autograd.Function):
+    """(gy; x, w) -> (gx, gw, gb) of a convolution.  Recorded only in
+    ``first_order_only`` mode, so the sole derivative ever taken is d/d gy, whose
+    transpose is the layer's tangent map ``v_gy = conv(v_gx, w) + conv(x, v_gw) + v_gb``.
+    PyTorch's generic double-backward evaluates the two convolutions separately
+    (2 MIOpen calls, their layout transposes, 2 strided copies, 1 add); here they
+    are ONE convolution over concatenated input channels."""
+
+    @staticmethod
+    def forward(ctx, gy, x, w, has_bias, stride, padding, dilation):
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, w)
+        ctx.conf = (stride, padding, dilation, has_bias)
+        gx, gw, gb = torch.ops.aten.convolution_backward(
+            gy, x, w, [w.shape[0]] if has_bias else None, stride, padding, dilation, False,
+            [0] * len(stride), 1, [True, True, has_bias])
+        return gx, gw, gb
+
+    @staticmethod
+    def backward(ctx, vgx, vgw, vgb):
+        x, w = ctx.saved_tensors
+        stride, padding, dilation, _ = ctx.conf
+        if vgx is None and vgw is None:
+            v_gy = None
+        elif vgx is None:
+            v_gy = torch.nn.functional.conv2d(x, vgw, None, stride, padding, dilation)
+        elif vgw is None:
+            v_gy = torch.nn.functional.conv2d(vgx, w, None, stride, padding, dilation)
+        else:
+            v_gy = torch.nn.functional.conv2d(
+                torch.cat([vgx, x], 1), torch.cat([w, vgw], 1), None, stride, padding, dilation)
+        if vgb is not None:
+            vb = vgb.view(1, -1, 1, 1)
+            v_gy = vb.expand(x.shape[0], -1, 1, 1) if v_gy is None else v_gy + vb
+        return v_gy, None, None, None, None, None, None
+
+
+class _Conv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding, dilation):
+        ctx.save_for_backward(x, w)
+        ctx.conf = (stride, padding, dilation, b is not None)
+        return torch.nn.functional.conv2d(x, w, b, stride, padding, dilation)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, padding, dilation, has_bias = ctx.conf
+        if _Mode.first_order_only:
+            gx, gw, gb = _ConvBwd.apply(gy, x.detach(), w.detach(), has_bias, stride, padding, dilation)
+        else:  # fully differentiable stock path (Hessian products, plain training)
+            gx, gw, gb = torch.ops.aten.convolution_backward(
+                gy, x, w, [w.shape[0]] if has_bias else None, stride, padding, dilation, False,
+                [0] * len(stride), 1, [True, True, has_bias])
+        return gx, gw, gb if has_bias else None, None, None, None
+
+
+def _conv_forward(self, x):
+    usable = (
+        x.is_cuda and self.groups == 1 and self.padding_mode == "zeros" and x.dim() == 4
+        and not isinstance(self.padding, str)
+    )
+    if not usable:
+        return self._hf_stock_forward(x)
+    return _Conv.apply(x, self.weight, self.bias, list(self.stride), list(self.padding),
+                       list(self.dilation))
+
+
+def fuse_conv_tangent(model):
+    """Patch every plain ``nn.Conv2d`` (groups=1, zero padding) so that, inside a GGN
+    product, its tangent map is one convolution (see ``_ConvBwd``).  Forward and
+    first-order backward are the stock MIOpen calls.  Returns the number patched."""
+    count = 0
+    for m in model.modules():
+        if type(m) is nn.Conv2d and not hasattr(m, "_hf_stock_forward"):
+            m._hf_stock_forward = m.forward
+            m.forward = types.MethodType(_conv_forward, m)
+            count += 1
+    return count
+
+
+def prepare_model(model):
+    """All opt-in preparations; returns ``model`` for chaining."""
+    fuse_eval_batchnorm(model)
+    fuse_conv_tangent(model)
+    return model
+
+
 def fuse_eval_batchnorm(model):
     """Patch all BatchNorm layers of ``model`` (see module docstring); returns the
     number of layers patched."""

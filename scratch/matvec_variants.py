@@ -7,6 +7,7 @@ if len(sys.argv) > 1:
     if "bench" in variant: torch.backends.cudnn.benchmark = True
     m, (x, t), lf = tp.resnet18_mnist(batch_size=32, device="cuda", data_seed=1000)
     if "bn" in variant: print("fused", modelprep.fuse_eval_batchnorm(m))
+    if "conv" in variant: print("fusedconv", modelprep.fuse_conv_tangent(m))
     if "cl" in variant:
         m = m.to(memory_format=torch.channels_last); x = x.contiguous(memory_format=torch.channels_last)
     ps = [p for p in m.parameters()]
@@ -29,7 +30,7 @@ else:
     db = os.path.join(os.getcwd(), "gpurun_out", "miopen_db2"); os.makedirs(db, exist_ok=True)
     import shutil
     for f in os.listdir("profiles/miopen_db"): shutil.copy(os.path.join("profiles/miopen_db", f), db)
-    for var, envx in [("bn_bench", {}), ("bn_cl_bench", {}), ("bn_cl_bench_nhwc", {"PYTORCH_MIOPEN_SUGGEST_NHWC": "1"})]:
+    for var, envx in [("bn_bench", {}), ("bn_conv_bench", {}), ("bn_conv_bench2", {})]:
         env = dict(os.environ, MIOPEN_USER_DB_PATH=db); env.update(envx)
         t0 = time.time()
         p = subprocess.run([sys.executable, __file__, var], capture_output=True, text=True, env=env)

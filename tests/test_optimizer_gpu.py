@@ -301,8 +301,8 @@ def test_resnet18_step_decreases_loss_and_graph_equals_eager():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_fused_eval_batchnorm_matches_stock(dtype):
-    """modelprep.fuse_eval_batchnorm: forward, gradient, GGN and Hessian products of
-    a conv-BN-ReLU net agree with PyTorch's stock eval-mode BatchNorm
+    """modelprep.fuse_eval_batchnorm + fuse_conv_tangent: forward, gradient, GGN and
+    Hessian products of a conv-BN-ReLU net agree with PyTorch's stock layers
     (rtol 1e-5 fp32 / 1e-11 fp64 of the max-norm)."""
     from pytorchhessianfree_amd import modelprep
 
@@ -323,6 +323,7 @@ def test_fused_eval_batchnorm_matches_stock(dtype):
 
     stock, fused = make(), make()
     assert modelprep.fuse_eval_batchnorm(fused) == 3
+    assert modelprep.fuse_conv_tangent(fused) == 2
     gen = torch.Generator().manual_seed(1)
     x = torch.rand(4, 3, 8, 8, generator=gen).to(DEV, dtype)
     t = torch.randint(0, 5, (4,), generator=gen).to(DEV)
