@@ -6,7 +6,7 @@ from pytorchhessianfree_amd import curvature, testproblems as tp, modelprep
 torch.backends.cudnn.benchmark = True
 os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(os.getcwd(), "profiles", "miopen_db"))
 m, (x, t), lf = tp.resnet18_mnist(batch_size=32, device="cuda", data_seed=1000)
-modelprep.fuse_eval_batchnorm(m)
+modelprep.prepare_model(m)
 ps = [p for p in m.parameters()]
 o = m(x); op = curvature.GGNOperator(lf(o, t), o, ps)
 v = torch.randn(op.n, device="cuda")
@@ -22,7 +22,8 @@ def walk(e, acc):
     for c in e.cpu_children: walk(c, acc)
 for e in tops:
     name = e.name.split(": ")[-1]; calls[name] += 1; walk(e, per[name])
-for name in ("ConvolutionBackwardBackward0", "ConvolutionBackward0", "_ChanAffineBwdBackward"):
+print("nodes:", sorted(((sum(per[n].values()), calls[n], n) for n in per), reverse=True)[:12])
+for name in ("_ConvBwdBackward", "ConvolutionBackward0", "_ConvBackward"):
     print(name, "calls", calls[name], "kernels", sum(per[name].values()))
     for k, c in per[name].most_common(14): print("   %4d %s" % (c, k))
 # kernels not under any evaluate_function
