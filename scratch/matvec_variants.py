@@ -30,7 +30,7 @@ else:
     db = os.path.join(os.getcwd(), "gpurun_out", "miopen_db2"); os.makedirs(db, exist_ok=True)
     import shutil
     for f in os.listdir("profiles/miopen_db"): shutil.copy(os.path.join("profiles/miopen_db", f), db)
-    for var, envx in [("bn_bench", {}), ("bn_conv_bench", {}), ("bn_conv_bench2", {})]:
+    for var, envx in [("bn_conv_bench", {}), ("bn_conv_bench_nowino", {"MIOPEN_DEBUG_CONV_WINOGRAD": "0"}), ("bn_conv_bench_nowino2", {"MIOPEN_DEBUG_CONV_WINOGRAD": "0"})]:
         env = dict(os.environ, MIOPEN_USER_DB_PATH=db); env.update(envx)
         t0 = time.time()
         p = subprocess.run([sys.executable, __file__, var], capture_output=True, text=True, env=env)
