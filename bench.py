@@ -52,10 +52,6 @@ def parse():
     ap.add_argument("--fuse-conv", type=int, default=1,
                     help="modelprep.fuse_conv_tangent: a conv layer's tangent map as ONE convolution")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
-    ap.add_argument("--miopen-find", type=int, default=1,
-                    help="let MIOpen measure its convolution solvers once (cudnn.benchmark); the "
-                         "results are cached in profiles/miopen_db (shipped) so this is free on "
-                         "configs seen before")
     return ap.parse_args()
 
 
@@ -131,13 +127,6 @@ def main():
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if args.miopen_find:
-        # Without measured find-db entries MIOpen's immediate mode sometimes picks a
-        # naive (2 ms) solver for one of the double-backward convolutions -- observed
-        # run-to-run on fresh boxes.  A user find-db travels with the repository.
-        db = os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "profiles", "miopen_db"))
-        os.makedirs(db, exist_ok=True)
-        torch.backends.cudnn.benchmark = True
     import pytorchhessianfree_amd as hf
     from pytorchhessianfree_amd import curvature, modelprep
     from pytorchhessianfree_amd.cg import enable_kernel_timing, read_kernel_timing

@@ -9,8 +9,20 @@ import os as _os
 # stays at 3e-7 -- at identical speed once MIOpen has measured its solvers
 # (scratch/conv_acc.py).  Parity with the reference's CPU path
 # needs the accurate ones; set HF_ALLOW_WINOGRAD=1 to keep MIOpen's default.
+#
+# Without Winograd, MIOpen's immediate mode (PyTorch's default) can fall back to
+# naive solvers (measured: 49 ms instead of 1.7 ms per product), so MIOpen is asked
+# to MEASURE its solvers once per convolution shape (cudnn.benchmark) and a find-db
+# with the shapes of the BASELINE.json workloads ships in ``miopen_db/`` (new
+# shapes are appended there; point MIOPEN_USER_DB_PATH elsewhere to relocate).
 if not _os.environ.get("HF_ALLOW_WINOGRAD"):
     _os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
+    _os.environ.setdefault(
+        "MIOPEN_USER_DB_PATH", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
+    )
+    import torch as _torch
+
+    _torch.backends.cudnn.benchmark = True
 
 from .cg import DampedCurvature, DiagonalPreconditioner, cg, storing_grid  # noqa: F401
 

@@ -4,7 +4,7 @@ import torch
 from torch.profiler import profile, ProfilerActivity
 from pytorchhessianfree_amd import curvature, testproblems as tp, modelprep
 torch.backends.cudnn.benchmark = True
-os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(os.getcwd(), "profiles", "miopen_db"))
+os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(os.getcwd(), "pytorchhessianfree_amd", "miopen_db"))
 m, (x, t), lf = tp.resnet18_mnist(batch_size=32, device="cuda", data_seed=1000)
 modelprep.prepare_model(m)
 ps = [p for p in m.parameters()]

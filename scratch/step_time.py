@@ -1,7 +1,7 @@
 import sys, os, time, warnings
 sys.path.insert(0, os.getcwd())
 import torch
-os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(os.getcwd(), "profiles", "miopen_db"))
+os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(os.getcwd(), "pytorchhessianfree_amd", "miopen_db"))
 torch.backends.cudnn.benchmark = True
 import pytorchhessianfree_amd as hf
 from pytorchhessianfree_amd import testproblems as tp, modelprep
