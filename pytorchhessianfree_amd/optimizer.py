@@ -84,8 +84,7 @@ class HessianFree(torch.optim.Optimizer):
             raise ValueError("`HessianFree` does not support per-parameter options.")
 
         self.verbose = verbose
-        self._group = self.param_groups[0]
-        self._params = self._group["params"]
+        self._params = self.param_groups[0]["params"]
         self._params_list = [p for p in self._params if p.requires_grad]
         self.device = self._params_list[0].device
 
@@ -106,6 +105,13 @@ class HessianFree(torch.optim.Optimizer):
     # ------------------------------------------------------------------------
     # helpers
     # ------------------------------------------------------------------------
+    @property
+    def _group(self):
+        # looked up on every use: ``load_state_dict`` REPLACES the param-group dicts
+        # (the reference caches the dict at construction, optimizer.py:118, and would
+        # keep adapting the damping of a stale one after a checkpoint restore)
+        return self.param_groups[0]
+
     def _log(self, *a):
         if self.verbose:
             print(*a)

@@ -309,3 +309,32 @@ def test_vector_utils():
         hf.vector_to_parameter_list([1.0, 2.0], params)
     with pytest.raises(TypeError):
         hf.vector_to_trainparams([1.0], params)
+
+
+def test_state_dict_round_trip_keeps_warm_start_and_damping():
+    """Checkpoint / resume through torch.optim.Optimizer.state_dict (string-keyed
+    state as in optimizer.py:183-192; examples/run_small_nn.py:47-52 reads it)."""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Tanh(), torch.nn.Linear(3, 2))
+    x, t = torch.rand(8, 4), torch.rand(8, 2)
+
+    def forward():
+        out = net(x)
+        return torch.nn.functional.mse_loss(out, t), out
+
+    opt = make_opt(net.parameters())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        opt.step(forward)
+    sd = opt.state_dict()
+    assert set(sd["state"].keys()) >= {"x0", "init_losses", "dampings", "cg_reasons", "num_cg_iters",
+                                       "best_cg_iters", "learning_rates"}
+    opt2 = make_opt(net.parameters())
+    opt2.load_state_dict(sd)
+    assert torch.equal(opt2.state["x0"], opt.state["x0"])
+    assert opt2._group["damping"] == opt._group["damping"] != 1.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        opt2.step(forward)
+    assert opt2.state["dampings"][-1] == sd["param_groups"][0]["damping"]
+    assert opt2.param_groups[0]["damping"] == opt2._group["damping"]
