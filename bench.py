@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--fuse-conv", type=int, default=1,
                     help="modelprep.fuse_conv_tangent: a conv layer's tangent map as ONE convolution")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--force-dist", type=int, default=0,
+                    help="create the process group even for WORLD_SIZE=1 (exercises the RCCL path on one GPU)")
     return ap.parse_args()
 
 
@@ -154,7 +156,7 @@ def main():
     op = curvature.maybe_graphed(builder, enable=bool(args.graph), params=params)
 
     group = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
         if args.backend == "nccl":

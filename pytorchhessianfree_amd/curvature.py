@@ -174,19 +174,25 @@ class GraphedOperator:
     mode = "hipGraph replay of autograd sweeps + hf_pack"
 
     _captured_before = False  # later captures in a process need a single warm-up run
+    _streams = {}             # one capture stream per device, shared by all instances
 
     def __init__(self, builder, warmup=None, params=None):
         if warmup is None:
             warmup = 1 if GraphedOperator._captured_before else 3
-        GraphedOperator._captured_before = True
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedOperator needs a GPU")
         import gc
 
+        first = not GraphedOperator._captured_before
+        GraphedOperator._captured_before = True
         stash = [(p, p.grad) for p in (params or []) if p.grad is not None]
         for p, _ in stash:
             p.grad = None
-        gc.collect()  # let dead graphs (and their AccumulateGrad nodes) go
+        if first or stash:
+            # let dead graphs (and their AccumulateGrad nodes) go.  Later captures
+            # skip this 40 ms sweep: every instance records on the SAME stream, so
+            # a lingering earlier graph of ours ties the parameters to that stream only
+            gc.collect()
         try:
             self._capture(builder, warmup)
         finally:
@@ -195,7 +201,10 @@ class GraphedOperator:
 
     def _capture(self, builder, warmup):
         cur = torch.cuda.current_stream()
-        self.stream = torch.cuda.Stream()
+        dev = torch.cuda.current_device()
+        if dev not in GraphedOperator._streams:
+            GraphedOperator._streams[dev] = torch.cuda.Stream()
+        self.stream = GraphedOperator._streams[dev]
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             self.op = builder()

@@ -5,9 +5,9 @@ os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(os.getcwd(), "pytorchh
 torch.backends.cudnn.benchmark = True
 import pytorchhessianfree_amd as hf
 from pytorchhessianfree_amd import testproblems as tp, modelprep
-for graph, fuse in [(False, True), (True, True)]:
+for graph, fuse in [(False, False), (False, True), (True, True)]:
     model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device="cuda")
-    if fuse: modelprep.fuse_eval_batchnorm(model)
+    if fuse: modelprep.prepare_model(model)
     def forward():
         out = model(x); return lossf(out, t), out
     opt = hf.HessianFree(model.parameters(), graph_matvec=graph)
