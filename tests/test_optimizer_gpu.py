@@ -507,3 +507,34 @@ def test_resnet18_newton_solve_matches_reference_cpu_path():
         assert dm < (1e-5 if i <= 10 else 5e-3), (i, dm)
     a, b_ = gx[-1].cpu(), ox[-1]
     assert float(a @ b_ / (a.norm() * b_.norm())) > 0.999
+
+
+def test_overlapped_two_graph_product_equals_single_graph():
+    """curvature.OverlappedGraphedOperator (data-parallel path: two hipGraphs, the
+    all-reduce of the tail overlapped with the head's adjoint sweep) computes the
+    same vector as the single-graph and the eager product."""
+    from pytorchhessianfree_amd import modelprep
+
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=8, device=DEV)
+    modelprep.prepare_model(model)
+    ps = list(model.parameters())
+
+    def builder():
+        o = model(x)
+        return curvature.GGNOperator(lossf(o, t), o, ps, weight=0.5)
+
+    v = torch.randn(sum(p.numel() for p in ps), device=DEV, generator=torch.Generator(device=DEV).manual_seed(0))
+    eager = builder()
+    ref = eager(v).clone()
+    cut, off = eager.split_point()
+    assert 0 < cut < len(ps) and 0.5 < (eager.n - off) / eager.n <= 0.75
+    del eager
+    two = curvature.OverlappedGraphedOperator(builder, params=ps)
+    a = two(v).clone()
+    b_ = two(v).clone()
+    # (not bitwise: MIOpen's split-K weight-gradient kernels accumulate with atomics)
+    assert float((a - b_).abs().max() / ref.abs().max()) < 1e-5
+    assert float((a - ref).abs().max() / ref.abs().max()) < 1e-5
+    del two
+    one = curvature.GraphedOperator(builder, params=ps)
+    assert float((one(v) - a).abs().max() / ref.abs().max()) < 1e-5
