@@ -428,6 +428,8 @@ def test_lockstep_termination_rule_gives_identical_results():
             assert torch.equal(a, c)
     assert torch.equal(torch.stack(m0), torch.stack(m1))
     assert c1 == 1 + (len(x1) - 1) + 2  # A(x0) + n_iters + LAG speculative (no-op) iterations
+    # the opportunistic poll sees the device's flag within a few speculative launches
+    assert 1 + (len(x0) - 1) <= c0 <= 1 + (len(x0) - 1) + 8
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 255, 256, 257, 1023])
@@ -458,3 +460,47 @@ def test_tiny_and_ragged_lengths(n, dtype):
             if a is not None:
                 assert _maxrel(a.cpu().numpy(), o.numpy()) < tol
         assert len(gm) == len(om)
+
+
+def test_c_abi_rejects_misuse_on_device():
+    """Error behaviour of the C ABI itself (include/hf_pcg.h): call order, alignment,
+    inconsistent arguments -- checked through ctypes with real device pointers."""
+    import ctypes
+
+    from pytorchhessianfree_amd import _lib
+
+    lib = _lib.load()
+    n = 1000
+    h = _lib.c_void_p()
+    assert lib.hf_pcg_create(ctypes.byref(h), n, 0, 0) == 0
+    buf = torch.zeros(8 * n, device=DEV)
+    P = lambda t: _lib.c_void_p(t.data_ptr())  # noqa: E731
+    x, r, p, b, bp = (buf[i * n:(i + 1) * n] for i in range(5))
+    s = _lib.current_stream_ptr(buf.device)
+    assert lib.hf_pcg_iterate(h, P(bp), 0.0, s) == -3          # iterate before begin/init
+    assert lib.hf_pcg_init(h, P(bp), s) == -3                  # init before begin
+    # misaligned vector
+    assert lib.hf_pcg_begin(h, P(buf[1:n + 1]), P(r), P(p), P(b), None, 0, 10, 1e-5, -1.0, 0,
+                            None, 0, 0, None, 0, None) == -2
+    # diag preconditioner without minv; Martens without m_hist; snapshots without slab
+    assert lib.hf_pcg_begin(h, P(x), P(r), P(p), P(b), None, 1, 10, 1e-5, -1.0, 0, None, 0, 0, None, 0, None) == -1
+    assert lib.hf_pcg_begin(h, P(x), P(r), P(p), P(b), None, 0, 10, 1e-5, -1.0, 1, None, 0, 0, None, 0, None) == -1
+    assert lib.hf_pcg_begin(h, P(x), P(r), P(p), P(b), None, 0, 10, 1e-5, -1.0, 0, None, 2, 0, None, 0, None) == -1
+    assert lib.hf_pcg_begin(h, P(x), P(r), P(p), P(b), None, 0, 0, 1e-5, -1.0, 0, None, 0, 0, None, 0, None) == -1
+    # a valid sequence on the raw ABI: A = 2 I, b = 1  ->  x = 0.5 after one iteration
+    b.fill_(1.0)
+    assert lib.hf_pcg_begin(h, P(x), P(r), P(p), P(b), None, 0, 10, 1e-5, -1.0, 0, None, 0, 0, None, 0, None) == 0
+    assert lib.hf_pcg_update_p(h, None, s) == -3               # phases before init
+    bp.zero_()                                                 # A x0 = 0
+    assert lib.hf_pcg_init(h, P(bp), s) == 0
+    assert lib.hf_pcg_init_external(h, P(bp), s) == -3         # wrong mode
+    torch.mul(p, 2.0, out=bp)
+    assert lib.hf_pcg_iterate(h, P(bp), 0.0, s) == 0
+    st = _lib.Status()
+    assert lib.hf_pcg_finish(h, ctypes.byref(st), s) == 0
+    assert st.done == 4 and st.n_iters == 1                    # "Convergence (tolerances)"
+    assert torch.allclose(x, torch.full_like(x, 0.5))
+    assert lib.hf_pcg_destroy(h) == 0
+    assert lib.hf_pack(P(x), None, None, 1, 1.0, 0, 0, s) == -1
+    assert lib.hf_axpy_out(P(x), P(x), None, 1.0, n, 0, s) == -1
+    assert lib.hf_precond_build(P(x), P(b), 0.1, 0.75, n, 7, s) == -1
