@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--iters", type=int, default=250, help="PCG iterations per step")
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU")
-    ap.add_argument("--workload", default="resnet18", choices=["resnet18", "allcnnc"])
+    ap.add_argument("--workload", default="resnet18", choices=["resnet18", "allcnnc", "resnet50"])
     ap.add_argument("--damping", type=float, default=1e-3,
                     help="Tikhonov damping; 1e-3 keeps all 250 iterations numerically alive "
                          "(with 1.0 this random-init problem converges to fp32 round-off in ~15)")
@@ -65,7 +65,8 @@ def parse():
 def build_problem(args, device, rank):
     from pytorchhessianfree_amd import testproblems as tp
 
-    make = tp.resnet18_mnist if args.workload == "resnet18" else tp.allcnnc_cifar100
+    make = {"resnet18": tp.resnet18_mnist, "allcnnc": tp.allcnnc_cifar100,
+            "resnet50": tp.resnet50_small_images}[args.workload]
     # same weights on every rank (seed 0), a different data shard per rank
     return make(batch_size=args.batch, seed=0, device=device, data_seed=1000 + rank)
 

@@ -59,6 +59,58 @@ class ResNet18(nn.Module):
         return self.fc(torch.flatten(x, -3))
 
 
+class _Bottleneck(nn.Module):
+    def __init__(self, cin, width, stride):
+        super().__init__()
+        cout = 4 * width
+        self.conv1 = nn.Conv2d(cin, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, cout, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=False)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout)
+            )
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + idt)
+
+
+class ResNet50(nn.Module):
+    """torchvision ResNet-50 topology: 25 557 032 parameters at 1000 classes."""
+
+    def __init__(self, in_channels=3, num_classes=1000):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=False)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        blocks, cin = [], 64
+        for width, count, stride in [(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)]:
+            for i in range(count):
+                blocks.append(_Bottleneck(cin, width, stride if i == 0 else 1))
+                cin = 4 * width
+        self.layers = nn.Sequential(*blocks)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(2048, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.avgpool(self.layers(x))
+        return self.fc(torch.flatten(x, -3))
+
+
 class AllCNNC(nn.Module):
     def __init__(self, num_classes=100):
         super().__init__()
@@ -93,6 +145,17 @@ def resnet18_mnist(batch_size=32, seed=0, device="cpu", data_seed=None):
     g = torch.Generator().manual_seed(seed if data_seed is None else data_seed)
     inputs = torch.rand(batch_size, 1, 28, 28, generator=g)
     targets = torch.randint(0, 10, (batch_size,), generator=g)
+    return model.to(device), (inputs.to(device), targets.to(device)), nn.CrossEntropyLoss()
+
+
+def resnet50_small_images(batch_size=32, seed=0, device="cpu", data_seed=None, image=64):
+    """BASELINE.json configs[4]: a ResNet-50-sized parameter vector (25 557 032);
+    eval-mode BN, inputs U[0,1) [B,3,image,image], 1000 classes, CE-mean."""
+    torch.manual_seed(seed)
+    model = ResNet50(3, 1000).eval()
+    g = torch.Generator().manual_seed(seed if data_seed is None else data_seed)
+    inputs = torch.rand(batch_size, 3, image, image, generator=g)
+    targets = torch.randint(0, 1000, (batch_size,), generator=g)
     return model.to(device), (inputs.to(device), targets.to(device)), nn.CrossEntropyLoss()
 
 
