@@ -49,9 +49,9 @@ def flatten_into(tensors, like_params, out=None, scale=1.0):
 
 
 def _all_reduce_sum(t, group):
-    if group is not None:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=group)
-    return t
+    from .distributed import all_reduce_sum
+
+    return all_reduce_sum(t, group)
 
 
 class _Operator:
