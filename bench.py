@@ -144,6 +144,8 @@ def main():
         modelprep.fuse_eval_batchnorm(model)
     if args.fuse_conv:
         modelprep.fuse_conv_tangent(model)
+    if args.fuse_bn and args.fuse_conv:
+        modelprep.fuse_residual_blocks(model)  # relu(bn(.)) / relu(bn(.) + identity) as one layer
     params = [p for p in model.parameters() if p.requires_grad]
     n = sum(p.numel() for p in params)
     weight = 1.0 / world

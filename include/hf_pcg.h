@@ -154,23 +154,28 @@ int hf_precond_build(void* minv, const void* diag, double damping,
 int hf_axpy_out(void* out, const void* a, const void* s, double alpha, int64_t n,
                 int dtype, void* stream);
 
-/* ---- eval-mode BatchNorm inside the curvature product ----------------------- */
+/* ---- eval-mode BatchNorm (+ residual add, + ReLU) inside the curvature product -- */
 /*
  * An eval-mode BatchNorm is y = xhat*w[c] + b[c], xhat = (x - mean[c])*rstd[c] on an
- * NCHW-contiguous [n, c, hw] tensor.  PyTorch's generic double-backward of
- * batch_norm (which BackPACK's R-op, and ours, differentiates through on every
- * GGN product, optimizer.py:461) issues ~16 small kernels per layer; these two
- * entry points are the whole layer in one launch each.
- *   hf_chan_affine    : out = a*(w*rstd) + xhat*q + r   (a, q, r, w nullable)
- *   hf_chan_affine_bwd: gx = gy*w*rstd, gw = sum_{n,hw} gy*xhat, gb = sum gy
- *                       (gx, gw, gb nullable)
+ * NCHW-contiguous [n, c, hw] tensor; ResNet blocks follow it by "+ identity" and/or
+ * ReLU.  PyTorch's generic double-backward of batch_norm (which BackPACK's R-op, and
+ * ours, differentiates through on every GGN product, optimizer.py:461) issues ~16
+ * small kernels per layer, plus 2 per add and 2 per ReLU; these two entry points are
+ * the whole group in one launch each.
+ *   hf_chan_affine    : t   = a*(w*rstd) + xhat*q + r + add      (a,q,r,add,w nullable)
+ *                       out = relu_self ? max(t,0) : mask_src ? (mask_src>0 ? t : 0) : t
+ *   hf_chan_affine_bwd: g = mask_src ? gy*(mask_src>0) : gy ;
+ *                       gx = g*w*rstd, gw = sum_{n,hw} g*xhat, gb = sum g, gres = g
+ *                       (gx, gw, gb, gres nullable)
  */
 int hf_chan_affine(void* out, const void* a, const void* x, const void* mean,
                    const void* rstd, const void* w, const void* q, const void* r,
-                   int64_t n, int64_t c, int64_t hw, int dtype, void* stream);
-int hf_chan_affine_bwd(void* gx, void* gw, void* gb, const void* gy, const void* x,
-                       const void* mean, const void* rstd, const void* w, int64_t n,
-                       int64_t c, int64_t hw, int dtype, void* stream);
+                   const void* add, const void* mask_src, int relu_self, int64_t n,
+                   int64_t c, int64_t hw, int dtype, void* stream);
+int hf_chan_affine_bwd(void* gx, void* gw, void* gb, void* gres, const void* gy,
+                       const void* x, const void* mean, const void* rstd, const void* w,
+                       const void* mask_src, int64_t n, int64_t c, int64_t hw, int dtype,
+                       void* stream);
 
 /* ---- RCCL (resolved at run time from the already-loaded librccl) ----------- */
 typedef struct hf_comm hf_comm_t;

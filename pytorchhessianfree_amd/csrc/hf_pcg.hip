@@ -618,24 +618,25 @@ __global__ __launch_bounds__(BLOCK) void k_axpy_out(T* out, const T* a, const T*
 }
 
 // ---------------------------------------------------------------------------
-// eval-mode BatchNorm as a per-channel affine map, fused (curvature-product path)
-//   xhat = (x - mean[c]) * rstd[c]
-//   k_chan_affine     : out = a*(w[c]*rstd[c]) + xhat*q[c] + r[c]   (each term optional)
-//       forward  y = xhat*w + b          (a = null, q = w, r = b)
-//       tangent / transpose of the backward map  (a = v_gx, q = v_gw, r = v_gb)
-//   k_chan_affine_bwd : gx = gy*w[c]*rstd[c] ; gw[c] = sum gy*xhat ; gb[c] = sum gy
+// eval-mode BatchNorm (+ residual add, + ReLU) as a per-channel affine map, fused
+// (curvature-product path).   xhat = (x - mean[c]) * rstd[c]
+//   k_chan_affine     : t = a*(w[c]*rstd[c]) + xhat*q[c] + r[c] + add   (each term optional)
+//                       out = relu_self ? max(t, 0) : (mask_src ? (mask_src > 0 ? t : 0) : t)
+//       forward  y = act(xhat*w + b + res)      (q = w, r = b, add = res, relu_self)
+//       tangent / transpose of the backward map (a = v_gx, q = v_gw, r = v_gb,
+//                                                add = v_gres, mask_src = y)
+//   k_chan_affine_bwd : g = mask_src ? gy*(mask_src > 0) : gy
+//                       gx = g*w[c]*rstd[c] ; gw[c] = sum g*xhat ; gb[c] = sum g ; gres = g
 // One launch each instead of the ~16 small ATen kernels autograd's generic
-// double-backward of batch_norm issues per layer and product.  NCHW-contiguous.
+// double-backward of batch_norm (+2 for the add, +2 for the ReLU) issues per layer
+// and product.  NCHW-contiguous.
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_chan_affine(T* __restrict__ out, const T* __restrict__ a,
-                                                       const T* __restrict__ x,
-                                                       const T* __restrict__ mean,
-                                                       const T* __restrict__ rstd,
-                                                       const T* __restrict__ w,
-                                                       const T* __restrict__ q,
-                                                       const T* __restrict__ r, long long total,
-                                                       long long C, long long HW) {
+__global__ __launch_bounds__(BLOCK) void k_chan_affine(
+    T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ x,
+    const T* __restrict__ mean, const T* __restrict__ rstd, const T* __restrict__ w,
+    const T* __restrict__ q, const T* __restrict__ r, const T* __restrict__ add,
+    const T* __restrict__ mask_src, int relu_self, long long total, long long C, long long HW) {
   for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < total;
        i += (long long)gridDim.x * BLOCK) {
     const long long c = (i / HW) % C;
@@ -644,19 +645,19 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine(T* __restrict__ out, cons
     if (a) acc = a[i] * ((w ? w[c] : (T)1) * rs);
     if (q) acc += ((x[i] - mean[c]) * rs) * q[c];
     if (r) acc += r[c];
+    if (add) acc += add[i];
+    if (relu_self) acc = acc > (T)0 ? acc : (T)0;
+    else if (mask_src) acc = mask_src[i] > (T)0 ? acc : (T)0;
     out[i] = acc;
   }
 }
 
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(T* __restrict__ gx, T* __restrict__ gw,
-                                                           T* __restrict__ gb,
-                                                           const T* __restrict__ gy,
-                                                           const T* __restrict__ x,
-                                                           const T* __restrict__ mean,
-                                                           const T* __restrict__ rstd,
-                                                           const T* __restrict__ w, long long N,
-                                                           long long C, long long HW) {
+__global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
+    T* __restrict__ gx, T* __restrict__ gw, T* __restrict__ gb, T* __restrict__ gres,
+    const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ mean,
+    const T* __restrict__ rstd, const T* __restrict__ w, const T* __restrict__ mask_src,
+    long long N, long long C, long long HW) {
   __shared__ double lds[2 * WAVES];
   const long long c = blockIdx.x;
   const T rs = rstd[c], mu = mean[c];
@@ -666,8 +667,10 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(T* __restrict__ gx, T
   for (long long e = threadIdx.x; e < per; e += BLOCK) {
     const long long n = e / HW, i = e - n * HW;
     const long long idx = (n * C + c) * HW + i;
-    const T g = gy[idx];
+    T g = gy[idx];
+    if (mask_src) g = mask_src[idx] > (T)0 ? g : (T)0;
     if (gx) gx[idx] = g * s;
+    if (gres) gres[idx] = g;
     acc[0] += (double)g * (double)(T)((x[idx] - mu) * rs);
     acc[1] += (double)g;
   }
@@ -1172,7 +1175,8 @@ int hf_axpy_out(void* out, const void* a, const void* sv, double alpha, int64_t 
 }
 
 int hf_chan_affine(void* out, const void* a, const void* x, const void* mean, const void* rstd,
-                   const void* w, const void* q, const void* r, int64_t n, int64_t c, int64_t hw,
+                   const void* w, const void* q, const void* r, const void* add,
+                   const void* mask_src, int relu_self, int64_t n, int64_t c, int64_t hw,
                    int dtype, void* stream) {
   if (!out || !rstd || n <= 0 || c <= 0 || hw <= 0) return HF_ERR_ARG;
   if (q && (!x || !mean)) return HF_ERR_ARG;
@@ -1182,33 +1186,36 @@ int hf_chan_affine(void* out, const void* a, const void* x, const void* mean, co
     hipLaunchKernelGGL((k_chan_affine<float>), dim3(small_grid(total)), dim3(BLOCK), 0, s,
                        (float*)out, (const float*)a, (const float*)x, (const float*)mean,
                        (const float*)rstd, (const float*)w, (const float*)q, (const float*)r,
-                       total, (long long)c, (long long)hw);
+                       (const float*)add, (const float*)mask_src, relu_self, total, (long long)c,
+                       (long long)hw);
   else if (dtype == HF_F64)
     hipLaunchKernelGGL((k_chan_affine<double>), dim3(small_grid(total)), dim3(BLOCK), 0, s,
                        (double*)out, (const double*)a, (const double*)x, (const double*)mean,
                        (const double*)rstd, (const double*)w, (const double*)q, (const double*)r,
-                       total, (long long)c, (long long)hw);
+                       (const double*)add, (const double*)mask_src, relu_self, total,
+                       (long long)c, (long long)hw);
   else
     return HF_ERR_ARG;
   HF_HIP(hipGetLastError());
   return HF_OK;
 }
 
-int hf_chan_affine_bwd(void* gx, void* gw, void* gb, const void* gy, const void* x,
-                       const void* mean, const void* rstd, const void* w, int64_t n, int64_t c,
-                       int64_t hw, int dtype, void* stream) {
+int hf_chan_affine_bwd(void* gx, void* gw, void* gb, void* gres, const void* gy, const void* x,
+                       const void* mean, const void* rstd, const void* w, const void* mask_src,
+                       int64_t n, int64_t c, int64_t hw, int dtype, void* stream) {
   if (!gy || !x || !mean || !rstd || n <= 0 || c <= 0 || hw <= 0) return HF_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == HF_F32)
     hipLaunchKernelGGL((k_chan_affine_bwd<float>), dim3((unsigned)c), dim3(BLOCK), 0, s, (float*)gx,
-                       (float*)gw, (float*)gb, (const float*)gy, (const float*)x,
-                       (const float*)mean, (const float*)rstd, (const float*)w, (long long)n,
-                       (long long)c, (long long)hw);
+                       (float*)gw, (float*)gb, (float*)gres, (const float*)gy, (const float*)x,
+                       (const float*)mean, (const float*)rstd, (const float*)w,
+                       (const float*)mask_src, (long long)n, (long long)c, (long long)hw);
   else if (dtype == HF_F64)
     hipLaunchKernelGGL((k_chan_affine_bwd<double>), dim3((unsigned)c), dim3(BLOCK), 0, s,
-                       (double*)gx, (double*)gw, (double*)gb, (const double*)gy, (const double*)x,
-                       (const double*)mean, (const double*)rstd, (const double*)w, (long long)n,
-                       (long long)c, (long long)hw);
+                       (double*)gx, (double*)gw, (double*)gb, (double*)gres, (const double*)gy,
+                       (const double*)x, (const double*)mean, (const double*)rstd,
+                       (const double*)w, (const double*)mask_src, (long long)n, (long long)c,
+                       (long long)hw);
   else
     return HF_ERR_ARG;
   HF_HIP(hipGetLastError());

@@ -53,92 +53,170 @@ def _p(t):
     return _lib.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _affine(a, x, mean, rstd, w, q, r, like):
-    """out = a*(w*rstd) + xhat*q + r (nullable terms), one launch."""
+def _affine(a, x, mean, rstd, w, q, r, like, add=None, mask_src=None, relu_self=False):
+    """out = act(a*(w*rstd) + xhat*q + r + add) (nullable terms), one launch."""
     out = torch.empty_like(like, memory_format=torch.contiguous_format)
     n, c, hw = _dims(like)
     _lib.check(
         _lib.load().hf_chan_affine(
-            _p(out), _p(a), _p(x), _p(mean), _p(rstd), _p(w), _p(q), _p(r), n, c, hw,
-            _lib.dtype_code(like.dtype), _lib.current_stream_ptr(like.device)),
+            _p(out), _p(a), _p(x), _p(mean), _p(rstd), _p(w), _p(q), _p(r), _p(add), _p(mask_src),
+            1 if relu_self else 0, n, c, hw, _lib.dtype_code(like.dtype),
+            _lib.current_stream_ptr(like.device)),
         "hf_chan_affine")
     return out
 
 
-def _affine_bwd(gy, x, mean, rstd, w, need_gx=True):
+def _affine_bwd(gy, x, mean, rstd, w, mask_src=None, need_gres=False):
     n, c, hw = _dims(x)
-    gx = torch.empty_like(x, memory_format=torch.contiguous_format) if need_gx else None
+    gx = torch.empty_like(x, memory_format=torch.contiguous_format)
+    gres = torch.empty_like(x, memory_format=torch.contiguous_format) if need_gres else None
     gw = torch.empty(c, dtype=x.dtype, device=x.device)
     gb = torch.empty(c, dtype=x.dtype, device=x.device)
     _lib.check(
         _lib.load().hf_chan_affine_bwd(
-            _p(gx), _p(gw), _p(gb), _p(gy), _p(x), _p(mean), _p(rstd), _p(w), n, c, hw,
-            _lib.dtype_code(x.dtype), _lib.current_stream_ptr(x.device)),
+            _p(gx), _p(gw), _p(gb), _p(gres), _p(gy), _p(x), _p(mean), _p(rstd), _p(w),
+            _p(mask_src), n, c, hw, _lib.dtype_code(x.dtype), _lib.current_stream_ptr(x.device)),
         "hf_chan_affine_bwd")
-    return gx, gw, gb
+    return gx, gw, gb, gres
 
 
 def _bshape(x):
     return [1, -1] + [1] * (x.dim() - 2)
 
 
+def _c(t):
+    return t.contiguous() if t is not None else None
+
+
 class _ChanAffineBwd(torch.autograd.Function):
-    """(gy; x, w) -> (gx, gw, gb).  Linear in gy; its transpose is ``_affine``."""
+    """(gy; x, w, y) -> (gx, gw, gb, gres) with g = gy * [y > 0] when the layer ends in
+    a ReLU.  Linear in gy; its transpose is one ``_affine`` launch."""
 
     @staticmethod
-    def forward(ctx, gy, x, w, mean, rstd):
+    def forward(ctx, gy, x, w, mean, rstd, y, has_res):
         gy = gy.contiguous()
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(gy, x, w, mean, rstd)
-        return _affine_bwd(gy, x, mean, rstd, w)
+        ctx.save_for_backward(gy, x, w, mean, rstd, y)
+        ctx.has_res = has_res
+        gx, gw, gb, gres = _affine_bwd(gy, x, mean, rstd, w, mask_src=y,
+                                       need_gres=has_res and y is not None)
+        if has_res and gres is None:
+            gres = gy  # no ReLU: the residual branch receives the cotangent itself
+        return gx, gw, gb, gres
 
     @staticmethod
-    def backward(ctx, vgx, vgw, vgb):
-        gy, x, w, mean, rstd = ctx.saved_tensors
-        if vgx is None and vgw is None and vgb is None:
-            return None, None, None, None, None
+    def backward(ctx, vgx, vgw, vgb, vgres):
+        gy, x, w, mean, rstd, y = ctx.saved_tensors
+        if vgx is None and vgw is None and vgb is None and vgres is None:
+            return (None,) * 7
         # d/d gy : one fused launch (this is the layer's tangent map)
-        v_gy = _affine(vgx.contiguous() if vgx is not None else None, x, mean, rstd, w,
-                       vgw.contiguous() if vgw is not None else None,
-                       vgb.contiguous() if vgb is not None else None, like=x)
+        v_gy = _affine(_c(vgx), x, mean, rstd, w, _c(vgw), _c(vgb), like=x, add=_c(vgres),
+                       mask_src=y)
         v_x = v_w = None
-        # second-order terms, only for Hessian products (plain ATen, rare path)
-        if ctx.needs_input_grad[1] and vgw is not None:
-            v_x = gy * (vgw * rstd).view(_bshape(x))
-        if ctx.needs_input_grad[2] and vgx is not None:
-            red = [d for d in range(x.dim()) if d != 1]
-            v_w = (vgx * gy).sum(red) * rstd
-        return v_gy, v_x, v_w, None, None
+        # second-order terms, only for Hessian products (plain ATen, rare path);
+        # the ReLU mask is piecewise constant, so it only gates the cotangent
+        if (ctx.needs_input_grad[1] and vgw is not None) or (ctx.needs_input_grad[2] and vgx is not None):
+            g = gy if y is None else gy * (y > 0)
+            if ctx.needs_input_grad[1] and vgw is not None:
+                v_x = g * (vgw * rstd).view(_bshape(x))
+            if ctx.needs_input_grad[2] and vgx is not None:
+                red = [d for d in range(x.dim()) if d != 1]
+                v_w = (vgx * g).sum(red) * rstd
+        return v_gy, v_x, v_w, None, None, None, None
 
 
 class _ChanAffine(torch.autograd.Function):
-    """y = xhat * w + b with fixed statistics."""
+    """y = act(xhat * w + b + res) with fixed statistics; act = ReLU or identity."""
 
     @staticmethod
-    def forward(ctx, x, w, b, mean, rstd):
+    def forward(ctx, x, w, b, mean, rstd, res, relu):
         x = x.contiguous()
-        ctx.save_for_backward(x, w, mean, rstd)
-        return _affine(None, x, mean, rstd, None, w, b, like=x)
+        res = _c(res)
+        y = _affine(None, x, mean, rstd, None, w, b, like=x, add=res, relu_self=relu)
+        ctx.save_for_backward(x, w, mean, rstd, y if relu else None)
+        ctx.has_res = res is not None
+        return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w, mean, rstd = ctx.saved_tensors
+        x, w, mean, rstd, y = ctx.saved_tensors
         if _Mode.first_order_only:
             x, w = x.detach(), w.detach()
-        gx, gw, gb = _ChanAffineBwd.apply(gy, x, w, mean, rstd)
-        return gx, gw, gb, None, None
+        gx, gw, gb, gres = _ChanAffineBwd.apply(gy, x, w, mean, rstd, y, ctx.has_res)
+        return gx, gw, gb, None, None, gres, None
+
+
+def _bn_usable(bn, x):
+    return (
+        isinstance(bn, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d))
+        and not bn.training and bn.track_running_stats and bn.running_var is not None
+        and x.is_cuda and bn.weight is not None and bn.bias is not None
+        and x.dtype in (torch.float32, torch.float64) and x.dim() >= 2
+    )
+
+
+def fused_bn_act(bn, x, res=None, relu=False):
+    """``act(bn(x) + res)`` -- one HIP launch per pass when ``bn`` is an eval-mode
+    BatchNorm on a GPU tensor, the stock ops otherwise."""
+    if not _bn_usable(bn, x):
+        fwd = getattr(bn, "_hf_stock_forward", None) or bn.forward
+        y = fwd(x)
+        if res is not None:
+            y = y + res
+        return torch.relu(y) if relu else y
+    rstd = torch.rsqrt(bn.running_var + bn.eps)
+    return _ChanAffine.apply(x, bn.weight, bn.bias, bn.running_mean, rstd, res, relu)
 
 
 def _fused_forward(self, x):
-    usable = (
-        not self.training and self.track_running_stats and self.running_var is not None
-        and x.is_cuda and self.weight is not None and self.bias is not None
-        and x.dtype in (torch.float32, torch.float64) and x.dim() >= 2
+    return fused_bn_act(self, x)
+
+
+# ------------------------------------------------------------------------------------
+# residual blocks: BN + ReLU and BN + identity + ReLU as one layer each
+# ------------------------------------------------------------------------------------
+def _basic_block_forward(self, x):
+    idt = x if self.downsample is None else self.downsample(x)
+    out = fused_bn_act(self.bn1, self.conv1(x), relu=True)
+    return fused_bn_act(self.bn2, self.conv2(out), res=idt, relu=True)
+
+
+def _bottleneck_forward(self, x):
+    idt = x if self.downsample is None else self.downsample(x)
+    out = fused_bn_act(self.bn1, self.conv1(x), relu=True)
+    out = fused_bn_act(self.bn2, self.conv2(out), relu=True)
+    return fused_bn_act(self.bn3, self.conv3(out), res=idt, relu=True)
+
+
+def _looks_like(block, convs):
+    names = [f"conv{i}" for i in range(1, convs + 1)] + [f"bn{i}" for i in range(1, convs + 1)]
+    return (
+        all(isinstance(getattr(block, n, None), nn.Module) for n in names)
+        and not hasattr(block, f"conv{convs + 1}") and hasattr(block, "downsample")
+        and isinstance(getattr(block, "relu", None), nn.ReLU)
     )
-    if not usable:
-        return self._hf_stock_forward(x)
-    rstd = torch.rsqrt(self.running_var + self.eps)
-    return _ChanAffine.apply(x, self.weight, self.bias, self.running_mean, rstd)
+
+
+def fuse_residual_blocks(model):
+    """Patch ResNet ``BasicBlock`` / ``Bottleneck`` modules (torchvision's or any module
+    with the same attributes ``conv1..k, bn1..k, relu, downsample`` and the standard
+    forward) so that ``relu(bn(.))`` and ``relu(bn(.) + identity)`` are single fused
+    layers in every pass of the curvature product.  Recognition is by attribute
+    structure, not by tracing; anything else is left alone.  Returns the number of
+    blocks patched."""
+    count = 0
+    for m in model.modules():
+        if hasattr(m, "_hf_block_patched"):
+            continue
+        if _looks_like(m, 2):
+            m.forward = types.MethodType(_basic_block_forward, m)
+        elif _looks_like(m, 3):
+            m.forward = types.MethodType(_bottleneck_forward, m)
+        else:
+            continue
+        m._hf_block_patched = True
+        count += 1
+    return count
 
 
 # ------------------------------------------------------------------------------------
@@ -229,6 +307,7 @@ def prepare_model(model):
     """All opt-in preparations; returns ``model`` for chaining."""
     fuse_eval_batchnorm(model)
     fuse_conv_tangent(model)
+    fuse_residual_blocks(model)
     return model
 
 

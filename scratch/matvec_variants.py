@@ -8,6 +8,7 @@ if len(sys.argv) > 1:
     m, (x, t), lf = tp.resnet18_mnist(batch_size=32, device="cuda", data_seed=1000)
     if "bn" in variant: print("fused", modelprep.fuse_eval_batchnorm(m))
     if "conv" in variant: print("fusedconv", modelprep.fuse_conv_tangent(m))
+    if "blk" in variant: print("fusedblk", modelprep.fuse_residual_blocks(m))
     if "cl" in variant:
         m = m.to(memory_format=torch.channels_last); x = x.contiguous(memory_format=torch.channels_last)
     ps = [p for p in m.parameters()]
@@ -29,8 +30,8 @@ if len(sys.argv) > 1:
 else:
     db = os.path.join(os.getcwd(), "gpurun_out", "miopen_db2"); os.makedirs(db, exist_ok=True)
     import shutil
-    for f in os.listdir("profiles/miopen_db"): shutil.copy(os.path.join("profiles/miopen_db", f), db)
-    for var, envx in [("bn_conv_bench", {}), ("bn_conv_bench_nowino", {"MIOPEN_DEBUG_CONV_WINOGRAD": "0"}), ("bn_conv_bench_nowino2", {"MIOPEN_DEBUG_CONV_WINOGRAD": "0"})]:
+    for f in os.listdir("pytorchhessianfree_amd/miopen_db"): shutil.copy(os.path.join("pytorchhessianfree_amd/miopen_db", f), db)
+    for var, envx in [("bn_conv_bench", {}), ("bn_conv_blk_bench", {})]:
         env = dict(os.environ, MIOPEN_USER_DB_PATH=db); env.update(envx)
         t0 = time.time()
         p = subprocess.run([sys.executable, __file__, var], capture_output=True, text=True, env=env)

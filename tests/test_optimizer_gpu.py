@@ -233,8 +233,9 @@ def _cpu_twin(make, **kw):
     return model, x, t, lossf
 
 
+@pytest.mark.parametrize("prepared", [False, True])
 @pytest.mark.parametrize("workload", ["resnet18", "allcnnc"])
-def test_curvature_products_on_conv_nets_match_cpu_oracle(workload):
+def test_curvature_products_on_conv_nets_match_cpu_oracle(workload, prepared):
     """GGN and Hessian products of the ResNet-18 / All-CNN-C shaped nets on the GPU
     (eager and hipGraph replay) against the oracle's BackPACK restatement on CPU.
     With MIOpen's Winograd solvers off (package default, see __init__) the products
@@ -255,6 +256,10 @@ def test_curvature_products_on_conv_nets_match_cpu_oracle(workload):
         loss, params, vector_to_parameter_list(v, params))])
 
     gmodel, (gx, gt), _ = make(batch_size=8, device=DEV)
+    if prepared:  # fused eval-BN(+add+ReLU) kernels, single-convolution tangent maps
+        from pytorchhessianfree_amd import modelprep
+
+        modelprep.prepare_model(gmodel)
     gparams = [p for p in gmodel.parameters()]
 
     def builder():
