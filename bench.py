@@ -111,8 +111,9 @@ def cpu_baseline(args):
     t0 = time.perf_counter()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
+        # same stopping rule as the GPU's timed region: exactly cpu_iters iterations
         xs, _, _ = oracle.pcg(lambda v: mvp(v) + lam * v, -grad, max_iter=args.cpu_iters, tol=0.0,
-                              martens_conv_crit=True, store_x_at_iters=None)
+                              martens_conv_crit=False, store_x_at_iters=[0])
     dt = time.perf_counter() - t0
     return {
         "value": calls[0] / dt,
