@@ -543,3 +543,44 @@ def test_overlapped_two_graph_product_equals_single_graph():
     del two
     one = curvature.GraphedOperator(builder, params=ps)
     assert float((one(v) - a).abs().max() / ref.abs().max()) < 1e-5
+
+
+def test_step_with_rccl_process_group_single_rank():
+    """The data-parallel code path of HessianFree.step on the real backend ("nccl" =
+    RCCL) with a 1-rank group: weighted all-reduce of loss / gradient / every
+    product, lockstep stop rule, hipGraph capture while the group exists.  With one
+    rank the results must equal the plain single-process run."""
+    import socket
+
+    import torch.distributed as dist
+    from pytorchhessianfree_amd import modelprep
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os_env = __import__("os").environ
+    os_env["MASTER_ADDR"], os_env["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        runs = {}
+        for name, kw in [("plain", {}), ("dp", dict(process_group=dist.group.WORLD)),
+                         ("dp_graph", dict(process_group=dist.group.WORLD, graph_matvec=True))]:
+            model, (x, t), lossf = tp.resnet18_mnist(batch_size=8, device=DEV)
+            modelprep.prepare_model(model)
+
+            def forward():
+                out = model(x)
+                return lossf(out, t), out
+
+            opt = hf.HessianFree(model.parameters(), cg_max_iter=15, **kw)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                final = opt.step(forward)
+            runs[name] = (opt.state["init_losses"][0], final, opt.state["num_cg_iters"][0],
+                          opt.state["cg_reasons"][0])
+        for name in ("dp", "dp_graph"):
+            assert runs[name][2:] == runs["plain"][2:]
+            assert abs(runs[name][0] - runs["plain"][0]) < 1e-6
+            assert abs(runs[name][1] - runs["plain"][1]) < 1e-3 * abs(runs["plain"][1])
+    finally:
+        dist.destroy_process_group()
