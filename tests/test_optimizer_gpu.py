@@ -77,14 +77,16 @@ def test_step_trace_run_mwe(graph):
     check_state(opt, g, "state/", 5)
 
 
+@pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("curv", ["ggn", "hessian"])
 @pytest.mark.parametrize("seed", [0, 1, 42])
-def test_step_trace_small_nn(curv, seed):
+def test_step_trace_small_nn(curv, seed, graph):
     g = load_golden("step_smallnn.npz")
     key = f"{curv}_s{seed}"
     model = small_nn(g, key, DEV)
     lossf = torch.nn.MSELoss()
-    opt = hf.HessianFree(model.parameters(), curvature_opt=curv, damping=float(g[key + "/damping"]))
+    opt = hf.HessianFree(model.parameters(), curvature_opt=curv, damping=float(g[key + "/damping"]),
+                         graph_matvec=graph)
     for s in range(3):
         inputs, targets = T(g[f"{key}/inputs/{s}"], DEV), T(g[f"{key}/targets/{s}"], DEV)
 
