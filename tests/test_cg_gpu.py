@@ -504,3 +504,51 @@ def test_c_abi_rejects_misuse_on_device():
     assert lib.hf_pack(P(x), None, None, 1, 1.0, 0, 0, s) == -1
     assert lib.hf_axpy_out(P(x), P(x), None, 1.0, n, 0, s) == -1
     assert lib.hf_precond_build(P(x), P(b), 0.1, 0.75, n, 7, s) == -1
+
+
+def test_randomised_configurations_match_kernel_arithmetic_oracle():
+    """200 random combinations of length (incl. 1..5, block-tile edges), preconditioner
+    mode (none / fused diagonal / generic callable), warm start, Martens on/off,
+    max_iter, snapshot request, damping, tol/atol -- fp32, against the oracle in the
+    kernels' reduction arithmetic: same reason, same iteration count, same None
+    pattern, iterates 3e-5, m_k 1e-4.  (float64 runs agree to 1e-15 initially and then
+    separate like any two float64 CG runs -- scratch/fuzz_one.py -- so they are not
+    part of this bitwise-style check.)"""
+    import random
+
+    product, oracle = _product(), _oracle()
+    rnd = random.Random(1234)
+    for case in range(200):
+        n = rnd.choice([1, 2, 3, 4, 5, 7, 63, 64, 65, 255, 256, 257, 511, 1000, 1023, 1025, 4097, 20011])
+        mode = rnd.choice(["none", "diag", "ext"])
+        warm, martens = rnd.random() < 0.5, rnd.random() < 0.6
+        max_iter = rnd.choice([1, 2, 5, 17, 60])
+        store = rnd.choice([[], [0], None, list(range(0, 61, 3)), [0, 1, 2, 1000]])
+        lam, tol, atol = rnd.choice([0.0, 0.3, 2.0]), rnd.choice([0.0, 1e-5, 1e-2]), rnd.choice([None, 1e-6])
+        g = torch.Generator().manual_seed(case)
+        d = torch.rand(n, generator=g) * 10 + 0.05
+        b = torch.randn(n, generator=g)
+        x0 = torch.randn(n, generator=g) if warm else None
+        diag = torch.rand(n, generator=g)
+        dd = d.to(DEV)
+        Mg = product.DiagonalPreconditioner(diag.to(DEV), lam if lam else 0.1) if mode != "none" else None
+        minv = Mg.minv.cpu() if Mg is not None else None
+        Mc = (lambda v: minv * v) if mode != "none" else None
+        Mgg = Mg if mode == "diag" else ((lambda v: Mg.minv * v) if mode == "ext" else None)
+        kw = dict(max_iter=max_iter, tol=tol, atol=atol, martens_conv_crit=martens, store_x_at_iters=store)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ox, om, orr = oracle.pcg(lambda v: (d.double() * v.double()).float() + lam * v, b, x0=x0,
+                                     M=Mc, accumulate="fp64", **kw)
+            gx, gm, grr = product.cg(
+                product.DampedCurvature(lambda v: (dd.double() * v.double()).float(), lam), b.to(DEV),
+                x0=None if x0 is None else x0.to(DEV), M=Mgg, **kw)
+        tag = (case, n, mode, warm, martens, max_iter, lam, tol, atol)
+        assert orr == grr and len(ox) == len(gx), tag
+        for a, o in zip(gx, ox):
+            assert (a is None) == (o is None), tag
+            if a is not None and np.isfinite(float(o.abs().max())):
+                assert _maxrel(a.cpu().numpy(), o.numpy()) < 3e-5, tag
+        if martens:
+            np.testing.assert_allclose(np.array([float(m) for m in gm]), np.array([float(m) for m in om]),
+                                       rtol=1e-4, atol=1e-6, equal_nan=True, err_msg=str(tag))
