@@ -92,6 +92,12 @@ class ParameterArena:
         roundings, as ``params_vec + lr * step_vec`` in optimizer.py:349)."""
         if self.theta.is_cuda:
             _lib.axpy_out(self.theta, base, step, alpha)
+            # the kernel wrote behind autograd's back: bump the parameters' version
+            # counters (``p.data = view`` keeps each parameter's own counter) so that
+            # a stale graph that saved the old weights fails loudly in backward
+            # instead of silently using the new ones
+            for p in self.params:
+                torch.autograd.graph.increment_version(p)
         else:
             with torch.no_grad():
                 torch.add(base, alpha * step if alpha != 1.0 else step, out=self.theta)

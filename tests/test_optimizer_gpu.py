@@ -586,3 +586,15 @@ def test_step_with_rccl_process_group_single_rank():
             assert abs(runs[name][1] - runs["plain"][1]) < 1e-3 * abs(runs["plain"][1])
     finally:
         dist.destroy_process_group()
+
+
+def test_stale_graph_fails_loudly_after_in_place_parameter_write():
+    """ParameterArena.write runs a raw HIP kernel on the parameters' storage; the
+    version counter is bumped so that autograd notices."""
+    lin = torch.nn.Linear(4, 3).to(DEV)
+    arena = ParameterArena(lin.parameters())
+    x = torch.rand(2, 4, device=DEV, requires_grad=True)  # weight is saved for d/dx
+    loss = lin(x).square().sum()
+    arena.write(arena.snapshot(), torch.ones(arena.n, device=DEV), 0.1)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss.backward()
