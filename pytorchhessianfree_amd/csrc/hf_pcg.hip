@@ -631,15 +631,16 @@ __global__ __launch_bounds__(BLOCK) void k_axpy_out(T* out, const T* a, const T*
 // double-backward of batch_norm (+2 for the add, +2 for the ReLU) issues per layer
 // and product.  NCHW-contiguous.
 // ---------------------------------------------------------------------------
-template <typename T>
+// I = unsigned (tensors < 2^31 elements: 32-bit index arithmetic, the per-element
+// division is what these tiny kernels spend their time on) or long long.
+template <typename T, typename I>
 __global__ __launch_bounds__(BLOCK) void k_chan_affine(
     T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ x,
     const T* __restrict__ mean, const T* __restrict__ rstd, const T* __restrict__ w,
     const T* __restrict__ q, const T* __restrict__ r, const T* __restrict__ add,
-    const T* __restrict__ mask_src, int relu_self, long long total, long long C, long long HW) {
-  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < total;
-       i += (long long)gridDim.x * BLOCK) {
-    const long long c = (i / HW) % C;
+    const T* __restrict__ mask_src, int relu_self, I total, I C, I HW) {
+  for (I i = (I)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (I)gridDim.x * BLOCK) {
+    const I c = (HW == 1 ? i : i / HW) % C;
     const T rs = rstd[c];
     T acc = (T)0;
     if (a) acc = a[i] * ((w ? w[c] : (T)1) * rs);
@@ -652,30 +653,46 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine(
   }
 }
 
-template <typename T>
+// One channel per GROUP of TPC threads (TPC = 64: one wave per channel, 4 channels
+// per block, no LDS / barrier -- for the late layers where a channel has only
+// N*HW <= 256 elements; TPC = 256: one block per channel).
+template <typename T, typename I, int TPC>
 __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
     T* __restrict__ gx, T* __restrict__ gw, T* __restrict__ gb, T* __restrict__ gres,
     const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ mean,
-    const T* __restrict__ rstd, const T* __restrict__ w, const T* __restrict__ mask_src,
-    long long N, long long C, long long HW) {
+    const T* __restrict__ rstd, const T* __restrict__ w, const T* __restrict__ mask_src, I N,
+    I C, I HW) {
   __shared__ double lds[2 * WAVES];
-  const long long c = blockIdx.x;
-  const T rs = rstd[c], mu = mean[c];
-  const T s = (w ? w[c] : (T)1) * rs;
+  constexpr int GROUPS = BLOCK / TPC;
+  const I c = (I)blockIdx.x * GROUPS + threadIdx.x / TPC;
+  const int lane = threadIdx.x % TPC;
+  const bool live = c < C;
   double acc[2] = {0.0, 0.0};
-  const long long per = N * HW;
-  for (long long e = threadIdx.x; e < per; e += BLOCK) {
-    const long long n = e / HW, i = e - n * HW;
-    const long long idx = (n * C + c) * HW + i;
-    T g = gy[idx];
-    if (mask_src) g = mask_src[idx] > (T)0 ? g : (T)0;
-    if (gx) gx[idx] = g * s;
-    if (gres) gres[idx] = g;
-    acc[0] += (double)g * (double)(T)((x[idx] - mu) * rs);
-    acc[1] += (double)g;
+  if (live) {
+    const T rs = rstd[c], mu = mean[c];
+    const T s = (w ? w[c] : (T)1) * rs;
+    const I per = N * HW;
+    for (I e = lane; e < per; e += TPC) {
+      const I n = HW == 1 ? e : e / HW;
+      const I idx = (n * C + c) * HW + (e - n * HW);
+      T g = gy[idx];
+      if (mask_src) g = mask_src[idx] > (T)0 ? g : (T)0;
+      if (gx) gx[idx] = g * s;
+      if (gres) gres[idx] = g;
+      acc[0] += (double)g * (double)(T)((x[idx] - mu) * rs);
+      acc[1] += (double)g;
+    }
   }
-  block_allreduce<2>(acc, lds);
-  if (threadIdx.x == 0) {
+  if (TPC == 64) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      acc[0] += __shfl_down(acc[0], off, 64);
+      acc[1] += __shfl_down(acc[1], off, 64);
+    }
+  } else {
+    block_allreduce<2>(acc, lds);
+  }
+  if (live && lane == 0) {
     if (gw) gw[c] = (T)acc[0];
     if (gb) gb[c] = (T)acc[1];
   }
@@ -1174,6 +1191,23 @@ int hf_axpy_out(void* out, const void* a, const void* sv, double alpha, int64_t 
   return HF_OK;
 }
 
+template <typename T>
+static void launch_chan_affine(hipStream_t s, void* out, const void* a, const void* x,
+                               const void* mean, const void* rstd, const void* w, const void* q,
+                               const void* r, const void* add, const void* mask_src,
+                               int relu_self, long long total, long long c, long long hw) {
+  if (total < 0x7fffffffLL)
+    hipLaunchKernelGGL((k_chan_affine<T, unsigned>), dim3(small_grid(total)), dim3(BLOCK), 0, s,
+                       (T*)out, (const T*)a, (const T*)x, (const T*)mean, (const T*)rstd,
+                       (const T*)w, (const T*)q, (const T*)r, (const T*)add, (const T*)mask_src,
+                       relu_self, (unsigned)total, (unsigned)c, (unsigned)hw);
+  else
+    hipLaunchKernelGGL((k_chan_affine<T, long long>), dim3(small_grid(total)), dim3(BLOCK), 0, s,
+                       (T*)out, (const T*)a, (const T*)x, (const T*)mean, (const T*)rstd,
+                       (const T*)w, (const T*)q, (const T*)r, (const T*)add, (const T*)mask_src,
+                       relu_self, total, c, hw);
+}
+
 int hf_chan_affine(void* out, const void* a, const void* x, const void* mean, const void* rstd,
                    const void* w, const void* q, const void* r, const void* add,
                    const void* mask_src, int relu_self, int64_t n, int64_t c, int64_t hw,
@@ -1183,21 +1217,32 @@ int hf_chan_affine(void* out, const void* a, const void* x, const void* mean, co
   const long long total = (long long)n * c * hw;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == HF_F32)
-    hipLaunchKernelGGL((k_chan_affine<float>), dim3(small_grid(total)), dim3(BLOCK), 0, s,
-                       (float*)out, (const float*)a, (const float*)x, (const float*)mean,
-                       (const float*)rstd, (const float*)w, (const float*)q, (const float*)r,
-                       (const float*)add, (const float*)mask_src, relu_self, total, (long long)c,
-                       (long long)hw);
+    launch_chan_affine<float>(s, out, a, x, mean, rstd, w, q, r, add, mask_src, relu_self, total, c, hw);
   else if (dtype == HF_F64)
-    hipLaunchKernelGGL((k_chan_affine<double>), dim3(small_grid(total)), dim3(BLOCK), 0, s,
-                       (double*)out, (const double*)a, (const double*)x, (const double*)mean,
-                       (const double*)rstd, (const double*)w, (const double*)q, (const double*)r,
-                       (const double*)add, (const double*)mask_src, relu_self, total,
-                       (long long)c, (long long)hw);
+    launch_chan_affine<double>(s, out, a, x, mean, rstd, w, q, r, add, mask_src, relu_self, total, c, hw);
   else
     return HF_ERR_ARG;
   HF_HIP(hipGetLastError());
   return HF_OK;
+}
+
+template <typename T>
+static void launch_chan_affine_bwd(hipStream_t s, void* gx, void* gw, void* gb, void* gres,
+                                   const void* gy, const void* x, const void* mean,
+                                   const void* rstd, const void* w, const void* mask_src,
+                                   long long n, long long c, long long hw) {
+  const long long total = n * c * hw;
+  const bool small = n * hw <= 256;
+#define HF_BWD(I, TPC, GRID)                                                                    \
+  hipLaunchKernelGGL((k_chan_affine_bwd<T, I, TPC>), dim3((unsigned)(GRID)), dim3(BLOCK), 0, s,  \
+                     (T*)gx, (T*)gw, (T*)gb, (T*)gres, (const T*)gy, (const T*)x, (const T*)mean, \
+                     (const T*)rstd, (const T*)w, (const T*)mask_src, (I)n, (I)c, (I)hw)
+  if (total < 0x7fffffffLL) {
+    if (small) HF_BWD(unsigned, 64, (c + 3) / 4); else HF_BWD(unsigned, 256, c);
+  } else {
+    HF_BWD(long long, 256, c);
+  }
+#undef HF_BWD
 }
 
 int hf_chan_affine_bwd(void* gx, void* gw, void* gb, void* gres, const void* gy, const void* x,
@@ -1206,16 +1251,9 @@ int hf_chan_affine_bwd(void* gx, void* gw, void* gb, void* gres, const void* gy,
   if (!gy || !x || !mean || !rstd || n <= 0 || c <= 0 || hw <= 0) return HF_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == HF_F32)
-    hipLaunchKernelGGL((k_chan_affine_bwd<float>), dim3((unsigned)c), dim3(BLOCK), 0, s, (float*)gx,
-                       (float*)gw, (float*)gb, (float*)gres, (const float*)gy, (const float*)x,
-                       (const float*)mean, (const float*)rstd, (const float*)w,
-                       (const float*)mask_src, (long long)n, (long long)c, (long long)hw);
+    launch_chan_affine_bwd<float>(s, gx, gw, gb, gres, gy, x, mean, rstd, w, mask_src, n, c, hw);
   else if (dtype == HF_F64)
-    hipLaunchKernelGGL((k_chan_affine_bwd<double>), dim3((unsigned)c), dim3(BLOCK), 0, s,
-                       (double*)gx, (double*)gw, (double*)gb, (double*)gres, (const double*)gy,
-                       (const double*)x, (const double*)mean, (const double*)rstd,
-                       (const double*)w, (const double*)mask_src, (long long)n, (long long)c,
-                       (long long)hw);
+    launch_chan_affine_bwd<double>(s, gx, gw, gb, gres, gy, x, mean, rstd, w, mask_src, n, c, hw);
   else
     return HF_ERR_ARG;
   HF_HIP(hipGetLastError());
