@@ -51,6 +51,9 @@ def parse():
                     help="modelprep.fuse_eval_batchnorm: eval-mode BN as one fused HIP kernel per pass")
     ap.add_argument("--fuse-conv", type=int, default=1,
                     help="modelprep.fuse_conv_tangent: a conv layer's tangent map as ONE convolution")
+    ap.add_argument("--channels-last", type=int, default=0,
+                    help="run the conv layers in NHWC (fewer MIOpen kernels; see modelprep.prepare_model "
+                         "for why this is not the default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--overlap", type=int, default=0,
                     help="data parallel: split the product into two hipGraphs and overlap the "
@@ -144,7 +147,7 @@ def main():
     if args.fuse_bn:
         modelprep.fuse_eval_batchnorm(model)
     if args.fuse_conv:
-        modelprep.fuse_conv_tangent(model)
+        modelprep.fuse_conv_tangent(model, channels_last=bool(args.channels_last))
     if args.fuse_bn and args.fuse_conv:
         modelprep.fuse_residual_blocks(model)  # relu(bn(.)) / relu(bn(.) + identity) as one layer
     params = [p for p in model.parameters() if p.requires_grad]

@@ -140,9 +140,14 @@ int hf_pcg_timing_read(hf_pcg_t* h, double* ms_k1, double* ms_k2, double* ms_k3,
  * `srcs` / `numels` are HOST arrays; pointers are passed to the kernel by value.
  * src tensors must be contiguous; only 4-byte (8 for f64) alignment is needed.
  * mode 0: dst = scale*src ; mode 1: dst += (scale*src)^2 (preconditioners.py:98).
+ * `perm` (HOST, 2 per tensor, or NULL): {I, H*W} for a 4-D tensor [O, I, H, W] that is
+ * stored channels-last, i.e. as (O, H, W, I) -- what MIOpen's NHWC weight-gradient
+ * kernels produce; {0, 0} for plain contiguous.  The gather writes the reference's
+ * (O, I, H, W) order either way.
  */
 int hf_pack(void* dst, const void* const* srcs, const int64_t* numels,
-            int n_tensors, double scale, int mode, int dtype, void* stream);
+            const int64_t* perm, int n_tensors, double scale, int mode, int dtype,
+            void* stream);
 
 /* minv = (diag + damping)^(-exponent)   (preconditioners.py:124, hoisted out of
  * the CG loop). */
@@ -157,7 +162,8 @@ int hf_axpy_out(void* out, const void* a, const void* s, double alpha, int64_t n
 /* ---- eval-mode BatchNorm (+ residual add, + ReLU) inside the curvature product -- */
 /*
  * An eval-mode BatchNorm is y = xhat*w[c] + b[c], xhat = (x - mean[c])*rstd[c] on an
- * NCHW-contiguous [n, c, hw] tensor; ResNet blocks follow it by "+ identity" and/or
+ * [n, c, hw] tensor stored NCHW (channels_last = 0) or NHWC (channels_last = 1, the layout
+ * MIOpen's implicit-GEMM kernels run in without transposes); ResNet blocks follow it by "+ identity" and/or
  * ReLU.  PyTorch's generic double-backward of batch_norm (which BackPACK's R-op, and
  * ours, differentiates through on every GGN product, optimizer.py:461) issues ~16
  * small kernels per layer, plus 2 per add and 2 per ReLU; these two entry points are
@@ -171,11 +177,11 @@ int hf_axpy_out(void* out, const void* a, const void* s, double alpha, int64_t n
 int hf_chan_affine(void* out, const void* a, const void* x, const void* mean,
                    const void* rstd, const void* w, const void* q, const void* r,
                    const void* add, const void* mask_src, int relu_self, int64_t n,
-                   int64_t c, int64_t hw, int dtype, void* stream);
+                   int64_t c, int64_t hw, int channels_last, int dtype, void* stream);
 int hf_chan_affine_bwd(void* gx, void* gw, void* gb, void* gres, const void* gy,
                        const void* x, const void* mean, const void* rstd, const void* w,
-                       const void* mask_src, int64_t n, int64_t c, int64_t hw, int dtype,
-                       void* stream);
+                       const void* mask_src, int64_t n, int64_t c, int64_t hw,
+                       int channels_last, int dtype, void* stream);
 
 /* ---- RCCL (resolved at run time from the already-loaded librccl) ----------- */
 typedef struct hf_comm hf_comm_t;

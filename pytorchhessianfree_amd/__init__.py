@@ -20,6 +20,9 @@ if not _os.environ.get("HF_ALLOW_WINOGRAD"):
     _os.environ.setdefault(
         "MIOPEN_USER_DB_PATH", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
     )
+    # let PyTorch hand channels_last tensors to MIOpen as NHWC (modelprep's conv layers
+    # compute in NHWC; without this PyTorch converts them back to NCHW first)
+    _os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
     import torch as _torch
 
     _torch.backends.cudnn.benchmark = True

@@ -78,12 +78,13 @@ SIGNATURES = {
     ),
     "hf_pack": (
         c_int,
-        [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), c_int, c_double, c_int, c_int, c_void_p],
+        [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), c_int,
+         c_double, c_int, c_int, c_void_p],
     ),
     "hf_precond_build": (c_int, [c_void_p, c_void_p, c_double, c_double, c_int64, c_int, c_void_p]),
     "hf_axpy_out": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int, c_void_p]),
-    "hf_chan_affine": (c_int, [c_void_p] * 10 + [c_int, c_int64, c_int64, c_int64, c_int, c_void_p]),
-    "hf_chan_affine_bwd": (c_int, [c_void_p] * 10 + [c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "hf_chan_affine": (c_int, [c_void_p] * 10 + [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "hf_chan_affine_bwd": (c_int, [c_void_p] * 10 + [c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "hf_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "hf_comm_create": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_char_p, c_int, c_int]),
     "hf_comm_destroy": (c_int, [c_void_p]),
@@ -163,13 +164,18 @@ def pack(dst, tensors, scale=1.0, mode=0):
     n = len(tensors)
     ptrs = (c_void_p * n)()
     numels = (c_int64 * n)()
+    perm = (c_int64 * (2 * n))()
     keep = []
     total = 0
     for i, t in enumerate(tensors):
         if t.dtype != dst.dtype or t.device != dst.device:
             raise RuntimeError("pack: dtype/device mismatch")
         if not t.is_contiguous():
-            t = t.contiguous()
+            if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+                # stored (O, H, W, I): un-permuted inside the gather, no copy
+                perm[2 * i], perm[2 * i + 1] = t.shape[1], t.shape[2] * t.shape[3]
+            else:
+                t = t.contiguous()
         keep.append(t)
         ptrs[i] = t.data_ptr()
         numels[i] = t.numel()
@@ -178,7 +184,7 @@ def pack(dst, tensors, scale=1.0, mode=0):
         raise RuntimeError(f"pack: {total} source elements for a vector of {dst.numel()}")
     check(
         lib.hf_pack(
-            c_void_p(dst.data_ptr()), ptrs, numels, n, float(scale), int(mode),
+            c_void_p(dst.data_ptr()), ptrs, numels, perm, n, float(scale), int(mode),
             dtype_code(dst.dtype), current_stream_ptr(dst.device),
         ),
         "hf_pack",

@@ -542,6 +542,10 @@ struct PackArgs {
   long long dst_off[PACK_MAXT];
   long long numel[PACK_MAXT];
   int blk_start[PACK_MAXT + 1];
+  // channels_last 4-D sources [O, I, H, W] stored as (O, H, W, I): inner channel count I
+  // and HW = H*W; 0 = plain contiguous.  The gather un-permutes while it copies.
+  int perm_I[PACK_MAXT];
+  int perm_HW[PACK_MAXT];
   int nt;
 };
 
@@ -567,6 +571,17 @@ __global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackA
   const long long j0 = (long long)(blockIdx.x - a.blk_start[lo]) * PACK_CHUNK;
   const long long j1 = (j0 + PACK_CHUNK < numel) ? j0 + PACK_CHUNK : numel;
   T* __restrict__ out = dst + a.dst_off[lo];
+  if (a.perm_I[lo] > 0) {
+    // dst index j = (o*I + i)*HW + hw   <-   src index (o*HW + hw)*I + i
+    const unsigned I = (unsigned)a.perm_I[lo], HW = (unsigned)a.perm_HW[lo], slab = I * HW;
+    for (long long j = j0 + threadIdx.x; j < j1; j += BLOCK) {
+      const long long o = j / slab;
+      const unsigned rem = (unsigned)(j - o * slab);
+      const unsigned i = rem / HW, hw = rem - i * HW;
+      out[j] = pack_op<T, OP>(out[j], src[o * slab + (long long)hw * I + i], scale);
+    }
+    return;
+  }
   const bool vec_ok = ((((uintptr_t)src) | ((uintptr_t)out)) & 15) == 0;
   if (vec_ok) {
     const long long v0 = j0 / W, v1 = j1 / W;
@@ -638,9 +653,9 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine(
     T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ x,
     const T* __restrict__ mean, const T* __restrict__ rstd, const T* __restrict__ w,
     const T* __restrict__ q, const T* __restrict__ r, const T* __restrict__ add,
-    const T* __restrict__ mask_src, int relu_self, I total, I C, I HW) {
+    const T* __restrict__ mask_src, int relu_self, I total, I C, I HW, int nhwc) {
   for (I i = (I)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (I)gridDim.x * BLOCK) {
-    const I c = (HW == 1 ? i : i / HW) % C;
+    const I c = (nhwc || HW == 1 ? i : i / HW) % C;  // NHWC: the channel is the fastest index
     const T rs = rstd[c];
     T acc = (T)0;
     if (a) acc = a[i] * ((w ? w[c] : (T)1) * rs);
@@ -695,6 +710,44 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
   if (live && lane == 0) {
     if (gw) gw[c] = (T)acc[0];
     if (gb) gb[c] = (T)acc[1];
+  }
+}
+
+// NHWC variant: element (row, c) at row*C + c, row = n*HW + hw.  A block owns 64
+// channels x 4 row groups: adjacent lanes read adjacent channels (coalesced rows),
+// the 4 row groups are summed through LDS.
+template <typename T, typename I>
+__global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd_nhwc(
+    T* __restrict__ gx, T* __restrict__ gw, T* __restrict__ gb, T* __restrict__ gres,
+    const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ mean,
+    const T* __restrict__ rstd, const T* __restrict__ w, const T* __restrict__ mask_src, I rows,
+    I C) {
+  __shared__ double lds[2][WAVES][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const I c = (I)blockIdx.x * 64 + cl;
+  double a0 = 0.0, a1 = 0.0;
+  if (c < C) {
+    const T rs = rstd[c], mu = mean[c];
+    const T s = (w ? w[c] : (T)1) * rs;
+    for (I r = rg; r < rows; r += WAVES) {
+      const I idx = r * C + c;
+      T g = gy[idx];
+      if (mask_src) g = mask_src[idx] > (T)0 ? g : (T)0;
+      if (gx) gx[idx] = g * s;
+      if (gres) gres[idx] = g;
+      a0 += (double)g * (double)(T)((x[idx] - mu) * rs);
+      a1 += (double)g;
+    }
+  }
+  lds[0][rg][cl] = a0;
+  lds[1][rg][cl] = a1;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    double s0 = lds[0][0][cl], s1 = lds[1][0][cl];
+#pragma unroll
+    for (int k = 1; k < WAVES; ++k) { s0 += lds[0][k][cl]; s1 += lds[1][k][cl]; }
+    if (gw) gw[c] = (T)s0;
+    if (gb) gb[c] = (T)s1;
   }
 }
 
@@ -1104,8 +1157,8 @@ int hf_pcg_timing_read(hf_pcg_t* h, double* ms_k1, double* ms_k2, double* ms_k3,
 
 // ---- vector helpers -------------------------------------------------------
 template <typename T>
-static int pack_impl(void* dst, const void* const* srcs, const int64_t* numels, int nt,
-                     double scale, int mode, hipStream_t s) {
+static int pack_impl(void* dst, const void* const* srcs, const int64_t* numels,
+                     const int64_t* perm, int nt, double scale, int mode, hipStream_t s) {
   int t = 0;
   long long off = 0;
   while (t < nt) {
@@ -1119,6 +1172,12 @@ static int pack_impl(void* dst, const void* const* srcs, const int64_t* numels, 
         a.src[k] = srcs[t];
         a.dst_off[k] = off;
         a.numel[k] = numels[t];
+        if (perm && perm[2 * t] > 0) {
+          const int64_t I = perm[2 * t], HW = perm[2 * t + 1];
+          if (HW <= 0 || numels[t] % (I * HW) != 0 || I * HW > 0x7fffffffLL) return HF_ERR_ARG;
+          a.perm_I[k] = (int)I;
+          a.perm_HW[k] = (int)HW;
+        }
         a.blk_start[k] = blocks;
         blocks += (int)((numels[t] + PACK_CHUNK - 1) / PACK_CHUNK);
         ++k;
@@ -1138,13 +1197,13 @@ static int pack_impl(void* dst, const void* const* srcs, const int64_t* numels, 
   return HF_OK;
 }
 
-int hf_pack(void* dst, const void* const* srcs, const int64_t* numels, int n_tensors,
-            double scale, int mode, int dtype, void* stream) {
+int hf_pack(void* dst, const void* const* srcs, const int64_t* numels, const int64_t* perm,
+            int n_tensors, double scale, int mode, int dtype, void* stream) {
   if (!dst || !srcs || !numels || n_tensors < 0 || (mode != 0 && mode != 1)) return HF_ERR_ARG;
   if (dtype == HF_F32)
-    return pack_impl<float>(dst, srcs, numels, n_tensors, scale, mode, (hipStream_t)stream);
+    return pack_impl<float>(dst, srcs, numels, perm, n_tensors, scale, mode, (hipStream_t)stream);
   if (dtype == HF_F64)
-    return pack_impl<double>(dst, srcs, numels, n_tensors, scale, mode, (hipStream_t)stream);
+    return pack_impl<double>(dst, srcs, numels, perm, n_tensors, scale, mode, (hipStream_t)stream);
   return HF_ERR_ARG;
 }
 
@@ -1195,31 +1254,34 @@ template <typename T>
 static void launch_chan_affine(hipStream_t s, void* out, const void* a, const void* x,
                                const void* mean, const void* rstd, const void* w, const void* q,
                                const void* r, const void* add, const void* mask_src,
-                               int relu_self, long long total, long long c, long long hw) {
+                               int relu_self, long long total, long long c, long long hw,
+                               int nhwc) {
   if (total < 0x7fffffffLL)
     hipLaunchKernelGGL((k_chan_affine<T, unsigned>), dim3(small_grid(total)), dim3(BLOCK), 0, s,
                        (T*)out, (const T*)a, (const T*)x, (const T*)mean, (const T*)rstd,
                        (const T*)w, (const T*)q, (const T*)r, (const T*)add, (const T*)mask_src,
-                       relu_self, (unsigned)total, (unsigned)c, (unsigned)hw);
+                       relu_self, (unsigned)total, (unsigned)c, (unsigned)hw, nhwc);
   else
     hipLaunchKernelGGL((k_chan_affine<T, long long>), dim3(small_grid(total)), dim3(BLOCK), 0, s,
                        (T*)out, (const T*)a, (const T*)x, (const T*)mean, (const T*)rstd,
                        (const T*)w, (const T*)q, (const T*)r, (const T*)add, (const T*)mask_src,
-                       relu_self, total, c, hw);
+                       relu_self, total, c, hw, nhwc);
 }
 
 int hf_chan_affine(void* out, const void* a, const void* x, const void* mean, const void* rstd,
                    const void* w, const void* q, const void* r, const void* add,
                    const void* mask_src, int relu_self, int64_t n, int64_t c, int64_t hw,
-                   int dtype, void* stream) {
+                   int channels_last, int dtype, void* stream) {
   if (!out || !rstd || n <= 0 || c <= 0 || hw <= 0) return HF_ERR_ARG;
   if (q && (!x || !mean)) return HF_ERR_ARG;
   const long long total = (long long)n * c * hw;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == HF_F32)
-    launch_chan_affine<float>(s, out, a, x, mean, rstd, w, q, r, add, mask_src, relu_self, total, c, hw);
+    launch_chan_affine<float>(s, out, a, x, mean, rstd, w, q, r, add, mask_src, relu_self, total, c, hw,
+                              channels_last);
   else if (dtype == HF_F64)
-    launch_chan_affine<double>(s, out, a, x, mean, rstd, w, q, r, add, mask_src, relu_self, total, c, hw);
+    launch_chan_affine<double>(s, out, a, x, mean, rstd, w, q, r, add, mask_src, relu_self, total, c, hw,
+                               channels_last);
   else
     return HF_ERR_ARG;
   HF_HIP(hipGetLastError());
@@ -1230,8 +1292,21 @@ template <typename T>
 static void launch_chan_affine_bwd(hipStream_t s, void* gx, void* gw, void* gb, void* gres,
                                    const void* gy, const void* x, const void* mean,
                                    const void* rstd, const void* w, const void* mask_src,
-                                   long long n, long long c, long long hw) {
+                                   long long n, long long c, long long hw, int nhwc) {
   const long long total = n * c * hw;
+  if (nhwc && hw > 1) {
+    const unsigned grid = (unsigned)((c + 63) / 64);
+    if (total < 0x7fffffffLL)
+      hipLaunchKernelGGL((k_chan_affine_bwd_nhwc<T, unsigned>), dim3(grid), dim3(BLOCK), 0, s, (T*)gx,
+                         (T*)gw, (T*)gb, (T*)gres, (const T*)gy, (const T*)x, (const T*)mean,
+                         (const T*)rstd, (const T*)w, (const T*)mask_src, (unsigned)(n * hw),
+                         (unsigned)c);
+    else
+      hipLaunchKernelGGL((k_chan_affine_bwd_nhwc<T, long long>), dim3(grid), dim3(BLOCK), 0, s,
+                         (T*)gx, (T*)gw, (T*)gb, (T*)gres, (const T*)gy, (const T*)x,
+                         (const T*)mean, (const T*)rstd, (const T*)w, (const T*)mask_src, n * hw, c);
+    return;
+  }
   const bool small = n * hw <= 256;
 #define HF_BWD(I, TPC, GRID)                                                                    \
   hipLaunchKernelGGL((k_chan_affine_bwd<T, I, TPC>), dim3((unsigned)(GRID)), dim3(BLOCK), 0, s,  \
@@ -1247,13 +1322,16 @@ static void launch_chan_affine_bwd(hipStream_t s, void* gx, void* gw, void* gb, 
 
 int hf_chan_affine_bwd(void* gx, void* gw, void* gb, void* gres, const void* gy, const void* x,
                        const void* mean, const void* rstd, const void* w, const void* mask_src,
-                       int64_t n, int64_t c, int64_t hw, int dtype, void* stream) {
+                       int64_t n, int64_t c, int64_t hw, int channels_last, int dtype,
+                       void* stream) {
   if (!gy || !x || !mean || !rstd || n <= 0 || c <= 0 || hw <= 0) return HF_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == HF_F32)
-    launch_chan_affine_bwd<float>(s, gx, gw, gb, gres, gy, x, mean, rstd, w, mask_src, n, c, hw);
+    launch_chan_affine_bwd<float>(s, gx, gw, gb, gres, gy, x, mean, rstd, w, mask_src, n, c, hw,
+                                  channels_last);
   else if (dtype == HF_F64)
-    launch_chan_affine_bwd<double>(s, gx, gw, gb, gres, gy, x, mean, rstd, w, mask_src, n, c, hw);
+    launch_chan_affine_bwd<double>(s, gx, gw, gb, gres, gy, x, mean, rstd, w, mask_src, n, c, hw,
+                                   channels_last);
   else
     return HF_ERR_ARG;
   HF_HIP(hipGetLastError());

@@ -53,14 +53,37 @@ def _p(t):
     return _lib.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _is_cl(t):
+    """True iff ``t`` is a 4-D tensor stored NHWC and NOT also NCHW-contiguous (for
+    C == 1 or H == W == 1 the two layouts coincide and NCHW is reported)."""
+    return t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def _dense(t):
+    """NCHW- or NHWC-dense version of ``t`` (the fused kernels handle both)."""
+    if t is None or t.is_contiguous() or _is_cl(t):
+        return t
+    return t.contiguous()
+
+
+def _like(t, ref):
+    """``t`` in the memory layout of ``ref`` (copy only if it differs)."""
+    if t is None:
+        return None
+    if _is_cl(ref):
+        return t.contiguous(memory_format=torch.channels_last)
+    return t.contiguous()
+
+
 def _affine(a, x, mean, rstd, w, q, r, like, add=None, mask_src=None, relu_self=False):
-    """out = act(a*(w*rstd) + xhat*q + r + add) (nullable terms), one launch."""
-    out = torch.empty_like(like, memory_format=torch.contiguous_format)
+    """out = act(a*(w*rstd) + xhat*q + r + add) (nullable terms), one launch; all
+    activation-sized operands share ``like``'s layout (NCHW or NHWC)."""
+    out = torch.empty_like(like)
     n, c, hw = _dims(like)
     _lib.check(
         _lib.load().hf_chan_affine(
             _p(out), _p(a), _p(x), _p(mean), _p(rstd), _p(w), _p(q), _p(r), _p(add), _p(mask_src),
-            1 if relu_self else 0, n, c, hw, _lib.dtype_code(like.dtype),
+            1 if relu_self else 0, n, c, hw, 1 if _is_cl(like) else 0, _lib.dtype_code(like.dtype),
             _lib.current_stream_ptr(like.device)),
         "hf_chan_affine")
     return out
@@ -68,14 +91,15 @@ def _affine(a, x, mean, rstd, w, q, r, like, add=None, mask_src=None, relu_self=
 
 def _affine_bwd(gy, x, mean, rstd, w, mask_src=None, need_gres=False):
     n, c, hw = _dims(x)
-    gx = torch.empty_like(x, memory_format=torch.contiguous_format)
-    gres = torch.empty_like(x, memory_format=torch.contiguous_format) if need_gres else None
+    gx = torch.empty_like(x)
+    gres = torch.empty_like(x) if need_gres else None
     gw = torch.empty(c, dtype=x.dtype, device=x.device)
     gb = torch.empty(c, dtype=x.dtype, device=x.device)
     _lib.check(
         _lib.load().hf_chan_affine_bwd(
             _p(gx), _p(gw), _p(gb), _p(gres), _p(gy), _p(x), _p(mean), _p(rstd), _p(w),
-            _p(mask_src), n, c, hw, _lib.dtype_code(x.dtype), _lib.current_stream_ptr(x.device)),
+            _p(mask_src), n, c, hw, 1 if _is_cl(x) else 0, _lib.dtype_code(x.dtype),
+            _lib.current_stream_ptr(x.device)),
         "hf_chan_affine_bwd")
     return gx, gw, gb, gres
 
@@ -84,8 +108,6 @@ def _bshape(x):
     return [1, -1] + [1] * (x.dim() - 2)
 
 
-def _c(t):
-    return t.contiguous() if t is not None else None
 
 
 class _ChanAffineBwd(torch.autograd.Function):
@@ -94,7 +116,7 @@ class _ChanAffineBwd(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, gy, x, w, mean, rstd, y, has_res):
-        gy = gy.contiguous()
+        gy = _like(gy, x)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(gy, x, w, mean, rstd, y)
         ctx.has_res = has_res
@@ -110,7 +132,9 @@ class _ChanAffineBwd(torch.autograd.Function):
         if vgx is None and vgw is None and vgb is None and vgres is None:
             return (None,) * 7
         # d/d gy : one fused launch (this is the layer's tangent map)
-        v_gy = _affine(_c(vgx), x, mean, rstd, w, _c(vgw), _c(vgb), like=x, add=_c(vgres),
+        v_gy = _affine(_like(vgx, x), x, mean, rstd, w,
+                       None if vgw is None else vgw.contiguous(),
+                       None if vgb is None else vgb.contiguous(), like=x, add=_like(vgres, x),
                        mask_src=y)
         v_x = v_w = None
         # second-order terms, only for Hessian products (plain ATen, rare path);
@@ -130,8 +154,8 @@ class _ChanAffine(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, mean, rstd, res, relu):
-        x = x.contiguous()
-        res = _c(res)
+        x = _dense(x)
+        res = _like(res, x)
         y = _affine(None, x, mean, rstd, None, w, b, like=x, add=res, relu_self=relu)
         ctx.save_for_backward(x, w, mean, rstd, y if relu else None)
         ctx.has_res = res is not None
@@ -222,61 +246,89 @@ def fuse_residual_blocks(model):
 # ------------------------------------------------------------------------------------
 # convolution: one launch for the tangent map
 # ------------------------------------------------------------------------------------
+def _fmt(t, cl):
+    if t is None:
+        return None
+    return t.contiguous(memory_format=torch.channels_last) if cl else t.contiguous()
+
+
 class _ConvBwd(torch.autograd.Function):
     """(gy; x, w) -> (gx, gw, gb) of a convolution.  Recorded only in
     ``first_order_only`` mode, so the sole derivative ever taken is d/d gy, whose
     transpose is the layer's tangent map ``v_gy = conv(v_gx, w) + conv(x, v_gw) + v_gb``.
     PyTorch's generic double-backward evaluates the two convolutions separately
     (2 MIOpen calls, their layout transposes, 2 strided copies, 1 add); here they
-    are ONE convolution over concatenated input channels."""
+    are ONE convolution over concatenated input channels, fed from two persistent
+    buffers whose constant halves (x, w) are written once per step.
+
+    With ``cl`` all operands are NHWC (channels_last): MIOpen's implicit-GEMM kernels
+    then run without the NCHW<->NHWC transposes that make up ~40 % of the kernels of
+    a product in NCHW (scratch/nhwc_probe.py: 261 -> 126 kernels, 1.08 -> 0.65 ms for
+    the 20 layers of ResNet-18)."""
 
     @staticmethod
-    def forward(ctx, gy, x, w, has_bias, stride, padding, dilation):
+    def forward(ctx, gy, x, w, has_bias, stride, padding, dilation, cl):
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, w)
-        ctx.conf = (stride, padding, dilation, has_bias)
+        ctx.conf = (stride, padding, dilation, has_bias, cl)
+        ctx.cat = None
         gx, gw, gb = torch.ops.aten.convolution_backward(
-            gy, x, w, [w.shape[0]] if has_bias else None, stride, padding, dilation, False,
-            [0] * len(stride), 1, [True, True, has_bias])
+            _fmt(gy, cl), x, w, [w.shape[0]] if has_bias else None, stride, padding, dilation,
+            False, [0] * len(stride), 1, [True, True, has_bias])
         return gx, gw, gb
 
     @staticmethod
     def backward(ctx, vgx, vgw, vgb):
         x, w = ctx.saved_tensors
-        stride, padding, dilation, _ = ctx.conf
+        stride, padding, dilation, _, cl = ctx.conf
+        conv = torch.nn.functional.conv2d
         if vgx is None and vgw is None:
             v_gy = None
         elif vgx is None:
-            v_gy = torch.nn.functional.conv2d(x, vgw, None, stride, padding, dilation)
+            v_gy = conv(x, _fmt(vgw, cl), None, stride, padding, dilation)
         elif vgw is None:
-            v_gy = torch.nn.functional.conv2d(vgx, w, None, stride, padding, dilation)
+            v_gy = conv(_fmt(vgx, cl), w, None, stride, padding, dilation)
         else:
-            v_gy = torch.nn.functional.conv2d(
-                torch.cat([vgx, x], 1), torch.cat([w, vgw], 1), None, stride, padding, dilation)
+            cin = x.shape[1]
+            if ctx.cat is None:
+                fmt = torch.channels_last if cl else torch.contiguous_format
+                xcat = torch.empty((x.shape[0], 2 * cin) + tuple(x.shape[2:]), dtype=x.dtype,
+                                   device=x.device).contiguous(memory_format=fmt)
+                wcat = torch.empty((w.shape[0], 2 * cin) + tuple(w.shape[2:]), dtype=w.dtype,
+                                   device=w.device).contiguous(memory_format=fmt)
+                xcat[:, cin:].copy_(x)
+                wcat[:, :cin].copy_(w)
+                ctx.cat = (xcat, wcat)
+            xcat, wcat = ctx.cat
+            xcat[:, :cin].copy_(vgx)
+            wcat[:, cin:].copy_(vgw)
+            v_gy = conv(xcat, wcat, None, stride, padding, dilation)
         if vgb is not None:
             vb = vgb.view(1, -1, 1, 1)
             v_gy = vb.expand(x.shape[0], -1, 1, 1) if v_gy is None else v_gy + vb
-        return v_gy, None, None, None, None, None, None
+        return v_gy, None, None, None, None, None, None, None
 
 
 class _Conv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding, dilation):
-        ctx.save_for_backward(x, w)
-        ctx.conf = (stride, padding, dilation, b is not None)
-        return torch.nn.functional.conv2d(x, w, b, stride, padding, dilation)
+    def forward(ctx, x, w, b, stride, padding, dilation, cl):
+        xf, wf = _fmt(x, cl), _fmt(w, cl)
+        ctx.save_for_backward(x, w, xf, wf)
+        ctx.conf = (stride, padding, dilation, b is not None, cl)
+        return torch.nn.functional.conv2d(xf, wf, b, stride, padding, dilation)
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
-        stride, padding, dilation, has_bias = ctx.conf
+        x, w, xf, wf = ctx.saved_tensors
+        stride, padding, dilation, has_bias, cl = ctx.conf
         if _Mode.first_order_only:
-            gx, gw, gb = _ConvBwd.apply(gy, x.detach(), w.detach(), has_bias, stride, padding, dilation)
+            gx, gw, gb = _ConvBwd.apply(gy, xf.detach(), wf.detach(), has_bias, stride, padding,
+                                        dilation, cl)
         else:  # fully differentiable stock path (Hessian products, plain training)
             gx, gw, gb = torch.ops.aten.convolution_backward(
                 gy, x, w, [w.shape[0]] if has_bias else None, stride, padding, dilation, False,
                 [0] * len(stride), 1, [True, True, has_bias])
-        return gx, gw, gb if has_bias else None, None, None, None
+        return gx, gw, gb if has_bias else None, None, None, None, None
 
 
 def _conv_forward(self, x):
@@ -287,26 +339,42 @@ def _conv_forward(self, x):
     if not usable:
         return self._hf_stock_forward(x)
     return _Conv.apply(x, self.weight, self.bias, list(self.stride), list(self.padding),
-                       list(self.dilation))
+                       list(self.dilation), bool(getattr(self, "_hf_channels_last", False)))
 
 
-def fuse_conv_tangent(model):
+def fuse_conv_tangent(model, channels_last=False):
     """Patch every plain ``nn.Conv2d`` (groups=1, zero padding) so that, inside a GGN
     product, its tangent map is one convolution (see ``_ConvBwd``).  Forward and
-    first-order backward are the stock MIOpen calls.  Returns the number patched."""
+    first-order backward are the stock MIOpen calls.  With ``channels_last`` the
+    layer computes in NHWC (activations and a per-step NHWC copy of the weight):
+    combined with the NHWC-capable fused BatchNorm kernels a whole conv net then
+    runs its curvature passes without layout transposes.  Parameters, their order
+    and the flat-vector layout are unchanged.  Returns the number patched."""
     count = 0
     for m in model.modules():
-        if type(m) is nn.Conv2d and not hasattr(m, "_hf_stock_forward"):
-            m._hf_stock_forward = m.forward
-            m.forward = types.MethodType(_conv_forward, m)
-            count += 1
+        if type(m) is nn.Conv2d:
+            m._hf_channels_last = bool(channels_last)
+            if not hasattr(m, "_hf_stock_forward"):
+                m._hf_stock_forward = m.forward
+                m.forward = types.MethodType(_conv_forward, m)
+                count += 1
     return count
 
 
-def prepare_model(model):
-    """All opt-in preparations; returns ``model`` for chaining."""
+def prepare_model(model, channels_last=False):
+    """All opt-in preparations; returns ``model`` for chaining.
+
+    ``channels_last=True`` additionally runs the convolution layers (and with them the
+    fused BatchNorm kernels) in NHWC, which removes MIOpen's layout transposes (~40 %
+    of the kernels of a product: 1.59 -> 1.25 ms on ResNet-18).  It is OFF by default:
+    in NHWC MIOpen 3.5 has more candidate solvers / tuning instances, and in ~1 of 10
+    cold-database runs its find step settled on one that is off by 1e-3 or produces
+    NaNs (scratch/nhwc_flaky*.py); NCHW with Winograd disabled never did.  Also the
+    NHWC BatchNorm reduction kernel is not yet parallelised over rows (115 us per call
+    on the early layers), so today the NHWC path is slower end to end (288 vs 571
+    matvecs/s on the bench) -- kept as the starting point for a later round."""
     fuse_eval_batchnorm(model)
-    fuse_conv_tangent(model)
+    fuse_conv_tangent(model, channels_last=channels_last)
     fuse_residual_blocks(model)
     return model
 

@@ -35,7 +35,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     lib = _lib.load()
     assert lib.hf_pcg_create(None, 10, 0, 0) == -1
     assert lib.hf_pcg_iterate(None, None, 0.0, None) == -1
-    assert lib.hf_pack(None, None, None, 0, 1.0, 0, 0, None) == -1
+    assert lib.hf_pack(None, None, None, None, 0, 1.0, 0, 0, None) == -1
     assert lib.hf_allreduce_sum(None, None, 1, 0, None) == -1
 
 

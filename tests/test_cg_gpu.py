@@ -501,7 +501,7 @@ def test_c_abi_rejects_misuse_on_device():
     assert st.done == 4 and st.n_iters == 1                    # "Convergence (tolerances)"
     assert torch.allclose(x, torch.full_like(x, 0.5))
     assert lib.hf_pcg_destroy(h) == 0
-    assert lib.hf_pack(P(x), None, None, 1, 1.0, 0, 0, s) == -1
+    assert lib.hf_pack(P(x), None, None, None, 1, 1.0, 0, 0, s) == -1
     assert lib.hf_axpy_out(P(x), P(x), None, 1.0, n, 0, s) == -1
     assert lib.hf_precond_build(P(x), P(b), 0.1, 0.75, n, 7, s) == -1
 
