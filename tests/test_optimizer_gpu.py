@@ -356,23 +356,35 @@ def test_fused_eval_batchnorm_matches_stock(dtype):
     assert fused(x).shape == (4, 5)
 
 
-def test_rccl_entry_points_single_rank():
-    """hf_comm_* / hf_allreduce_sum resolve RCCL from the already-loaded librccl and
-    work on a 1-rank communicator (sum over one rank = identity, on our stream)."""
-    import ctypes
+def _run_worker(name, timeout=600):
+    """Run tests/gpu_workers/<name> in its own interpreter; return its RESULT json."""
+    import json
+    import os
+    import subprocess
+    import sys
 
-    lib = _lib.load()
-    uid = ctypes.create_string_buffer(128)
-    _lib.check(lib.hf_comm_unique_id(uid), "hf_comm_unique_id")
-    comm = _lib.c_void_p()
-    _lib.check(lib.hf_comm_create(ctypes.byref(comm), uid, 1, 0), "hf_comm_create")
-    v = torch.arange(1000.0, device=DEV)
-    ref = v.clone()
-    _lib.check(lib.hf_allreduce_sum(comm, _lib.c_void_p(v.data_ptr()), v.numel(), 0,
-                                    _lib.current_stream_ptr(v.device)), "hf_allreduce_sum")
-    torch.cuda.synchronize()
-    assert torch.equal(v, ref)
-    _lib.check(lib.hf_comm_destroy(comm), "hf_comm_destroy")
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, os.path.join(here, "gpu_workers", name)],
+                       capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert lines, (p.returncode, p.stdout[-1500:], p.stderr[-1500:])
+    return json.loads(lines[-1][len("RESULT "):])
+
+
+def test_rccl_paths_single_rank():
+    """(1) hf_comm_* / hf_allreduce_sum resolve RCCL from the already-loaded librccl and
+    work on a 1-rank communicator (sum over one rank = identity, on our stream);
+    (2) the data-parallel code path of HessianFree.step on the real backend ("nccl" =
+    RCCL) with a 1-rank group -- weighted all-reduce of loss / gradient / every product,
+    lockstep stop rule, hipGraph capture while the group exists -- equals the plain
+    single-process run.  Runs in a worker process (see tests/gpu_workers)."""
+    res = _run_worker("rccl_single_rank.py")
+    assert res["abi_allreduce_identity"] is True
+    runs = res["runs"]
+    for name in ("dp", "dp_graph"):
+        assert runs[name][2:] == runs["plain"][2:]
+        assert abs(runs[name][0] - runs["plain"][0]) < 1e-6
+        assert abs(runs[name][1] - runs["plain"][1]) < 1e-3 * abs(runs["plain"][1])
 
 
 def _mlp25m(device):
@@ -547,47 +559,6 @@ def test_overlapped_two_graph_product_equals_single_graph():
     del two
     one = curvature.GraphedOperator(builder, params=ps)
     assert float((one(v) - a).abs().max() / ref.abs().max()) < 1e-5
-
-
-def test_step_with_rccl_process_group_single_rank():
-    """The data-parallel code path of HessianFree.step on the real backend ("nccl" =
-    RCCL) with a 1-rank group: weighted all-reduce of loss / gradient / every
-    product, lockstep stop rule, hipGraph capture while the group exists.  With one
-    rank the results must equal the plain single-process run."""
-    import socket
-
-    import torch.distributed as dist
-    from pytorchhessianfree_amd import modelprep
-
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    os_env = __import__("os").environ
-    os_env["MASTER_ADDR"], os_env["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        runs = {}
-        for name, kw in [("plain", {}), ("dp", dict(process_group=dist.group.WORLD)),
-                         ("dp_graph", dict(process_group=dist.group.WORLD, graph_matvec=True))]:
-            model, (x, t), lossf = tp.resnet18_mnist(batch_size=8, device=DEV)
-            modelprep.prepare_model(model)
-
-            def forward():
-                out = model(x)
-                return lossf(out, t), out
-
-            opt = hf.HessianFree(model.parameters(), cg_max_iter=15, **kw)
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
-                final = opt.step(forward)
-            runs[name] = (opt.state["init_losses"][0], final, opt.state["num_cg_iters"][0],
-                          opt.state["cg_reasons"][0])
-        for name in ("dp", "dp_graph"):
-            assert runs[name][2:] == runs["plain"][2:]
-            assert abs(runs[name][0] - runs["plain"][0]) < 1e-6
-            assert abs(runs[name][1] - runs["plain"][1]) < 1e-3 * abs(runs["plain"][1])
-    finally:
-        dist.destroy_process_group()
 
 
 def test_stale_graph_fails_loudly_after_in_place_parameter_write():
