@@ -369,7 +369,11 @@ def prepare_model(model, channels_last=False):
     of the kernels of a product: 1.59 -> 1.25 ms on ResNet-18).  It is OFF by default:
     in NHWC MIOpen 3.5 has more candidate solvers / tuning instances, and in ~1 of 10
     cold-database runs its find step settled on one that is off by 1e-3 or produces
-    NaNs (scratch/nhwc_flaky*.py); NCHW with Winograd disabled never did.  Also the
+    NaNs (scratch/nhwc_flaky*.py); NCHW with Winograd disabled never did.  The pattern
+    (only the FIRST operator built while MIOpen is still benchmarking is wrong, a second
+    one in the same process with the same solvers is right; a stock model sharing no
+    tensors stays right) points at a candidate kernel writing out of bounds during the
+    find step -- not something a result check can guard against.  Also the
     NHWC BatchNorm reduction kernel is not yet parallelised over rows (115 us per call
     on the early layers), so today the NHWC path is slower end to end (288 vs 571
     matvecs/s on the bench) -- kept as the starting point for a later round."""
