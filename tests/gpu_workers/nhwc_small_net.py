@@ -1,0 +1,53 @@
+"""Worker for tests/test_optimizer_gpu.py::test_channels_last_curvature_path_small_net."""
+
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import pytorchhessianfree_amd  # noqa: E402,F401
+from pytorchhessianfree_amd import _lib, curvature, modelprep  # noqa: E402
+
+DEV = "cuda"
+
+
+def make():
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(
+        torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+        torch.nn.Conv2d(8, 16, 3, stride=2, padding=1, bias=False), torch.nn.BatchNorm2d(16),
+        torch.nn.ReLU(), torch.nn.Conv2d(16, 6, 1), torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(),
+    )
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.5, 0.5)
+            m.running_var.uniform_(0.5, 2.0)
+    return net.to(DEV).eval()
+
+
+stock, fused = make(), make()
+modelprep.prepare_model(fused, channels_last=True)
+gen = torch.Generator().manual_seed(1)
+x = torch.rand(6, 3, 10, 10, generator=gen).to(DEV)
+t = torch.randint(0, 6, (6,), generator=gen).to(DEV)
+lossf = torch.nn.CrossEntropyLoss()
+outs = []
+for net in (stock, fused):
+    ps = list(net.parameters())
+    out = net(x)
+    loss = lossf(out, t)
+    v = torch.randn(sum(p.numel() for p in ps), generator=torch.Generator().manual_seed(2)).to(DEV)
+    grads = curvature.flatten_into(torch.autograd.grad(loss, ps, retain_graph=True), ps)
+    outs.append((out.detach(), grads, curvature.GGNOperator(loss, out, ps)(v)))
+errors = [float((a - b).abs().max() / b.abs().max()) for a, b in zip(outs[1], outs[0])]
+
+# the gather itself, on a channels_last tensor: exact
+w = torch.randn(12, 5, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last)
+flat = torch.empty(w.numel() + 7, device=DEV)
+_lib.pack(flat, [torch.arange(7.0, device=DEV), w])
+exact = bool(torch.equal(flat[7:], w.contiguous().reshape(-1)))
+print("RESULT " + json.dumps({"errors": errors, "gather_exact": exact}), flush=True)
