@@ -338,3 +338,35 @@ def test_state_dict_round_trip_keeps_warm_start_and_damping():
         opt2.step(forward)
     assert opt2.state["dampings"][-1] == sd["param_groups"][0]["damping"]
     assert opt2.param_groups[0]["damping"] == opt2._group["damping"]
+
+
+def test_modelprep_is_transparent_on_cpu():
+    """modelprep patches keep parameters, their order and the state_dict; on CPU
+    tensors (and in training mode) every patched layer falls back to the stock op."""
+    from pytorchhessianfree_amd import modelprep
+    from pytorchhessianfree_amd import testproblems as tp
+
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=3)
+    names = [n for n, _ in model.named_parameters()]
+    ids = [id(p) for p in model.parameters()]
+    ref = model(x)
+    modelprep.prepare_model(model)
+    assert [n for n, _ in model.named_parameters()] == names
+    assert [id(p) for p in model.parameters()] == ids
+    assert torch.equal(model(x), ref)
+    assert modelprep.fuse_eval_batchnorm(model) == 0 and modelprep.fuse_residual_blocks(model) == 0  # idempotent
+    model.train()
+    assert model(x).shape == ref.shape
+    model.eval()
+    # curvature products through the patched model equal the stock ones on CPU
+    stock, _, _ = tp.resnet18_mnist(batch_size=3)
+    v = torch.randn(tp.count_trainable(stock), generator=torch.Generator().manual_seed(0))
+    res = []
+    for m in (stock, model):
+        ps = list(m.parameters())
+        out = m(x)
+        res.append(curvature.GGNOperator(lossf(out, t), out, ps)(v))
+    assert torch.equal(res[0], res[1])
+    with modelprep.first_order_only():
+        assert modelprep._Mode.first_order_only is True
+    assert modelprep._Mode.first_order_only is False
