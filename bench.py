@@ -143,32 +143,58 @@ def main():
     from pytorchhessianfree_amd import curvature, modelprep
     from pytorchhessianfree_amd.cg import enable_kernel_timing, read_kernel_timing
 
-    model, (x, t), lossf = build_problem(args, device, rank)
-    if args.fuse_bn:
-        modelprep.fuse_eval_batchnorm(model)
-    if args.fuse_conv:
-        modelprep.fuse_conv_tangent(model, channels_last=bool(args.channels_last))
-    if args.fuse_bn and args.fuse_conv:
-        modelprep.fuse_residual_blocks(model)  # relu(bn(.)) / relu(bn(.) + identity) as one layer
-    params = [p for p in model.parameters() if p.requires_grad]
-    n = sum(p.numel() for p in params)
     weight = 1.0 / world
 
-    # local gradient first (its graph is freed again: nothing may tie the parameters
-    # to the default stream while the product is captured, see GraphedOperator)
-    grad = curvature.flatten_into(torch.autograd.grad(lossf(model(x), t), params), params,
-                                  scale=weight)
+    def build_operator(channels_last):
+        model, (x, t), lossf = build_problem(args, device, rank)
+        if args.fuse_bn:
+            modelprep.fuse_eval_batchnorm(model)
+        if args.fuse_conv:
+            modelprep.fuse_conv_tangent(model, channels_last=channels_last)
+        if args.fuse_bn and args.fuse_conv:
+            modelprep.fuse_residual_blocks(model)  # relu(bn(.)) / relu(bn(.) + identity) as one layer
+        params = [p for p in model.parameters() if p.requires_grad]
+        # local gradient first (its graph is freed again: nothing may tie the parameters
+        # to the default stream while the product is captured, see GraphedOperator)
+        grad = curvature.flatten_into(torch.autograd.grad(lossf(model(x), t), params), params,
+                                      scale=weight)
 
-    def builder():  # forward graph + recorded J^T / H_L maps (once per Newton step)
+        def builder():  # forward graph + recorded J^T / H_L maps (once per Newton step)
+            out = model(x)
+            return curvature.GGNOperator(lossf(out, t), out, params, weight=weight, group=None)
+
+        # The local product is captured BEFORE the process group exists: RCCL's
+        # watchdog thread must not touch the runtime while a capture is open.
+        if args.graph and args.overlap and (world > 1 or args.force_dist):
+            op = curvature.OverlappedGraphedOperator(builder, params=params)
+        else:
+            op = curvature.maybe_graphed(builder, enable=bool(args.graph), params=params)
+        return op, grad, sum(p.numel() for p in params)
+
+    def stock_product(v):
+        """The same product by stock PyTorch-ROCm autograd on an unpatched NCHW model."""
+        model, (x, t), lossf = build_problem(args, device, rank)
+        params = [p for p in model.parameters() if p.requires_grad]
         out = model(x)
-        return curvature.GGNOperator(lossf(out, t), out, params, weight=weight, group=None)
+        return curvature.GGNOperator(lossf(out, t), out, params, weight=weight, group=None)(v).clone()
 
-    # The local product is captured BEFORE the process group exists: RCCL's
-    # watchdog thread must not touch the runtime while a capture is open.
-    if args.graph and args.overlap and (world > 1 or args.force_dist):
-        op = curvature.OverlappedGraphedOperator(builder, params=params)
-    else:
-        op = curvature.maybe_graphed(builder, enable=bool(args.graph), params=params)
+    layout = "NHWC" if args.channels_last else "NCHW"
+    op, grad, n = build_operator(bool(args.channels_last))
+    if args.channels_last:
+        # MIOpen's find step on NHWC shapes has been seen to settle on a wrong tuning
+        # instance in a cold database (modelprep.prepare_model): the NHWC operator is
+        # only timed after it reproduced a stock product, else the NCHW one is used.
+        v = torch.randn(n, device=device, generator=torch.Generator(device=device).manual_seed(7))
+        want, got = stock_product(v), op(v).clone()
+        err = float((got - want).abs().max() / want.abs().max())
+        if not err < 1e-4:
+            print(f"[bench] NHWC product off by {err:.2e} relative to stock autograd; using NCHW",
+                  file=sys.stderr, flush=True)
+            del op
+            layout = "NCHW (NHWC failed its check)"
+            op, grad, n = build_operator(False)
+        else:
+            layout = f"NHWC (checked against stock autograd: {err:.1e})"
 
     group = None
     if world > 1 or args.force_dist:
@@ -249,7 +275,7 @@ def main():
                 "parallelism": f"dp{world} (batch sharded, one all-reduce of 4N bytes per matvec)",
                 "matvec": getattr(op, "mode", "eager autograd")
                           + ("; eval-BN fused (hf_chan_affine)" if args.fuse_bn else "")
-                          + ("; conv tangent fused" if args.fuse_conv else ""),
+                          + ("; conv tangent fused" if args.fuse_conv else "") + "; " + layout,
                 "termination": reason,
             },
             "cg_iters_per_s": world * args.steps * iters_done / dt,

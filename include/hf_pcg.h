@@ -149,6 +149,21 @@ int hf_pack(void* dst, const void* const* srcs, const int64_t* numels,
             const int64_t* perm, int n_tensors, double scale, int mode, int dtype,
             void* stream);
 
+/*
+ * Multi-tensor scatter for the tangent sweep, the counterpart of hf_pack: tensor t is the
+ * contiguous [O, slab] block at src + src_offs[t] (a weight-shaped slice of the CG
+ * vector, slab = I*H*W).  It is written into the SECOND half of the input-channel axis of
+ * dsts[t], a [O, 2I, H, W] buffer -- the weight operand [W | v_W] of the single
+ * convolution conv([v_x | x], [W | v_W]) that evaluates a conv layer's tangent map
+ * inside BackPACK's R-op (optimizer.py:461):
+ *   inners[t] == 0 : dst stored (O, 2I, H, W):  dst[o*2*slab + slab + r]      = src[o*slab + r]
+ *   inners[t] == I : dst stored (O, H, W, 2I):  dst[(o*HW + hw)*2I + I + i]   = src[(o*I + i)*HW + hw]
+ * One launch instead of one strided copy per conv layer and product.  All arrays HOST.
+ */
+int hf_unpack_tangent(const void* src, void* const* dsts, const int64_t* src_offs,
+                      const int64_t* numels, const int64_t* slabs, const int64_t* inners,
+                      int n_tensors, int dtype, void* stream);
+
 /* minv = (diag + damping)^(-exponent)   (preconditioners.py:124, hoisted out of
  * the CG loop). */
 int hf_precond_build(void* minv, const void* diag, double damping,

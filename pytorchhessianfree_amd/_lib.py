@@ -81,6 +81,10 @@ SIGNATURES = {
         [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), c_int,
          c_double, c_int, c_int, c_void_p],
     ),
+    "hf_unpack_tangent": (
+        c_int,
+        [c_void_p, ctypes.POINTER(c_void_p)] + [ctypes.POINTER(c_int64)] * 4 + [c_int, c_int, c_void_p],
+    ),
     "hf_precond_build": (c_int, [c_void_p, c_void_p, c_double, c_double, c_int64, c_int, c_void_p]),
     "hf_axpy_out": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int, c_void_p]),
     "hf_chan_affine": (c_int, [c_void_p] * 10 + [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
@@ -190,6 +194,41 @@ def pack(dst, tensors, scale=1.0, mode=0):
         "hf_pack",
     )
     return dst
+
+
+def unpack_tangent(v, slots):
+    """Scatter weight-shaped slices of the flat vector ``v`` into the ``v_W`` halves of
+    the tangent convolutions' weight buffers, all layers in one launch.  ``slots`` is
+    a list of ``(offset into v, buffer [O, 2I, H, W], I)``; the buffer is NCHW-contiguous
+    or channels_last."""
+    lib = load()
+    require_device_tensor(v, "v")
+    n = len(slots)
+    dsts = (c_void_p * n)()
+    offs, numels, slabs, inners = ((c_int64 * n)() for _ in range(4))
+    for k, (off, buf, cin) in enumerate(slots):
+        if buf.dtype != v.dtype or buf.device != v.device or buf.dim() != 4 or buf.shape[1] != 2 * cin:
+            raise RuntimeError("unpack_tangent: buffer does not match")
+        hw = buf.shape[2] * buf.shape[3]
+        if buf.is_contiguous():
+            inners[k] = 0
+        elif buf.is_contiguous(memory_format=torch.channels_last):
+            inners[k] = cin
+        else:
+            raise RuntimeError("unpack_tangent: buffer is neither NCHW- nor NHWC-contiguous")
+        dsts[k] = buf.data_ptr()
+        offs[k] = off
+        slabs[k] = cin * hw
+        numels[k] = buf.shape[0] * cin * hw
+        if off < 0 or off + numels[k] > v.numel():
+            raise RuntimeError("unpack_tangent: slice outside the vector")
+    check(
+        lib.hf_unpack_tangent(
+            c_void_p(v.data_ptr()), dsts, offs, numels, slabs, inners, n, dtype_code(v.dtype),
+            current_stream_ptr(v.device),
+        ),
+        "hf_unpack_tangent",
+    )
 
 
 def axpy_out(out, a, s, alpha):

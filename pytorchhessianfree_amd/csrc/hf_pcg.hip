@@ -601,6 +601,72 @@ __global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackA
   }
 }
 
+// Multi-tensor scatter for the tangent sweep (inverse of the gather above): tensor t,
+// the contiguous [O, slab] block at src + src_off[t], goes into the second half of the
+// input-channel axis of a [O, 2I, H, W] buffer stored NCHW (inner = 0) or NHWC (inner = I).
+struct UnpackArgs {
+  void* dst[PACK_MAXT];
+  long long src_off[PACK_MAXT];
+  long long numel[PACK_MAXT];
+  int blk_start[PACK_MAXT + 1];
+  int slab[PACK_MAXT];   // I*H*W
+  int inner[PACK_MAXT];  // 0 (NCHW) or I (NHWC)
+  int nt;
+};
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_unpack_tangent(const T* __restrict__ src_base,
+                                                          const UnpackArgs a) {
+  int lo = 0, hi = a.nt;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.blk_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const T* __restrict__ src = src_base + a.src_off[lo];
+  T* __restrict__ dst = reinterpret_cast<T*>(a.dst[lo]);
+  const long long numel = a.numel[lo];
+  const long long j0 = (long long)(blockIdx.x - a.blk_start[lo]) * PACK_CHUNK;
+  const long long j1 = (j0 + PACK_CHUNK < numel) ? j0 + PACK_CHUNK : numel;
+  const unsigned slab = (unsigned)a.slab[lo], I = (unsigned)a.inner[lo];
+  constexpr int W = VecOf<T>::W;
+  typedef typename VecOf<T>::type V;
+  const bool al = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+  if (I == 0) {  // dst[o*2*slab + slab + r] = src[o*slab + r]
+    if (al && slab % W == 0) {
+      for (long long j = j0 + (long long)threadIdx.x * W; j < j1; j += (long long)BLOCK * W) {
+        const long long o = j / slab;
+        *reinterpret_cast<V*>(dst + j + (o + 1) * slab) = *reinterpret_cast<const V*>(src + j);
+      }
+    } else {
+      for (long long j = j0 + threadIdx.x; j < j1; j += BLOCK) dst[j + (j / slab + 1) * slab] = src[j];
+    }
+    return;
+  }
+  // destination order d = (o*HW + hw)*I + i  ->  dst[(o*HW + hw)*2I + I + i] = src[(o*I + i)*HW + hw]
+  const unsigned HW = slab / I;
+  if (al && I % W == 0) {
+    for (long long d = j0 + (long long)threadIdx.x * W; d < j1; d += (long long)BLOCK * W) {
+      const long long row = d / I;  // o*HW + hw
+      const unsigned i = (unsigned)(d - row * I);
+      const long long o = row / HW;
+      const unsigned hw = (unsigned)(row - o * HW);
+      const T* s = src + o * slab + (long long)i * HW + hw;
+      VU<T> v;
+#pragma unroll
+      for (int c = 0; c < W; ++c) v.e[c] = s[(long long)c * HW];
+      *reinterpret_cast<V*>(dst + row * 2 * I + I + i) = v.v;
+    }
+  } else {
+    for (long long d = j0 + threadIdx.x; d < j1; d += BLOCK) {
+      const long long row = d / I;
+      const unsigned i = (unsigned)(d - row * I);
+      const long long o = row / HW;
+      const unsigned hw = (unsigned)(row - o * HW);
+      dst[row * 2 * I + I + i] = src[o * slab + (long long)i * HW + hw];
+    }
+  }
+}
+
 // minv = (diag + damping)^(-exponent)
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_precond_build(T* __restrict__ minv,
@@ -713,41 +779,60 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
   }
 }
 
-// NHWC variant: element (row, c) at row*C + c, row = n*HW + hw.  A block owns 64
-// channels x 4 row groups: adjacent lanes read adjacent channels (coalesced rows),
-// the 4 row groups are summed through LDS.
-template <typename T, typename I>
+// NHWC variant: element (row, c) at row*C + c, row = n*HW + hw.  A block owns W
+// adjacent channels (W = 4: one 16-byte column) and spreads the rows over its 256
+// threads, so the per-channel sums need no cross-block step (deterministic, no
+// workspace) and C/W blocks are in flight; the tensors of this path are a few MB
+// and L2-resident, the strided 16-byte reads cost less than a second launch would.
+template <typename T, typename I, int W>
 __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd_nhwc(
     T* __restrict__ gx, T* __restrict__ gw, T* __restrict__ gb, T* __restrict__ gres,
     const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ mean,
     const T* __restrict__ rstd, const T* __restrict__ w, const T* __restrict__ mask_src, I rows,
     I C) {
-  __shared__ double lds[2][WAVES][64];
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const I c = (I)blockIdx.x * 64 + cl;
-  double a0 = 0.0, a1 = 0.0;
-  if (c < C) {
-    const T rs = rstd[c], mu = mean[c];
-    const T s = (w ? w[c] : (T)1) * rs;
-    for (I r = rg; r < rows; r += WAVES) {
-      const I idx = r * C + c;
-      T g = gy[idx];
-      if (mask_src) g = mask_src[idx] > (T)0 ? g : (T)0;
-      if (gx) gx[idx] = g * s;
-      if (gres) gres[idx] = g;
-      a0 += (double)g * (double)(T)((x[idx] - mu) * rs);
-      a1 += (double)g;
+  __shared__ double lds[2 * W * WAVES];
+  struct alignas(sizeof(T) * W) Col { T e[W]; };
+  const I c0 = (I)blockIdx.x * W;
+  T rs[W], mu[W], sc[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) {
+    rs[k] = rstd[c0 + k];
+    mu[k] = mean[c0 + k];
+    sc[k] = (w ? w[c0 + k] : (T)1) * rs[k];
+  }
+  double acc[2 * W];
+#pragma unroll
+  for (int k = 0; k < 2 * W; ++k) acc[k] = 0.0;
+#pragma unroll 4
+  for (I r = threadIdx.x; r < rows; r += BLOCK) {
+    const I idx = r * C + c0;
+    Col g = *reinterpret_cast<const Col*>(gy + idx);
+    const Col xv = *reinterpret_cast<const Col*>(x + idx);
+    if (mask_src) {
+      const Col m = *reinterpret_cast<const Col*>(mask_src + idx);
+#pragma unroll
+      for (int k = 0; k < W; ++k) g.e[k] = m.e[k] > (T)0 ? g.e[k] : (T)0;
+    }
+    if (gres) *reinterpret_cast<Col*>(gres + idx) = g;
+    if (gx) {
+      Col o;
+#pragma unroll
+      for (int k = 0; k < W; ++k) o.e[k] = g.e[k] * sc[k];
+      *reinterpret_cast<Col*>(gx + idx) = o;
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      acc[2 * k] += (double)g.e[k] * (double)(T)((xv.e[k] - mu[k]) * rs[k]);
+      acc[2 * k + 1] += (double)g.e[k];
     }
   }
-  lds[0][rg][cl] = a0;
-  lds[1][rg][cl] = a1;
-  __syncthreads();
-  if (rg == 0 && c < C) {
-    double s0 = lds[0][0][cl], s1 = lds[1][0][cl];
+  block_allreduce<2 * W>(acc, lds);
+  if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 1; k < WAVES; ++k) { s0 += lds[0][k][cl]; s1 += lds[1][k][cl]; }
-    if (gw) gw[c] = (T)s0;
-    if (gb) gb[c] = (T)s1;
+    for (int k = 0; k < W; ++k) {
+      if (gw) gw[c0 + k] = (T)acc[2 * k];
+      if (gb) gb[c0 + k] = (T)acc[2 * k + 1];
+    }
   }
 }
 
@@ -1214,6 +1299,53 @@ static int small_grid(int64_t n) {
   return (int)g;
 }
 
+template <typename T>
+static int unpack_impl(const void* src, void* const* dsts, const int64_t* src_offs,
+                       const int64_t* numels, const int64_t* slabs, const int64_t* inners, int nt,
+                       hipStream_t s) {
+  int t = 0;
+  while (t < nt) {
+    UnpackArgs a;
+    memset(&a, 0, sizeof(a));
+    int k = 0, blocks = 0;
+    while (t < nt && k < PACK_MAXT) {
+      if (numels[t] < 0) return HF_ERR_ARG;
+      if (numels[t] > 0) {
+        const int64_t slab = slabs[t], I = inners[t];
+        if (!dsts[t] || src_offs[t] < 0 || slab <= 0 || slab > 0x3fffffffLL || numels[t] % slab != 0 ||
+            I < 0 || (I > 0 && slab % I != 0))
+          return HF_ERR_ARG;
+        a.dst[k] = dsts[t];
+        a.src_off[k] = src_offs[t];
+        a.numel[k] = numels[t];
+        a.slab[k] = (int)slab;
+        a.inner[k] = (int)I;
+        a.blk_start[k] = blocks;
+        blocks += (int)((numels[t] + PACK_CHUNK - 1) / PACK_CHUNK);
+        ++k;
+      }
+      ++t;
+    }
+    a.blk_start[k] = blocks;
+    a.nt = k;
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL((k_unpack_tangent<T>), dim3(blocks), dim3(BLOCK), 0, s, (const T*)src, a);
+    HF_HIP(hipGetLastError());
+  }
+  return HF_OK;
+}
+
+int hf_unpack_tangent(const void* src, void* const* dsts, const int64_t* src_offs,
+                      const int64_t* numels, const int64_t* slabs, const int64_t* inners,
+                      int n_tensors, int dtype, void* stream) {
+  if (!src || !dsts || !src_offs || !numels || !slabs || !inners || n_tensors < 0) return HF_ERR_ARG;
+  if (dtype == HF_F32)
+    return unpack_impl<float>(src, dsts, src_offs, numels, slabs, inners, n_tensors, (hipStream_t)stream);
+  if (dtype == HF_F64)
+    return unpack_impl<double>(src, dsts, src_offs, numels, slabs, inners, n_tensors, (hipStream_t)stream);
+  return HF_ERR_ARG;
+}
+
 int hf_precond_build(void* minv, const void* diag, double damping, double exponent, int64_t n,
                      int dtype, void* stream) {
   if (!minv || !diag || n <= 0) return HF_ERR_ARG;
@@ -1295,16 +1427,18 @@ static void launch_chan_affine_bwd(hipStream_t s, void* gx, void* gw, void* gb, 
                                    long long n, long long c, long long hw, int nhwc) {
   const long long total = n * c * hw;
   if (nhwc && hw > 1) {
-    const unsigned grid = (unsigned)((c + 63) / 64);
-    if (total < 0x7fffffffLL)
-      hipLaunchKernelGGL((k_chan_affine_bwd_nhwc<T, unsigned>), dim3(grid), dim3(BLOCK), 0, s, (T*)gx,
-                         (T*)gw, (T*)gb, (T*)gres, (const T*)gy, (const T*)x, (const T*)mean,
-                         (const T*)rstd, (const T*)w, (const T*)mask_src, (unsigned)(n * hw),
-                         (unsigned)c);
-    else
-      hipLaunchKernelGGL((k_chan_affine_bwd_nhwc<T, long long>), dim3(grid), dim3(BLOCK), 0, s,
-                         (T*)gx, (T*)gw, (T*)gb, (T*)gres, (const T*)gy, (const T*)x,
-                         (const T*)mean, (const T*)rstd, (const T*)w, (const T*)mask_src, n * hw, c);
+    const bool vec = c % 4 == 0 && aligned16(gy) && aligned16(x) && (!mask_src || aligned16(mask_src)) &&
+                     (!gx || aligned16(gx)) && (!gres || aligned16(gres)) && sizeof(T) == 4;
+#define HF_BWD_CL(I, W)                                                                           \
+  hipLaunchKernelGGL((k_chan_affine_bwd_nhwc<T, I, W>), dim3((unsigned)(c / W)), dim3(BLOCK), 0, s, \
+                     (T*)gx, (T*)gw, (T*)gb, (T*)gres, (const T*)gy, (const T*)x, (const T*)mean,   \
+                     (const T*)rstd, (const T*)w, (const T*)mask_src, (I)(n * hw), (I)c)
+    if (total < 0x7fffffffLL) {
+      if (vec) HF_BWD_CL(unsigned, 4); else HF_BWD_CL(unsigned, 1);
+    } else {
+      if (vec) HF_BWD_CL(long long, 4); else HF_BWD_CL(long long, 1);
+    }
+#undef HF_BWD_CL
     return;
   }
   const bool small = n * hw <= 256;

@@ -25,7 +25,7 @@ GPU the HIP kernel is mandatory (``_lib`` raises if the library is missing).
 import torch
 
 from . import _lib
-from .modelprep import first_order_only
+from .modelprep import first_order_only, tangent_owner
 from .utils import vector_to_parameter_list
 
 
@@ -101,9 +101,10 @@ class GGNOperator(_Operator):
 
     def local(self, v, out=None):
         vs = vector_to_parameter_list(v, self.params)
-        (Jv,) = torch.autograd.grad(
-            self._JTu, self._u, grad_outputs=[vs[i] for i in self._used], retain_graph=True
-        )
+        with tangent_owner(self, v):  # conv layers' v_W operands: one scatter launch
+            (Jv,) = torch.autograd.grad(
+                self._JTu, self._u, grad_outputs=[vs[i] for i in self._used], retain_graph=True
+            )
         if self._dl.requires_grad:
             (HJv,) = torch.autograd.grad(
                 self._dl, self.outputs, grad_outputs=Jv, retain_graph=True, allow_unused=True
@@ -130,9 +131,10 @@ class GGNOperator(_Operator):
 
     def _H_J(self, v):
         vs = vector_to_parameter_list(v, self.params)
-        (Jv,) = torch.autograd.grad(
-            self._JTu, self._u, grad_outputs=[vs[i] for i in self._used], retain_graph=True
-        )
+        with tangent_owner(self, v):
+            (Jv,) = torch.autograd.grad(
+                self._JTu, self._u, grad_outputs=[vs[i] for i in self._used], retain_graph=True
+            )
         if not self._dl.requires_grad:
             return torch.zeros_like(Jv)
         (HJv,) = torch.autograd.grad(

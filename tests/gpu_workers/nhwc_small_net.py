@@ -50,4 +50,22 @@ w = torch.randn(12, 5, 3, 3, device=DEV).contiguous(memory_format=torch.channels
 flat = torch.empty(w.numel() + 7, device=DEV)
 _lib.pack(flat, [torch.arange(7.0, device=DEV), w])
 exact = bool(torch.equal(flat[7:], w.contiguous().reshape(-1)))
-print("RESULT " + json.dumps({"errors": errors, "gather_exact": exact}), flush=True)
+
+# the NHWC BatchNorm adjoint kernel against the NCHW one on the same numbers
+# (vector columns for C % 4 == 0, scalar columns otherwise, with and without the mask)
+cl = torch.channels_last
+kernel_err = 0.0
+for dtype in (torch.float32, torch.float64):
+    for (n, c, h) in [(5, 6, 3), (32, 64, 7), (7, 512, 2), (3, 20, 9), (128, 64, 7)]:
+        g = torch.Generator(device=DEV).manual_seed(n * c)
+        gy, xx, yy = (torch.randn(n, c, h, h, device=DEV, dtype=dtype, generator=g) for _ in range(3))
+        mean, w = (torch.randn(c, device=DEV, dtype=dtype, generator=g) for _ in range(2))
+        rstd = torch.rand(c, device=DEV, dtype=dtype, generator=g) + 0.5
+        for mask in (None, yy):
+            ref = modelprep._affine_bwd(gy, xx, mean, rstd, w, mask, need_gres=True)
+            got = modelprep._affine_bwd(gy.contiguous(memory_format=cl), xx.contiguous(memory_format=cl), mean, rstd,
+                                        w, None if mask is None else mask.contiguous(memory_format=cl), need_gres=True)
+            assert got[0].is_contiguous(memory_format=cl) and got[3].is_contiguous(memory_format=cl)
+            for a, b in zip(got, ref):
+                kernel_err = max(kernel_err, float((a - b).abs().max() / b.abs().max()))
+print("RESULT " + json.dumps({"errors": errors, "gather_exact": exact, "kernel_err": kernel_err}), flush=True)

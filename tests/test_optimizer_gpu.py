@@ -195,6 +195,62 @@ def test_pack_gathers_like_cat(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_unpack_tangent_scatters_like_copy(dtype):
+    """hf_unpack_tangent: weight-shaped slices of the flat vector into the v_W halves of
+    [O, 2I, H, W] buffers, NCHW and channels_last, vector and scalar paths, > one table."""
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    shapes = [(64, 1, 7, 7), (8, 3, 3, 3), (128, 64, 3, 3), (16, 64, 1, 1), (5, 6, 2, 3), (512, 512, 3, 3),
+              (1, 4, 1, 1)] + [(3, 2, 1, 2)] * 120
+    sizes = [int(np.prod(sh)) for sh in shapes]
+    pad = 5  # entries of v that belong to no conv weight (biases, BN, fc)
+    v = torch.randn(sum(sizes) + pad * len(shapes), device=DEV, dtype=dtype, generator=gen)
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        slots, want, off = [], [], 0
+        for sh, size in zip(shapes, sizes):
+            o, i, h, w = sh
+            buf = torch.full((o, 2 * i, h, w), 7.0, device=DEV, dtype=dtype).contiguous(memory_format=fmt)
+            ref = buf.clone()
+            ref[:, i:].copy_(v[off:off + size].view(sh))
+            slots.append((off, buf, i))
+            want.append(ref)
+            off += size + pad
+        _lib.unpack_tangent(v, slots)
+        for (_, buf, _), ref in zip(slots, want):
+            assert torch.equal(buf, ref)
+    with pytest.raises(RuntimeError):
+        _lib.unpack_tangent(v, [(v.numel() - 3, torch.empty(2, 2, 1, 2, device=DEV, dtype=dtype), 1)])
+
+
+def test_tangent_scatter_product_equals_per_layer_copies():
+    """The first product of an operator fills the conv layers' v_W operands with one
+    strided copy per layer and registers them; later products use the single scatter
+    launch.  Same numbers either way."""
+    from pytorchhessianfree_amd import modelprep
+
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=4, device=DEV)
+    modelprep.prepare_model(model)
+    params = list(model.parameters())
+    out = model(x)
+    op = curvature.GGNOperator(lossf(out, t), out, params)
+    v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    first = op(v).clone()
+    assert len(op._tangent_slots) == 19  # every conv layer but the stem (its input has no tangent)
+    second = op(v).clone()
+
+    # MIOpen's split-K kernels accumulate with atomics: two identical calls agree to
+    # rounding only; a misplaced slice would be an O(1) error
+    def close(p, q):
+        return float((p - q).abs().max() / q.abs().max()) < 1e-5
+
+    assert close(first, second)
+    w = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    op._tangent_slots.clear()
+    a = op(w).clone()   # per-layer copies again
+    b = op(w).clone()   # scatter
+    assert close(a, b) and not close(a, first)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("n", [1, 5, 1003, 1 << 20])
 def test_axpy_out_and_precond_build(dtype, n):
     gen = torch.Generator(device=DEV).manual_seed(n)
@@ -582,4 +638,5 @@ def test_channels_last_curvature_path_small_net():
     and must not share an address space with the rest of the session."""
     res = _run_worker("nhwc_small_net.py")
     assert res["gather_exact"] is True
+    assert res["kernel_err"] < 1e-6, res  # elementwise parts exact, sums in fp64 then rounded
     assert max(res["errors"]) < 5e-3, res
