@@ -187,7 +187,11 @@ int hf_axpy_out(void* out, const void* a, const void* s, double alpha, int64_t n
  *                       out = relu_self ? max(t,0) : mask_src ? (mask_src>0 ? t : 0) : t
  *   hf_chan_affine_bwd: g = mask_src ? gy*(mask_src>0) : gy ;
  *                       gx = g*w*rstd, gw = sum_{n,hw} g*xhat, gb = sum g, gres = g
- *                       (gx, gw, gb, gres nullable)
+ *                       (gx, gw, gb, gres nullable; with gw == NULL, x/mean may be NULL,
+ *                       and with gx == NULL too rstd may be NULL: gb alone is the bias
+ *                       gradient of a convolution layer, sum_{n,hw} gy -- deterministic and
+ *                       safe inside a hipGraph, which PyTorch's multi-block reduction of an
+ *                       NHWC tensor was measured not to be on this stack)
  */
 int hf_chan_affine(void* out, const void* a, const void* x, const void* mean,
                    const void* rstd, const void* w, const void* q, const void* r,

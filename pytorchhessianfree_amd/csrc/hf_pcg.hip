@@ -750,7 +750,7 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
   const bool live = c < C;
   double acc[2] = {0.0, 0.0};
   if (live) {
-    const T rs = rstd[c], mu = mean[c];
+    const T rs = rstd ? rstd[c] : (T)1, mu = mean ? mean[c] : (T)0;
     const T s = (w ? w[c] : (T)1) * rs;
     const I per = N * HW;
     for (I e = lane; e < per; e += TPC) {
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
       if (mask_src) g = mask_src[idx] > (T)0 ? g : (T)0;
       if (gx) gx[idx] = g * s;
       if (gres) gres[idx] = g;
-      acc[0] += (double)g * (double)(T)((x[idx] - mu) * rs);
+      if (x) acc[0] += (double)g * (double)(T)((x[idx] - mu) * rs);
       acc[1] += (double)g;
     }
   }
@@ -796,8 +796,8 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd_nhwc(
   T rs[W], mu[W], sc[W];
 #pragma unroll
   for (int k = 0; k < W; ++k) {
-    rs[k] = rstd[c0 + k];
-    mu[k] = mean[c0 + k];
+    rs[k] = rstd ? rstd[c0 + k] : (T)1;
+    mu[k] = mean ? mean[c0 + k] : (T)0;
     sc[k] = (w ? w[c0 + k] : (T)1) * rs[k];
   }
   double acc[2 * W];
@@ -807,7 +807,8 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd_nhwc(
   for (I r = threadIdx.x; r < rows; r += BLOCK) {
     const I idx = r * C + c0;
     Col g = *reinterpret_cast<const Col*>(gy + idx);
-    const Col xv = *reinterpret_cast<const Col*>(x + idx);
+    Col xv;
+    if (x) xv = *reinterpret_cast<const Col*>(x + idx);
     if (mask_src) {
       const Col m = *reinterpret_cast<const Col*>(mask_src + idx);
 #pragma unroll
@@ -822,7 +823,7 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd_nhwc(
     }
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-      acc[2 * k] += (double)g.e[k] * (double)(T)((xv.e[k] - mu[k]) * rs[k]);
+      if (x) acc[2 * k] += (double)g.e[k] * (double)(T)((xv.e[k] - mu[k]) * rs[k]);
       acc[2 * k + 1] += (double)g.e[k];
     }
   }
@@ -1427,7 +1428,7 @@ static void launch_chan_affine_bwd(hipStream_t s, void* gx, void* gw, void* gb, 
                                    long long n, long long c, long long hw, int nhwc) {
   const long long total = n * c * hw;
   if (nhwc && hw > 1) {
-    const bool vec = c % 4 == 0 && aligned16(gy) && aligned16(x) && (!mask_src || aligned16(mask_src)) &&
+    const bool vec = c % 4 == 0 && aligned16(gy) && (!x || aligned16(x)) && (!mask_src || aligned16(mask_src)) &&
                      (!gx || aligned16(gx)) && (!gres || aligned16(gres)) && sizeof(T) == 4;
 #define HF_BWD_CL(I, W)                                                                           \
   hipLaunchKernelGGL((k_chan_affine_bwd_nhwc<T, I, W>), dim3((unsigned)(c / W)), dim3(BLOCK), 0, s, \
@@ -1458,7 +1459,9 @@ int hf_chan_affine_bwd(void* gx, void* gw, void* gb, void* gres, const void* gy,
                        const void* mean, const void* rstd, const void* w, const void* mask_src,
                        int64_t n, int64_t c, int64_t hw, int channels_last, int dtype,
                        void* stream) {
-  if (!gy || !x || !mean || !rstd || n <= 0 || c <= 0 || hw <= 0) return HF_ERR_ARG;
+  if (!gy || n <= 0 || c <= 0 || hw <= 0) return HF_ERR_ARG;
+  if ((gw && (!x || !mean || !rstd)) || (gx && !rstd)) return HF_ERR_ARG;
+  if (!gw) x = nullptr;  // plain per-channel sums (a conv layer's bias gradient)
   hipStream_t s = (hipStream_t)stream;
   if (dtype == HF_F32)
     launch_chan_affine_bwd<float>(s, gx, gw, gb, gres, gy, x, mean, rstd, w, mask_src, n, c, hw,

@@ -264,6 +264,51 @@ class GraphedOperator:
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
         self.calls = 0
+        self._verify_replay()
+
+    _verified = set()  # signatures whose first capture in this process was checked
+
+    def _verify_replay(self):
+        """Replay twice on a random vector and compare with the eager product.
+
+        Not paranoia: on this stack (PyTorch-ROCm 2.10, HIP 7.0, MIOpen 3.5) library
+        routines that zero a scratch buffer and then accumulate into it (MIOpen's CK
+        split-K weight gradient, its backward-bias, PyTorch's multi-block reductions of
+        NHWC tensors) were measured to be right when issued eagerly and wrong when
+        replayed from a hipGraph, the second replay differently from the first.  The
+        package routes around the instances it met; a model that brings a new one
+        must fail here, loudly, instead of producing wrong Newton steps.  By default
+        the first capture of every (size, parameter count, device) signature in the
+        process is checked (~2 products); ``HF_GRAPH_VERIFY=always|never`` overrides."""
+        import os
+
+        policy = os.environ.get("HF_GRAPH_VERIFY", "first")
+        key = (self.n, len(self.params), str(self.input_buffer.device), self.input_buffer.dtype)
+        if policy == "never" or (policy != "always" and key in GraphedOperator._verified):
+            return
+        gen = torch.Generator(device=self.input_buffer.device).manual_seed(1234)
+        with torch.cuda.stream(self.stream):
+            self.input_buffer.copy_(torch.randn(self.n, dtype=self.input_buffer.dtype,
+                                                device=self.input_buffer.device, generator=gen))
+            want = torch.empty_like(self.output_buffer)
+            self.op.local(self.input_buffer, out=want)
+            errs = []
+            for _ in range(2):
+                self._replay()
+                errs.append(float((self.output_buffer - want).abs().max() / want.abs().max().clamp_min(1e-30)))
+            self.input_buffer.zero_()
+        self.stream.synchronize()
+        torch.cuda.current_stream().wait_stream(self.stream)
+        if not all(e < 1e-3 for e in errs):
+            raise RuntimeError(
+                "hipGraph replay of the curvature product does not reproduce the eager product "
+                f"(relative max-norm error of two replays: {errs[0]:.2e}, {errs[1]:.2e}). A library "
+                "routine inside the product is not capture-safe on this stack; run with "
+                "graph_matvec=False (eager) or prepare the model with modelprep.prepare_model.")
+        GraphedOperator._verified.add(key)
+
+    def _replay(self):
+        self.graph.replay()
 
     def local(self, v, out=None):
         if v.data_ptr() != self.input_buffer.data_ptr():
@@ -336,6 +381,11 @@ class OverlappedGraphedOperator(GraphedOperator):
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
         self.calls = 0
+        self._verify_replay()
+
+    def _replay(self):
+        self.graph.replay()
+        self.graph_head.replay()
 
     def local(self, v, out=None):
         if v.data_ptr() != self.input_buffer.data_ptr():

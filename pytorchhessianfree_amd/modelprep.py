@@ -257,13 +257,17 @@ def _fmt(t, cl):
 
 
 class _miopen_mode:
-    """NHWC convolutions run in MIOpen's IMMEDIATE mode (``cudnn.benchmark`` off for
-    the duration of the call): the solver comes from the find-db record of the shape
-    (``miopen_db/`` ships the records of the BASELINE.json workloads) or, without a
-    record, from MIOpen's heuristic -- never from a find step, whose NHWC candidate
-    kernels are the suspected source of corrupted tensors (``prepare_model``).
-    ``HF_NHWC_FIND=1`` keeps the find step (used once, with the result checked, to
-    produce the shipped records).  NCHW calls are left as configured."""
+    """NHWC convolutions run in MIOpen's IMMEDIATE mode (``cudnn.benchmark`` off for the
+    duration of the call): the solver is the one the find-db record of the shape ranks
+    first (``miopen_db/`` ships the records of the BASELINE.json workloads) or, without
+    a record, MIOpen's heuristic choice -- never the outcome of a find step.  Measured:
+    on a machine with a cold kernel cache (every fresh box) MIOpen's find step
+    re-measures even shapes that have a record, rankings between close candidates flip
+    from process to process, and with NHWC operands one of the candidates is only good
+    to 1.5e-4; in immediate mode on the shipped records 40 of 40 processes reproduced
+    the float64 product to 3e-7 (scratch/nhwc_mode.sh, nhwc_diag.sh).
+    ``HF_NHWC_FIND=1`` keeps the find step (used once, result checked, to produce the
+    shipped records).  NCHW calls are left as configured."""
 
     def __init__(self, cl):
         self.active = bool(cl) and not os.environ.get("HF_NHWC_FIND")
@@ -324,6 +328,27 @@ def _tangent_prefilled(ctx, vgw, wcat, cin):
     return False
 
 
+def _bias_grad(gy):
+    """Bias gradient ``sum_{n,hw} gy`` of a conv layer by the ``hf_chan_affine_bwd``
+    reduction kernel.  Neither MIOpen's backward-bias routine nor ``gy.sum((0, 2, 3))``
+    is used on this path: for NHWC cotangents of some shapes (All-CNN-C at batch 32: two
+    of nine layers) both were right when issued eagerly and wrong -- drifting from
+    replay to replay -- once captured in a hipGraph (scratch/nhwc_diag.py,
+    scratch/bias_diag.sh); they zero a scratch buffer with a memset that does not
+    survive the capture intact.  The kernel here has no scratch state."""
+    if torch.is_grad_enabled() and gy.requires_grad:  # differentiable (Hessian products)
+        return gy.sum(dim=(0, 2, 3))
+    g = _dense(gy)
+    n, c, hw = _dims(g)
+    gb = torch.empty(c, dtype=g.dtype, device=g.device)
+    _lib.check(
+        _lib.load().hf_chan_affine_bwd(
+            None, None, _p(gb), None, _p(g), None, None, None, None, None, n, c, hw,
+            1 if _is_cl(g) else 0, _lib.dtype_code(g.dtype), _lib.current_stream_ptr(g.device)),
+        "hf_chan_affine_bwd")
+    return gb
+
+
 class _ConvBwd(torch.autograd.Function):
     """(gy; x, w) -> (gx, gw, gb) of a convolution.  Recorded only in
     ``first_order_only`` mode, so the sole derivative ever taken is d/d gy, whose
@@ -344,11 +369,12 @@ class _ConvBwd(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.conf = (stride, padding, dilation, has_bias, cl)
         ctx.cat = None
+        gy = _fmt(gy, cl)
         with _miopen_mode(cl):
-            gx, gw, gb = torch.ops.aten.convolution_backward(
-                _fmt(gy, cl), x, w, [w.shape[0]] if has_bias else None, stride, padding, dilation,
-                False, [0] * len(stride), 1, [need_gx, True, has_bias])
-        return gx, gw, gb
+            gx, gw, _ = torch.ops.aten.convolution_backward(
+                gy, x, w, None, stride, padding, dilation, False, [0] * len(stride), 1,
+                [need_gx, True, False])
+        return gx, gw, _bias_grad(gy) if has_bias else None
 
     @staticmethod
     def backward(ctx, vgx, vgw, vgb):
@@ -413,9 +439,10 @@ class _Conv(torch.autograd.Function):
             else:
                 xa, wa = xf, wf
             with _miopen_mode(cl):
-                gx, gw, gb = torch.ops.aten.convolution_backward(
-                    gy, xa, wa, [w.shape[0]] if has_bias else None, stride, padding, dilation, False,
-                    [0] * len(stride), 1, [need_gx, True, has_bias])
+                gx, gw, _ = torch.ops.aten.convolution_backward(
+                    gy, xa, wa, None, stride, padding, dilation, False, [0] * len(stride), 1,
+                    [need_gx, True, False])
+            gb = _bias_grad(gy) if has_bias else None
         return gx, gw, gb if has_bias else None, None, None, None, None
 
 
@@ -452,19 +479,24 @@ def fuse_conv_tangent(model, channels_last=False):
 def prepare_model(model, channels_last=False):
     """All opt-in preparations; returns ``model`` for chaining.
 
-    ``channels_last=True`` additionally runs the convolution layers (and with them the
-    fused BatchNorm kernels) in NHWC, which removes MIOpen's layout transposes (~40 %
-    of the kernels of a product: 1.59 -> 1.25 ms on ResNet-18).  It is OFF by default:
-    in NHWC MIOpen 3.5 has more candidate solvers / tuning instances, and in ~1 of 10
-    cold-database runs its find step settled on one that is off by 1e-3 or produces
-    NaNs (scratch/nhwc_flaky*.py); NCHW with Winograd disabled never did.  The pattern
-    (only the FIRST operator built while MIOpen is still benchmarking is wrong, a second
-    one in the same process with the same solvers is right; a stock model sharing no
-    tensors stays right) points at a candidate kernel writing out of bounds during the
-    find step -- not something a result check can guard against.  Also the
-    NHWC BatchNorm reduction kernel is not yet parallelised over rows (115 us per call
-    on the early layers), so today the NHWC path is slower end to end (288 vs 571
-    matvecs/s on the bench) -- kept as the starting point for a later round."""
+    ``channels_last=True`` additionally runs the convolution layers, and with them the
+    fused BatchNorm kernels, in NHWC: MIOpen's implicit-GEMM kernels then need no layout
+    transposes (~40 % of the kernels of a product in NCHW; ResNet-18 bench 588 -> 765
+    matvecs/s).  Parameters, their order and the flat-vector layout do not change:
+    layers keep a per-step NHWC copy of their weight and ``hf_pack`` un-permutes the
+    NHWC weight gradients while it gathers them.  NHWC convolutions run in MIOpen's
+    immediate mode (``_miopen_mode``), i.e. at full speed for shapes with a find-db
+    record (shipped for the BASELINE.json ResNet-18 workload; ``HF_NHWC_FIND=1`` once to
+    add yours) and on MIOpen's heuristic choice otherwise -- which is why NCHW, where
+    the find step has been reliable, stays the default.
+
+    History: the NHWC path used to produce, in about one process of ten, a product that
+    was off by 1e-3 or plain garbage.  Causes found (scratch/nhwc_diag.py): MIOpen's
+    composable-kernel split-K weight gradient, now disabled package-wide (``__init__``),
+    and reductions that zero a scratch buffer before accumulating (MIOpen's backward-bias,
+    PyTorch's multi-block ``sum`` of an NHWC tensor), which break inside a hipGraph and
+    are replaced by ``_bias_grad``.  ``GraphedOperator`` now checks its first replay
+    against the eager product."""
     fuse_eval_batchnorm(model)
     fuse_conv_tangent(model, channels_last=channels_last)
     fuse_residual_blocks(model)

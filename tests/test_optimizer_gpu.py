@@ -291,7 +291,7 @@ def _cpu_twin(make, **kw):
     return model, x, t, lossf
 
 
-@pytest.mark.parametrize("prepared", [False, True])
+@pytest.mark.parametrize("prepared", [False, "nchw", "nhwc"])
 @pytest.mark.parametrize("workload", ["resnet18", "allcnnc"])
 def test_curvature_products_on_conv_nets_match_cpu_oracle(workload, prepared):
     """GGN and Hessian products of the ResNet-18 / All-CNN-C shaped nets on the GPU
@@ -317,7 +317,7 @@ def test_curvature_products_on_conv_nets_match_cpu_oracle(workload, prepared):
     if prepared:  # fused eval-BN(+add+ReLU) kernels, single-convolution tangent maps
         from pytorchhessianfree_amd import modelprep
 
-        modelprep.prepare_model(gmodel)
+        modelprep.prepare_model(gmodel, channels_last=prepared == "nhwc")
     gparams = [p for p in gmodel.parameters()]
 
     def builder():
@@ -630,13 +630,12 @@ def test_stale_graph_fails_loudly_after_in_place_parameter_write():
 
 
 def test_channels_last_curvature_path_small_net():
-    """Opt-in NHWC path (prepare_model(channels_last=True)): NHWC BatchNorm kernels,
-    channels_last conv Functions, un-permuting gather of NHWC weight gradients.  Layout
-    bugs give O(1) errors; the tolerance (5e-3 of the max-norm) leaves room for
-    MIOpen's less accurate NHWC tuning instances.  Runs in a worker process: MIOpen's
-    find step on NHWC shapes is suspected of out-of-bounds writes (modelprep.prepare_model)
-    and must not share an address space with the rest of the session."""
+    """NHWC path (prepare_model(channels_last=True)) on a small net with conv biases and channel
+    counts that are / are not multiples of four: NHWC BatchNorm kernels (also checked
+    directly against the NCHW kernels), channels_last conv Functions, un-permuting gather
+    of NHWC weight gradients.  In a worker process (history: a broken MIOpen solver, now
+    disabled in the package __init__, used to corrupt results here; the isolation stays)."""
     res = _run_worker("nhwc_small_net.py")
     assert res["gather_exact"] is True
     assert res["kernel_err"] < 1e-6, res  # elementwise parts exact, sums in fp64 then rounded
-    assert max(res["errors"]) < 5e-3, res
+    assert max(res["errors"]) < 1e-5, res
