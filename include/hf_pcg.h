@@ -202,6 +202,18 @@ int hf_chan_affine_bwd(void* gx, void* gw, void* gb, void* gres, const void* gy,
                        const void* mask_src, int64_t n, int64_t c, int64_t hw,
                        int channels_last, int dtype, void* stream);
 
+/* ---- loss Hessian inside the GGN product ------------------------------------ */
+/*
+ * out[r, :] = scale * p[r, :] * (v[r, :] - <p[r, :], v[r, :]>),  p = softmax(logits) row-wise:
+ * the Hessian of a softmax cross-entropy w.r.t. the logits applied to v = J v (scale = 1/B
+ * for reduction "mean").  It is the middle factor of J^T H_L J v, which BackPACK's
+ * ggn_vector_product_from_plist (optimizer.py:461) obtains by differentiating the loss
+ * twice (~14 small kernels per product); the host verifies this closed form against that
+ * autograd sweep once per operator before using it.  [rows, cols] row-major, contiguous.
+ */
+int hf_softmax_ce_hvp(void* out, const void* p, const void* v, double scale, int64_t rows,
+                      int64_t cols, int dtype, void* stream);
+
 /* ---- RCCL (resolved at run time from the already-loaded librccl) ----------- */
 typedef struct hf_comm hf_comm_t;
 int hf_comm_unique_id(char* out128);                        /* ncclGetUniqueId */

@@ -89,6 +89,7 @@ SIGNATURES = {
     "hf_axpy_out": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int, c_void_p]),
     "hf_chan_affine": (c_int, [c_void_p] * 10 + [c_int, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "hf_chan_affine_bwd": (c_int, [c_void_p] * 10 + [c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "hf_softmax_ce_hvp": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int64, c_int, c_void_p]),
     "hf_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "hf_comm_create": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_char_p, c_int, c_int]),
     "hf_comm_destroy": (c_int, [c_void_p]),
@@ -229,6 +230,24 @@ def unpack_tangent(v, slots):
         ),
         "hf_unpack_tangent",
     )
+
+
+def softmax_ce_hvp(p, v, scale):
+    """scale * p * (v - <p, v>) row-wise (Hessian of softmax cross-entropy applied to v)."""
+    lib = load()
+    require_device_tensor(v, "v")
+    p, v = p.contiguous(), v.contiguous()
+    if p.shape != v.shape or p.dim() != 2 or p.dtype != v.dtype:
+        raise RuntimeError("softmax_ce_hvp: p and v must be [rows, cols] of one dtype")
+    out = torch.empty_like(v)
+    check(
+        lib.hf_softmax_ce_hvp(
+            c_void_p(out.data_ptr()), c_void_p(p.data_ptr()), c_void_p(v.data_ptr()), float(scale),
+            v.shape[0], v.shape[1], dtype_code(v.dtype), current_stream_ptr(v.device),
+        ),
+        "hf_softmax_ce_hvp",
+    )
+    return out
 
 
 def axpy_out(out, a, s, alpha):

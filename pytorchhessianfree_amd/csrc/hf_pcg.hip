@@ -837,6 +837,24 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd_nhwc(
   }
 }
 
+// Hessian of a softmax cross-entropy w.r.t. the logits, applied to v, row by row:
+//   out[r, :] = scale * p[r, :] * (v[r, :] - <p[r, :], v[r, :]>)      (p = softmax(logits))
+// One block per row; the dot product is accumulated in fp64.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_softmax_ce_hvp(T* __restrict__ out,
+                                                          const T* __restrict__ p,
+                                                          const T* __restrict__ v, T scale,
+                                                          int cols) {
+  __shared__ double lds[WAVES];
+  const long long base = (long long)blockIdx.x * cols;
+  double acc[1] = {0.0};
+  for (int j = threadIdx.x; j < cols; j += BLOCK) acc[0] += (double)p[base + j] * (double)v[base + j];
+  block_allreduce<1>(acc, lds);
+  const T d = (T)acc[0];
+  for (int j = threadIdx.x; j < cols; j += BLOCK)
+    out[base + j] = scale * (p[base + j] * (v[base + j] - d));
+}
+
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
@@ -1377,6 +1395,23 @@ int hf_axpy_out(void* out, const void* a, const void* sv, double alpha, int64_t 
     hipLaunchKernelGGL((k_axpy_out<double>), dim3(small_grid(n / 2 + 1)), dim3(BLOCK), 0, s,
                        (double*)out, (const double*)a, (const double*)sv, alpha, (long long)n,
                        vec_ok);
+  else
+    return HF_ERR_ARG;
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_softmax_ce_hvp(void* out, const void* p, const void* v, double scale, int64_t rows,
+                      int64_t cols, int dtype, void* stream) {
+  if (!out || !p || !v || rows <= 0 || cols <= 0 || cols > 0x7fffffffLL || rows > 0x7fffffffLL)
+    return HF_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == HF_F32)
+    hipLaunchKernelGGL((k_softmax_ce_hvp<float>), dim3((unsigned)rows), dim3(BLOCK), 0, s, (float*)out,
+                       (const float*)p, (const float*)v, (float)scale, (int)cols);
+  else if (dtype == HF_F64)
+    hipLaunchKernelGGL((k_softmax_ce_hvp<double>), dim3((unsigned)rows), dim3(BLOCK), 0, s,
+                       (double*)out, (const double*)p, (const double*)v, scale, (int)cols);
   else
     return HF_ERR_ARG;
   HF_HIP(hipGetLastError());

@@ -98,6 +98,46 @@ class GGNOperator(_Operator):
         self._JTu = [JTu[i] for i in self._used]
         # d loss / d outputs with graph -> H_L by one more sweep
         (self._dl,) = torch.autograd.grad(loss, outputs, create_graph=True, retain_graph=True)
+        self._ce = self._closed_form_loss_hessian(loss, outputs)
+
+    def _closed_form_loss_hessian(self, loss, outputs):
+        """``(p, scale)`` if the loss is a softmax cross-entropy of ``outputs`` whose
+        Hessian ``scale * (diag(p) - p p^T)`` (per row) reproduces the autograd sweep
+        through ``d loss / d outputs`` on a random vector, else ``None``.  The structural
+        test only nominates; the numerical check decides (class weights, ignored targets,
+        label smoothing etc. fail it and keep the generic sweep).  GPU tensors only."""
+        fn = loss.grad_fn
+        try:
+            if not outputs.is_cuda or outputs.dim() != 2 or fn is None or fn.name() != "NllLossBackward0":
+                return None
+            lsm = fn.next_functions[0][0]
+            if lsm is None or lsm.name() != "LogSoftmaxBackward0" or lsm._saved_dim not in (1, -1):
+                return None
+            if lsm.next_functions[0][0] is not outputs.grad_fn or not self._dl.requires_grad:
+                return None
+            scale = {1: 1.0 / outputs.shape[0], 2: 1.0}.get(fn._saved_reduction)
+        except AttributeError:
+            return None
+        if scale is None:
+            return None
+        p = torch.softmax(outputs.detach(), dim=1)
+        gen = torch.Generator(device=outputs.device).manual_seed(99)
+        probe = torch.randn(outputs.shape, dtype=outputs.dtype, device=outputs.device, generator=gen)
+        (want,) = torch.autograd.grad(self._dl, outputs, grad_outputs=probe, retain_graph=True)
+        got = _lib.softmax_ce_hvp(p, probe, scale)
+        if not float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()):
+            return None
+        return p, scale
+
+    def _loss_hessian(self, Jv):
+        if self._ce is not None:
+            return _lib.softmax_ce_hvp(self._ce[0], Jv, self._ce[1])
+        if not self._dl.requires_grad:  # loss linear in the outputs: H_L = 0
+            return torch.zeros_like(Jv)
+        (HJv,) = torch.autograd.grad(
+            self._dl, self.outputs, grad_outputs=Jv, retain_graph=True, allow_unused=True
+        )
+        return torch.zeros_like(Jv) if HJv is None else HJv
 
     def local(self, v, out=None):
         vs = vector_to_parameter_list(v, self.params)
@@ -105,14 +145,7 @@ class GGNOperator(_Operator):
             (Jv,) = torch.autograd.grad(
                 self._JTu, self._u, grad_outputs=[vs[i] for i in self._used], retain_graph=True
             )
-        if self._dl.requires_grad:
-            (HJv,) = torch.autograd.grad(
-                self._dl, self.outputs, grad_outputs=Jv, retain_graph=True, allow_unused=True
-            )
-            if HJv is None:
-                HJv = torch.zeros_like(Jv)
-        else:  # loss linear in the outputs: H_L = 0
-            HJv = torch.zeros_like(Jv)
+        HJv = self._loss_hessian(Jv)
         JTHJv = torch.autograd.grad(
             self.outputs, self.params, grad_outputs=HJv, retain_graph=True, allow_unused=True
         )
@@ -135,12 +168,7 @@ class GGNOperator(_Operator):
             (Jv,) = torch.autograd.grad(
                 self._JTu, self._u, grad_outputs=[vs[i] for i in self._used], retain_graph=True
             )
-        if not self._dl.requires_grad:
-            return torch.zeros_like(Jv)
-        (HJv,) = torch.autograd.grad(
-            self._dl, self.outputs, grad_outputs=Jv, retain_graph=True, allow_unused=True
-        )
-        return torch.zeros_like(Jv) if HJv is None else HJv
+        return self._loss_hessian(Jv)
 
     def phase_tail(self, v, out, cut, offset):
         """``out[offset:] = weight * (J^T H_L J v)[offset:]`` -- tangent sweep, loss

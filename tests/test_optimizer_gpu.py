@@ -251,6 +251,45 @@ def test_tangent_scatter_product_equals_per_layer_copies():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_closed_form_softmax_ce_hessian_is_used_only_where_it_matches_autograd(dtype):
+    """GGNOperator replaces the autograd sweep through the loss by ``hf_softmax_ce_hvp``
+    for a plain softmax cross-entropy (mean or sum) after checking it numerically; class
+    weights, ignored targets, label smoothing and other losses keep the generic sweep.
+    Products agree with forward-mode J v -> autograd H_L -> reverse-mode J^T either way."""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 9), torch.nn.Tanh(), torch.nn.Linear(9, 300)).to(DEV, dtype)
+    params = list(net.parameters())
+    x = torch.randn(11, 7, device=DEV, dtype=dtype)
+    t = torch.randint(0, 300, (11,), device=DEV)
+    t[3] = 5
+    n = sum(p.numel() for p in params)
+    v = torch.randn(n, device=DEV, dtype=dtype)
+    cases = [
+        (torch.nn.CrossEntropyLoss(), True), (torch.nn.CrossEntropyLoss(reduction="sum"), True),
+        (torch.nn.CrossEntropyLoss(label_smoothing=0.1), False),
+        (torch.nn.CrossEntropyLoss(weight=torch.rand(300, device=DEV, dtype=dtype) + 0.5), False),
+        (torch.nn.CrossEntropyLoss(ignore_index=5), False),
+        (lambda o, tt: (o ** 2).mean(), False),
+    ]
+    for lossf, fused in cases:
+        out = net(x)
+        loss = lossf(out, t)
+        op = curvature.GGNOperator(loss, out, params)
+        assert (op._ce is not None) == fused, lossf
+        # reference: forward-mode J v, autograd H_L, reverse-mode J^T
+        (dl,) = torch.autograd.grad(loss, out, create_graph=True)
+        Jv = torch.autograd.functional.jvp(lambda *ps: torch.func.functional_call(net, dict(zip(
+            [k for k, _ in net.named_parameters()], ps)), (x,)), tuple(params),
+            tuple(hf.vector_to_parameter_list(v, params)))[1]
+        (HJv,) = torch.autograd.grad(dl, out, grad_outputs=Jv, retain_graph=True)
+        want = torch.cat([g.reshape(-1) for g in torch.autograd.grad(out, params, grad_outputs=HJv,
+                                                                    retain_graph=True)])
+        got = op(v)
+        tol = 2e-5 if dtype == torch.float32 else 1e-12
+        assert float((got - want).abs().max()) <= tol * float(want.abs().max()), lossf
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("n", [1, 5, 1003, 1 << 20])
 def test_axpy_out_and_precond_build(dtype, n):
     gen = torch.Generator(device=DEV).manual_seed(n)
