@@ -193,10 +193,16 @@ int hf_axpy_out(void* out, const void* a, const void* s, double alpha, int64_t n
  *                       safe inside a hipGraph, which PyTorch's multi-block reduction of an
  *                       NHWC tensor was measured not to be on this stack)
  */
+/* out_ld / add_ld (elements, 0 = dense): `out` resp. `add` is the slice of the first c channels
+ * of a buffer with more channels -- NHWC: element (row, ch) at row*ld + ch; NCHW: (n, ch, hw)
+ * at n*ld + ch*hw_count + hw.  The tangent sweep uses it to write a layer's output tangent
+ * straight into the next convolution's [v_x | x] operand (and to read it from there for
+ * the residual branch) instead of copying it. */
 int hf_chan_affine(void* out, const void* a, const void* x, const void* mean,
                    const void* rstd, const void* w, const void* q, const void* r,
                    const void* add, const void* mask_src, int relu_self, int64_t n,
-                   int64_t c, int64_t hw, int channels_last, int dtype, void* stream);
+                   int64_t c, int64_t hw, int channels_last, int64_t out_ld, int64_t add_ld,
+                   int dtype, void* stream);
 int hf_chan_affine_bwd(void* gx, void* gw, void* gb, void* gres, const void* gy,
                        const void* x, const void* mean, const void* rstd, const void* w,
                        const void* mask_src, int64_t n, int64_t c, int64_t hw,

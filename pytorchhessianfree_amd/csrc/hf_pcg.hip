@@ -719,7 +719,11 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine(
     T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ x,
     const T* __restrict__ mean, const T* __restrict__ rstd, const T* __restrict__ w,
     const T* __restrict__ q, const T* __restrict__ r, const T* __restrict__ add,
-    const T* __restrict__ mask_src, int relu_self, I total, I C, I HW, int nhwc) {
+    const T* __restrict__ mask_src, int relu_self, I total, I C, I HW, int nhwc, I out_ld,
+    I add_ld) {
+  // out_ld / add_ld != 0: that operand is the first-C-channels slice of a wider buffer --
+  // NHWC: element (row, c) at row*ld + c; NCHW: (n, c, hw) at n*ld + c*HW + hw.
+  const I CHW = C * HW;
   for (I i = (I)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (I)gridDim.x * BLOCK) {
     const I c = (nhwc || HW == 1 ? i : i / HW) % C;  // NHWC: the channel is the fastest index
     const T rs = rstd[c];
@@ -727,10 +731,12 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine(
     if (a) acc = a[i] * ((w ? w[c] : (T)1) * rs);
     if (q) acc += ((x[i] - mean[c]) * rs) * q[c];
     if (r) acc += r[c];
-    if (add) acc += add[i];
+    I outer = 0;
+    if (out_ld | add_ld) outer = nhwc ? i / C : i / CHW;  // row resp. sample
+    if (add) acc += add[add_ld ? i + outer * (add_ld - (nhwc ? C : CHW)) : i];
     if (relu_self) acc = acc > (T)0 ? acc : (T)0;
     else if (mask_src) acc = mask_src[i] > (T)0 ? acc : (T)0;
-    out[i] = acc;
+    out[out_ld ? i + outer * (out_ld - (nhwc ? C : CHW)) : i] = acc;
   }
 }
 
@@ -1423,33 +1429,40 @@ static void launch_chan_affine(hipStream_t s, void* out, const void* a, const vo
                                const void* mean, const void* rstd, const void* w, const void* q,
                                const void* r, const void* add, const void* mask_src,
                                int relu_self, long long total, long long c, long long hw,
-                               int nhwc) {
-  if (total < 0x7fffffffLL)
+                               int nhwc, long long out_ld, long long add_ld) {
+  if (2 * total < 0x7fffffffLL)  // strided operands reach at most 2*total
     hipLaunchKernelGGL((k_chan_affine<T, unsigned>), dim3(small_grid(total)), dim3(BLOCK), 0, s,
                        (T*)out, (const T*)a, (const T*)x, (const T*)mean, (const T*)rstd,
                        (const T*)w, (const T*)q, (const T*)r, (const T*)add, (const T*)mask_src,
-                       relu_self, (unsigned)total, (unsigned)c, (unsigned)hw, nhwc);
+                       relu_self, (unsigned)total, (unsigned)c, (unsigned)hw, nhwc,
+                       (unsigned)out_ld, (unsigned)add_ld);
   else
     hipLaunchKernelGGL((k_chan_affine<T, long long>), dim3(small_grid(total)), dim3(BLOCK), 0, s,
                        (T*)out, (const T*)a, (const T*)x, (const T*)mean, (const T*)rstd,
                        (const T*)w, (const T*)q, (const T*)r, (const T*)add, (const T*)mask_src,
-                       relu_self, total, c, hw, nhwc);
+                       relu_self, total, c, hw, nhwc, out_ld, add_ld);
 }
 
 int hf_chan_affine(void* out, const void* a, const void* x, const void* mean, const void* rstd,
                    const void* w, const void* q, const void* r, const void* add,
                    const void* mask_src, int relu_self, int64_t n, int64_t c, int64_t hw,
-                   int channels_last, int dtype, void* stream) {
+                   int channels_last, int64_t out_ld, int64_t add_ld, int dtype, void* stream) {
   if (!out || !rstd || n <= 0 || c <= 0 || hw <= 0) return HF_ERR_ARG;
   if (q && (!x || !mean)) return HF_ERR_ARG;
+  // a leading dimension is that of a buffer with MORE channels: >= 2x would be the
+  // tangent buffers' case, anything above the dense one is accepted
+  const int64_t dense = channels_last ? c : c * hw;
+  if ((out_ld && out_ld < dense) || (add_ld && (add_ld < dense || !add)) ||
+      out_ld > 0x3fffffffLL || add_ld > 0x3fffffffLL)
+    return HF_ERR_ARG;
   const long long total = (long long)n * c * hw;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == HF_F32)
     launch_chan_affine<float>(s, out, a, x, mean, rstd, w, q, r, add, mask_src, relu_self, total, c, hw,
-                              channels_last);
+                              channels_last, out_ld, add_ld);
   else if (dtype == HF_F64)
     launch_chan_affine<double>(s, out, a, x, mean, rstd, w, q, r, add, mask_src, relu_self, total, c, hw,
-                               channels_last);
+                               channels_last, out_ld, add_ld);
   else
     return HF_ERR_ARG;
   HF_HIP(hipGetLastError());

@@ -29,6 +29,7 @@ class _Mode:
     owner = None      # operator running its tangent sweep (see ``tangent_owner``)
     vector = None     # the flat vector that sweep differentiates against
     prefilled = False
+    producers = {}    # data_ptr -> (ctx, tensor) of this sweep's fused-layer tangent outputs
 
 
 class first_order_only:
@@ -79,16 +80,49 @@ def _like(t, ref):
     return t.contiguous()
 
 
-def _affine(a, x, mean, rstd, w, q, r, like, add=None, mask_src=None, relu_self=False):
+def _slice_ld(t, like):
+    """Leading dimension if ``t`` (shaped like ``like``) is the first-channels slice of a
+    wider buffer in ``like``'s layout -- NHWC: (row, c) at row*ld + c; NCHW: (n, c, hw) at
+    n*ld + c*HW + hw --, 0 if it is dense in that layout, None if it is neither."""
+    if t.shape != like.shape or t.dim() != 4 or t.dtype != like.dtype:
+        return None
+    n, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    if _is_cl(like):
+        ld = sw if w > 1 else (sh if h > 1 else (sn if n > 1 else c))
+        ok = (c == 1 or sc == 1) and (w == 1 or sw == ld) and (h == 1 or sh == w * ld) and (n == 1 or sn == h * w * ld)
+        dense = c
+    else:
+        ld = sn if n > 1 else c * h * w
+        ok = (w == 1 or sw == 1) and (h == 1 or sh == w) and (c == 1 or sc == h * w)
+        dense = c * h * w
+    if not ok or ld < dense:
+        return None
+    return 0 if ld == dense else ld
+
+
+def _affine(a, x, mean, rstd, w, q, r, like, add=None, mask_src=None, relu_self=False, out=None):
     """out = act(a*(w*rstd) + xhat*q + r + add) (nullable terms), one launch; all
-    activation-sized operands share ``like``'s layout (NCHW or NHWC)."""
-    out = torch.empty_like(like)
+    activation-sized operands share ``like``'s layout (NCHW or NHWC).  ``out`` / ``add``
+    may be first-channels slices of wider buffers in that layout (``_slice_ld``)."""
+    out_ld = 0
+    if out is None:
+        out = torch.empty_like(like)
+    else:
+        out_ld = _slice_ld(out, like)
+        if out_ld is None:
+            raise RuntimeError("_affine: unusable output slice")
+    add_ld = 0
+    if add is not None:
+        add_ld = _slice_ld(add, like)
+        if add_ld is None:
+            add, add_ld = _like(add, like), 0
     n, c, hw = _dims(like)
     _lib.check(
         _lib.load().hf_chan_affine(
             _p(out), _p(a), _p(x), _p(mean), _p(rstd), _p(w), _p(q), _p(r), _p(add), _p(mask_src),
-            1 if relu_self else 0, n, c, hw, 1 if _is_cl(like) else 0, _lib.dtype_code(like.dtype),
-            _lib.current_stream_ptr(like.device)),
+            1 if relu_self else 0, n, c, hw, 1 if _is_cl(like) else 0, out_ld, add_ld,
+            _lib.dtype_code(like.dtype), _lib.current_stream_ptr(like.device)),
         "hf_chan_affine")
     return out
 
@@ -136,10 +170,16 @@ class _ChanAffineBwd(torch.autograd.Function):
         if vgx is None and vgw is None and vgb is None and vgres is None:
             return (None,) * 7
         # d/d gy : one fused launch (this is the layer's tangent map)
+        # ... written straight into the next convolution's [v_x | x] operand once that
+        # layer has claimed this output (``_claim_direct``); the residual branch reads its
+        # operand from such a slice without a copy as well
+        direct = getattr(ctx, "_hf_direct", None)
         v_gy = _affine(_like(vgx, x), x, mean, rstd, w,
                        None if vgw is None else vgw.contiguous(),
-                       None if vgb is None else vgb.contiguous(), like=x, add=_like(vgres, x),
-                       mask_src=y)
+                       None if vgb is None else vgb.contiguous(), like=x, add=vgres,
+                       mask_src=y, out=direct)
+        if direct is None and _Mode.owner is not None:
+            _Mode.producers[v_gy.data_ptr()] = (ctx, v_gy)  # holding v_gy pins the address
         v_x = v_w = None
         # second-order terms, only for Hessian products (plain ATen, rare path);
         # the ReLU mask is piecewise constant, so it only gates the cotangent
@@ -297,17 +337,38 @@ class tangent_owner:
         op = self.operator
         if not hasattr(op, "_tangent_slots"):
             op._tangent_slots = {}  # id(ctx) -> (offset, wcat, cin)
-        self.saved = (_Mode.owner, _Mode.vector, _Mode.prefilled)
+        self.saved = (_Mode.owner, _Mode.vector, _Mode.prefilled, _Mode.producers)
         _Mode.owner, _Mode.vector = op, self.v
-        _Mode.prefilled = False
+        _Mode.prefilled, _Mode.producers = False, {}
         if op._tangent_slots and self.v.is_cuda and self.v.is_contiguous():
             _lib.unpack_tangent(self.v, list(op._tangent_slots.values()))
             _Mode.prefilled = True
         return self
 
     def __exit__(self, *exc):
-        _Mode.owner, _Mode.vector, _Mode.prefilled = self.saved
+        _Mode.owner, _Mode.vector, _Mode.prefilled, _Mode.producers = self.saved
         return False
+
+
+def _claim_direct(vgx, dst, cl):
+    """First sweep of an operator: if ``vgx`` is the tangent output of a fused BatchNorm
+    layer of this sweep, dense in the layout of the conv's operand buffer, let that layer
+    write into ``dst`` (= ``xcat[:, :cin]``) from the next sweep on.  One claim per
+    producer; its other consumers (a downsample conv, the residual branch) then see the
+    slice, which they handle as a strided tensor."""
+    if _Mode.owner is None:
+        return
+    entry = _Mode.producers.get(vgx.data_ptr())
+    if entry is None or entry[1] is not vgx and entry[1].data_ptr() != vgx.data_ptr():
+        return
+    prod, t = entry
+    if getattr(prod, "_hf_direct", None) is not None or t.shape != dst.shape or t.dtype != dst.dtype:
+        return
+    if _is_cl(t) != bool(cl) and not (t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last)):
+        return
+    if _slice_ld(dst, t) in (None, 0):
+        return
+    prod._hf_direct = dst
 
 
 def _tangent_prefilled(ctx, vgw, wcat, cin):
@@ -402,7 +463,11 @@ class _ConvBwd(torch.autograd.Function):
                 wcat[:, :cin].copy_(w)
                 ctx.cat = (xcat, wcat)
             xcat, wcat = ctx.cat
-            xcat[:, :cin].copy_(vgx)
+            dst = xcat[:, :cin]
+            if not (vgx.data_ptr() == dst.data_ptr() and vgx.shape == dst.shape
+                    and vgx.stride() == dst.stride()):  # else: the producer wrote it in place
+                dst.copy_(vgx)
+                _claim_direct(vgx, dst, cl)
             if not _tangent_prefilled(ctx, vgw, wcat, cin):
                 wcat[:, cin:].copy_(vgw)
             v_gy = conv(xcat, wcat, None, stride, padding, dilation)

@@ -290,6 +290,40 @@ def test_closed_form_softmax_ce_hessian_is_used_only_where_it_matches_autograd(d
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("cl", [False, True])
+def test_chan_affine_writes_and_reads_channel_slices_of_wider_buffers(dtype, cl):
+    """hf_chan_affine with out_ld / add_ld: the output goes into, and the residual operand
+    comes from, the first-C-channels slice of a [B, 2C, H, W] buffer (NCHW or NHWC) --
+    what lets the tangent sweep skip the copy into the next convolution's operand."""
+    from pytorchhessianfree_amd import modelprep
+
+    fmt = torch.channels_last if cl else torch.contiguous_format
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    for (n, c, h, w) in [(3, 8, 5, 4), (2, 6, 3, 3), (4, 16, 1, 1), (1, 4, 2, 7)]:
+        def rnd(*shape):
+            return torch.randn(*shape, device=DEV, dtype=dtype, generator=gen)
+
+        x, a, add, y = (rnd(n, c, h, w).contiguous(memory_format=fmt) for _ in range(4))
+        mean, wgt, q, r = (rnd(c) for _ in range(4))
+        rstd = torch.rand(c, device=DEV, dtype=dtype, generator=gen) + 0.5
+        want = modelprep._affine(a, x, mean, rstd, wgt, q, r, like=x, add=add, mask_src=y)
+        wide_out = torch.full((n, 2 * c, h, w), 7.0, device=DEV, dtype=dtype).contiguous(memory_format=fmt)
+        wide_add = rnd(n, 2 * c, h, w).contiguous(memory_format=fmt)
+        wide_add[:, :c].copy_(add)
+        got = modelprep._affine(a, x, mean, rstd, wgt, q, r, like=x, add=wide_add[:, :c], mask_src=y,
+                                out=wide_out[:, :c])
+        assert got.data_ptr() == wide_out.data_ptr()
+        assert torch.equal(wide_out[:, :c], want)
+        assert bool((wide_out[:, c:] == 7.0).all())  # the other half is untouched
+        if cl and (h, w) != (1, 1):
+            ld = 2 * c                      # NHWC: row stride
+        else:
+            ld = 2 * c * h * w if n > 1 else 0  # NCHW: sample stride (one sample: the slice is dense)
+        assert modelprep._slice_ld(wide_out[:, :c], x) == ld
+        assert modelprep._slice_ld(x, x) == 0 and modelprep._slice_ld(wide_out[:, ::2], x) is None  # every other channel
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("n", [1, 5, 1003, 1 << 20])
 def test_axpy_out_and_precond_build(dtype, n):
     gen = torch.Generator(device=DEV).manual_seed(n)
