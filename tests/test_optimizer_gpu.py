@@ -192,6 +192,15 @@ def test_pack_gathers_like_cat(dtype):
     assert torch.equal(out, torch.cat(many))
     with pytest.raises(RuntimeError):
         _lib.pack(out, many[:-1])
+    # channels_last sources (MIOpen's NHWC weight gradients) are un-permuted inside the gather:
+    # LDS-tiled path (whole [I, HW] slabs per block) and the direct one (slab too large for the tile)
+    shapes = [(128, 64, 3, 3), (7,), (512, 512, 3, 3), (64, 2, 7, 7), (5, 3, 1, 1), (3, 700, 5, 5), (9, 6, 2, 3)]
+    ts = [torch.randn(s, device=DEV, dtype=dtype, generator=gen) for s in shapes]
+    cl = [t.contiguous(memory_format=torch.channels_last) if t.dim() == 4 else t for t in ts]
+    ref = torch.cat([t.reshape(-1) for t in ts])
+    out = torch.empty_like(ref)
+    _lib.pack(out, cl, scale=2.0)
+    assert torch.equal(out, 2.0 * ref)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
