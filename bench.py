@@ -227,6 +227,10 @@ def main():
     if world > 1 or args.force_dist:
         import torch.distributed as dist
 
+        if world == 1:  # --force-dist on a single GPU, started without a launcher
+            for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"),
+                             ("MASTER_PORT", "29517")):
+                os.environ.setdefault(key, val)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:

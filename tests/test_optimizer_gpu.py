@@ -699,6 +699,96 @@ def test_overlapped_two_graph_product_equals_single_graph():
     assert float((one(v) - a).abs().max() / ref.abs().max()) < 1e-5
 
 
+def test_graphed_operator_refuses_a_replay_that_differs_from_the_eager_product(monkeypatch):
+    """GraphedOperator replays its first capture twice against the eager product and raises
+    when they disagree (library routines that are not capture-safe on this stack must not
+    turn into silently wrong Newton steps).  Simulated here with an operator whose eager
+    result changes from call to call."""
+    monkeypatch.setenv("HF_GRAPH_VERIFY", "always")
+    lin = torch.nn.Linear(6, 4).to(DEV)
+    params = list(lin.parameters())
+    x = torch.randn(5, 6, device=DEV)
+    t = torch.randint(0, 4, (5,), device=DEV)
+
+    def builder():
+        out = lin(x)
+        return curvature.GGNOperator(torch.nn.functional.cross_entropy(out, t), out, params)
+
+    good = curvature.GraphedOperator(builder, params=params)  # passes its own check
+    v = torch.randn(good.n, device=DEV)
+    assert torch.isfinite(good(v)).all()
+
+    class Drifting(curvature.GGNOperator):
+        eager_calls = 0
+
+        def local(self, vec, out=None):
+            res = super().local(vec, out)
+            if not torch.cuda.is_current_stream_capturing():
+                Drifting.eager_calls += 1
+                if Drifting.eager_calls >= 2:  # everything after the first warm-up run
+                    res.mul_(1.5)
+            return res
+
+    def bad_builder():
+        out = lin(x)
+        return Drifting(torch.nn.functional.cross_entropy(out, t), out, params)
+
+    with pytest.raises(RuntimeError, match="does not reproduce the eager product"):
+        curvature.GraphedOperator(bad_builder, params=params)
+
+
+def test_convolutions_on_1x1_maps_run_as_centre_tap_gemms():
+    """NHWC layers that see a 1x1 map through an odd kernel with "same" padding (stride 1 or
+    2, with and without bias) are evaluated as GEMMs on the kernel's centre tap in every
+    pass; products agree with the stock model, eager and replayed."""
+    from pytorchhessianfree_amd import modelprep
+
+    def make():
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(
+            torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(1),
+            torch.nn.Conv2d(8, 12, 3, padding=1, bias=False), torch.nn.BatchNorm2d(12), torch.nn.ReLU(),
+            torch.nn.Conv2d(12, 16, 5, stride=2, padding=2), torch.nn.ReLU(),
+            torch.nn.Conv2d(16, 7, 1), torch.nn.Flatten())
+        return net.to(DEV).eval()
+
+    stock, fused = make(), make()
+    modelprep.prepare_model(fused, channels_last=True)
+    x = torch.rand(6, 3, 5, 5, device=DEV)
+    t = torch.randint(0, 7, (6,), device=DEV)
+    lossf = torch.nn.CrossEntropyLoss()
+    hits = []
+    orig = modelprep._point
+
+    def spy(*a):
+        r = orig(*a)
+        hits.append(r)
+        return r
+
+    modelprep._point = spy
+    try:
+        sp, fp = list(stock.parameters()), list(fused.parameters())
+        v = torch.randn(sum(p.numel() for p in sp), device=DEV)
+        o = stock(x)
+        want = curvature.GGNOperator(lossf(o, t), o, sp)(v).clone()
+
+        def builder():
+            out = fused(x)
+            return curvature.GGNOperator(lossf(out, t), out, fp)
+
+        eager = builder()
+        got = eager(v).clone()
+        del eager
+        graphed = curvature.GraphedOperator(builder, params=fp)
+        got2 = graphed(v).clone()
+    finally:
+        modelprep._point = orig
+    assert hits.count(1) >= 3 and hits.count(2) >= 3 and hits.count(0) >= 3 and None in hits  # 3x3, 5x5, 1x1; first layer: MIOpen
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) < 1e-5 * scale
+    assert float((got2 - want).abs().max()) < 1e-5 * scale
+
+
 def test_stale_graph_fails_loudly_after_in_place_parameter_write():
     """ParameterArena.write runs a raw HIP kernel on the parameters' storage; the
     version counter is bumped so that autograd notices."""
