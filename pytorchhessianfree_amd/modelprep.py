@@ -588,6 +588,25 @@ def fuse_conv_tangent(model, channels_last=False):
     return count
 
 
+def _pool_forward(self, x):
+    if x.dim() >= 3 and tuple(x.shape[-2:]) == (1, 1):
+        return x  # the mean over a single pixel: skip the kernel (and its two in every product)
+    return self._hf_stock_forward(x)
+
+
+def skip_identity_pools(model):
+    """``AdaptiveAvgPool2d(1)`` applied to a map that is already 1x1 (ResNets on MNIST-sized
+    inputs) returns its input: patch the module so that it issues no kernel then.  Exact.
+    Returns the number of modules patched."""
+    count = 0
+    for m in model.modules():
+        if type(m) is nn.AdaptiveAvgPool2d and m.output_size in (1, (1, 1)) and not hasattr(m, "_hf_stock_forward"):
+            m._hf_stock_forward = m.forward
+            m.forward = types.MethodType(_pool_forward, m)
+            count += 1
+    return count
+
+
 def prepare_model(model, channels_last=False):
     """All opt-in preparations; returns ``model`` for chaining.
 
@@ -612,6 +631,7 @@ def prepare_model(model, channels_last=False):
     fuse_eval_batchnorm(model)
     fuse_conv_tangent(model, channels_last=channels_last)
     fuse_residual_blocks(model)
+    skip_identity_pools(model)
     return model
 
 
