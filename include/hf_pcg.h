@@ -185,7 +185,7 @@ int hf_axpy_out(void* out, const void* a, const void* s, double alpha, int64_t n
  * the whole group in one launch each.
  *   hf_chan_affine    : t   = a*(w*rstd) + xhat*q + r + add      (a,q,r,add,w nullable)
  *                       out = relu_self ? max(t,0) : mask_src ? (mask_src>0 ? t : 0) : t
- *   hf_chan_affine_bwd: g = mask_src ? gy*(mask_src>0) : gy ;
+ *   hf_chan_affine_bwd: g = mask_src ? (gy+gy2)*(mask_src>0) : gy+gy2 ;
  *                       gx = g*w*rstd, gw = sum_{n,hw} g*xhat, gb = sum g, gres = g
  *                       (gx, gw, gb, gres nullable; with gw == NULL, x/mean may be NULL,
  *                       and with gx == NULL too rstd may be NULL: gb alone is the bias
@@ -203,9 +203,12 @@ int hf_chan_affine(void* out, const void* a, const void* x, const void* mean,
                    const void* add, const void* mask_src, int relu_self, int64_t n,
                    int64_t c, int64_t hw, int channels_last, int64_t out_ld, int64_t add_ld,
                    int dtype, void* stream);
+/* gy2 (nullable): a second cotangent, added to gy first -- the output of a residual block has
+ * two consumers (the next block's first convolution and its identity / downsample branch);
+ * handing their cotangents over separately saves the addition autograd would issue. */
 int hf_chan_affine_bwd(void* gx, void* gw, void* gb, void* gres, const void* gy,
-                       const void* x, const void* mean, const void* rstd, const void* w,
-                       const void* mask_src, int64_t n, int64_t c, int64_t hw,
+                       const void* gy2, const void* x, const void* mean, const void* rstd,
+                       const void* w, const void* mask_src, int64_t n, int64_t c, int64_t hw,
                        int channels_last, int dtype, void* stream);
 
 /* ---- loss Hessian inside the GGN product ------------------------------------ */

@@ -89,7 +89,7 @@ SIGNATURES = {
     "hf_axpy_out": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int, c_void_p]),
     "hf_chan_affine": (c_int, [c_void_p] * 10 + [c_int, c_int64, c_int64, c_int64, c_int, c_int64, c_int64,
                                                   c_int, c_void_p]),
-    "hf_chan_affine_bwd": (c_int, [c_void_p] * 10 + [c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "hf_chan_affine_bwd": (c_int, [c_void_p] * 11 + [c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "hf_softmax_ce_hvp": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int64, c_int, c_void_p]),
     "hf_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "hf_comm_create": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_char_p, c_int, c_int]),

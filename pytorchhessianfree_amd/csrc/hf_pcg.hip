@@ -767,9 +767,9 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine(
 template <typename T, typename I, int TPC>
 __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
     T* __restrict__ gx, T* __restrict__ gw, T* __restrict__ gb, T* __restrict__ gres,
-    const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ mean,
-    const T* __restrict__ rstd, const T* __restrict__ w, const T* __restrict__ mask_src, I N,
-    I C, I HW) {
+    const T* __restrict__ gy, const T* __restrict__ gy2, const T* __restrict__ x,
+    const T* __restrict__ mean, const T* __restrict__ rstd, const T* __restrict__ w,
+    const T* __restrict__ mask_src, I N, I C, I HW) {
   __shared__ double lds[2 * WAVES];
   constexpr int GROUPS = BLOCK / TPC;
   const I c = (I)blockIdx.x * GROUPS + threadIdx.x / TPC;
@@ -784,6 +784,7 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
       const I n = HW == 1 ? e : e / HW;
       const I idx = (n * C + c) * HW + (e - n * HW);
       T g = gy[idx];
+      if (gy2) g = g + gy2[idx];  // the cotangents of the output's two consumers
       if (mask_src) g = mask_src[idx] > (T)0 ? g : (T)0;
       if (gx) gx[idx] = g * s;
       if (gres) gres[idx] = g;
@@ -814,9 +815,9 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
 template <typename T, typename I, int W>
 __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd_nhwc(
     T* __restrict__ gx, T* __restrict__ gw, T* __restrict__ gb, T* __restrict__ gres,
-    const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ mean,
-    const T* __restrict__ rstd, const T* __restrict__ w, const T* __restrict__ mask_src, I rows,
-    I C) {
+    const T* __restrict__ gy, const T* __restrict__ gy2, const T* __restrict__ x,
+    const T* __restrict__ mean, const T* __restrict__ rstd, const T* __restrict__ w,
+    const T* __restrict__ mask_src, I rows, I C) {
   __shared__ double lds[2 * W * WAVES];
   struct alignas(sizeof(T) * W) Col { T e[W]; };
   const I c0 = (I)blockIdx.x * W;
@@ -834,6 +835,11 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd_nhwc(
   for (I r = threadIdx.x; r < rows; r += BLOCK) {
     const I idx = r * C + c0;
     Col g = *reinterpret_cast<const Col*>(gy + idx);
+    if (gy2) {
+      const Col h = *reinterpret_cast<const Col*>(gy2 + idx);
+#pragma unroll
+      for (int k = 0; k < W; ++k) g.e[k] = g.e[k] + h.e[k];
+    }
     Col xv;
     if (x) xv = *reinterpret_cast<const Col*>(x + idx);
     if (mask_src) {
@@ -1496,17 +1502,18 @@ int hf_chan_affine(void* out, const void* a, const void* x, const void* mean, co
 
 template <typename T>
 static void launch_chan_affine_bwd(hipStream_t s, void* gx, void* gw, void* gb, void* gres,
-                                   const void* gy, const void* x, const void* mean,
+                                   const void* gy, const void* gy2, const void* x, const void* mean,
                                    const void* rstd, const void* w, const void* mask_src,
                                    long long n, long long c, long long hw, int nhwc) {
   const long long total = n * c * hw;
   if (nhwc && hw > 1) {
-    const bool vec = c % 4 == 0 && aligned16(gy) && (!x || aligned16(x)) && (!mask_src || aligned16(mask_src)) &&
+    const bool vec = c % 4 == 0 && aligned16(gy) && (!gy2 || aligned16(gy2)) && (!x || aligned16(x)) &&
+                     (!mask_src || aligned16(mask_src)) &&
                      (!gx || aligned16(gx)) && (!gres || aligned16(gres)) && sizeof(T) == 4;
 #define HF_BWD_CL(I, W)                                                                           \
   hipLaunchKernelGGL((k_chan_affine_bwd_nhwc<T, I, W>), dim3((unsigned)(c / W)), dim3(BLOCK), 0, s, \
-                     (T*)gx, (T*)gw, (T*)gb, (T*)gres, (const T*)gy, (const T*)x, (const T*)mean,   \
-                     (const T*)rstd, (const T*)w, (const T*)mask_src, (I)(n * hw), (I)c)
+                     (T*)gx, (T*)gw, (T*)gb, (T*)gres, (const T*)gy, (const T*)gy2, (const T*)x,    \
+                     (const T*)mean, (const T*)rstd, (const T*)w, (const T*)mask_src, (I)(n * hw), (I)c)
     if (total < 0x7fffffffLL) {
       if (vec) HF_BWD_CL(unsigned, 4); else HF_BWD_CL(unsigned, 1);
     } else {
@@ -1518,8 +1525,8 @@ static void launch_chan_affine_bwd(hipStream_t s, void* gx, void* gw, void* gb, 
   const bool small = n * hw <= 256;
 #define HF_BWD(I, TPC, GRID)                                                                    \
   hipLaunchKernelGGL((k_chan_affine_bwd<T, I, TPC>), dim3((unsigned)(GRID)), dim3(BLOCK), 0, s,  \
-                     (T*)gx, (T*)gw, (T*)gb, (T*)gres, (const T*)gy, (const T*)x, (const T*)mean, \
-                     (const T*)rstd, (const T*)w, (const T*)mask_src, (I)n, (I)c, (I)hw)
+                     (T*)gx, (T*)gw, (T*)gb, (T*)gres, (const T*)gy, (const T*)gy2, (const T*)x,  \
+                     (const T*)mean, (const T*)rstd, (const T*)w, (const T*)mask_src, (I)n, (I)c, (I)hw)
   if (total < 0x7fffffffLL) {
     if (small) HF_BWD(unsigned, 64, (c + 3) / 4); else HF_BWD(unsigned, 256, c);
   } else {
@@ -1528,19 +1535,19 @@ static void launch_chan_affine_bwd(hipStream_t s, void* gx, void* gw, void* gb, 
 #undef HF_BWD
 }
 
-int hf_chan_affine_bwd(void* gx, void* gw, void* gb, void* gres, const void* gy, const void* x,
-                       const void* mean, const void* rstd, const void* w, const void* mask_src,
-                       int64_t n, int64_t c, int64_t hw, int channels_last, int dtype,
-                       void* stream) {
+int hf_chan_affine_bwd(void* gx, void* gw, void* gb, void* gres, const void* gy, const void* gy2,
+                       const void* x, const void* mean, const void* rstd, const void* w,
+                       const void* mask_src, int64_t n, int64_t c, int64_t hw, int channels_last,
+                       int dtype, void* stream) {
   if (!gy || n <= 0 || c <= 0 || hw <= 0) return HF_ERR_ARG;
   if ((gw && (!x || !mean || !rstd)) || (gx && !rstd)) return HF_ERR_ARG;
   if (!gw) x = nullptr;  // plain per-channel sums (a conv layer's bias gradient)
   hipStream_t s = (hipStream_t)stream;
   if (dtype == HF_F32)
-    launch_chan_affine_bwd<float>(s, gx, gw, gb, gres, gy, x, mean, rstd, w, mask_src, n, c, hw,
+    launch_chan_affine_bwd<float>(s, gx, gw, gb, gres, gy, gy2, x, mean, rstd, w, mask_src, n, c, hw,
                                   channels_last);
   else if (dtype == HF_F64)
-    launch_chan_affine_bwd<double>(s, gx, gw, gb, gres, gy, x, mean, rstd, w, mask_src, n, c, hw,
+    launch_chan_affine_bwd<double>(s, gx, gw, gb, gres, gy, gy2, x, mean, rstd, w, mask_src, n, c, hw,
                                    channels_last);
   else
     return HF_ERR_ARG;

@@ -127,7 +127,7 @@ def _affine(a, x, mean, rstd, w, q, r, like, add=None, mask_src=None, relu_self=
     return out
 
 
-def _affine_bwd(gy, x, mean, rstd, w, mask_src=None, need_gres=False):
+def _affine_bwd(gy, x, mean, rstd, w, mask_src=None, need_gres=False, gy2=None):
     n, c, hw = _dims(x)
     gx = torch.empty_like(x)
     gres = torch.empty_like(x) if need_gres else None
@@ -135,7 +135,7 @@ def _affine_bwd(gy, x, mean, rstd, w, mask_src=None, need_gres=False):
     gb = torch.empty(c, dtype=x.dtype, device=x.device)
     _lib.check(
         _lib.load().hf_chan_affine_bwd(
-            _p(gx), _p(gw), _p(gb), _p(gres), _p(gy), _p(x), _p(mean), _p(rstd), _p(w),
+            _p(gx), _p(gw), _p(gb), _p(gres), _p(gy), _p(gy2), _p(x), _p(mean), _p(rstd), _p(w),
             _p(mask_src), n, c, hw, 1 if _is_cl(x) else 0, _lib.dtype_code(x.dtype),
             _lib.current_stream_ptr(x.device)),
         "hf_chan_affine_bwd")
@@ -149,27 +149,32 @@ def _bshape(x):
 
 
 class _ChanAffineBwd(torch.autograd.Function):
-    """(gy; x, w, y) -> (gx, gw, gb, gres) with g = gy * [y > 0] when the layer ends in
-    a ReLU.  Linear in gy; its transpose is one ``_affine`` launch."""
+    """(gy [, gy2]; x, w, y) -> (gx, gw, gb, gres) with g = (gy + gy2) * [y > 0] when the
+    layer ends in a ReLU.  Linear in the cotangents; its transpose is one ``_affine``
+    launch.  ``gy2`` is the cotangent of the output's twin (``_ChanAffine`` with
+    ``twin=True``): the two consumers of a residual block's output hand their cotangents
+    over separately and the kernel adds them, instead of autograd's own add kernel."""
 
     @staticmethod
-    def forward(ctx, gy, x, w, mean, rstd, y, has_res):
-        gy = _like(gy, x)
+    def forward(ctx, gy, gy2, x, w, mean, rstd, y, has_res):
+        if gy is None:
+            gy, gy2 = gy2, None
+        gy, gy2 = _like(gy, x), _like(gy2, x)
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(gy, x, w, mean, rstd, y)
+        ctx.save_for_backward(gy, gy2, x, w, mean, rstd, y)
         ctx.has_res = has_res
         gx, gw, gb, gres = _affine_bwd(gy, x, mean, rstd, w, mask_src=y,
-                                       need_gres=has_res and y is not None)
+                                       need_gres=has_res and (y is not None or gy2 is not None), gy2=gy2)
         if has_res and gres is None:
-            gres = gy  # no ReLU: the residual branch receives the cotangent itself
+            gres = gy  # no ReLU, one cotangent: the residual branch receives it as it is
         return gx, gw, gb, gres
 
     @staticmethod
     def backward(ctx, vgx, vgw, vgb, vgres):
-        gy, x, w, mean, rstd, y = ctx.saved_tensors
+        gy, gy2, x, w, mean, rstd, y = ctx.saved_tensors
         if vgx is None and vgw is None and vgb is None and vgres is None:
-            return (None,) * 7
-        # d/d gy : one fused launch (this is the layer's tangent map)
+            return (None,) * 8
+        # d/d gy : one fused launch (this is the layer's tangent map) ...
         # ... written straight into the next convolution's [v_x | x] operand once that
         # layer has claimed this output (``_claim_direct``); the residual branch reads its
         # operand from such a slice without a copy as well
@@ -183,35 +188,43 @@ class _ChanAffineBwd(torch.autograd.Function):
         v_x = v_w = None
         # second-order terms, only for Hessian products (plain ATen, rare path);
         # the ReLU mask is piecewise constant, so it only gates the cotangent
-        if (ctx.needs_input_grad[1] and vgw is not None) or (ctx.needs_input_grad[2] and vgx is not None):
-            g = gy if y is None else gy * (y > 0)
-            if ctx.needs_input_grad[1] and vgw is not None:
+        if (ctx.needs_input_grad[2] and vgw is not None) or (ctx.needs_input_grad[3] and vgx is not None):
+            g = gy if gy2 is None else gy + gy2
+            g = g if y is None else g * (y > 0)
+            if ctx.needs_input_grad[2] and vgw is not None:
                 v_x = g * (vgw * rstd).view(_bshape(x))
-            if ctx.needs_input_grad[2] and vgx is not None:
+            if ctx.needs_input_grad[3] and vgx is not None:
                 red = [d for d in range(x.dim()) if d != 1]
                 v_w = (vgx * g).sum(red) * rstd
-        return v_gy, v_x, v_w, None, None, None, None
+        return v_gy, (v_gy if ctx.needs_input_grad[1] else None), v_x, v_w, None, None, None, None
 
 
 class _ChanAffine(torch.autograd.Function):
-    """y = act(xhat * w + b + res) with fixed statistics; act = ReLU or identity."""
+    """y = act(xhat * w + b + res) with fixed statistics; act = ReLU or identity.  With
+    ``twin`` the output is returned twice (the second an alias of the first) so that its two
+    consumers' cotangents reach ``backward`` separately."""
 
     @staticmethod
-    def forward(ctx, x, w, b, mean, rstd, res, relu):
+    def forward(ctx, x, w, b, mean, rstd, res, relu, twin=False):
         x = _dense(x)
         res = _like(res, x)
         y = _affine(None, x, mean, rstd, None, w, b, like=x, add=res, relu_self=relu)
         ctx.save_for_backward(x, w, mean, rstd, y if relu else None)
         ctx.has_res = res is not None
-        return y
+        ctx.set_materialize_grads(False)  # an unused twin must not cost a zero-fill and an add
+        # the twin shares y's storage but is not a view OF y (detach): tagging y with it
+        # must not close a reference cycle that would keep the whole graph alive
+        return (y, y.detach()) if twin else y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gy2=None):
         x, w, mean, rstd, y = ctx.saved_tensors
         if _Mode.first_order_only:
             x, w = x.detach(), w.detach()
-        gx, gw, gb, gres = _ChanAffineBwd.apply(gy, x, w, mean, rstd, y, ctx.has_res)
-        return gx, gw, gb, None, None, gres, None
+        if gy is None and gy2 is None:
+            return (None,) * 8
+        gx, gw, gb, gres = _ChanAffineBwd.apply(gy, gy2, x, w, mean, rstd, y, ctx.has_res)
+        return gx, gw, gb, None, None, gres, None, None
 
 
 def _bn_usable(bn, x):
@@ -223,9 +236,10 @@ def _bn_usable(bn, x):
     )
 
 
-def fused_bn_act(bn, x, res=None, relu=False):
+def fused_bn_act(bn, x, res=None, relu=False, twin=False):
     """``act(bn(x) + res)`` -- one HIP launch per pass when ``bn`` is an eval-mode
-    BatchNorm on a GPU tensor, the stock ops otherwise."""
+    BatchNorm on a GPU tensor, the stock ops otherwise.  ``twin``: tag the result with an
+    alias (``y._hf_twin``) for its second consumer, see ``_ChanAffine``."""
     if not _bn_usable(bn, x):
         fwd = getattr(bn, "_hf_stock_forward", None) or bn.forward
         y = fwd(x)
@@ -233,7 +247,11 @@ def fused_bn_act(bn, x, res=None, relu=False):
             y = y + res
         return torch.relu(y) if relu else y
     rstd = torch.rsqrt(bn.running_var + bn.eps)
-    return _ChanAffine.apply(x, bn.weight, bn.bias, bn.running_mean, rstd, res, relu)
+    if not twin:
+        return _ChanAffine.apply(x, bn.weight, bn.bias, bn.running_mean, rstd, res, relu)
+    y, y2 = _ChanAffine.apply(x, bn.weight, bn.bias, bn.running_mean, rstd, res, relu, True)
+    y._hf_twin = y2
+    return y
 
 
 def _fused_forward(self, x):
@@ -243,17 +261,27 @@ def _fused_forward(self, x):
 # ------------------------------------------------------------------------------------
 # residual blocks: BN + ReLU and BN + identity + ReLU as one layer each
 # ------------------------------------------------------------------------------------
+def _second_consumer_view(x):
+    """The alias a fused layer attached to its output for its second consumer (the
+    residual branch), or ``x`` itself: cotangents of ``x`` and of the alias reach the
+    producing layer separately and are added inside its adjoint kernel."""
+    twin = getattr(x, "_hf_twin", None)
+    return x if twin is None else twin
+
+
 def _basic_block_forward(self, x):
-    idt = x if self.downsample is None else self.downsample(x)
+    x2 = _second_consumer_view(x)
+    idt = x2 if self.downsample is None else self.downsample(x2)
     out = fused_bn_act(self.bn1, self.conv1(x), relu=True)
-    return fused_bn_act(self.bn2, self.conv2(out), res=idt, relu=True)
+    return fused_bn_act(self.bn2, self.conv2(out), res=idt, relu=True, twin=True)
 
 
 def _bottleneck_forward(self, x):
-    idt = x if self.downsample is None else self.downsample(x)
+    x2 = _second_consumer_view(x)
+    idt = x2 if self.downsample is None else self.downsample(x2)
     out = fused_bn_act(self.bn1, self.conv1(x), relu=True)
     out = fused_bn_act(self.bn2, self.conv2(out), relu=True)
-    return fused_bn_act(self.bn3, self.conv3(out), res=idt, relu=True)
+    return fused_bn_act(self.bn3, self.conv3(out), res=idt, relu=True, twin=True)
 
 
 def _looks_like(block, convs):
@@ -431,7 +459,7 @@ def _bias_grad(gy):
     gb = torch.empty(c, dtype=g.dtype, device=g.device)
     _lib.check(
         _lib.load().hf_chan_affine_bwd(
-            None, None, _p(gb), None, _p(g), None, None, None, None, None, n, c, hw,
+            None, None, _p(gb), None, _p(g), None, None, None, None, None, None, n, c, hw,
             1 if _is_cl(g) else 0, _lib.dtype_code(g.dtype), _lib.current_stream_ptr(g.device)),
         "hf_chan_affine_bwd")
     return gb
