@@ -196,7 +196,8 @@ class _ChanAffineBwd(torch.autograd.Function):
             if ctx.needs_input_grad[3] and vgx is not None:
                 red = [d for d in range(x.dim()) if d != 1]
                 v_w = (vgx * g).sum(red) * rstd
-        return v_gy, (v_gy if ctx.needs_input_grad[1] else None), v_x, v_w, None, None, None, None
+        return (v_gy if ctx.needs_input_grad[0] else None, v_gy if ctx.needs_input_grad[1] else None,
+                v_x, v_w, None, None, None, None)
 
 
 class _ChanAffine(torch.autograd.Function):
