@@ -230,14 +230,15 @@ def test_unpack_tangent_scatters_like_copy(dtype):
         _lib.unpack_tangent(v, [(v.numel() - 3, torch.empty(2, 2, 1, 2, device=DEV, dtype=dtype), 1)])
 
 
-def test_tangent_scatter_product_equals_per_layer_copies():
+@pytest.mark.parametrize("cl", [False, True])
+def test_tangent_scatter_product_equals_per_layer_copies(cl):
     """The first product of an operator fills the conv layers' v_W operands with one
     strided copy per layer and registers them; later products use the single scatter
     launch.  Same numbers either way."""
     from pytorchhessianfree_amd import modelprep
 
     model, (x, t), lossf = tp.resnet18_mnist(batch_size=4, device=DEV)
-    modelprep.prepare_model(model)
+    modelprep.prepare_model(model, channels_last=cl)
     params = list(model.parameters())
     out = model(x)
     op = curvature.GGNOperator(lossf(out, t), out, params)
@@ -252,6 +253,13 @@ def test_tangent_scatter_product_equals_per_layer_copies():
         return float((p - q).abs().max() / q.abs().max()) < 1e-5
 
     assert close(first, second)
+    # ... and both are the stock model's product (the second and later sweeps also write
+    # the fused layers' output tangents straight into the next convolution's operand)
+    stock, (xs, ts), _ = tp.resnet18_mnist(batch_size=4, device=DEV)
+    so = stock(xs)
+    want = curvature.GGNOperator(lossf(so, ts), so, list(stock.parameters()))(v).clone()
+    third = op(v).clone()
+    assert close(first, want) and close(second, want) and close(third, want)
     w = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
     op._tangent_slots.clear()
     a = op(w).clone()   # per-layer copies again
