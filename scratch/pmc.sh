@@ -19,7 +19,7 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
         rd = csv.DictReader(f)
         for row in rd:
             name = row.get("Kernel_Name", "")
-            if "k_update" in name or "k_curv" in name or "k_pack" in name:
+            if "k_update" in name or "k_curv" in name or "k_pack" in name or "k_unpack" in name:
                 key = name.split("(")[0].split("::")[-1][:40]
                 if row.get("Counter_Name") == C:
                     acc[key].append(float(row["Counter_Value"]))
