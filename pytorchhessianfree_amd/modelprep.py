@@ -1,18 +1,31 @@
-"""Optional, opt-in model preparation for faster curvature products.
+"""Optional, opt-in model preparation for faster curvature products
+(``prepare_model(model)``; every patch keeps the ``Parameter`` objects, their order, the
+state_dict and the flat-vector layout, and falls back to the stock op for CPU tensors,
+training mode or layers it does not recognise).
 
-``fuse_eval_batchnorm(model)``: an eval-mode BatchNorm is the per-channel affine
-map ``y = xhat * w + b`` with ``xhat = (x - running_mean) * rsqrt(running_var + eps)``.
-PyTorch's generic double-backward of ``native_batch_norm`` -- which every GGN /
-Hessian product differentiates through -- expands into ~40 tiny kernels per layer
-and product (measured on ResNet-18: ~800 of the ~1050 kernels of one product).
-Here the layer is an autograd ``Function`` whose forward, backward and
-backward-of-backward are ONE HIP kernel each (``hf_chan_affine`` /
-``hf_chan_affine_bwd``).
+A GGN product differentiates the network twice (BackPACK's R-op is a backward of a
+backward, ``optimizer.py:461``); PyTorch's generic double-backward formulas issue many
+small kernels, and on an MI355X a product of a ResNet-18 is bound by the NUMBER of
+kernels (~4.5 us each inside a hipGraph), not by bytes or flops.  The patches:
 
-The function patches ``forward`` of every BatchNorm{1,2,3}d IN PLACE: same
-``Parameter`` objects, same order, same state_dict; training mode and CPU tensors
-still use the stock implementation.  Results agree with the stock eval-mode
-forward to fp32 rounding.
+* ``fuse_eval_batchnorm`` -- an eval-mode BatchNorm is the per-channel affine map
+  ``y = xhat * w + b``, ``xhat = (x - running_mean) * rsqrt(running_var + eps)``.  The
+  generic double-backward of ``native_batch_norm`` is ~40 kernels per layer and product
+  (~800 of the ~1050 of a stock ResNet-18 product); here forward, backward and
+  backward-of-backward are ONE HIP kernel each (``hf_chan_affine`` / ``hf_chan_affine_bwd``).
+* ``fuse_residual_blocks`` -- ``relu(bn(.))`` / ``relu(bn(.) + identity)`` of ResNet blocks
+  as one such layer; the block output's two consumers return their cotangents separately
+  and the kernel adds them.
+* ``fuse_conv_tangent`` -- a conv layer's tangent map ``conv(v_x, W) + conv(x, v_W)`` as ONE
+  convolution over concatenated input channels; ``v_W`` arrives by one multi-tensor
+  scatter per product (``hf_unpack_tangent``), ``v_x`` is written in place by the
+  preceding fused layer; optionally everything in NHWC (no MIOpen layout transposes);
+  convolutions on 1x1 maps as GEMMs on the kernel's centre tap; bias gradients by a
+  reduction kernel that is safe inside a hipGraph.
+* ``skip_identity_pools`` -- ``AdaptiveAvgPool2d(1)`` of a 1x1 map issues no kernel.
+
+``first_order_only`` / ``tangent_owner`` are the two contexts the curvature operators hold
+while recording ``u -> J^T u`` and while sweeping a tangent through it.
 """
 
 import os
