@@ -75,8 +75,8 @@ template <typename T> union VU {
 // ---------------------------------------------------------------------------
 // reductions: 64-lane __shfl_down tree -> LDS partial per wave -> fixed-order sum
 // ---------------------------------------------------------------------------
-template <int K>
-__device__ __forceinline__ void block_allreduce(double (&v)[K], double* lds /*K*WAVES*/) {
+template <int K, int NW = WAVES>
+__device__ __forceinline__ void block_allreduce(double (&v)[K], double* lds /*K*NW*/) {
 #pragma unroll
   for (int k = 0; k < K; ++k) {
 #pragma unroll
@@ -85,14 +85,14 @@ __device__ __forceinline__ void block_allreduce(double (&v)[K], double* lds /*K*
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) lds[k * WAVES + wave] = v[k];
+    for (int k = 0; k < K; ++k) lds[k * NW + wave] = v[k];
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    double s = lds[k * WAVES];
+    double s = lds[k * NW];
 #pragma unroll
-    for (int w = 1; w < WAVES; ++w) s += lds[k * WAVES + w];
+    for (int w = 1; w < NW; ++w) s += lds[k * NW + w];
     v[k] = s;
   }
   __syncthreads();
@@ -812,13 +812,13 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
 // threads, so the per-channel sums need no cross-block step (deterministic, no
 // workspace) and C/W blocks are in flight; the tensors of this path are a few MB
 // and L2-resident, the strided 16-byte reads cost less than a second launch would.
-template <typename T, typename I, int W>
-__global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd_nhwc(
+template <typename T, typename I, int W, int BS>
+__global__ __launch_bounds__(BS) void k_chan_affine_bwd_nhwc(
     T* __restrict__ gx, T* __restrict__ gw, T* __restrict__ gb, T* __restrict__ gres,
     const T* __restrict__ gy, const T* __restrict__ gy2, const T* __restrict__ x,
     const T* __restrict__ mean, const T* __restrict__ rstd, const T* __restrict__ w,
     const T* __restrict__ mask_src, I rows, I C) {
-  __shared__ double lds[2 * W * WAVES];
+  __shared__ double lds[2 * W * (BS / 64)];
   struct alignas(sizeof(T) * W) Col { T e[W]; };
   const I c0 = (I)blockIdx.x * W;
   T rs[W], mu[W], sc[W];
@@ -831,36 +831,51 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd_nhwc(
   double acc[2 * W];
 #pragma unroll
   for (int k = 0; k < 2 * W; ++k) acc[k] = 0.0;
-#pragma unroll 4
-  for (I r = threadIdx.x; r < rows; r += BLOCK) {
-    const I idx = r * C + c0;
-    Col g = *reinterpret_cast<const Col*>(gy + idx);
-    if (gy2) {
-      const Col h = *reinterpret_cast<const Col*>(gy2 + idx);
+  // rows are visited ITER at a time with all loads issued before the first use: these
+  // activation-sized kernels are latency-bound, one round trip per 8 rows instead of one each
+  constexpr int ITER = 8;
+  for (I r0 = threadIdx.x; r0 < rows; r0 += (I)BS * ITER) {
+    Col g[ITER], h[ITER], xv[ITER], m[ITER];
 #pragma unroll
-      for (int k = 0; k < W; ++k) g.e[k] = g.e[k] + h.e[k];
-    }
-    Col xv;
-    if (x) xv = *reinterpret_cast<const Col*>(x + idx);
-    if (mask_src) {
-      const Col m = *reinterpret_cast<const Col*>(mask_src + idx);
-#pragma unroll
-      for (int k = 0; k < W; ++k) g.e[k] = m.e[k] > (T)0 ? g.e[k] : (T)0;
-    }
-    if (gres) *reinterpret_cast<Col*>(gres + idx) = g;
-    if (gx) {
-      Col o;
-#pragma unroll
-      for (int k = 0; k < W; ++k) o.e[k] = g.e[k] * sc[k];
-      *reinterpret_cast<Col*>(gx + idx) = o;
+    for (int t = 0; t < ITER; ++t) {
+      const I r = r0 + (I)t * BS;
+      if (r < rows) {
+        const I idx = r * C + c0;
+        g[t] = *reinterpret_cast<const Col*>(gy + idx);
+        if (gy2) h[t] = *reinterpret_cast<const Col*>(gy2 + idx);
+        if (x) xv[t] = *reinterpret_cast<const Col*>(x + idx);
+        if (mask_src) m[t] = *reinterpret_cast<const Col*>(mask_src + idx);
+      }
     }
 #pragma unroll
-    for (int k = 0; k < W; ++k) {
-      if (x) acc[2 * k] += (double)g.e[k] * (double)(T)((xv.e[k] - mu[k]) * rs[k]);
-      acc[2 * k + 1] += (double)g.e[k];
+    for (int t = 0; t < ITER; ++t) {
+      const I r = r0 + (I)t * BS;
+      if (r < rows) {
+        const I idx = r * C + c0;
+        if (gy2) {
+#pragma unroll
+          for (int k = 0; k < W; ++k) g[t].e[k] = g[t].e[k] + h[t].e[k];
+        }
+        if (mask_src) {
+#pragma unroll
+          for (int k = 0; k < W; ++k) g[t].e[k] = m[t].e[k] > (T)0 ? g[t].e[k] : (T)0;
+        }
+        if (gres) *reinterpret_cast<Col*>(gres + idx) = g[t];
+        if (gx) {
+          Col o;
+#pragma unroll
+          for (int k = 0; k < W; ++k) o.e[k] = g[t].e[k] * sc[k];
+          *reinterpret_cast<Col*>(gx + idx) = o;
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          if (x) acc[2 * k] += (double)g[t].e[k] * (double)(T)((xv[t].e[k] - mu[k]) * rs[k]);
+          acc[2 * k + 1] += (double)g[t].e[k];
+        }
+      }
     }
   }
-  block_allreduce<2 * W>(acc, lds);
+  block_allreduce<2 * W, BS / 64>(acc, lds);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < W; ++k) {
@@ -1347,6 +1362,15 @@ int hf_pack(void* dst, const void* const* srcs, const int64_t* numels, const int
   return HF_ERR_ARG;
 }
 
+// one element per thread: these activation-sized kernels (<= a few hundred thousand
+// elements) are latency-bound, every extra grid-stride iteration adds a full round trip
+static int wide_grid(int64_t n) {
+  int64_t g = (n + BLOCK - 1) / BLOCK;
+  if (g < 1) g = 1;
+  if (g > 16384) g = 16384;
+  return (int)g;
+}
+
 static int small_grid(int64_t n) {
   int64_t g = (n + BLOCK * 4 - 1) / (BLOCK * 4);
   if (g < 1) g = 1;
@@ -1462,13 +1486,13 @@ static void launch_chan_affine(hipStream_t s, void* out, const void* a, const vo
                                int relu_self, long long total, long long c, long long hw,
                                int nhwc, long long out_ld, long long add_ld) {
   if (2 * total < 0x7fffffffLL)  // strided operands reach at most 2*total
-    hipLaunchKernelGGL((k_chan_affine<T, unsigned>), dim3(small_grid(total)), dim3(BLOCK), 0, s,
+    hipLaunchKernelGGL((k_chan_affine<T, unsigned>), dim3(wide_grid(total)), dim3(BLOCK), 0, s,
                        (T*)out, (const T*)a, (const T*)x, (const T*)mean, (const T*)rstd,
                        (const T*)w, (const T*)q, (const T*)r, (const T*)add, (const T*)mask_src,
                        relu_self, (unsigned)total, (unsigned)c, (unsigned)hw, nhwc,
                        (unsigned)out_ld, (unsigned)add_ld);
   else
-    hipLaunchKernelGGL((k_chan_affine<T, long long>), dim3(small_grid(total)), dim3(BLOCK), 0, s,
+    hipLaunchKernelGGL((k_chan_affine<T, long long>), dim3(wide_grid(total)), dim3(BLOCK), 0, s,
                        (T*)out, (const T*)a, (const T*)x, (const T*)mean, (const T*)rstd,
                        (const T*)w, (const T*)q, (const T*)r, (const T*)add, (const T*)mask_src,
                        relu_self, total, c, hw, nhwc, out_ld, add_ld);
@@ -1510,14 +1534,17 @@ static void launch_chan_affine_bwd(hipStream_t s, void* gx, void* gw, void* gb, 
     const bool vec = c % 4 == 0 && aligned16(gy) && (!gy2 || aligned16(gy2)) && (!x || aligned16(x)) &&
                      (!mask_src || aligned16(mask_src)) &&
                      (!gx || aligned16(gx)) && (!gres || aligned16(gres)) && sizeof(T) == 4;
-#define HF_BWD_CL(I, W)                                                                           \
-  hipLaunchKernelGGL((k_chan_affine_bwd_nhwc<T, I, W>), dim3((unsigned)(c / W)), dim3(BLOCK), 0, s, \
+#define HF_BWD_CL(I, W, BS)                                                                        \
+  hipLaunchKernelGGL((k_chan_affine_bwd_nhwc<T, I, W, BS>), dim3((unsigned)(c / W)), dim3(BS), 0, s, \
                      (T*)gx, (T*)gw, (T*)gb, (T*)gres, (const T*)gy, (const T*)gy2, (const T*)x,    \
                      (const T*)mean, (const T*)rstd, (const T*)w, (const T*)mask_src, (I)(n * hw), (I)c)
+    // (512- and 1024-thread blocks for the early layers' tall reductions were measured: no
+    // gain -- those launches are bound by the strided 16-byte column accesses, not by the
+    // number of rows per thread; a row-major two-phase reduction is the next step)
     if (total < 0x7fffffffLL) {
-      if (vec) HF_BWD_CL(unsigned, 4); else HF_BWD_CL(unsigned, 1);
+      if (vec) HF_BWD_CL(unsigned, 4, BLOCK); else HF_BWD_CL(unsigned, 1, BLOCK);
     } else {
-      if (vec) HF_BWD_CL(long long, 4); else HF_BWD_CL(long long, 1);
+      if (vec) HF_BWD_CL(long long, 4, BLOCK); else HF_BWD_CL(long long, 1, BLOCK);
     }
 #undef HF_BWD_CL
     return;
