@@ -780,16 +780,35 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
     const T rs = rstd ? rstd[c] : (T)1, mu = mean ? mean[c] : (T)0;
     const T s = (w ? w[c] : (T)1) * rs;
     const I per = N * HW;
-    for (I e = lane; e < per; e += TPC) {
-      const I n = HW == 1 ? e : e / HW;
-      const I idx = (n * C + c) * HW + (e - n * HW);
-      T g = gy[idx];
-      if (gy2) g = g + gy2[idx];  // the cotangents of the output's two consumers
-      if (mask_src) g = mask_src[idx] > (T)0 ? g : (T)0;
-      if (gx) gx[idx] = g * s;
-      if (gres) gres[idx] = g;
-      if (x) acc[0] += (double)g * (double)(T)((x[idx] - mu) * rs);
-      acc[1] += (double)g;
+    // ITER elements per thread with all loads issued before the first use (latency-bound)
+    constexpr int ITER = 8;
+    for (I e0 = lane; e0 < per; e0 += (I)TPC * ITER) {
+      I idx[ITER];
+      T g[ITER], h[ITER], xv[ITER], m[ITER];
+#pragma unroll
+      for (int t = 0; t < ITER; ++t) {
+        const I e = e0 + (I)t * TPC;
+        if (e < per) {
+          const I n = HW == 1 ? e : e / HW;
+          idx[t] = (n * C + c) * HW + (e - n * HW);
+          g[t] = gy[idx[t]];
+          if (gy2) h[t] = gy2[idx[t]];
+          if (mask_src) m[t] = mask_src[idx[t]];
+          if (x) xv[t] = x[idx[t]];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < ITER; ++t) {
+        if (e0 + (I)t * TPC < per) {
+          T gg = g[t];
+          if (gy2) gg = gg + h[t];  // the cotangents of the output's two consumers
+          if (mask_src) gg = m[t] > (T)0 ? gg : (T)0;
+          if (gx) gx[idx[t]] = gg * s;
+          if (gres) gres[idx[t]] = gg;
+          if (x) acc[0] += (double)gg * (double)(T)((xv[t] - mu) * rs);
+          acc[1] += (double)gg;
+        }
+      }
     }
   }
   if (TPC == 64) {
