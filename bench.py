@@ -53,7 +53,7 @@ def parse():
                     help="modelprep.fuse_conv_tangent: a conv layer's tangent map as ONE convolution")
     ap.add_argument("--channels-last", type=int, default=-1,
                     help="run the conv layers in NHWC (no MIOpen layout transposes); -1 = where it was "
-                         "measured to win and find-db records ship (resnet18 +35 %%, allcnnc +10 %%; resnet50: "
+                         "measured to win and find-db records ship (resnet18 +38 %%, allcnnc +10 %%; resnet50: "
                          "same speed, less accurate NHWC solvers, so NCHW). Any operator is checked against a "
                          "float64 stock-autograd product before it is timed; NHWC falls back to NCHW, and "
                          "config.matvec says which one ran")

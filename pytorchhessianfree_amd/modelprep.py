@@ -654,7 +654,7 @@ def prepare_model(model, channels_last=False):
 
     ``channels_last=True`` additionally runs the convolution layers, and with them the
     fused BatchNorm kernels, in NHWC: MIOpen's implicit-GEMM kernels then need no layout
-    transposes (~40 % of the kernels of a product in NCHW; ResNet-18 bench 613 -> 845
+    transposes (~40 % of the kernels of a product in NCHW; ResNet-18 bench 668 -> 925
     matvecs/s).  Parameters, their order and the flat-vector layout do not change:
     layers keep a per-step NHWC copy of their weight and ``hf_pack`` un-permutes the
     NHWC weight gradients while it gathers them.  NHWC convolutions run in MIOpen's
