@@ -1558,8 +1558,9 @@ static void launch_chan_affine_bwd(hipStream_t s, void* gx, void* gw, void* gb, 
                      (T*)gx, (T*)gw, (T*)gb, (T*)gres, (const T*)gy, (const T*)gy2, (const T*)x,    \
                      (const T*)mean, (const T*)rstd, (const T*)w, (const T*)mask_src, (I)(n * hw), (I)c)
     // (512- and 1024-thread blocks for the early layers' tall reductions were measured: no
-    // gain -- those launches are bound by the strided 16-byte column accesses, not by the
-    // number of rows per thread; a row-major two-phase reduction is the next step)
+    // gain; a row-major kernel with a two-level reduction (block partials + last-ticket block)
+    // was correct but slower end to end (885 vs 915 matvecs/s): its extra dependent round
+    // trips cost more than the coalescing wins on tensors this small)
     if (total < 0x7fffffffLL) {
       if (vec) HF_BWD_CL(unsigned, 4, BLOCK); else HF_BWD_CL(unsigned, 1, BLOCK);
     } else {

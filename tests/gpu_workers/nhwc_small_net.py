@@ -56,7 +56,8 @@ exact = bool(torch.equal(flat[7:], w.contiguous().reshape(-1)))
 cl = torch.channels_last
 kernel_err = 0.0
 for dtype in (torch.float32, torch.float64):
-    for (n, c, h) in [(5, 6, 3), (32, 64, 7), (7, 512, 2), (3, 20, 9), (128, 64, 7)]:
+    for (n, c, h) in [(5, 6, 3), (32, 64, 7), (7, 512, 2), (3, 20, 9), (128, 64, 7), (32, 128, 4), (32, 256, 2),
+                      (2, 4, 5), (64, 8, 13), (32, 64, 7), (1, 16, 3)]:
         g = torch.Generator(device=DEV).manual_seed(n * c)
         gy, xx, yy = (torch.randn(n, c, h, h, device=DEV, dtype=dtype, generator=g) for _ in range(3))
         mean, w = (torch.randn(c, device=DEV, dtype=dtype, generator=g) for _ in range(2))
@@ -68,4 +69,31 @@ for dtype in (torch.float32, torch.float64):
             assert got[0].is_contiguous(memory_format=cl) and got[3].is_contiguous(memory_format=cl)
             for a, b in zip(got, ref):
                 kernel_err = max(kernel_err, float((a - b).abs().max() / b.abs().max()))
+            # two cotangents (residual blocks) and the sums-only mode (conv bias gradients)
+            ref2 = modelprep._affine_bwd(gy + xx, xx, mean, rstd, w, mask, need_gres=True)
+            got2 = modelprep._affine_bwd(gy.contiguous(memory_format=cl), xx.contiguous(memory_format=cl), mean, rstd,
+                                         w, None if mask is None else mask.contiguous(memory_format=cl),
+                                         need_gres=True, gy2=xx.contiguous(memory_format=cl))
+            for a, b in zip(got2, ref2):
+                kernel_err = max(kernel_err, float((a - b).abs().max() / b.abs().max()))
+            gb = modelprep._bias_grad(gy.contiguous(memory_format=cl))
+            kernel_err = max(kernel_err, float((gb - gy.sum((0, 2, 3))).abs().max() / gy.sum((0, 2, 3)).abs().max()))
+# the same kernel captured in a hipGraph and replayed (its scratch is self-resetting)
+gyc, xc = (torch.randn(32, 64, 7, 7, device=DEV).contiguous(memory_format=cl) for _ in range(2))
+mean, w = torch.randn(64, device=DEV), torch.randn(64, device=DEV)
+rstd = torch.rand(64, device=DEV) + 0.5
+ref = modelprep._affine_bwd(gyc.contiguous(), xc.contiguous(), mean, rstd, w, None, need_gres=False)
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    modelprep._affine_bwd(gyc, xc, mean, rstd, w, None)  # warm-up: allocates the stream's scratch
+side.synchronize()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph, stream=side):
+    out = modelprep._affine_bwd(gyc, xc, mean, rstd, w, None)
+for _ in range(4):
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(out[:3], ref[:3]):
+        kernel_err = max(kernel_err, float((a - b).abs().max() / b.abs().max()))
 print("RESULT " + json.dumps({"errors": errors, "gather_exact": exact, "kernel_err": kernel_err}), flush=True)
