@@ -4,7 +4,7 @@ import torch
 import pytorchhessianfree_amd as hf
 from pytorchhessianfree_amd import testproblems as tp, modelprep
 model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device="cuda")
-modelprep.prepare_model(model)
+modelprep.prepare_model(model, channels_last=len(sys.argv) > 1 and sys.argv[1] == "nhwc")
 opt = hf.HessianFree(model.parameters(), graph_matvec=True)
 g = torch.Generator(device="cuda").manual_seed(0)
 t0 = time.time()
