@@ -158,6 +158,7 @@ def main():
             modelprep.fuse_conv_tangent(model, channels_last=channels_last)
         if args.fuse_bn and args.fuse_conv:
             modelprep.fuse_residual_blocks(model)  # relu(bn(.)) / relu(bn(.) + identity) as one layer
+            modelprep.fuse_bn_relu(model)          # relu(bn(.)) outside residual blocks (the stem)
             modelprep.skip_identity_pools(model)   # AdaptiveAvgPool2d(1) of a 1x1 map
         params = [p for p in model.parameters() if p.requires_grad]
         # local gradient first (its graph is freed again: nothing may tie the parameters

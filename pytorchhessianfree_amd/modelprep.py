@@ -22,6 +22,8 @@ kernels (~4.5 us each inside a hipGraph), not by bytes or flops.  The patches:
   preceding fused layer; optionally everything in NHWC (no MIOpen layout transposes);
   convolutions on 1x1 maps as GEMMs on the kernel's centre tap; bias gradients by a
   reduction kernel that is safe inside a hipGraph.
+* ``fuse_bn_relu`` -- a ``ReLU`` module fed by a fused BatchNorm (ResNet stem, Sequential
+  stacks) becomes part of that layer.
 * ``skip_identity_pools`` -- ``AdaptiveAvgPool2d(1)`` of a 1x1 map issues no kernel.
 
 ``first_order_only`` / ``tangent_owner`` are the two contexts the curvature operators hold
@@ -29,6 +31,7 @@ while recording ``u -> J^T u`` and while sweeping a tangent through it.
 """
 
 import os
+import threading
 import types
 
 import torch
@@ -269,7 +272,33 @@ def fused_bn_act(bn, x, res=None, relu=False, twin=False):
 
 
 def _fused_forward(self, x):
-    return fused_bn_act(self, x)
+    y = fused_bn_act(self, x)
+    if _bn_usable(self, x):
+        y._hf_bn_src = (self, x)  # lets a directly following ReLU module fuse with this layer
+    return y
+
+
+def _relu_forward(self, x):
+    src = getattr(x, "_hf_bn_src", None)
+    if src is None:
+        return self._hf_stock_forward(x)
+    bn, xin = src
+    return fused_bn_act(bn, xin, relu=True)  # the unfused BatchNorm output drops out of the graph
+
+
+def fuse_bn_relu(model):
+    """``ReLU`` modules whose input is the output of a fused eval-mode BatchNorm (a ResNet
+    stem, ``Sequential(conv, bn, relu)`` stacks) evaluate ``relu(bn(x))`` as ONE fused layer:
+    the separately computed BatchNorm output is left unused, so every curvature product
+    runs one kernel per pass instead of two.  Needs ``fuse_eval_batchnorm``.  Returns the
+    number of modules patched."""
+    count = 0
+    for m in model.modules():
+        if type(m) is nn.ReLU and not hasattr(m, "_hf_stock_forward"):
+            m._hf_stock_forward = m.forward
+            m.forward = types.MethodType(_relu_forward, m)
+            count += 1
+    return count
 
 
 # ------------------------------------------------------------------------------------
@@ -351,17 +380,27 @@ class _miopen_mode:
     ``HF_NHWC_FIND=1`` keeps the find step (used once, result checked, to produce the
     shipped records).  NCHW calls are left as configured."""
 
+    _lock = threading.Lock()
+    _depth = 0      # the flag is process-global and the autograd engine calls in from its own
+    _saved = None   # threads: only the outermost entry saves, only the last exit restores
+
     def __init__(self, cl):
         self.active = bool(cl) and not os.environ.get("HF_NHWC_FIND")
 
     def __enter__(self):
         if self.active:
-            self.saved = torch.backends.cudnn.benchmark
-            torch.backends.cudnn.benchmark = False
+            with _miopen_mode._lock:
+                if _miopen_mode._depth == 0:
+                    _miopen_mode._saved = torch.backends.cudnn.benchmark
+                    torch.backends.cudnn.benchmark = False
+                _miopen_mode._depth += 1
 
     def __exit__(self, *exc):
         if self.active:
-            torch.backends.cudnn.benchmark = self.saved
+            with _miopen_mode._lock:
+                _miopen_mode._depth -= 1
+                if _miopen_mode._depth == 0:
+                    torch.backends.cudnn.benchmark = _miopen_mode._saved
         return False
 
 
@@ -673,6 +712,7 @@ def prepare_model(model, channels_last=False):
     fuse_eval_batchnorm(model)
     fuse_conv_tangent(model, channels_last=channels_last)
     fuse_residual_blocks(model)
+    fuse_bn_relu(model)
     skip_identity_pools(model)
     return model
 
