@@ -371,3 +371,36 @@ def test_modelprep_is_transparent_on_cpu():
     with modelprep.first_order_only():
         assert modelprep._Mode.first_order_only is True
     assert modelprep._Mode.first_order_only is False
+
+
+def test_modelprep_layout_helpers_on_cpu_tensors():
+    """Pure-Python pieces of the tangent plumbing: recognising the first-channels slice of a
+    wider NCHW / NHWC buffer (``_slice_ld``) and the layers that are GEMMs on one kernel
+    tap (``_point``)."""
+    from pytorchhessianfree_amd import modelprep as mp
+
+    cl = torch.channels_last
+    for fmt in (torch.contiguous_format, cl):
+        x = torch.zeros(3, 8, 5, 4).contiguous(memory_format=fmt)
+        wide = torch.zeros(3, 16, 5, 4).contiguous(memory_format=fmt)
+        assert mp._slice_ld(x, x) == 0
+        assert mp._slice_ld(wide[:, :8], x) == (16 if fmt is cl else 16 * 20)
+        assert mp._slice_ld(wide[:, 8:], x) == (16 if fmt is cl else 16 * 20)   # any channel offset
+        assert mp._slice_ld(wide[:, ::2], x) is None                            # every other channel
+        assert mp._slice_ld(wide[:, :8, :, :3], x) is None                      # wrong shape
+        assert mp._slice_ld(x.double(), x) is None
+    other = torch.zeros(3, 8, 5, 4).contiguous(memory_format=cl)
+    assert mp._slice_ld(other, torch.zeros(3, 8, 5, 4)) is None                 # dense, but in the other layout
+    one = torch.zeros(4, 16, 1, 1)
+    assert mp._slice_ld(torch.zeros(4, 32, 1, 1)[:, :16], one) == 32            # 1x1 maps: layouts coincide
+
+    x1 = torch.zeros(2, 8, 1, 1)
+    w3, w5, w1, w2 = (torch.zeros(6, 8, k, k) for k in (3, 5, 1, 2))
+    assert mp._point(x1, w3, [1, 1], [1, 1], True) == 1
+    assert mp._point(x1, w5, [2, 2], [1, 1], True) == 2
+    assert mp._point(x1, w1, [0, 0], [1, 1], True) == 0
+    assert mp._point(x1, w3, [1, 1], [1, 1], False) is None                     # NCHW: the tap is strided
+    assert mp._point(x1, w3, [0, 0], [1, 1], True) is None                      # not "same" padding
+    assert mp._point(x1, w3, [1, 1], [2, 2], True) is None                      # dilated
+    assert mp._point(x1, w2, [1, 1], [1, 1], True) is None                      # even kernel
+    assert mp._point(torch.zeros(2, 8, 2, 2), w3, [1, 1], [1, 1], True) is None  # larger map
