@@ -5,14 +5,14 @@ os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(os.getcwd(), "pytorchh
 torch.backends.cudnn.benchmark = True
 import pytorchhessianfree_amd as hf
 from pytorchhessianfree_amd import testproblems as tp, modelprep
-for graph, fuse in [(False, False), (False, True), (True, True)]:
+for graph, fuse in [(False, False), (False, True), (True, True), (True, "nhwc")]:
     model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device="cuda")
-    if fuse: modelprep.prepare_model(model)
+    if fuse: modelprep.prepare_model(model, channels_last=fuse == "nhwc")
     def forward():
         out = model(x); return lossf(out, t), out
     opt = hf.HessianFree(model.parameters(), graph_matvec=graph)
     times = []
-    for s in range(4):
+    for s in range(6):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
