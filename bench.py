@@ -58,14 +58,47 @@ def parse():
                          "float64 stock-autograd product before it is timed; NHWC falls back to NCHW, and "
                          "config.matvec says which one ran")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
-    ap.add_argument("--overlap", type=int, default=0,
+    ap.add_argument("--overlap", type=int, default=-1,
                     help="data parallel: split the product into two hipGraphs and overlap the "
                          "all-reduce of the tail with the head's adjoint sweep (measured on one MI355X: "
                          "the split costs +0.19 ms and the two async collectives +0.4 ms per product, "
-                         "so it only pays when the all-reduce itself takes > ~0.6 ms; off by default)")
+                         "so it only pays when the all-reduce itself takes > ~0.6 ms; -1 = decided from a one-off "
+                         "timing of the all-reduce at start-up)")
     ap.add_argument("--force-dist", type=int, default=0,
                     help="create the process group even for WORLD_SIZE=1 (exercises the RCCL path on one GPU)")
+    ap.add_argument("--curvature", default="ggn", choices=["ggn", "hessian"],
+                    help="curvature_opt of the reference (optimizer.py:25); hessian = BASELINE.json configs[3]")
+    ap.add_argument("--precond", type=int, default=0,
+                    help="1: diagonal empirical-Fisher preconditioner, exponent 0.75, per-sample autograd "
+                         "path (preconditioners.py:63-127), fused into K2/K3 (56 N bytes per iteration)")
+    ap.add_argument("--l2", type=float, default=-1.0,
+                    help="L2 regularisation weight added to the loss as in examples/example_utils.py:77-81 "
+                         "(-1: 5e-4 for --workload allcnnc with --curvature hessian, else 0)")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: start N rank processes (one per
+    GPU) and relay rank 0's JSON line.  The parent never touches the GPU
+    (``device_count`` does not initialise it), so nothing is re-exec'ed after a HIP
+    call.  With fewer devices than ranks (a 1-GPU box) the ranks share devices and
+    talk over gloo -- a functional check of the multi-rank path, not a scaling number."""
+    import socket
+    import subprocess
+
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    raise SystemExit(max(abs(rc) for rc in rcs))
 
 
 def build_problem(args, device, rank):
@@ -85,17 +118,38 @@ def cpu_baseline(args):
     from oracle import pcg as oracle
     from pytorchhessianfree_amd.utils import vector_to_parameter_list
 
+    from pytorchhessianfree_amd import testproblems as tp
+
     model, (x, t), lossf = build_problem(args, "cpu", 0)
+    l2 = args.l2 if args.l2 >= 0 else (5e-4 if (args.workload == "allcnnc" and args.curvature == "hessian") else 0.0)
+    if l2 > 0:
+        lossf = tp.l2_regularized(lossf, model, l2)
     params = [p for p in model.parameters() if p.requires_grad]
     out = model(x)
     loss = lossf(out, t)
+    hessian = args.curvature == "hessian"
     grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, params, retain_graph=True)])
     calls = [0]
 
-    def mvp(v):  # optimizer.py:457-462 with BackPACK's published algorithm
+    def mvp(v):  # optimizer.py:450-462 with BackPACK's published algorithms
         calls[0] += 1
-        Gv = bp.ggn_vector_product_from_plist(loss, out, params, vector_to_parameter_list(v, params))
-        return torch.cat([g.reshape(-1) for g in Gv]).detach()
+        vs = vector_to_parameter_list(v, params)
+        if hessian:
+            Bv = bp.hessian_vector_product(loss, params, vs)
+        else:
+            Bv = bp.ggn_vector_product_from_plist(loss, out, params, vs)
+        return torch.cat([g.reshape(-1) for g in Bv]).detach()
+
+    M = None
+    if args.precond:  # preconditioners.py:63-127, the power re-evaluated on every call as there
+        diag = torch.zeros_like(grad)
+        for x_i, t_i in zip(x, t):
+            g_i = torch.autograd.grad(lossf(model(x_i), t_i), params)
+            diag += torch.cat([g.reshape(-1) for g in g_i]) ** 2
+        diag /= x.shape[0]
+
+        def M(v):
+            return (diag + args.damping) ** -0.75 * v
 
     lam = args.damping
     # give the CPU path its best thread count on this box (torch's default of one
@@ -118,12 +172,12 @@ def cpu_baseline(args):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         # same stopping rule as the GPU's timed region: exactly cpu_iters iterations
-        xs, _, _ = oracle.pcg(lambda v: mvp(v) + lam * v, -grad, max_iter=args.cpu_iters, tol=0.0,
+        xs, _, _ = oracle.pcg(lambda v: mvp(v) + lam * v, -grad, M=M, max_iter=args.cpu_iters, tol=0.0,
                               martens_conv_crit=False, store_x_at_iters=[0])
     dt = time.perf_counter() - t0
     return {
         "value": calls[0] / dt,
-        "unit": "GGN-matvecs/s",
+        "unit": ("Hessian" if hessian else "GGN") + "-matvecs/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
         "sample": f"{len(xs)-1} PCG iterations ({calls[0]} matvecs) of the same {args.workload} "
@@ -137,21 +191,51 @@ def main():
     args = parse()
     if args.channels_last < 0:
         args.channels_last = int(args.workload in ("resnet18", "allcnnc"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} ranks; reporting {world}",
+              file=sys.stderr, flush=True)
+    ndev = torch.cuda.device_count()
+    if ndev < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    oversubscribed = world > ndev  # several ranks per device: gloo (RCCL wants one device per rank)
+    if oversubscribed and args.backend == "nccl":
+        args.backend = "gloo"
+    local_dev = local_rank % ndev
+    torch.cuda.set_device(local_dev)
+    device = torch.device("cuda", local_dev)
     import pytorchhessianfree_amd as hf
+
+    hf.configure()  # MIOpen: accurate fp32 solvers, find step, shipped find-db (config.py)
     from pytorchhessianfree_amd import curvature, modelprep
-    from pytorchhessianfree_amd.cg import enable_kernel_timing, read_kernel_timing
+    from pytorchhessianfree_amd.cg import _TIMING_SAMPLE, enable_kernel_timing, read_kernel_timing
+
+    from pytorchhessianfree_amd import preconditioners
+    from pytorchhessianfree_amd import testproblems as tp
 
     weight = 1.0 / world
+    l2 = args.l2 if args.l2 >= 0 else (5e-4 if (args.workload == "allcnnc" and args.curvature == "hessian") else 0.0)
+    hessian = args.curvature == "hessian"
+    dist_on = world > 1 or bool(args.force_dist)
 
-    def build_operator(channels_last):
-        model, (x, t), lossf = build_problem(args, device, rank)
+    def problem(dev, dtype=torch.float32):
+        model, (x, t), lossf = build_problem(args, dev, rank)
+        model, x = model.to(dtype), x.to(dtype)
+        if l2 > 0:  # examples/example_utils.py:77-81 (DeepOBS' L2 term on the weights)
+            lossf = tp.l2_regularized(lossf, model, l2)
+        return model, x, t, lossf
+
+    def make_operator(loss, out, params):
+        if hessian:
+            return curvature.HessianOperator(loss, params, weight=weight, group=None)
+        return curvature.GGNOperator(loss, out, params, weight=weight, group=None)
+
+    def build_operator(channels_last, overlap=False):
+        model, x, t, lossf = problem(device)
         if args.fuse_bn:
             modelprep.fuse_eval_batchnorm(model)
         if args.fuse_conv:
@@ -165,24 +249,24 @@ def main():
         # to the default stream while the product is captured, see GraphedOperator)
         grad = curvature.flatten_into(torch.autograd.grad(lossf(model(x), t), params), params,
                                       scale=weight)
+        diag = None
+        if args.precond:  # per-sample autograd path, preconditioners.py:63-105
+            diag = preconditioners.diag_EF_autograd(model, lossf, x, t, "mean") * weight
 
         def builder():  # forward graph + recorded J^T / H_L maps (once per Newton step)
             out = model(x)
-            return curvature.GGNOperator(lossf(out, t), out, params, weight=weight, group=None)
+            return make_operator(lossf(out, t), out, params)
 
-        # The local product is captured BEFORE the process group exists: RCCL's
-        # watchdog thread must not touch the runtime while a capture is open.
-        if args.graph and args.overlap and (world > 1 or args.force_dist):
+        if args.graph and overlap and not hessian:
             op = curvature.OverlappedGraphedOperator(builder, params=params)
         else:
             op = curvature.maybe_graphed(builder, enable=bool(args.graph), params=params)
-        return op, grad, sum(p.numel() for p in params)
+        return op, grad, diag, sum(p.numel() for p in params)
 
     def stock_product(v, dtype):
         """The same product by stock PyTorch-ROCm autograd on an unpatched NCHW model
         (float64: the reference; float32: what the stock fp32 path itself achieves)."""
-        model, (x, t), lossf = build_problem(args, device, rank)
-        model, x = model.to(dtype), x.to(dtype)
+        model, x, t, lossf = problem(device, dtype)
         params = [p for p in model.parameters() if p.requires_grad]
         find = torch.backends.cudnn.benchmark
         # one product only: MIOpen's immediate mode, no find step (and no find-db records)
@@ -190,7 +274,7 @@ def main():
         torch.backends.cudnn.benchmark = False
         try:
             out = model(x)
-            op = curvature.GGNOperator(lossf(out, t), out, params, weight=weight, group=None)
+            op = make_operator(lossf(out, t), out, params)
             return op(v.to(dtype)).double().clone()
         finally:
             torch.backends.cudnn.benchmark = find
@@ -202,32 +286,38 @@ def main():
     check = {}
 
     def checked(channels_last):
-        op, grad, n = build_operator(channels_last)
+        op, grad, diag, n = build_operator(channels_last)
         if "want" not in check:
             v = torch.randn(n, device=device, generator=torch.Generator(device=device).manual_seed(7))
             want = stock_product(v, torch.float64)
             scale = float(want.abs().max())
             stock_err = float((stock_product(v, torch.float32) - want).abs().max()) / scale
             check.update(v=v, want=want, scale=scale, stock_err=stock_err, tol=max(1e-5, 5.0 * stock_err))
-        err = float((op(check["v"]).double() - check["want"]).abs().max()) / check["scale"]
-        return op, grad, n, err
+        got = op(check["v"]).double()
+        err = float((got - check["want"]).abs().max()) / check["scale"]
+        # the reference's own check (optimizer.py:414-448): the same product twice
+        check["deterministic"] = bool(torch.equal(op(check["v"]).double(), got))
+        return op, grad, diag, n, err
 
-    op, grad, n, err = checked(bool(args.channels_last))
+    op, grad, diag, n, err = checked(bool(args.channels_last))
     note = "max-norm error against float64 stock autograd {:.1e}, stock fp32 autograd {:.1e}"
     layout = ("NHWC" if args.channels_last else "NCHW") + " (" + note.format(err, check["stock_err"]) + ")"
     if not err < check["tol"] and args.channels_last:
         print(f"[bench] NHWC product off by {err:.2e} (float64 reference); using NCHW",
               file=sys.stderr, flush=True)
         del op
-        op, grad, n, err = checked(False)
+        args.channels_last = 0
+        op, grad, diag, n, err = checked(False)
         layout = "NCHW (NHWC failed its check; " + note.format(err, check["stock_err"]) + ")"
     if not err < check["tol"]:
         raise SystemExit(f"bench: the curvature product is off by {err:.2e} against float64 stock autograd")
     del check["want"], check["v"]
 
-    group = None
-    if world > 1 or args.force_dist:
+    group, allreduce_ms, comm_path = None, None, "none"
+    if dist_on:
         import torch.distributed as dist
+
+        from pytorchhessianfree_amd import distributed as hfdist
 
         if world == 1:  # --force-dist on a single GPU, started without a launcher
             for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"),
@@ -238,17 +328,42 @@ def main():
         else:
             dist.init_process_group(args.backend)
         group = dist.group.WORLD
+        world = dist.get_world_size(group)  # what the backend reports is what gets printed
+        # one-off timing of THE collective of this path: the 4N-byte all-reduce
+        probe = torch.zeros(n, device=device)
+        for _ in range(3):
+            hfdist.all_reduce_sum(probe, group)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            hfdist.all_reduce_sum(probe, group)
+        torch.cuda.synchronize()
+        tt = torch.tensor([(time.perf_counter() - t0) / 10 * 1e3], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)  # one number, one decision, on every rank
+        allreduce_ms = float(tt.item())
+        comm_path = hfdist.path_name(probe, group)
+        del probe
+        # policy: the two-graph overlap costs ~0.2 ms per product on its own,
+        # so it is only worth switching on when the exposed all-reduce is slower than that
+        if args.overlap < 0:
+            args.overlap = int(world > 1 and allreduce_ms > 0.6 and bool(args.graph) and not hessian)
+        if args.overlap and not isinstance(op, curvature.OverlappedGraphedOperator):
+            del op
+            op, grad, diag, n = build_operator(bool(args.channels_last), overlap=True)
     op.group = group  # one all-reduce (sum) of the 4N-byte partial product per matvec
 
     if group is not None:
         torch.distributed.all_reduce(grad, group=group)
+        if diag is not None:
+            torch.distributed.all_reduce(diag, group=group)
     b = -grad
     A = hf.DampedCurvature(op, args.damping)
+    M = hf.DiagonalPreconditioner(diag, args.damping, 0.75) if diag is not None else None
 
     def solve(martens=False, max_iter=args.iters):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            return hf.cg(A, b, max_iter=max_iter, tol=0.0, martens_conv_crit=martens,
+            return hf.cg(A, b, M=M, max_iter=max_iter, tol=0.0, martens_conv_crit=martens,
                          store_x_at_iters=[0])
 
     def barrier():
@@ -285,9 +400,12 @@ def main():
 
     if rank == 0:
         k2_s = timing["k2_ms"] * 1e-3
-        alg_bytes = 28.0 * n  # K2: reads x,r,p,Bp,b, writes x,r (fp32)  SURVEY.md 8(d)
-        achieved = alg_bytes / k2_s / 1e9 if k2_s > 0 else 0.0
+        # K2 reads x,r,p,Bp,b(,minv), writes x,r; K1 8N, K3 12N (16N with minv)
+        k2_bytes = (32.0 if M is not None else 28.0) * n
+        it_bytes = (56.0 if M is not None else 48.0) * n
+        achieved = k2_bytes / k2_s / 1e9 if k2_s > 0 else 0.0
         all3 = (timing["k1_ms"] + timing["k2_ms"] + timing["k3_ms"]) * 1e-3
+        fused = bool(getattr(op, "_iteration_graphs", None))
         line = {
             "metric": "GGN-matvecs/sec (damped operator calls inside the PCG loop)",
             "value": world * matvecs / dt,
@@ -302,14 +420,27 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload} GGN PCG solve: N={n} fp32 parameters, "
-                            f"batch {args.batch}/GPU, {iters_done} PCG iterations/step, "
-                            f"damping {args.damping}, eval-mode BN, CE-mean, x0=0, tol=0",
-                "parallelism": f"dp{world} (batch sharded, one all-reduce of 4N bytes per matvec)",
+                "workload": f"{args.workload} {args.curvature.upper()} PCG solve: N={n} fp32 parameters, "
+                            f"batch {args.batch}/GPU, {iters_done} PCG iterations in the last step "
+                            f"({matvecs} operator calls in {args.steps} steps, max_iter {args.iters}), "
+                            f"damping {args.damping}, eval-mode BN, CE-mean"
+                            + (f" + L2 {l2:g}" if l2 > 0 else "") + ", x0=0, tol=0"
+                            + (", diag empirical-Fisher preconditioner ^-0.75 (per-sample autograd)" if M is not None else ""),
+                "parallelism": f"dp{world} (batch sharded, one all-reduce of 4N bytes per matvec)"
+                               + (f"; {world} ranks share {ndev} device(s) over gloo: functional run, not a "
+                                  "scaling number" if oversubscribed else ""),
                 "matvec": getattr(op, "mode", "eager autograd")
                           + ("; eval-BN fused (hf_chan_affine)" if args.fuse_bn else "")
-                          + ("; conv tangent fused" if args.fuse_conv else "") + "; " + layout,
+                          + ("; conv tangent fused" if args.fuse_conv else "") + "; " + layout
+                          + ("; deterministic (two products bitwise equal)" if check.get("deterministic")
+                             else "; NOT bitwise repeatable (library kernels with atomics)"),
+                "iteration": ("one hipGraph launch per PCG iteration (product -> K1 -> K2 -> K3)" if fused and group is None
+                              else "product graph -> all-reduce -> K1-K3 graph" if fused
+                              else "product, then K1, K2, K3 as separate launches"),
                 "termination": reason,
+                "allreduce": None if allreduce_ms is None else {
+                    "path": comm_path, "bytes": 4 * n, "ms": allreduce_ms,
+                    "overlap_two_graphs": bool(args.overlap)},
             },
             "cg_iters_per_s": world * args.steps * iters_done / dt,
             "cg_to_martens": {"iters": len(xs_m) - 1, "reason": reason_m,
@@ -322,20 +453,30 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "alg_bytes_per_launch": alg_bytes,
+                "traffic_source": None,
+                "alg_bytes_per_launch": k2_bytes,
                 "avg_launch_ms": timing["k2_ms"],
                 "launches_timed": timing["n"],
+                "timing": "HIP events on the launch stream around K1/K2/K3"
+                          + (f" (event-record nodes of every {_TIMING_SAMPLE}th iteration's graph)" if fused else
+                             " of every iteration"),
                 "all_pcg_kernels": {
                     "k1_ms": timing["k1_ms"], "k2_ms": timing["k2_ms"], "k3_ms": timing["k3_ms"],
-                    "alg_bytes_per_iter": 48.0 * n,
-                    "achieved_GBs": 48.0 * n / all3 / 1e9 if all3 > 0 else 0.0,
+                    "alg_bytes_per_iter": it_bytes,
+                    "achieved_GBs": it_bytes / all3 / 1e9 if all3 > 0 else 0.0,
                 },
             },
         }
         prof = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(prof):
             try:
-                line["roofline"]["traffic"] = json.load(open(prof)).get(f"k_update_xr_{n}")
+                key = f"k_update_xr_{n}" + ("_precond" if M is not None else "")
+                val = json.load(open(prof)).get(key)
+                if val is not None:
+                    line["roofline"]["traffic"] = val
+                    line["roofline"]["traffic_source"] = (
+                        "static: profiles/traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                        "this command (not re-measured in this run)")
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 1
+#define HF_ABI_VERSION 2
 
 enum hf_dtype { HF_F32 = 0, HF_F64 = 1 };
 
@@ -118,6 +118,27 @@ int hf_pcg_iterate(hf_pcg_t* h, const void* Bp, double damping, void* stream);
 int hf_pcg_curvature(hf_pcg_t* h, const void* Bp, double damping, void* stream);
 int hf_pcg_update_xr(hf_pcg_t* h, const void* Bp, double damping, void* stream);
 int hf_pcg_update_p(hf_pcg_t* h, const void* y_external, void* stream);
+
+/*
+ * ONE hipGraph launch per PCG iteration (cg.py:200-227 as a single device-side unit):
+ *   [curvature product] -> K1 -> K2 -> K3.
+ * `product_graph` is a hipGraph_t (as void*) holding the captured curvature product
+ * B.p -- the autograd sweeps of optimizer.py:457-462 + hf_pack, reading the solver's `p`
+ * and writing `Bp`; it is CLONED, the caller keeps ownership.  NULL builds K1-K3 only
+ * (data-parallel runs: product graph -> all-reduce -> this graph).  Call after
+ * hf_pcg_begin; `hf_pcg_graph_update` refreshes the kernel arguments after a later
+ * hf_pcg_begin (new x / b / slab / m_hist / damping) without re-instantiating.
+ * `with_timing` adds a second executable with event-record nodes around K1/K2/K3;
+ * `hf_pcg_graph_launch(g, timed=1, ...)` runs that one, `hf_pcg_graph_collect_timing`
+ * waits for it and adds its three durations to what hf_pcg_timing_read reports.
+ */
+typedef struct hf_pcg_graph hf_pcg_graph_t;
+int hf_pcg_graph_create(hf_pcg_graph_t** out, hf_pcg_t* h, void* product_graph,
+                        const void* Bp, double damping, int with_timing);
+int hf_pcg_graph_update(hf_pcg_graph_t* g, const void* Bp, double damping);
+int hf_pcg_graph_launch(hf_pcg_graph_t* g, int timed, void* stream);
+int hf_pcg_graph_collect_timing(hf_pcg_graph_t* g);
+int hf_pcg_graph_destroy(hf_pcg_graph_t* g);
 
 /* Non-blocking: reads the pinned host mirror the device writes at termination
  * (fills done/reason and, once done, n_iters = the terminating iteration). */

@@ -1,45 +1,16 @@
 """MI355X-native Hessian-free Newton-step solver (drop-in for the PCG /
 curvature-matvec hot path of ltatzel/PyTorchHessianFree)."""
 
-import os as _os
-
-# MIOpen's fp32 Winograd solvers are not fp32-accurate: measured on MI355X, the
-# stock PyTorch-ROCm gradient of the ResNet-18 workload is off by 7e-4 (relative,
-# first block) and 2.3e-4 overall against float64, while every other solver family
-# stays at 3e-7 -- at identical speed once MIOpen has measured its solvers
-# (scratch/conv_acc.py).  Parity with the reference's CPU path
-# needs the accurate ones; set HF_ALLOW_WINOGRAD=1 to keep MIOpen's default.
-#
-# Without Winograd, MIOpen's immediate mode (PyTorch's default) can fall back to
-# naive solvers (measured: 49 ms instead of 1.7 ms per product), so MIOpen is asked
-# to MEASURE its solvers once per convolution shape (cudnn.benchmark) and a find-db
-# with the shapes of the BASELINE.json workloads ships in ``miopen_db/`` (new
-# shapes are appended there; point MIOPEN_USER_DB_PATH elsewhere to relocate).
-#
-# MIOpen's composable-kernel weight-gradient solver ConvHipImplicitGemmGroupWrwXdlops
-# (split-K: a memset of the output followed by an atomically accumulating kernel) is
-# switched off as well: whenever the find step ranked it first for a layer, that layer's
-# weight gradient came out wrong -- off by 1e-3 in eager mode, arbitrary garbage when the
-# memset + kernel pair is replayed from a hipGraph (first replay 1e8..1e34, reproducible
-# in every second process under rocprofv3; scratch/nhwc_diag.py pins the error to exactly
-# the one parameter whose record named this solver).  The asm implicit-GEMM solver that
-# otherwise wins is within 3 % of its speed.
-if not _os.environ.get("HF_ALLOW_WINOGRAD"):
-    _os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
-    _os.environ.setdefault("MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_WRW_XDLOPS", "0")
-    _os.environ.setdefault(
-        "MIOPEN_USER_DB_PATH", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
-    )
-    # let PyTorch hand channels_last tensors to MIOpen as NHWC (modelprep's conv layers
-    # compute in NHWC; without this PyTorch converts them back to NCHW first)
-    _os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
-    import torch as _torch
-
-    _torch.backends.cudnn.benchmark = True
+# Importing this package changes nothing in the process.  MIOpen settings that make
+# stock fp32 convolutions reference-accurate (no Winograd, no split-K CK weight
+# gradient), the solver find step and the shipped find-db are applied by
+# ``configure()`` -- called by ``modelprep.prepare_model``, ``bench.py`` and the tests;
+# see ``config.py`` for every switch.
+from .config import configure, configured  # noqa: F401
 
 from .cg import DampedCurvature, DiagonalPreconditioner, cg, storing_grid  # noqa: F401
 
-__all__ = ["cg", "DampedCurvature", "DiagonalPreconditioner", "storing_grid"]
+__all__ = ["cg", "DampedCurvature", "DiagonalPreconditioner", "storing_grid", "configure"]
 from .optimizer import HessianFree  # noqa: F401,E402
 from .preconditioners import (  # noqa: F401,E402
     diag_EF_autograd,

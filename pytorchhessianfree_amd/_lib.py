@@ -65,6 +65,11 @@ SIGNATURES = {
     "hf_pcg_curvature": (c_int, [c_void_p, c_void_p, c_double, c_void_p]),
     "hf_pcg_update_xr": (c_int, [c_void_p, c_void_p, c_double, c_void_p]),
     "hf_pcg_update_p": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "hf_pcg_graph_create": (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_double, c_int]),
+    "hf_pcg_graph_update": (c_int, [c_void_p, c_void_p, c_double]),
+    "hf_pcg_graph_launch": (c_int, [c_void_p, c_int, c_void_p]),
+    "hf_pcg_graph_collect_timing": (c_int, [c_void_p]),
+    "hf_pcg_graph_destroy": (c_int, [c_void_p]),
     "hf_pcg_poll": (c_int, [c_void_p, ctypes.POINTER(Status)]),
     "hf_pcg_finish": (c_int, [c_void_p, ctypes.POINTER(Status), c_void_p]),
     "hf_pcg_read_nonpos": (
@@ -125,7 +130,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.hf_abi_version() != 1:
+    if lib.hf_abi_version() != 2:
         raise RuntimeError("libhfpcg.so ABI version mismatch")
     _lib = lib
     return lib

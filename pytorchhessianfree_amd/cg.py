@@ -43,9 +43,12 @@ class DampedCurvature:
     """``x -> mvp(x) + damping * x`` (the ``A`` of optimizer.py:266) as an object,
     so that :func:`cg` can fuse the damping into its kernels."""
 
-    def __init__(self, mvp, damping):
+    def __init__(self, mvp, damping, lockstep=False):
         self.mvp = mvp
         self.damping = float(damping)
+        # data-parallel callers: every rank must leave the PCG loop at the same
+        # iteration (``mvp`` ends in a collective even if it does not say so)
+        self.lockstep = bool(lockstep)
 
     def __call__(self, x):
         return self.mvp(x) + self.damping * x
@@ -81,6 +84,65 @@ def storing_grid(max_iter, gamma=1.3):
     return sorted(set((torch.ceil(gamma**js) - 1).int().tolist()))
 
 
+class _IterationGraph:
+    """``[curvature product] -> K1 -> K2 -> K3`` as ONE hipGraph launch per PCG
+    iteration (``hf_pcg_graph_*``).  Built once per (operator, workspace,
+    preconditioner mode) from the operator's captured product graph (or without a
+    product, for data-parallel runs where an all-reduce separates the two halves);
+    the K1-K3 kernel arguments are refreshed at the start of every solve."""
+
+    def __init__(self, ws, raw_graph, Bp, damping, mode, timing):
+        self.ws, self.mode, self.timing = ws, mode, bool(timing)
+        self.handle = _lib.c_void_p()
+        _lib.check(
+            ws.lib.hf_pcg_graph_create(ctypes.byref(self.handle), ws.handle,
+                                       _lib.c_void_p(raw_graph) if raw_graph else None,
+                                       _lib.c_void_p(Bp.data_ptr()), float(damping), 1 if timing else 0),
+            "hf_pcg_graph_create")
+        self.fresh = True
+
+    def refresh(self, Bp, damping):
+        if self.fresh:  # created with this solve's arguments
+            self.fresh = False
+            return
+        _lib.check(self.ws.lib.hf_pcg_graph_update(self.handle, _lib.c_void_p(Bp.data_ptr()),
+                                                   float(damping)), "hf_pcg_graph_update")
+
+    def launch(self, stream, timed=False):
+        _lib.check(self.ws.lib.hf_pcg_graph_launch(self.handle, 1 if timed else 0, stream),
+                   "hf_pcg_graph_launch")
+
+    def collect(self):
+        _lib.check(self.ws.lib.hf_pcg_graph_collect_timing(self.handle), "hf_pcg_graph_collect_timing")
+
+    def __del__(self):
+        try:
+            self.ws.lib.hf_pcg_graph_destroy(self.handle)
+        except Exception:
+            pass
+
+
+_TIMING_SAMPLE = 16  # with kernel timing on, every 16th fused iteration runs the event-carrying graph
+
+
+def _iteration_graph(matvec, ws, Bp, damping, mode, with_product):
+    """The operator's cached :class:`_IterationGraph` for this workspace, or ``None``
+    when the operator is not a captured graph / fusion is switched off
+    (``HF_FUSE_ITERATION=0``)."""
+    if os.environ.get("HF_FUSE_ITERATION", "1") == "0":
+        return None
+    raw = getattr(matvec, "raw_graph", None)
+    if raw is None:
+        return None
+    cache = matvec.__dict__.setdefault("_iteration_graphs", {})
+    key = (id(ws), mode, bool(with_product), bool(ws.timing))
+    g = cache.get(key)
+    if g is None:
+        g = cache[key] = _IterationGraph(ws, raw() if with_product else None, Bp, damping, mode, ws.timing)
+    g.refresh(Bp, damping)
+    return g
+
+
 class _Workspace:
     """Per (device, N, dtype): the native handle and the two vectors that never
     leave the solver (r, p)."""
@@ -101,6 +163,12 @@ class _Workspace:
         self.r = torch.empty(n, dtype=dtype, device=device)
         self.p = torch.empty(n, dtype=dtype, device=device)
         self.timing = False
+        self._events = [torch.cuda.Event() for _ in range(_LAG + 2)]
+        self.checked_groups = set()
+
+    def event(self, it):
+        """Recycled completion events: at most _LAG + 1 are pending at any time."""
+        return self._events[it % len(self._events)]
 
     @classmethod
     def get(cls, device, n, dtype):
@@ -115,6 +183,27 @@ class _Workspace:
             self.lib.hf_pcg_destroy(self.handle)
         except Exception:
             pass
+
+
+def _check_ranks_agree(ws, group):
+    """Data-parallel solves stay in lockstep only if every rank computes bitwise
+    identical scalars, i.e. runs the PCG kernels with the same grid (= the same
+    partial-sum order).  Checked once per (workspace, group): ranks on GPUs with
+    different CU counts or different ``HF_PCG_BLOCKS`` are refused up front instead of
+    dead-locking in a later all-reduce."""
+    if id(group) in ws.checked_groups:
+        return
+    dist = torch.distributed
+    mine = int(os.environ.get("HF_PCG_BLOCKS", "0")) or 2 * torch.cuda.get_device_properties(
+        ws.device).multi_processor_count
+    t = torch.tensor([mine, -mine], dtype=torch.int64, device=ws.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = int(t[0]), -int(t[1])
+    if hi != lo:
+        raise RuntimeError(
+            f"data-parallel PCG needs the same kernel grid on every rank (got {lo}..{hi} blocks): "
+            "set HF_PCG_BLOCKS to one value on all ranks")
+    ws.checked_groups.add(id(group))
 
 
 def _as_operand(t, like, name):
@@ -253,21 +342,48 @@ def cg(
     # a deterministic rule: at host iteration i wait for the event of iteration
     # i-LAG and stop iff the device terminated at an iteration <= i-LAG.  Every rank
     # thus performs exactly n_iters+LAG operator calls, with no pipeline bubble.
-    lockstep = getattr(matvec, "group", None) is not None or bool(getattr(matvec, "collective", False))
+    group = getattr(matvec, "group", None)
+    lockstep = group is not None or bool(getattr(matvec, "collective", False)) or bool(
+        getattr(A, "lockstep", False))
+    if group is not None:
+        _check_ranks_agree(ws, group)
+
+    # A hipGraph-captured operator whose buffers the solver adopted runs the whole
+    # iteration -- product, K1, K2, K3 -- as ONE graph launch; with a process group the
+    # all-reduce separates the product graph from a K1-K3 graph.
+    fused = None
+    if mode != _lib.HF_M_EXTERNAL and p_vec is ib and hasattr(matvec, "replay_local"):
+        fused = _iteration_graph(matvec, ws, matvec.output_buffer, damping, mode,
+                                 with_product=group is None)
+
     status = _lib.Status()
     events = []
+    timed_pending = False
     for it in range(1, max_iter + 1):
         if verbose:
             print(f"  cg-iteration {it}")
-        Bp = _as_operand(matvec(p_vec), b, "A(p)")
-        if mode == _lib.HF_M_EXTERNAL:
-            _lib.check(lib.hf_pcg_curvature(ws.handle, ptr(Bp), damping, stream), "curvature")
-            _lib.check(lib.hf_pcg_update_xr(ws.handle, ptr(Bp), damping, stream), "update_xr")
-            y = _as_operand(M(ws.r), b, "M(r)")
-            _lib.check(lib.hf_pcg_update_p(ws.handle, ptr(y), stream), "update_p")
+        if fused is not None:
+            timed = fused.timing and it % _TIMING_SAMPLE == 0
+            if timed and timed_pending:
+                fused.collect()  # iteration it-16: long finished, does not stall the pipeline
+            if group is None:
+                matvec.calls += 1
+            else:
+                matvec.replay_local()
+                matvec.reduce(matvec.output_buffer)
+                matvec.calls += 1
+            fused.launch(stream, timed)
+            timed_pending = timed_pending or timed
         else:
-            _lib.check(lib.hf_pcg_iterate(ws.handle, ptr(Bp), damping, stream), "hf_pcg_iterate")
-        ev = torch.cuda.Event()
+            Bp = _as_operand(matvec(p_vec), b, "A(p)")
+            if mode == _lib.HF_M_EXTERNAL:
+                _lib.check(lib.hf_pcg_curvature(ws.handle, ptr(Bp), damping, stream), "curvature")
+                _lib.check(lib.hf_pcg_update_xr(ws.handle, ptr(Bp), damping, stream), "update_xr")
+                y = _as_operand(M(ws.r), b, "M(r)")
+                _lib.check(lib.hf_pcg_update_p(ws.handle, ptr(y), stream), "update_p")
+            else:
+                _lib.check(lib.hf_pcg_iterate(ws.handle, ptr(Bp), damping, stream), "hf_pcg_iterate")
+        ev = ws.event(it)
         ev.record()
         events.append(ev)
         if lockstep:
@@ -283,6 +399,8 @@ def cg(
             break
         if len(events) > _LAG:
             events.pop(0).synchronize()
+    if timed_pending:
+        fused.collect()
 
     _lib.check(lib.hf_pcg_finish(ws.handle, ctypes.byref(status), stream), "hf_pcg_finish")
     if not status.done:

@@ -27,6 +27,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <new>
+#include <vector>
 
 #include "hf_pcg.h"
 
@@ -254,30 +255,35 @@ __global__ __launch_bounds__(BLOCK) void k_init_finalize(DevState* __restrict__ 
 // ---------------------------------------------------------------------------
 // K1: partial sums of p.(Bp + lambda p)                         8N bytes
 // ---------------------------------------------------------------------------
+// All three streaming kernels issue the loads of their FIRST tile before anything
+// else (the done flag, the re-reduction of the previous kernel's partials): at small N
+// (All-CNN-C: 5.5 MB vectors, one tile per block) that prologue used to sit in front of
+// the first load and cost more than the streaming itself.
 template <typename T, int UNROLL>
 __global__ __launch_bounds__(BLOCK) void k_curvature(const DevState* __restrict__ st,
                                                      double* __restrict__ part1, int stride,
                                                      const T* __restrict__ p,
                                                      const T* __restrict__ Bp, T lam, int damped,
                                                      long long n) {
-  if (st->done) return;
   constexpr int W = VecOf<T>::W;
   typedef typename VecOf<T>::type V;
   __shared__ double lds[WAVES];
   double acc[1] = {0.0};
   const long long nvec = n / W;
   const long long tile = (long long)BLOCK * UNROLL;
-  for (long long base = (long long)blockIdx.x * tile; base < nvec;
-       base += (long long)gridDim.x * tile) {
-    VU<T> vp[UNROLL], vg[UNROLL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const long long i = base + u * BLOCK + threadIdx.x;
-      if (i < nvec) {
-        vp[u].v = reinterpret_cast<const V*>(p)[i];
-        vg[u].v = reinterpret_cast<const V*>(Bp)[i];
-      }
-    }
+  long long base = (long long)blockIdx.x * tile;
+  VU<T> vp[UNROLL], vg[UNROLL];
+#define HF_K1_LOAD()                                                        \
+  _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                       \
+    const long long i = base + u * BLOCK + threadIdx.x;                     \
+    if (i < nvec) {                                                         \
+      vp[u].v = reinterpret_cast<const V*>(p)[i];                           \
+      vg[u].v = reinterpret_cast<const V*>(Bp)[i];                          \
+    }                                                                       \
+  }
+  HF_K1_LOAD();
+  if (st->done) return;
+  while (base < nvec) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const long long i = base + u * BLOCK + threadIdx.x;
@@ -289,7 +295,10 @@ __global__ __launch_bounds__(BLOCK) void k_curvature(const DevState* __restrict_
         }
       }
     }
+    base += (long long)gridDim.x * tile;
+    HF_K1_LOAD();
   }
+#undef HF_K1_LOAD
   if (blockIdx.x == 0) {
     const long long j = nvec * W + threadIdx.x;
     if (j < n) acc[0] += (double)p[j] * (double)apply_damping<T>(Bp[j], p[j], lam, damped);
@@ -308,10 +317,27 @@ __global__ __launch_bounds__(BLOCK) void k_update_xr(
     const T* __restrict__ Bp, const T* __restrict__ b, const T* __restrict__ minv, T lam,
     int damped, const long long* __restrict__ store_iters, long long n_store,
     T* __restrict__ slab, long long slab_stride, long long n) {
-  if (st->done) return;
   constexpr int W = VecOf<T>::W;
   typedef typename VecOf<T>::type V;
   __shared__ double lds[3 * WAVES];
+  const long long nvec = n / W;
+  const long long tile = (long long)BLOCK * UNROLL;
+  long long base = (long long)blockIdx.x * tile;
+  VU<T> vx[UNROLL], vr[UNROLL], vp[UNROLL], vg[UNROLL], vb[UNROLL], vm[UNROLL];
+#define HF_K2_LOAD()                                                        \
+  _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                       \
+    const long long i = base + u * BLOCK + threadIdx.x;                     \
+    if (i < nvec) {                                                         \
+      vx[u].v = reinterpret_cast<const V*>(x)[i];                           \
+      vr[u].v = reinterpret_cast<const V*>(r)[i];                           \
+      vp[u].v = reinterpret_cast<const V*>(p)[i];                           \
+      vg[u].v = reinterpret_cast<const V*>(Bp)[i];                          \
+      vb[u].v = reinterpret_cast<const V*>(b)[i];                           \
+      if (MODE == HF_M_DIAG) vm[u].v = reinterpret_cast<const V*>(minv)[i]; \
+    }                                                                       \
+  }
+  HF_K2_LOAD();  // in flight while alpha is being put together
+  if (st->done) return;
 
   double s[1];
   reduce_partials<1>(part1, nparts, stride, s, lds);
@@ -338,23 +364,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_xr(
   }
 
   double acc[3] = {0.0, 0.0, 0.0};
-  const long long nvec = n / W;
-  const long long tile = (long long)BLOCK * UNROLL;
-  for (long long base = (long long)blockIdx.x * tile; base < nvec;
-       base += (long long)gridDim.x * tile) {
-    VU<T> vx[UNROLL], vr[UNROLL], vp[UNROLL], vg[UNROLL], vb[UNROLL], vm[UNROLL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const long long i = base + u * BLOCK + threadIdx.x;
-      if (i < nvec) {
-        vx[u].v = reinterpret_cast<const V*>(x)[i];
-        vr[u].v = reinterpret_cast<const V*>(r)[i];
-        vp[u].v = reinterpret_cast<const V*>(p)[i];
-        vg[u].v = reinterpret_cast<const V*>(Bp)[i];
-        vb[u].v = reinterpret_cast<const V*>(b)[i];
-        if (MODE == HF_M_DIAG) vm[u].v = reinterpret_cast<const V*>(minv)[i];
-      }
-    }
+  while (base < nvec) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const long long i = base + u * BLOCK + threadIdx.x;
@@ -376,7 +386,10 @@ __global__ __launch_bounds__(BLOCK) void k_update_xr(
         if (snap) reinterpret_cast<V*>(snap)[i] = vx[u].v;
       }
     }
+    base += (long long)gridDim.x * tile;
+    HF_K2_LOAD();
   }
+#undef HF_K2_LOAD
   if (blockIdx.x == 0) {
     const long long j = nvec * W + threadIdx.x;
     if (j < n) {
@@ -440,10 +453,25 @@ __global__ __launch_bounds__(BLOCK) void k_update_p(
     const double* __restrict__ part3, int nparts, int stride, const T* __restrict__ r,
     T* __restrict__ p, const T* __restrict__ minv, const T* __restrict__ yext,
     T* __restrict__ m_hist, long long max_iter, int* host_flag, long long n) {
-  if (st->done) return;
   constexpr int W = VecOf<T>::W;
   typedef typename VecOf<T>::type V;
   __shared__ double lds[3 * WAVES];
+  const long long nvec = n / W;
+  const long long tile = (long long)BLOCK * UNROLL;
+  long long base = (long long)blockIdx.x * tile;
+  VU<T> vr[UNROLL], vp[UNROLL], vm[UNROLL];
+#define HF_K3_LOAD()                                                        \
+  _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                       \
+    const long long i = base + u * BLOCK + threadIdx.x;                     \
+    if (i < nvec) {                                                         \
+      if (MODE == HF_M_EXTERNAL) vr[u].v = reinterpret_cast<const V*>(yext)[i]; \
+      else vr[u].v = reinterpret_cast<const V*>(r)[i];                      \
+      vp[u].v = reinterpret_cast<const V*>(p)[i];                           \
+      if (MODE == HF_M_DIAG) vm[u].v = reinterpret_cast<const V*>(minv)[i]; \
+    }                                                                       \
+  }
+  HF_K3_LOAD();  // in flight while beta and the termination tests are evaluated
+  if (st->done) return;
 
   double s[3];
   reduce_partials<3>(part2, nparts, stride, s, lds);
@@ -494,21 +522,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_p(
   }
   if (reason != HF_RUNNING) return;
 
-  const long long nvec = n / W;
-  const long long tile = (long long)BLOCK * UNROLL;
-  for (long long base = (long long)blockIdx.x * tile; base < nvec;
-       base += (long long)gridDim.x * tile) {
-    VU<T> vr[UNROLL], vp[UNROLL], vm[UNROLL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const long long i = base + u * BLOCK + threadIdx.x;
-      if (i < nvec) {
-        if (MODE == HF_M_EXTERNAL) vr[u].v = reinterpret_cast<const V*>(yext)[i];
-        else vr[u].v = reinterpret_cast<const V*>(r)[i];
-        vp[u].v = reinterpret_cast<const V*>(p)[i];
-        if (MODE == HF_M_DIAG) vm[u].v = reinterpret_cast<const V*>(minv)[i];
-      }
-    }
+  while (base < nvec) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const long long i = base + u * BLOCK + threadIdx.x;
@@ -521,7 +535,10 @@ __global__ __launch_bounds__(BLOCK) void k_update_p(
         reinterpret_cast<V*>(p)[i] = vp[u].v;
       }
     }
+    base += (long long)gridDim.x * tile;
+    HF_K3_LOAD();
   }
+#undef HF_K3_LOAD
   if (blockIdx.x == 0) {
     const long long j = nvec * W + threadIdx.x;
     if (j < n) {
@@ -932,7 +949,8 @@ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 struct hf_pcg {
   int64_t n;
   int dtype;
-  int grid;            // blocks of the vector kernels == partials per sum
+  int grid;            // blocks of the vector kernels at large N (2 per CU)
+  int grid_cap;        // partial-sum slots per sum (>= any grid a kernel is launched with)
   DevState* d_state;
   double* d_part;      // [3 sums][3 slots][grid]
   DevState* h_state;   // pinned
@@ -956,6 +974,8 @@ struct hf_pcg {
   int timing;
   int64_t t_count;
   hipEvent_t* ev;      // 4 per iteration
+  double g_ms[3];      // sums of the sampled per-kernel times of hf_pcg_graph launches
+  int64_t g_count;
 };
 
 #define HF_HIP(expr)                         \
@@ -965,14 +985,20 @@ struct hf_pcg {
   } while (0)
 
 namespace {
-inline double* part_ptr(hf_pcg* h, int which) { return h->d_part + (size_t)which * 3 * h->grid; }
+inline double* part_ptr(hf_pcg* h, int which) { return h->d_part + (size_t)which * 3 * h->grid_cap; }
 
-// blocks for a kernel whose blocks walk tiles of BLOCK*unroll 16-byte vectors
+// Blocks for a kernel whose blocks walk tiles of BLOCK*unroll 16-byte vectors.  Large
+// vectors: 2 blocks per CU, each walking many tiles (tuned).  Small
+// vectors (<= SMALL_TILES tiles, e.g. All-CNN-C's 5.5 MB): ONE tile per block -- with the
+// capped grid some blocks walked two tiles and the rest one, a 2x tail on a kernel that
+// lasts a few microseconds.
+constexpr int SMALL_TILES = 2048;
 int grid_for(const hf_pcg* h, int unroll) {
   const int W = h->dtype == HF_F32 ? 4 : 2;
   const int64_t nvec = h->n / W;
   int64_t tiles = (nvec + (int64_t)BLOCK * unroll - 1) / ((int64_t)BLOCK * unroll);
   if (tiles < 1) tiles = 1;
+  if (tiles <= SMALL_TILES && tiles <= h->grid_cap) return (int)tiles;
   return (int)(tiles < h->grid ? tiles : h->grid);
 }
 }  // namespace
@@ -1000,17 +1026,21 @@ int hf_pcg_create(hf_pcg_t** out, int64_t n, int dtype, int max_blocks) {
   memset(h, 0, sizeof(*h));
   h->n = n;
   h->dtype = dtype;
+  const bool explicit_blocks = max_blocks != 0;
   if (max_blocks == 0) {
     int dev = 0, cus = 256;
     HF_HIP(hipGetDevice(&dev));
     HF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    max_blocks = 2 * cus;  // tuned on MI355X (scratch/tune.py): 2 per CU, unroll 2
+    max_blocks = 2 * cus;  // tuned on MI355X (scripts/experiments/tune.py): 2 per CU, unroll 2
   }
   h->grid = max_blocks;
+  // an explicit max_blocks (tests, tuning) is a hard cap; the default allows the
+  // one-tile-per-block grids of small vectors
+  h->grid_cap = explicit_blocks ? max_blocks : (max_blocks > SMALL_TILES ? max_blocks : SMALL_TILES);
   HF_HIP(hipMalloc((void**)&h->d_state, sizeof(DevState)));
   HF_HIP(hipMemset(h->d_state, 0, sizeof(DevState)));
-  HF_HIP(hipMalloc((void**)&h->d_part, sizeof(double) * 3 * 3 * (size_t)h->grid));
-  HF_HIP(hipMemset(h->d_part, 0, sizeof(double) * 3 * 3 * (size_t)h->grid));
+  HF_HIP(hipMalloc((void**)&h->d_part, sizeof(double) * 3 * 3 * (size_t)h->grid_cap));
+  HF_HIP(hipMemset(h->d_part, 0, sizeof(double) * 3 * 3 * (size_t)h->grid_cap));
   HF_HIP(hipHostMalloc((void**)&h->h_state, sizeof(DevState), hipHostMallocDefault));
   HF_HIP(hipHostMalloc((void**)&h->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
   h->h_flag[0] = 0;
@@ -1072,7 +1102,7 @@ static int init_impl(hf_pcg* h, const void* Ax0, int slot0, hipStream_t s) {
   double* part = part_ptr(h, 0);
   T* snap = slot0 ? (T*)h->slab : nullptr;
 #define HF_LAUNCH_INIT(MODE)                                                                   \
-  hipLaunchKernelGGL((k_init<T, MODE>), dim3(g), dim3(BLOCK), 0, s, part, h->grid,             \
+  hipLaunchKernelGGL((k_init<T, MODE>), dim3(g), dim3(BLOCK), 0, s, part, h->grid_cap,         \
                      (const T*)h->x, (T*)h->r, (T*)h->p, (const T*)Ax0, (const T*)h->b,        \
                      (const T*)h->minv, snap, (long long)h->n)
   switch (h->precond) {
@@ -1084,7 +1114,7 @@ static int init_impl(hf_pcg* h, const void* Ax0, int slot0, hipStream_t s) {
   HF_HIP(hipGetLastError());
   if (h->precond != HF_M_EXTERNAL) {
     hipLaunchKernelGGL((k_init_finalize<T>), dim3(1), dim3(BLOCK), 0, s, h->d_state, part, g,
-                       h->grid, h->tol, h->atol, (T*)h->m_hist,
+                       h->grid_cap, h->tol, h->atol, (T*)h->m_hist,
                        (const long long*)h->store_iters, (long long)h->n_store, h->d_flag);
     HF_HIP(hipGetLastError());
     h->inited = 1;
@@ -1109,16 +1139,16 @@ int hf_pcg_init_external(hf_pcg_t* h, const void* y, void* stream) {
   const int g = grid_for(h, 1);
   double* part = part_ptr(h, 0);
   if (h->dtype == HF_F32) {
-    hipLaunchKernelGGL((k_init_external<float>), dim3(g), dim3(BLOCK), 0, s, part, h->grid,
+    hipLaunchKernelGGL((k_init_external<float>), dim3(g), dim3(BLOCK), 0, s, part, h->grid_cap,
                        (const float*)h->r, (float*)h->p, (const float*)y, (long long)h->n);
     hipLaunchKernelGGL((k_init_finalize<float>), dim3(1), dim3(BLOCK), 0, s, h->d_state, part, g,
-                       h->grid, h->tol, h->atol, (float*)h->m_hist,
+                       h->grid_cap, h->tol, h->atol, (float*)h->m_hist,
                        (const long long*)h->store_iters, (long long)h->n_store, h->d_flag);
   } else {
-    hipLaunchKernelGGL((k_init_external<double>), dim3(g), dim3(BLOCK), 0, s, part, h->grid,
+    hipLaunchKernelGGL((k_init_external<double>), dim3(g), dim3(BLOCK), 0, s, part, h->grid_cap,
                        (const double*)h->r, (double*)h->p, (const double*)y, (long long)h->n);
     hipLaunchKernelGGL((k_init_finalize<double>), dim3(1), dim3(BLOCK), 0, s, h->d_state, part,
-                       g, h->grid, h->tol, h->atol, (double*)h->m_hist,
+                       g, h->grid_cap, h->tol, h->atol, (double*)h->m_hist,
                        (const long long*)h->store_iters, (long long)h->n_store, h->d_flag);
   }
   HF_HIP(hipGetLastError());
@@ -1140,60 +1170,118 @@ int hf_pcg_init_external(hf_pcg_t* h, const void* y, void* stream) {
 #endif
 constexpr int U1 = HF_U1, U2 = HF_U2, U3 = HF_U3;
 
+// ---- launch descriptors -----------------------------------------------------
+// One description of a K1/K2/K3 launch (function, grid, argument values) serves both
+// the direct launch (hipLaunchKernel) and the kernel nodes of the per-iteration
+// hipGraph (hf_pcg_graph_*), whose arguments are refreshed per solve.
+struct KLaunch {
+  const void* func;
+  int grid;
+  void* args[20];
+  // argument storage
+  DevState* st;
+  const double *pa, *pb;
+  double* pw;
+  int i0, i1, i2;
+  void *v0, *v1, *v2, *v3, *v4, *v5, *v6, *v7;
+  float lam_f;
+  double lam_d;
+  long long l0, l1, l2;
+  int* flag;
+};
+
+template <typename T>
+static void* lam_slot(KLaunch& k, double damping);
+template <> void* lam_slot<float>(KLaunch& k, double damping) { k.lam_f = (float)damping; return &k.lam_f; }
+template <> void* lam_slot<double>(KLaunch& k, double damping) { k.lam_d = damping; return &k.lam_d; }
+
+template <typename T>
+static void build_k1(hf_pcg* h, const void* Bp, double damping, KLaunch& k) {
+  k.func = (const void*)&k_curvature<T, U1>;
+  k.grid = grid_for(h, U1);
+  k.st = h->d_state; k.pw = part_ptr(h, 1); k.i0 = h->grid_cap;
+  k.v0 = h->p; k.v1 = const_cast<void*>(Bp); k.i1 = damping != 0.0 ? 1 : 0; k.l0 = h->n;
+  void* a[] = {&k.st, &k.pw, &k.i0, &k.v0, &k.v1, lam_slot<T>(k, damping), &k.i1, &k.l0};
+  memcpy(k.args, a, sizeof(a));
+}
+
+template <typename T>
+static void build_k2(hf_pcg* h, const void* Bp, double damping, KLaunch& k) {
+  switch (h->precond) {
+    case HF_M_NONE: k.func = (const void*)&k_update_xr<T, HF_M_NONE, U2>; break;
+    case HF_M_DIAG: k.func = (const void*)&k_update_xr<T, HF_M_DIAG, U2>; break;
+    default: k.func = (const void*)&k_update_xr<T, HF_M_EXTERNAL, U2>; break;
+  }
+  k.grid = grid_for(h, U2);
+  k.st = h->d_state; k.pa = part_ptr(h, 1); k.pw = part_ptr(h, 2);
+  k.i0 = grid_for(h, U1); k.i1 = h->grid_cap;
+  k.v0 = h->x; k.v1 = h->r; k.v2 = h->p; k.v3 = const_cast<void*>(Bp);
+  k.v4 = const_cast<void*>(h->b); k.v5 = const_cast<void*>(h->minv);
+  k.i2 = damping != 0.0 ? 1 : 0;
+  k.v6 = const_cast<int64_t*>(h->store_iters); k.l0 = h->n_store; k.v7 = h->slab;
+  k.l1 = h->slab_stride; k.l2 = h->n;
+  void* a[] = {&k.st, &k.pa, &k.pw, &k.i0, &k.i1, &k.v0, &k.v1, &k.v2, &k.v3, &k.v4, &k.v5,
+               lam_slot<T>(k, damping), &k.i2, &k.v6, &k.l0, &k.v7, &k.l1, &k.l2};
+  memcpy(k.args, a, sizeof(a));
+}
+
+template <typename T>
+static void build_k3(hf_pcg* h, const void* yext, KLaunch& k) {
+  switch (h->precond) {
+    case HF_M_NONE: k.func = (const void*)&k_update_p<T, HF_M_NONE, U3>; break;
+    case HF_M_DIAG: k.func = (const void*)&k_update_p<T, HF_M_DIAG, U3>; break;
+    default: k.func = (const void*)&k_update_p<T, HF_M_EXTERNAL, U3>; break;
+  }
+  k.grid = grid_for(h, U3);
+  k.st = h->d_state; k.pa = part_ptr(h, 2); k.pb = part_ptr(h, 0);
+  k.i0 = grid_for(h, U2); k.i1 = h->grid_cap;
+  k.v0 = h->r; k.v1 = h->p; k.v2 = const_cast<void*>(h->minv); k.v3 = const_cast<void*>(yext);
+  k.v4 = h->m_hist; k.l0 = h->max_iter; k.flag = h->d_flag; k.l1 = h->n;
+  void* a[] = {&k.st, &k.pa, &k.pb, &k.i0, &k.i1, &k.v0, &k.v1, &k.v2, &k.v3, &k.v4, &k.l0,
+               &k.flag, &k.l1};
+  memcpy(k.args, a, sizeof(a));
+}
+
+static void build_iteration(hf_pcg* h, const void* Bp, double damping, KLaunch (&k)[3]) {
+  if (h->dtype == HF_F32) {
+    build_k1<float>(h, Bp, damping, k[0]); build_k2<float>(h, Bp, damping, k[1]);
+    build_k3<float>(h, nullptr, k[2]);
+  } else {
+    build_k1<double>(h, Bp, damping, k[0]); build_k2<double>(h, Bp, damping, k[1]);
+    build_k3<double>(h, nullptr, k[2]);
+  }
+}
+
+static int launch(const KLaunch& k, hipStream_t s) {
+  HF_HIP(hipLaunchKernel(k.func, dim3(k.grid), dim3(BLOCK), const_cast<void**>(k.args), 0, s));
+  return HF_OK;
+}
+
 template <typename T>
 static int curvature_impl(hf_pcg* h, const void* Bp, double damping, hipStream_t s) {
-  const int g = grid_for(h, U1);
-  hipLaunchKernelGGL((k_curvature<T, U1>), dim3(g), dim3(BLOCK), 0, s, h->d_state,
-                     part_ptr(h, 1), h->grid, (const T*)h->p, (const T*)Bp, (T)damping,
-                     damping != 0.0 ? 1 : 0, (long long)h->n);
-  HF_HIP(hipGetLastError());
-  return HF_OK;
+  KLaunch k;
+  build_k1<T>(h, Bp, damping, k);
+  return launch(k, s);
 }
 
 template <typename T>
 static int update_xr_impl(hf_pcg* h, const void* Bp, double damping, hipStream_t s) {
-  const int g1 = grid_for(h, U1);
-  const int g = grid_for(h, U2);
-#define HF_LAUNCH_XR(MODE)                                                                     \
-  hipLaunchKernelGGL((k_update_xr<T, MODE, U2>), dim3(g), dim3(BLOCK), 0, s, h->d_state,       \
-                     part_ptr(h, 1), part_ptr(h, 2), g1, h->grid, (T*)h->x, (T*)h->r,          \
-                     (const T*)h->p, (const T*)Bp, (const T*)h->b, (const T*)h->minv,          \
-                     (T)damping, damping != 0.0 ? 1 : 0, (const long long*)h->store_iters,     \
-                     (long long)h->n_store, (T*)h->slab, (long long)h->slab_stride,            \
-                     (long long)h->n)
-  switch (h->precond) {
-    case HF_M_NONE: HF_LAUNCH_XR(HF_M_NONE); break;
-    case HF_M_DIAG: HF_LAUNCH_XR(HF_M_DIAG); break;
-    default: HF_LAUNCH_XR(HF_M_EXTERNAL); break;
-  }
-#undef HF_LAUNCH_XR
-  HF_HIP(hipGetLastError());
-  return HF_OK;
+  KLaunch k;
+  build_k2<T>(h, Bp, damping, k);
+  return launch(k, s);
 }
 
 template <typename T>
 static int update_p_impl(hf_pcg* h, const void* yext, hipStream_t s) {
-  const int g2 = grid_for(h, U2);
-  const int g = grid_for(h, U3);
   if (h->precond == HF_M_EXTERNAL) {
     // same grid as K2 so that part2 and part3 hold the same number of partials
-    hipLaunchKernelGGL((k_dot_ry<T, U2>), dim3(g2), dim3(BLOCK), 0, s, h->d_state, part_ptr(h, 0),
-                       h->grid, (const T*)h->r, (const T*)yext, (long long)h->n);
+    hipLaunchKernelGGL((k_dot_ry<T, U2>), dim3(grid_for(h, U2)), dim3(BLOCK), 0, s, h->d_state,
+                       part_ptr(h, 0), h->grid_cap, (const T*)h->r, (const T*)yext, (long long)h->n);
     HF_HIP(hipGetLastError());
   }
-#define HF_LAUNCH_P(MODE, NP3)                                                                 \
-  hipLaunchKernelGGL((k_update_p<T, MODE, U3>), dim3(g), dim3(BLOCK), 0, s, h->d_state,        \
-                     part_ptr(h, 2), part_ptr(h, 0), NP3, h->grid, (const T*)h->r, (T*)h->p,   \
-                     (const T*)h->minv, (const T*)yext, (T*)h->m_hist,                         \
-                     (long long)h->max_iter, h->d_flag, (long long)h->n)
-  switch (h->precond) {
-    case HF_M_NONE: HF_LAUNCH_P(HF_M_NONE, g2); break;
-    case HF_M_DIAG: HF_LAUNCH_P(HF_M_DIAG, g2); break;
-    default: HF_LAUNCH_P(HF_M_EXTERNAL, g2); break;
-  }
-#undef HF_LAUNCH_P
-  HF_HIP(hipGetLastError());
-  return HF_OK;
+  KLaunch k;
+  build_k3<T>(h, yext, k);
+  return launch(k, s);
 }
 
 int hf_pcg_curvature(hf_pcg_t* h, const void* Bp, double damping, void* stream) {
@@ -1245,6 +1333,155 @@ int hf_pcg_iterate(hf_pcg_t* h, const void* Bp, double damping, void* stream) {
     HF_HIP(hipEventRecord(ev[3], s));
     h->t_count++;
   }
+  return HF_OK;
+}
+
+// ---- one hipGraph per PCG iteration ---------------------------------------------
+// [curvature product (a captured graph of the caller, cloned)] -> K1 -> K2 -> K3 as ONE
+// graph launch per iteration.  The K1-K3 nodes are explicit kernel nodes whose
+// arguments are refreshed per solve (hf_pcg_graph_update), so the caller's
+// per-solve vectors (x, b, snapshot slab, m_hist ...) need not be persistent.  A second
+// executable of the same graph carries event-record nodes around K1/K2/K3: the host
+// launches it for a sample of the iterations to time the kernels without touching the
+// others.
+struct hf_pcg_graph {
+  hf_pcg* h;
+  hipGraph_t graph[2];
+  hipGraphExec_t exec[2];
+  hipGraphNode_t knode[2][3];
+  hipEvent_t ev[4];
+  int have_events;
+  int timed_in_flight;
+};
+
+namespace {
+int graph_leaves(hipGraph_t g, std::vector<hipGraphNode_t>& leaves) {
+  size_t nn = 0, ne = 0;
+  HF_HIP(hipGraphGetNodes(g, nullptr, &nn));
+  std::vector<hipGraphNode_t> nodes(nn);
+  if (nn) HF_HIP(hipGraphGetNodes(g, nodes.data(), &nn));
+  HF_HIP(hipGraphGetEdges(g, nullptr, nullptr, &ne));
+  std::vector<hipGraphNode_t> from(ne), to(ne);
+  if (ne) HF_HIP(hipGraphGetEdges(g, from.data(), to.data(), &ne));
+  leaves.clear();
+  for (size_t i = 0; i < nn; ++i) {
+    bool has_out = false;
+    for (size_t e = 0; e < ne && !has_out; ++e) has_out = from[e] == nodes[i];
+    if (!has_out) leaves.push_back(nodes[i]);
+  }
+  return HF_OK;
+}
+
+hipKernelNodeParams node_params(const KLaunch& k) {
+  hipKernelNodeParams p;
+  memset(&p, 0, sizeof(p));
+  p.func = const_cast<void*>(k.func);
+  p.gridDim = dim3(k.grid);
+  p.blockDim = dim3(BLOCK);
+  p.sharedMemBytes = 0;
+  p.kernelParams = const_cast<void**>(k.args);
+  p.extra = nullptr;
+  return p;
+}
+
+int build_iteration_graph(hf_pcg_graph* g, int which, hipGraph_t product, const KLaunch (&k)[3]) {
+  const bool timed = which == 1;
+  if (product) HF_HIP(hipGraphClone(&g->graph[which], product));
+  else HF_HIP(hipGraphCreate(&g->graph[which], 0));
+  std::vector<hipGraphNode_t> deps;
+  const int rc = graph_leaves(g->graph[which], deps);
+  if (rc) return rc;
+  for (int i = 0; i < 3; ++i) {
+    if (timed) {
+      hipGraphNode_t e;
+      HF_HIP(hipGraphAddEventRecordNode(&e, g->graph[which], deps.data(), deps.size(), g->ev[i]));
+      deps.assign(1, e);
+    }
+    hipKernelNodeParams p = node_params(k[i]);
+    HF_HIP(hipGraphAddKernelNode(&g->knode[which][i], g->graph[which], deps.data(), deps.size(), &p));
+    deps.assign(1, g->knode[which][i]);
+  }
+  if (timed) {
+    hipGraphNode_t e;
+    HF_HIP(hipGraphAddEventRecordNode(&e, g->graph[which], deps.data(), deps.size(), g->ev[3]));
+  }
+  HF_HIP(hipGraphInstantiate(&g->exec[which], g->graph[which], nullptr, nullptr, 0));
+  return HF_OK;
+}
+}  // namespace
+
+int hf_pcg_graph_create(hf_pcg_graph_t** out, hf_pcg_t* h, void* product_graph, const void* Bp,
+                        double damping, int with_timing) {
+  if (!out || !h || !Bp) return HF_ERR_ARG;
+  if (!h->begun || h->precond == HF_M_EXTERNAL) return HF_ERR_STATE;
+  if (!aligned16(Bp)) return HF_ERR_ALIGN;
+  hf_pcg_graph* g = new (std::nothrow) hf_pcg_graph();
+  if (!g) return HF_ERR_ARG;
+  memset(g, 0, sizeof(*g));
+  g->h = h;
+  KLaunch k[3];
+  build_iteration(h, Bp, damping, k);
+  int rc = build_iteration_graph(g, 0, (hipGraph_t)product_graph, k);
+  if (!rc && with_timing) {
+    for (int i = 0; i < 4 && !rc; ++i) rc = (int)hipEventCreate(&g->ev[i]);
+    g->have_events = 1;
+    if (!rc) rc = build_iteration_graph(g, 1, (hipGraph_t)product_graph, k);
+  }
+  if (rc) { hf_pcg_graph_destroy(g); return rc; }
+  *out = g;
+  return HF_OK;
+}
+
+int hf_pcg_graph_update(hf_pcg_graph_t* g, const void* Bp, double damping) {
+  if (!g || !Bp) return HF_ERR_ARG;
+  hf_pcg* h = g->h;
+  if (!h->begun || h->precond == HF_M_EXTERNAL) return HF_ERR_STATE;
+  if (!aligned16(Bp)) return HF_ERR_ALIGN;
+  KLaunch k[3];
+  build_iteration(h, Bp, damping, k);
+  for (int w = 0; w < 2; ++w) {
+    if (!g->exec[w]) continue;
+    for (int i = 0; i < 3; ++i) {
+      hipKernelNodeParams p = node_params(k[i]);
+      HF_HIP(hipGraphExecKernelNodeSetParams(g->exec[w], g->knode[w][i], &p));
+    }
+  }
+  return HF_OK;
+}
+
+int hf_pcg_graph_launch(hf_pcg_graph_t* g, int timed, void* stream) {
+  if (!g) return HF_ERR_ARG;
+  if (!g->h->inited) return HF_ERR_STATE;
+  const int w = (timed && g->exec[1]) ? 1 : 0;
+  HF_HIP(hipGraphLaunch(g->exec[w], (hipStream_t)stream));
+  if (w == 1) g->timed_in_flight = 1;
+  return HF_OK;
+}
+
+int hf_pcg_graph_collect_timing(hf_pcg_graph_t* g) {
+  if (!g) return HF_ERR_ARG;
+  if (!g->timed_in_flight) return HF_OK;
+  HF_HIP(hipEventSynchronize(g->ev[3]));
+  for (int i = 0; i < 3; ++i) {
+    float t = 0;
+    HF_HIP(hipEventElapsedTime(&t, g->ev[i], g->ev[i + 1]));
+    g->h->g_ms[i] += t;
+  }
+  g->h->g_count++;
+  g->timed_in_flight = 0;
+  return HF_OK;
+}
+
+int hf_pcg_graph_destroy(hf_pcg_graph_t* g) {
+  if (!g) return HF_OK;
+  for (int w = 0; w < 2; ++w) {
+    if (g->exec[w]) (void)hipGraphExecDestroy(g->exec[w]);
+    if (g->graph[w]) (void)hipGraphDestroy(g->graph[w]);
+  }
+  if (g->have_events)
+    for (int i = 0; i < 4; ++i)
+      if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
+  delete g;
   return HF_OK;
 }
 
@@ -1306,6 +1543,8 @@ int hf_pcg_timing_enable(hf_pcg_t* h, int enable) {
   }
   h->timing = enable ? 1 : 0;
   h->t_count = 0;
+  h->g_ms[0] = h->g_ms[1] = h->g_ms[2] = 0.0;
+  h->g_count = 0;
   return HF_OK;
 }
 
@@ -1320,9 +1559,11 @@ int hf_pcg_timing_read(hf_pcg_t* h, double* ms_k1, double* ms_k2, double* ms_k3,
     HF_HIP(hipEventElapsedTime(&t, ev[1], ev[2])); b += t;
     HF_HIP(hipEventElapsedTime(&t, ev[2], ev[3])); c += t;
   }
-  const double k = h->t_count > 0 ? 1.0 / (double)h->t_count : 0.0;
+  a += h->g_ms[0]; b += h->g_ms[1]; c += h->g_ms[2];  // sampled hf_pcg_graph launches
+  const int64_t cnt = h->t_count + h->g_count;
+  const double k = cnt > 0 ? 1.0 / (double)cnt : 0.0;
   *ms_k1 = a * k; *ms_k2 = b * k; *ms_k3 = c * k;
-  *n_recorded = h->t_count;
+  *n_recorded = cnt;
   return HF_OK;
 }
 

@@ -234,7 +234,7 @@ class GraphedOperator:
     the stream their forward ran on.
 
     Precondition (PyTorch-ROCm 2.10 / HIP 7.0 crash the process otherwise, measured
-    in scratch/graph_repro*.py): while capturing, no autograd state that ties the
+    in scripts/experiments/graph_repro*.py): while capturing, no autograd state that ties the
     parameters to ANOTHER stream may be alive -- i.e. no ``.grad`` on them (stashed
     and restored here when ``params`` is given) and no live autograd graph built
     on another stream that reaches them (their ``AccumulateGrad`` nodes remember
@@ -286,13 +286,27 @@ class GraphedOperator:
             for _ in range(warmup):
                 self.op.local(self.input_buffer, out=self.output_buffer)
         self.stream.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
+        # keep_graph: the raw hipGraph_t stays available, so that cg() can clone it into
+        # its one-launch-per-iteration graph (product -> K1 -> K2 -> K3, hf_pcg_graph_*)
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         with torch.cuda.graph(self.graph, stream=self.stream):
             self.op.local(self.input_buffer, out=self.output_buffer)
+        self.graph.instantiate()
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
         self.calls = 0
         self._verify_replay()
+
+    def raw_graph(self):
+        """The captured product as a raw ``hipGraph_t`` (an int), owned by ``self.graph``."""
+        return self.graph.raw_cuda_graph()
+
+    def replay_local(self):
+        """Replay the captured local product: reads ``input_buffer``, writes ``output_buffer``."""
+        self.graph.replay()
+
+    def reduce(self, t):
+        return _all_reduce_sum(t, self.group)
 
     _verified = set()  # signatures whose first capture in this process was checked
 
@@ -306,12 +320,18 @@ class GraphedOperator:
         replayed from a hipGraph, the second replay differently from the first.  The
         package routes around the instances it met; a model that brings a new one
         must fail here, loudly, instead of producing wrong Newton steps.  By default
-        the first capture of every (size, parameter count, device) signature in the
-        process is checked (~2 products); ``HF_GRAPH_VERIFY=always|never`` overrides."""
+        the first capture of every signature in the process -- vector size, parameter
+        shapes, shape of the network output (batch size!), operator type, device: a
+        different batch or input shape selects different library kernels -- is checked
+        (~2 products); ``HF_GRAPH_VERIFY=always|never`` overrides."""
         import os
 
         policy = os.environ.get("HF_GRAPH_VERIFY", "first")
-        key = (self.n, len(self.params), str(self.input_buffer.device), self.input_buffer.dtype)
+        outputs = getattr(self.op, "outputs", None)
+        key = (self.n, tuple(tuple(p.shape) for p in self.params), str(self.input_buffer.device),
+               self.input_buffer.dtype, type(self.op).__name__,
+               None if outputs is None else tuple(outputs.shape),
+               getattr(self.op, "input_signature", None))
         if policy == "never" or (policy != "always" and key in GraphedOperator._verified):
             return
         gen = torch.Generator(device=self.input_buffer.device).manual_seed(1234)
@@ -375,6 +395,7 @@ class OverlappedGraphedOperator(GraphedOperator):
     all-reduce is slow (many ranks over few links, much larger vectors)."""
 
     mode = "2 hipGraphs per product, all-reduce of the tail overlapped with the head's adjoint sweep"
+    raw_graph = None  # two graphs: cg() keeps its separate K1-K3 launches
 
     def __init__(self, builder, params=None, tail_fraction=0.75):
         self._tail_fraction = tail_fraction

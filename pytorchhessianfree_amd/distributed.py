@@ -1,16 +1,26 @@
-"""Data-parallel sum of the curvature partials across ranks.
+"""Data-parallel sum of the curvature partials across ranks -- the ONE exchange step of
+the path (the ``result += N * mb_result`` of optimizer.py:677-684 turned sideways).
 
-Default: ``torch.distributed.all_reduce`` (backend ``nccl`` is RCCL on ROCm; ``gloo``
-in the CPU tests).  Optional (``HF_RCCL_DIRECT=1``): the library's own RCCL
-communicator (``hf_comm_*`` / ``hf_allreduce_sum`` of include/hf_pcg.h), which
-enqueues the collective on the SAME stream as the PCG kernels -- no hand-off to
-the process group's stream and back.  The communicator is bootstrapped through
-the existing process group (rank 0's unique id is broadcast), so both paths need
-``torch.distributed`` to be initialised.
+Two ways to issue the collective:
+
+* **direct RCCL on the kernels' own stream** (``hf_comm_*`` / ``hf_allreduce_sum`` of
+  include/hf_pcg.h).  Default whenever the process group's backend is ``nccl`` (= RCCL
+  on ROCm): the all-reduce is enqueued on the SAME HIP stream as the product graph
+  and K1-K3, so an iteration is ``graph -> ncclAllReduce -> graph`` with no event
+  hand-off to the process group's side stream and back (two stream hops per product
+  with ``torch.distributed.all_reduce``; measured ~0.2 ms per collective on a 1-rank
+  group).  The communicator is bootstrapped through the existing process group (rank
+  0's unique id is broadcast).  ``HF_RCCL_DIRECT=0`` switches it off; if creating the
+  communicator fails, a warning is issued and the process-group path is used.
+* ``torch.distributed.all_reduce`` -- gloo in the CPU / shared-GPU tests, and the
+  fall-back for RCCL.
+
+Both reduce in place and return their argument.
 """
 
 import ctypes
 import os
+import warnings
 
 import torch
 
@@ -42,18 +52,49 @@ class _DirectComm:
         return t
 
 
-def use_direct_rccl(t):
-    return bool(os.environ.get("HF_RCCL_DIRECT")) and t.is_cuda and t.is_contiguous()
+def _wants_direct(t, group):
+    if os.environ.get("HF_RCCL_DIRECT", "1") == "0" or not (t.is_cuda and t.is_contiguous()):
+        return False
+    if t.dtype not in (torch.float32, torch.float64):
+        return False
+    try:
+        return torch.distributed.get_backend(group) == "nccl"
+    except Exception:
+        return False
+
+
+def _direct_comm(group):
+    """The group's direct communicator, ``None`` if it could not be created (decided
+    collectively: either every rank has one or none uses it)."""
+    key = id(group)
+    if key not in _comms:
+        comm = None
+        try:
+            comm = _DirectComm(group)
+        except Exception as exc:  # noqa: BLE001
+            warnings.warn(f"direct RCCL communicator unavailable ({exc!r}); using torch.distributed")
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32,
+                          device=torch.device("cuda", torch.cuda.current_device()))
+        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=group)
+        _comms[key] = comm if int(ok.item()) == 1 else None
+    return _comms[key]
+
+
+def path_name(t, group):
+    if group is None:
+        return "none"
+    if _wants_direct(t, group) and _direct_comm(group) is not None:
+        return "ncclAllReduce (RCCL) enqueued on the compute stream (hf_allreduce_sum)"
+    return f"torch.distributed.all_reduce ({torch.distributed.get_backend(group)})"
 
 
 def all_reduce_sum(t, group):
     """In-place sum of ``t`` over ``group`` (``None``: single process, no-op)."""
     if group is None:
         return t
-    if use_direct_rccl(t):
-        comm = _comms.get(id(group))
-        if comm is None:
-            comm = _comms[id(group)] = _DirectComm(group)
-        return comm.all_reduce_sum(t)
+    if _wants_direct(t, group):
+        comm = _direct_comm(group)
+        if comm is not None:
+            return comm.all_reduce_sum(t)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=group)
     return t

@@ -376,7 +376,7 @@ class _miopen_mode:
     re-measures even shapes that have a record, rankings between close candidates flip
     from process to process, and with NHWC operands one of the candidates is only good
     to 1.5e-4; in immediate mode on the shipped records 40 of 40 processes reproduced
-    the float64 product to 3e-7 (scratch/nhwc_mode.sh, nhwc_diag.sh).
+    the float64 product to 3e-7 (scripts/experiments/nhwc_mode.sh, nhwc_diag.sh).
     ``HF_NHWC_FIND=1`` keeps the find step (used once, result checked, to produce the
     shipped records).  NCHW calls are left as configured."""
 
@@ -502,8 +502,8 @@ def _bias_grad(gy):
     reduction kernel.  Neither MIOpen's backward-bias routine nor ``gy.sum((0, 2, 3))``
     is used on this path: for NHWC cotangents of some shapes (All-CNN-C at batch 32: two
     of nine layers) both were right when issued eagerly and wrong -- drifting from
-    replay to replay -- once captured in a hipGraph (scratch/nhwc_diag.py,
-    scratch/bias_diag.sh); they zero a scratch buffer with a memset that does not
+    replay to replay -- once captured in a hipGraph (scripts/experiments/nhwc_diag.py,
+    scripts/experiments/bias_diag.sh); they zero a scratch buffer with a memset that does not
     survive the capture intact.  The kernel here has no scratch state."""
     if torch.is_grad_enabled() and gy.requires_grad:  # differentiable (Hessian products)
         return gy.sum(dim=(0, 2, 3))
@@ -529,7 +529,7 @@ class _ConvBwd(torch.autograd.Function):
 
     With ``cl`` all operands are NHWC (channels_last): MIOpen's implicit-GEMM kernels
     then run without the NCHW<->NHWC transposes that make up ~40 % of the kernels of
-    a product in NCHW (scratch/nhwc_probe.py: 261 -> 126 kernels, 1.08 -> 0.65 ms for
+    a product in NCHW (scripts/experiments/nhwc_probe.py: 261 -> 126 kernels, 1.08 -> 0.65 ms for
     the 20 layers of ResNet-18)."""
 
     @staticmethod
@@ -703,12 +703,15 @@ def prepare_model(model, channels_last=False):
     the find step has been reliable, stays the default.
 
     History: the NHWC path used to produce, in about one process of ten, a product that
-    was off by 1e-3 or plain garbage.  Causes found (scratch/nhwc_diag.py): MIOpen's
+    was off by 1e-3 or plain garbage.  Causes found (scripts/experiments/nhwc_diag.py): MIOpen's
     composable-kernel split-K weight gradient, now disabled package-wide (``__init__``),
     and reductions that zero a scratch buffer before accumulating (MIOpen's backward-bias,
     PyTorch's multi-block ``sum`` of an NHWC tensor), which break inside a hipGraph and
     are replaced by ``_bias_grad``.  ``GraphedOperator`` now checks its first replay
     against the eager product."""
+    from .config import configure
+
+    configure()  # MIOpen settings the patched layers were validated with (config.py)
     fuse_eval_batchnorm(model)
     fuse_conv_tangent(model, channels_last=channels_last)
     fuse_residual_blocks(model)

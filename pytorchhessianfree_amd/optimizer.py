@@ -99,6 +99,8 @@ class HessianFree(torch.optim.Optimizer):
         self.cache_acc_graphs = bool(cache_acc_graphs)
 
         self._acc_comm = process_group  # group `_acc` sums over (None: this process only)
+        self._acc_comm_active = False   # True while `acc_step` runs its data-parallel `step`
+        self._acc_counts = {}           # id(datalist) -> samples over all ranks (per acc_step)
         self._arena = None
         self._cg = cg  # the HIP PCG; tests swap in the CPU oracle to check host logic
 
@@ -212,7 +214,8 @@ class HessianFree(torch.optim.Optimizer):
         damping = self._group["damping"]
         state["dampings"].append(damping)
         x_iters, m_iters, cg_reason = self._cg(
-            A=DampedCurvature(mvp, damping),
+            A=DampedCurvature(mvp, damping,
+                              lockstep=self.process_group is not None or self._acc_comm_active),
             b=-grad,
             x0=state["x0"],
             M=M_func,
@@ -362,6 +365,9 @@ class HessianFree(torch.optim.Optimizer):
         grad_datalist = loss_datalist if grad_datalist is None else grad_datalist
         mvp_datalist = loss_datalist if mvp_datalist is None else mvp_datalist
         curvature_opt = self._group["curvature_opt"]
+        if reduction not in ["mean", "sum"]:
+            raise ValueError(f"Invalid reduction {reduction}")
+        self._count_samples(loss_datalist, grad_datalist, mvp_datalist)
 
         def forward():
             return self._acc_loss(model, loss_func, loss_datalist, reduction), None
@@ -381,21 +387,47 @@ class HessianFree(torch.optim.Optimizer):
         # `step` must not re-weight what `_acc` already reduced over ranks
         saved = (self.process_group, self.shard_weight)
         self.process_group, self.shard_weight = None, 1.0
+        self._acc_comm_active = self._acc_comm is not None
         try:
             return self.step(forward=forward, grad=grad, mvp=mvp, M_func=M_func,
                              test_deterministic=test_deterministic)
         finally:
             self.process_group, self.shard_weight = saved
+            self._acc_comm_active = False
+            self._acc_counts = {}
+
+    def _count_samples(self, *datalists):
+        """Samples per data list, summed over the ranks of a data-parallel run -- ONCE
+        per ``acc_step`` (one all-reduce for all lists), not once per product: the
+        counts are constants of the step, and reading them back inside ``mvp`` would
+        put a second collective and a host sync into every PCG iteration."""
+        distinct = {id(dl): dl for dl in datalists}
+        local = [float(sum(targets.shape[0] for _, targets in dl)) for dl in distinct.values()]
+        if self._acc_comm is not None:
+            t = torch.tensor(local, dtype=torch.float64, device=self.device)
+            torch.distributed.all_reduce(t, group=self._acc_comm)
+            local = t.tolist()
+        self._acc_counts = dict(zip(distinct.keys(), local))
+
+    def _total_count(self, datalist):
+        count = self._acc_counts.get(id(datalist))
+        if count is None:  # called outside acc_step (test_reduction, direct use)
+            count = float(sum(targets.shape[0] for _, targets in datalist))
+            if self._acc_comm is not None:
+                t = torch.tensor([count], dtype=torch.float64, device=self.device)
+                torch.distributed.all_reduce(t, group=self._acc_comm)
+                count = float(t.item())
+        return count
 
     def _acc(self, model, loss_func, datalist, device, with_grad, init_result, eval_mb, reduction):
         """Generic accumulator (optimizer.py:608-684): ``sum_k N_k q_k / sum_k N_k``
         (``mean``) or ``sum_k q_k`` (``sum``) over the chunks -- and over ranks."""
         if reduction not in ["mean", "sum"]:
             raise ValueError(f"Invalid reduction {reduction}")
-        total, count = init_result, 0
+        count = self._total_count(datalist)
+        total = init_result
         for inputs, targets in datalist:
             n_chunk = targets.shape[0]
-            count += n_chunk
             inputs, targets = inputs.to(device), targets.to(device)
             with nullcontext() if with_grad else torch.no_grad():
                 outputs = model(inputs)
@@ -405,13 +437,10 @@ class HessianFree(torch.optim.Optimizer):
                 total += n_chunk * piece
             else:
                 total += piece
-        if self._acc_comm is not None:  # the same sum, continued over the ranks
+        if self._acc_comm is not None:  # the same sum, continued over the ranks: ONE collective
             if not isinstance(total, torch.Tensor):
                 total = torch.tensor(float(total), device=device)
             torch.distributed.all_reduce(total, group=self._acc_comm)
-            cnt = torch.tensor([float(count)], dtype=torch.float64, device=device)
-            torch.distributed.all_reduce(cnt, group=self._acc_comm)
-            count = cnt.item()
         return total / count if reduction == "mean" else total
 
     def _acc_loss(self, model, loss_func, datalist, reduction):
@@ -465,20 +494,18 @@ class HessianFree(torch.optim.Optimizer):
                 op = curvature.GGNOperator(loss, outputs, self._params_list)
             chunks.append((targets.shape[0], op))
 
+        count = self._total_count(datalist)  # over all ranks; constant for the step
+
         def mvp(x):
-            total, count = self._zeros_flat(), 0
+            total = self._zeros_flat()
             for n_chunk, op in chunks:
-                count += n_chunk
                 piece = op(x)
                 if reduction == "mean":
                     total += n_chunk * piece
                 else:
                     total += piece
-            if self._acc_comm is not None:
+            if self._acc_comm is not None:  # one collective, no host read-back
                 torch.distributed.all_reduce(total, group=self._acc_comm)
-                cnt = torch.tensor([float(count)], dtype=torch.float64, device=self.device)
-                torch.distributed.all_reduce(cnt, group=self._acc_comm)
-                count = cnt.item()
             return total / count if reduction == "mean" else total
 
         if self._acc_comm is not None:

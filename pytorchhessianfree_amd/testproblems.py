@@ -132,6 +132,22 @@ class AllCNNC(nn.Module):
         return torch.flatten(self.net(x), -3)  # also for one unbatched sample [C,H,W]
 
 
+def l2_regularized(loss_function, model, l2=5e-4):
+    """``loss + 0.5 * l2 * sum ||W||^2`` over the WEIGHTS (no biases): the regularised
+    loss the reference's All-CNN-C example trains (examples/example_utils.py:77-81 adds
+    DeepOBS' ``get_regularization_loss()``; DeepOBS -- not vendored, PyPI ``deepobs`` --
+    sums ``factor * ||p||_2^2`` over the non-bias parameters and halves the total;
+    ``cifar100_allcnnc`` defaults to ``l2_reg = 5e-4``).  The GGN ignores the term (it
+    does not depend on the network output); the Hessian gains ``l2 * I`` on the weights."""
+    weights = [p for name, p in model.named_parameters() if "bias" not in name]
+
+    def regularized(outputs, targets):
+        reg = sum((w * w).sum() for w in weights)
+        return loss_function(outputs, targets) + (0.5 * l2) * reg
+
+    return regularized
+
+
 def count_trainable(model):
     return sum(p.numel() for p in model.parameters() if p.requires_grad)
 

@@ -15,6 +15,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the package no longer configures MIOpen at import; the GPU tests compare stock
+    # fp32 convolutions with the float64 / CPU oracle and need the accurate solvers
+    import pytorchhessianfree_amd
+
+    pytorchhessianfree_amd.configure()
 
 
 def pytest_collection_modifyitems(config, items):

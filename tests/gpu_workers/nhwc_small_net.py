@@ -10,6 +10,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import pytorchhessianfree_amd  # noqa: E402,F401
+
+pytorchhessianfree_amd.configure()
 from pytorchhessianfree_amd import _lib, curvature, modelprep  # noqa: E402
 
 DEV = "cuda"

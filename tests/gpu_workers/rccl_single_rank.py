@@ -17,6 +17,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import pytorchhessianfree_amd as hf  # noqa: E402
+
+hf.configure()
 from pytorchhessianfree_amd import _lib, modelprep  # noqa: E402
 from pytorchhessianfree_amd import testproblems as tp  # noqa: E402
 

@@ -512,7 +512,7 @@ def test_randomised_configurations_match_kernel_arithmetic_oracle():
     max_iter, snapshot request, damping, tol/atol -- fp32, against the oracle in the
     kernels' reduction arithmetic: same reason, same iteration count, same None
     pattern, iterates 3e-5, m_k 1e-4.  (float64 runs agree to 1e-15 initially and then
-    separate like any two float64 CG runs -- scratch/fuzz_one.py -- so they are not
+    separate like any two float64 CG runs -- scripts/experiments/fuzz_one.py -- so they are not
     part of this bitwise-style check.)"""
     import random
 
