@@ -66,6 +66,10 @@ def parse():
                          "timing of the all-reduce at start-up)")
     ap.add_argument("--force-dist", type=int, default=0,
                     help="create the process group even for WORLD_SIZE=1 (exercises the RCCL path on one GPU)")
+    ap.add_argument("--conv", default="", choices=["", "auto", "own", "miopen"],
+                    help="implementation of the product's NHWC convolutions: own = the package's one-launch "
+                         "deterministic kernels everywhere, miopen = MIOpen everywhere, auto = the faster one "
+                         "per layer as measured (default)")
     ap.add_argument("--curvature", default="ggn", choices=["ggn", "hessian"],
                     help="curvature_opt of the reference (optimizer.py:25); hessian = BASELINE.json configs[3]")
     ap.add_argument("--precond", type=int, default=0,
@@ -189,6 +193,8 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    if args.conv:
+        os.environ["HF_CONV"] = args.conv
     if args.channels_last < 0:
         args.channels_last = int(args.workload in ("resnet18", "allcnnc"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -431,7 +437,8 @@ def main():
                                   "scaling number" if oversubscribed else ""),
                 "matvec": getattr(op, "mode", "eager autograd")
                           + ("; eval-BN fused (hf_chan_affine)" if args.fuse_bn else "")
-                          + ("; conv tangent fused" if args.fuse_conv else "") + "; " + layout
+                          + ("; conv tangent fused" if args.fuse_conv else "")
+                          + "; convolutions: " + (os.environ.get("HF_CONV") or "auto") + "; " + layout
                           + ("; deterministic (two products bitwise equal)" if check.get("deterministic")
                              else "; NOT bitwise repeatable (library kernels with atomics)"),
                 "iteration": ("one hipGraph launch per PCG iteration (product -> K1 -> K2 -> K3)" if fused and group is None

@@ -232,6 +232,42 @@ int hf_chan_affine_bwd(void* gx, void* gw, void* gb, void* gres, const void* gy,
                        const void* w, const void* mask_src, int64_t n, int64_t c, int64_t hw,
                        int channels_last, int dtype, void* stream);
 
+/* ---- convolution layers on small feature maps inside the curvature product -------- */
+/*
+ * Implicit-GEMM convolution, fp32 MFMA, NHWC, DETERMINISTIC split-K (one launch: every
+ * K-split writes its partial tile to `workspace`, the last workgroup to arrive at a tile
+ * sums them in split order -- no zero-fill launch, no float atomics).  These are the three
+ * convolutions BackPACK's R-op / L-op (optimizer.py:461) run per layer and product through
+ * PyTorch -> MIOpen, whose split-K kernels cost one extra launch each and are not bitwise
+ * repeatable.  Kernel taps that only ever meet padding (3x3 windows on 1x1 / 2x2 maps) are
+ * skipped.
+ *   direction 0 (F): out[n,oh,ow,k] = sum act[n, oh*s-p+r, ow*s-p+q, c] * mat[k][r][q][c]
+ *                    act = X [n,h,w,c] (pixel stride act_ld >= c, 0 = dense), mat = weights (O,H,W,I)
+ *   direction 1 (D): out[n,h,w,c]   = sum act[n, (ih+p-r)/s, (iw+p-q)/s, k] * mat[c][r][q][k]
+ *                    act = dY [n,oh,ow,k], mat = weights transposed to (I,H,W,O)
+ *   direction 2 (W): out[k][r][q][c] = sum_m mat[m][k] * act[pix(m,r,q)][c]
+ *                    act = X, mat = dY [n*oh*ow][k]; entries of taps that never meet data are
+ *                    NOT written (keep `out` zero-initialised)
+ * c and k must be multiples of 4; all pointers 16-byte aligned.  `tickets`: n_tickets zeroed
+ * ints (self-resetting); `workspace`: scratch for the partial tiles -- both may be shared by
+ * all calls enqueued on ONE stream.  target_blocks <= 0: the number of K-splits comes from a
+ * measured cost model; > 0: split until about that many workgroups exist.  HF_F32 only.
+ */
+int hf_conv2d_nhwc(int direction, void* out, const void* act, const void* mat, int64_t n,
+                   int64_t h, int64_t w, int64_t c, int64_t k, int64_t r, int64_t s,
+                   int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
+                   int64_t act_ld, void* workspace, int64_t workspace_bytes, void* tickets,
+                   int64_t n_tickets, int target_blocks, int dtype, void* stream);
+
+/* Data gradient AND weight gradient of one layer (directions 1 and 2 above) in ONE launch:
+ * both read dY [n,oh,ow,k], neither depends on the other.  dx [n,h,w,c]; dw [k][r][q][c]
+ * (dead taps not written); x [n,h,w,c]; w_t = weights stored (I,H,W,O). */
+int hf_conv2d_nhwc_backward(void* dx, void* dw, const void* dy, const void* x, const void* w_t,
+                            int64_t n, int64_t h, int64_t w, int64_t c, int64_t k, int64_t r,
+                            int64_t s, int64_t stride_h, int64_t stride_w, int64_t pad_h,
+                            int64_t pad_w, void* workspace, int64_t workspace_bytes, void* tickets,
+                            int64_t n_tickets, int target_blocks, int dtype, void* stream);
+
 /* ---- loss Hessian inside the GGN product ------------------------------------ */
 /*
  * out[r, :] = scale * p[r, :] * (v[r, :] - <p[r, :], v[r, :]>),  p = softmax(logits) row-wise:

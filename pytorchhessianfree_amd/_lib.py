@@ -95,6 +95,10 @@ SIGNATURES = {
     "hf_chan_affine": (c_int, [c_void_p] * 10 + [c_int, c_int64, c_int64, c_int64, c_int, c_int64, c_int64,
                                                   c_int, c_void_p]),
     "hf_chan_affine_bwd": (c_int, [c_void_p] * 11 + [c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "hf_conv2d_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int64] * 12
+                       + [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "hf_conv2d_nhwc_backward": (c_int, [c_void_p] * 5 + [c_int64] * 11
+                                + [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "hf_softmax_ce_hvp": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int64, c_int, c_void_p]),
     "hf_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "hf_comm_create": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_char_p, c_int, c_int]),
@@ -282,3 +286,49 @@ def precond_build(minv, diag, damping, exponent):
         "hf_precond_build",
     )
     return minv
+
+
+_conv_scratch = {}
+
+
+def conv_scratch(device):
+    """Per-device scratch of the split-K convolution kernels: partial-tile workspace and
+    the (self-resetting) ticket counters.  Shared by every call on the device: the calls
+    of one product are enqueued on one stream / replayed from one graph, in order."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    sc = _conv_scratch.get(key)
+    if sc is None:
+        ws = torch.empty(int(os.environ.get("HF_CONV_WS_MB", "64")) << 18, dtype=torch.float32, device=device)
+        tickets = torch.zeros(8192, dtype=torch.int32, device=device)
+        sc = _conv_scratch[key] = (ws, tickets)
+    return sc
+
+
+def conv2d_nhwc(direction, out, act, mat, n, h, w, c, k, r, s, stride, padding, act_ld=0):
+    """``hf_conv2d_nhwc`` on raw NHWC buffers (see include/hf_pcg.h)."""
+    lib = load()
+    require_device_tensor(out, "out")
+    ws, tickets = conv_scratch(out.device)
+    check(
+        lib.hf_conv2d_nhwc(
+            int(direction), c_void_p(out.data_ptr()), c_void_p(act.data_ptr()), c_void_p(mat.data_ptr()),
+            n, h, w, c, k, r, s, stride[0], stride[1], padding[0], padding[1], act_ld,
+            c_void_p(ws.data_ptr()), ws.numel() * 4, c_void_p(tickets.data_ptr()), tickets.numel(),
+            int(os.environ.get("HF_CONV_BLOCKS", "0")), HF_F32, current_stream_ptr(out.device)),
+        "hf_conv2d_nhwc")
+    return out
+
+
+def conv2d_nhwc_backward(dx, dw, dy, x, w_t, n, h, w, c, k, r, s, stride, padding):
+    """Data and weight gradient in one launch (``hf_conv2d_nhwc_backward``)."""
+    lib = load()
+    require_device_tensor(dx, "dx")
+    ws, tickets = conv_scratch(dx.device)
+    check(
+        lib.hf_conv2d_nhwc_backward(
+            c_void_p(dx.data_ptr()), c_void_p(dw.data_ptr()), c_void_p(dy.data_ptr()), c_void_p(x.data_ptr()),
+            c_void_p(w_t.data_ptr()), n, h, w, c, k, r, s, stride[0], stride[1], padding[0], padding[1],
+            c_void_p(ws.data_ptr()), ws.numel() * 4, c_void_p(tickets.data_ptr()), tickets.numel(),
+            int(os.environ.get("HF_CONV_BLOCKS", "0")), HF_F32, current_stream_ptr(dx.device)),
+        "hf_conv2d_nhwc_backward")
+    return dx, dw

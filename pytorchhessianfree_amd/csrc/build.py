@@ -11,6 +11,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SRC = os.path.join(HERE, "hf_pcg.hip")
+SRC_CONV = os.path.join(HERE, "hf_conv.hip")
+SOURCES = [SRC, SRC_CONV]
 HDR = os.path.join(ROOT, "include", "hf_pcg.h")
 OUT = os.path.join(HERE, "libhfpcg.so")
 
@@ -32,7 +34,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in (SRC, HDR, __file__))
+    return any(os.path.getmtime(f) > t for f in (*SOURCES, HDR, __file__))
 
 
 def build(force=False, verbose=True, out=None, extra_flags=()):
@@ -42,7 +44,7 @@ def build(force=False, verbose=True, out=None, extra_flags=()):
     if out == OUT and not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *FLAGS, *extra_flags, "-I", os.path.join(ROOT, "include"), SRC, "-o", out, "-ldl"]
+    cmd = [hipcc, *FLAGS, *extra_flags, "-I", os.path.join(ROOT, "include"), *SOURCES, "-o", out, "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

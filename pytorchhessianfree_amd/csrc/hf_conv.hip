@@ -1,0 +1,544 @@
+// hf_conv.hip -- implicit-GEMM convolution kernels for the curvature product's conv
+// layers on SMALL feature maps (gfx950, fp32 MFMA, NHWC), deterministic split-K.
+//
+// Why these exist.  A GGN product of a ResNet-18 on 28x28 inputs runs 48 convolutions
+// (tangent, data-gradient and weight-gradient of 16 layers) whose GEMM view has a tiny
+// M (N*OH*OW = 32..1568 rows) and a long K (9*Cin up to 4608).  The only way to fill
+// 256 CUs is to split K.  MIOpen's kernels do that with a zero-fill launch in front
+// and atomic accumulation: 48 extra launches per product (16 % of the GPU time) and a
+// product that is not bitwise repeatable.  Here every K-split writes its partial tile
+// to a workspace and the LAST workgroup to arrive at a tile (ticket counter) sums the
+// partials in split order: one launch, no zero-fill, no float atomics, bitwise
+// deterministic.  Taps of the kernel window that can never meet data (3x3 kernels on
+// 1x1 / 2x2 maps) are dropped on the host, so such layers cost what a GEMM costs.
+//
+// Three directions, all "activation rows gathered on the fly" (implicit im2col):
+//   F  out[m=(n,oh,ow)][k]  = sum_{tap,c} X[n, oh*s-p+r, ow*s-p+q][c] * Wt[k][tap][c]
+//   D  dX [m=(n,ih,iw)][c]  = sum_{tap,k} dY[n,(ih+p-r)/s,(iw+p-q)/s][k] * WT[c][tap][k]
+//   W  dW [k][tap][c]       = sum_{m}     dY[m][k] * X[pix(m,tap)][c]
+// F and D are one kernel (operands contiguous along the reduction index: "NT"); W reduces
+// over the rows ("TN").  v_mfma_f32_32x32x2_f32, 64x64 block tiles, 4 waves of 32x32,
+// BK = 32, double-buffered LDS, register prefetch of the next tile.
+//
+// MFMA operand maps (cdna_hip_programming.md section 3): lane l supplies A[i=l&31][k=l>>5],
+// B[k=l>>5][j=l&31]; C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// The 32 k of a step are assigned as k = 16*(l>>5) + step (A and B alike), so that a lane's
+// 16 operands are 64 contiguous bytes of an LDS row.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "hf_pcg.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CT = 256;            // threads per block
+#ifndef HF_CONV_BK
+#define HF_CONV_BK 32
+#endif
+constexpr int BM = 64, BN = 64, BK = HF_CONV_BK;  // (BK = 64 measured the same: these kernels are latency-, not issue-bound)
+constexpr int KQ = BK / 4;          // float4 per row of a k-contiguous tile
+constexpr int RPT = CT / KQ;        // NT: rows covered per pass of the staging threads
+constexpr int NU = BM / RPT;        // NT: passes (float4 per thread and operand)
+constexpr int HK = BK / 2;          // k per lane half
+constexpr int LDK = BK + 4;        // NT: LDS row stride (floats): 16-B aligned, conflict-free b128 reads
+constexpr int LDT = BM + 4;        // TN: LDS row stride
+constexpr int MAX_TAPS = 64;
+
+struct ConvArgs {
+  const float* src;    // gathered activations (F: X, D: dY, W: X)
+  const float* mat;    // F: Wt [Nout][RS][Cs]; D: WT [Nout][RS][Cs]; W: dY [M][Kout]
+  float* out;
+  float* ws;           // split-K partial tiles
+  int* tickets;        // one counter per output tile, zero between launches
+  int dgrad;           // gather rule: 0 = forward window, 1 = transposed (data gradient)
+  // geometry of the gathered tensor and of the row index space
+  int rows;            // M: F: N*OH*OW, D: N*H*W, W: N*OH*OW
+  int rh, rw;          // spatial extent the row index decodes over (F/W: OH,OW; D: H,W)
+  int sh_, sw_;        // spatial extent of the gathered tensor (F/W: H,W; D: OH,OW)
+  int cs, cs_ld;       // channels gathered per pixel, pixel stride of src
+  int nout, ldc;       // output columns (F: K, D: C, W: unused), output row stride
+  int kout;            // W: number of dY channels (output rows of dW)
+  int R, S, stride_h, stride_w, pad_h, pad_w;
+  int ntaps;           // live taps
+  unsigned char tap_r[MAX_TAPS], tap_s[MAX_TAPS];
+  int tiles_m, tiles_n, splits, steps;  // steps = reduction steps in total
+  int scalar;          // 1: channel counts not multiples of 4 -> element-wise gathers
+};
+
+// pixel index into the gathered tensor for row coordinates (n, y, x) and tap (r, q); -1 = padding
+__device__ __forceinline__ int gather_pixel(const ConvArgs& a, int n, int y, int x, int r, int q) {
+  int sy, sx;
+  if (!a.dgrad) {
+    sy = y * a.stride_h - a.pad_h + r;
+    sx = x * a.stride_w - a.pad_w + q;
+  } else {
+    const int ty = y + a.pad_h - r, tx = x + a.pad_w - q;
+    if (ty < 0 || tx < 0) return -1;
+    sy = ty / a.stride_h;
+    sx = tx / a.stride_w;
+    if (sy * a.stride_h != ty || sx * a.stride_w != tx) return -1;
+  }
+  if (sy < 0 || sy >= a.sh_ || sx < 0 || sx >= a.sw_) return -1;
+  return (n * a.sh_ + sy) * a.sw_ + sx;
+}
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// four consecutive floats of which only the first `valid` exist, no alignment assumed
+// (channel counts that are not multiples of 4: the 49-tap im2col of a 1-channel stem)
+__device__ __forceinline__ float4 ldg4s(const float* p, int valid) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid > 0) v.x = p[0];
+  if (valid > 1) v.y = p[1];
+  if (valid > 2) v.z = p[2];
+  if (valid > 3) v.w = p[3];
+  return v;
+}
+
+// Last-arriver reduction of the split-K partials of one 64x64 tile (fixed order).
+__device__ __forceinline__ void finish_tile(const ConvArgs& a, const f32x16& acc, int tile, int split,
+                                            int wm, int wn, int lane, float* out_tile_base,
+                                            int row0, int col0, int row_lim, int col_lim, int ldc,
+                                            int* flag_lds) {
+  const int i = lane & 31, h = lane >> 5;
+  if (a.splits == 1) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h, col = wn * 32 + i;
+      if (row0 + row < row_lim && col0 + col < col_lim)
+        out_tile_base[(size_t)(row0 + row) * ldc + col0 + col] = acc[reg];
+    }
+    return;
+  }
+  const int tiles = a.tiles_m * a.tiles_n;
+  float* mine = a.ws + ((size_t)split * tiles + tile) * (BM * BN);
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h, col = wn * 32 + i;
+    // write-through (sc1) store: visible device-wide once drained, no release fence needed
+    __hip_atomic_store(mine + row * BN + col, acc[reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // publish (cdna_hip_programming.md, in-launch split-K reduction, write-through form):
+  // every wave drains its sc1 stores, ONE lane draws the ticket; the last arriver's lane 0
+  // acquires once (drops stale lines), then all its waves read the slabs with plain loads
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(a.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == a.splits - 1;
+    if (last) {
+      __hip_atomic_store(a.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *flag_lds = last;
+  }
+  __syncthreads();
+  if (!*flag_lds) return;
+  const float* base = a.ws + (size_t)tile * (BM * BN);
+  const size_t slab = (size_t)tiles * (BM * BN);
+  for (int e = threadIdx.x; e < BM * BN / 4; e += CT) {
+    float4 s = *reinterpret_cast<const float4*>(base + 4 * e);
+    int sp = 1;
+    for (; sp + 4 <= a.splits; sp += 4) {  // four slabs in flight, summed in split order
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(base + (sp + u) * slab + 4 * e);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; sp < a.splits; ++sp) {
+      const float4 v = *reinterpret_cast<const float4*>(base + sp * slab + 4 * e);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int row = (4 * e) / BN, col = (4 * e) % BN;
+    if (row0 + row < row_lim) {
+      float* o = out_tile_base + (size_t)(row0 + row) * ldc + col0 + col;
+      const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (col0 + col + c < col_lim) o[c] = v[c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// NT kernel: F and D.   out[m][j] = sum_{tap, c} src[pix(m,tap)][c] * mat[j][tap][c]
+// ---------------------------------------------------------------------------------
+constexpr int LDS_FLOATS = 2 * 2 * BM * LDK + 4;  // NT: As + Bs (double-buffered) + the last-arriver flag
+
+__device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int bid) {
+  float (*As)[BM][LDK] = reinterpret_cast<float (*)[BM][LDK]>(lds);
+  float (*Bs)[BN][LDK] = reinterpret_cast<float (*)[BN][LDK]>(lds + 2 * BM * LDK);
+  int& flag = *reinterpret_cast<int*>(lds + 4 * BM * LDK);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  const int tile_n = bid % a.tiles_n; bid /= a.tiles_n;
+  const int tile_m = bid % a.tiles_m;
+  const int split = bid / a.tiles_m;
+  const int tile = tile_m * a.tiles_n + tile_n;
+  const int per = (a.steps + a.splits - 1) / a.splits;
+  const int j0 = split * per, j1 = (j0 + per < a.steps) ? j0 + per : a.steps;
+
+  // staging assignment: thread -> rows lr + RPT*u and the float4 at k offset 4*kq
+  const int lr = t / KQ, kq = t % KQ;
+  int rn[NU], ry[NU], rx[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int m = tile_m * BM + lr + RPT * u;
+    if (m < a.rows) {
+      const int xx = m % a.rw, tq = m / a.rw;
+      rx[u] = xx; ry[u] = tq % a.rh; rn[u] = tq / a.rh;
+    } else {
+      rn[u] = -1; ry[u] = rx[u] = 0;
+    }
+  }
+  const int csteps = (a.cs + BK - 1) / BK;
+  const int RS = a.R * a.S;
+  const float* brow[NU];
+  bool bok[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int j = tile_n * BN + lr + RPT * u;
+    bok[u] = j < a.nout;
+    brow[u] = a.mat + (size_t)(bok[u] ? j : 0) * RS * a.cs;
+  }
+
+  float4 ra[NU], rb[NU];
+  auto fetch = [&](int step) {
+    const int ti = step / csteps, c = (step - ti * csteps) * BK + 4 * kq;
+    const int r = a.tap_r[ti], q = a.tap_s[ti];
+    const bool cok = c < a.cs;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cok && rn[u] >= 0) {
+        const int pix = gather_pixel(a, rn[u], ry[u], rx[u], r, q);
+        if (pix >= 0) {
+          const float* p = a.src + (size_t)pix * a.cs_ld + c;
+          ra[u] = a.scalar ? ldg4s(p, a.cs - c) : ldg4(p);
+        }
+      }
+      if (cok && bok[u]) {
+        const float* p = brow[u] + (size_t)(r * a.S + q) * a.cs + c;
+        rb[u] = a.scalar ? ldg4s(p, a.cs - c) : ldg4(p);
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      *reinterpret_cast<float4*>(&As[buf][lr + RPT * u][4 * kq]) = ra[u];
+      *reinterpret_cast<float4*>(&Bs[buf][lr + RPT * u][4 * kq]) = rb[u];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int i = lane & 31, h = lane >> 5;
+  if (j0 < j1) {
+    fetch(j0);
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (int j = j0; j < j1; ++j) {
+      const bool more = j + 1 < j1;
+      if (more) fetch(j + 1);
+      const float* ap = &As[cur][wm * 32 + i][HK * h];
+      const float* bp = &Bs[cur][wn * 32 + i][HK * h];
+      float av[HK], bv[HK];
+#pragma unroll
+      for (int v = 0; v < HK / 4; ++v) {
+        *reinterpret_cast<float4*>(av + 4 * v) = *reinterpret_cast<const float4*>(ap + 4 * v);
+        *reinterpret_cast<float4*>(bv + 4 * v) = *reinterpret_cast<const float4*>(bp + 4 * v);
+      }
+#pragma unroll
+      for (int s = 0; s < HK; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+      if (more) stash(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  finish_tile(a, acc, tile, split, wm, wn, lane, a.out, tile_m * BM, tile_n * BN, a.rows, a.nout, a.ldc,
+              &flag);
+}
+
+// ---------------------------------------------------------------------------------
+// TN kernel: W.   dW[k][tap][c] = sum_m dY[m][k] * X[pix(m,tap)][c]
+//   tile_m over k (dY channels), tile_n over (live tap, 64-channel block of X)
+// ---------------------------------------------------------------------------------
+static_assert(2 * 2 * BK * LDT + 4 <= LDS_FLOATS, "TN tiles must fit the shared LDS array");
+
+__device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int bid) {
+  float (*As)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(lds);
+  float (*Bs)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(lds + 2 * BK * LDT);
+  int& flag = *reinterpret_cast<int*>(lds + 4 * BK * LDT);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  const int tile_n = bid % a.tiles_n; bid /= a.tiles_n;
+  const int tile_m = bid % a.tiles_m;
+  const int split = bid / a.tiles_m;
+  const int tile = tile_m * a.tiles_n + tile_n;
+  const int per = (a.steps + a.splits - 1) / a.splits;
+  const int j0 = split * per, j1 = (j0 + per < a.steps) ? j0 + per : a.steps;
+
+  const int cblocks = (a.cs + BN - 1) / BN;
+  const int ti = tile_n / cblocks, c0 = (tile_n - ti * cblocks) * BN;
+  const int r = a.tap_r[ti], q = a.tap_s[ti];
+
+  // staging: thread -> rows kr, kr+16 of the step and the float4 at column 4*cq
+  const int kr = t >> 4, cq = t & 15;
+  const int ka = tile_m * BM + 4 * cq;  // dY channel
+  const int cb = c0 + 4 * cq;           // X channel
+  const bool aok = ka < a.kout, bkok = cb < a.cs;
+
+  constexpr int TU = BK / 16;
+  float4 ra[TU], rb[TU];
+  auto fetch = [&](int step) {
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const int m = step * BK + kr + 16 * u;
+      ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < a.rows) {
+        if (aok) {
+          const float* p = a.mat + (size_t)m * a.kout + ka;
+          ra[u] = a.scalar ? ldg4s(p, a.kout - ka) : ldg4(p);
+        }
+        if (bkok) {
+          const int xx = m % a.rw, tq = m / a.rw;
+          const int pix = gather_pixel(a, tq / a.rh, tq % a.rh, xx, r, q);
+          if (pix >= 0) {
+            const float* p = a.src + (size_t)pix * a.cs_ld + cb;
+            rb[u] = a.scalar ? ldg4s(p, a.cs - cb) : ldg4(p);
+          }
+        }
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      *reinterpret_cast<float4*>(&As[buf][kr + 16 * u][4 * cq]) = ra[u];
+      *reinterpret_cast<float4*>(&Bs[buf][kr + 16 * u][4 * cq]) = rb[u];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int x = 0; x < 16; ++x) acc[x] = 0.f;
+  const int i = lane & 31, h = lane >> 5;
+  if (j0 < j1) {
+    fetch(j0);
+    stash(0);
+    __syncthreads();
+    int cur = 0;
+    for (int j = j0; j < j1; ++j) {
+      const bool more = j + 1 < j1;
+      if (more) fetch(j + 1);
+      float av[HK], bv[HK];
+#pragma unroll
+      for (int s = 0; s < HK; ++s) {
+        av[s] = As[cur][HK * h + s][wm * 32 + i];
+        bv[s] = Bs[cur][HK * h + s][wn * 32 + i];
+      }
+#pragma unroll
+      for (int s = 0; s < HK; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+      if (more) stash(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  // output element (k, tap, c) at (k*RS + tap)*cs + c: rows = k, "columns" = c within this tap
+  float* base = a.out + (size_t)(r * a.S + q) * a.cs;
+  finish_tile(a, acc, tile, split, wm, wn, lane, base, tile_m * BM, c0, a.kout, a.cs, a.R * a.S * a.cs,
+              &flag);
+}
+
+__global__ __launch_bounds__(CT) void k_conv_nt(const ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  conv_nt_body(a, lds, blockIdx.x);
+}
+
+__global__ __launch_bounds__(CT) void k_conv_tn(const ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  conv_tn_body(a, lds, blockIdx.x);
+}
+
+// Data gradient AND weight gradient of one layer in ONE launch: both read the same dY,
+// neither depends on the other; the first `nblocks_d` workgroups run the NT body.
+__global__ __launch_bounds__(CT) void k_conv_dw(const ConvArgs d, const ConvArgs w, int nblocks_d) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  if ((int)blockIdx.x < nblocks_d) conv_nt_body(d, lds, blockIdx.x);
+  else conv_tn_body(w, lds, blockIdx.x - nblocks_d);
+}
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+#define HF_HIP(expr)                         \
+  do {                                       \
+    hipError_t e_ = (expr);                  \
+    if (e_ != hipSuccess) return (int)e_;    \
+  } while (0)
+
+namespace {
+
+// Number of K-splits.  target_blocks > 0: split until about that many workgroups exist
+// (>= 2 steps per split).  Otherwise a cost model in microseconds (measured on MI355X):
+// one 64x64xBK step costs a global->LDS round trip that the one-step prefetch only partly
+// hides (~1.0 us at BK = 32, ~1.5 us at BK = 64; the fp32 MFMA work itself is 0.43 / 0.86 us),
+// a split run pays ~3 us to publish and collect tickets plus ~0.15 us per slab the last
+// arriver sums; workgroups beyond two per CU queue.
+int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_bytes) {
+  int64_t best = 1;
+  if (target_blocks > 0) {
+    best = (target_blocks + tiles - 1) / tiles;
+    if (best > steps / 2) best = steps / 2;
+    if (best < 1) best = 1;
+  } else {
+    double best_cost = 1e30;
+    const int64_t cap = steps < 64 ? steps : 64;
+    for (int64_t sp = 1; sp <= cap; ++sp) {
+      const int64_t per = (steps + sp - 1) / sp;
+      if (sp > 1 && per * (sp - 1) >= steps) continue;  // would leave a split empty
+      const double rounds = (double)(tiles * sp) / 512.0;
+      double cost = (0.6 + 0.014 * BK) * (double)per * (rounds > 1.0 ? rounds : 1.0);
+      if (sp > 1) cost += 3.0 + 0.15 * (double)sp;
+      if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
+    }
+  }
+  while (best > 1 && best * tiles * BM * BN * (int64_t)sizeof(float) > ws_bytes) --best;
+  while (best > 1 && ((steps + best - 1) / best) * (best - 1) >= steps) --best;
+  return (int)best;
+}
+
+// Fill `a` for one direction; returns the number of workgroups (<= 0: error code).
+int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void* mat, int64_t n, int64_t h,
+              int64_t w, int64_t c, int64_t k, int64_t r, int64_t s, int64_t stride_h, int64_t stride_w,
+              int64_t pad_h, int64_t pad_w, int64_t act_ld, float* ws, int64_t ws_bytes, int* tickets,
+              int64_t n_tickets, int target_blocks) {
+  const int64_t oh = (h + 2 * pad_h - r) / stride_h + 1, ow = (w + 2 * pad_w - s) / stride_w + 1;
+  memset(&a, 0, sizeof(a));
+  a.src = (const float*)act;
+  a.mat = (const float*)mat;
+  a.out = (float*)out;
+  a.ws = ws;
+  a.tickets = tickets;
+  a.R = (int)r; a.S = (int)s;
+  a.stride_h = (int)stride_h; a.stride_w = (int)stride_w; a.pad_h = (int)pad_h; a.pad_w = (int)pad_w;
+  // taps that meet data for at least one output position
+  for (int rr = 0; rr < r; ++rr) {
+    bool live_r = false;
+    for (int64_t y = 0; y < oh && !live_r; ++y) { const int64_t iy = y * stride_h - pad_h + rr; live_r = iy >= 0 && iy < h; }
+    if (!live_r) continue;
+    for (int qq = 0; qq < s; ++qq) {
+      bool live_q = false;
+      for (int64_t x = 0; x < ow && !live_q; ++x) { const int64_t ix = x * stride_w - pad_w + qq; live_q = ix >= 0 && ix < w; }
+      if (live_q) { a.tap_r[a.ntaps] = (unsigned char)rr; a.tap_s[a.ntaps] = (unsigned char)qq; a.ntaps++; }
+    }
+  }
+  if (a.ntaps == 0) return HF_ERR_ARG;
+  int64_t rows, red_steps;
+  if (direction == 0) {        // F: act = X [n,h,w,c] (pixel stride act_ld), mat = Wt [k][r*s][c], out [n,oh,ow,k]
+    a.dgrad = 0; rows = n * oh * ow; a.rh = (int)oh; a.rw = (int)ow; a.sh_ = (int)h; a.sw_ = (int)w;
+    a.cs = (int)c; a.nout = (int)k; a.ldc = (int)k;
+  } else if (direction == 1) { // D: act = dY [n,oh,ow,k], mat = WT [c][r*s][k], out = dX [n,h,w,c]
+    a.dgrad = 1; rows = n * h * w; a.rh = (int)h; a.rw = (int)w; a.sh_ = (int)oh; a.sw_ = (int)ow;
+    a.cs = (int)k; a.nout = (int)c; a.ldc = (int)c;
+  } else {                     // W: act = X [n,h,w,c], mat = dY [n*oh*ow][k], out = dW [k][r*s][c]
+    a.dgrad = 0; rows = n * oh * ow; a.rh = (int)oh; a.rw = (int)ow; a.sh_ = (int)h; a.sw_ = (int)w;
+    a.cs = (int)c; a.kout = (int)k;
+  }
+  a.rows = (int)rows;
+  a.cs_ld = (int)(act_ld > 0 ? act_ld : a.cs);
+  a.scalar = ((c % 4) || (k % 4) || (a.cs_ld % 4)) ? 1 : 0;
+  if (a.cs_ld < a.cs) return HF_ERR_ARG;
+  if (direction <= 1) {
+    a.tiles_m = (int)((rows + BM - 1) / BM);
+    a.tiles_n = (a.nout + BN - 1) / BN;
+    red_steps = (int64_t)a.ntaps * ((a.cs + BK - 1) / BK);
+  } else {
+    a.tiles_m = (a.kout + BM - 1) / BM;
+    a.tiles_n = a.ntaps * ((a.cs + BN - 1) / BN);
+    red_steps = (rows + BK - 1) / BK;
+  }
+  a.steps = (int)red_steps;
+  const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
+  if (tiles > n_tickets) return HF_ERR_CAPACITY;
+  a.splits = choose_splits(tiles, red_steps, target_blocks, ws_bytes);
+  return tiles * a.splits;
+}
+
+int check_common(const void* out, const void* act, const void* mat, const void* workspace, const void* tickets,
+                 int dtype, int64_t n, int64_t h, int64_t w, int64_t c, int64_t k, int64_t r, int64_t s,
+                 int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w) {
+  if (!out || !act || !mat || !workspace || !tickets) return HF_ERR_ARG;
+  if (dtype != HF_F32) return HF_ERR_ARG;
+  if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || k <= 0 || r <= 0 || s <= 0 || stride_h <= 0 ||
+      stride_w <= 0 || pad_h < 0 || pad_w < 0 || r * s > MAX_TAPS)
+    return HF_ERR_ARG;
+  const int64_t oh = (h + 2 * pad_h - r) / stride_h + 1, ow = (w + 2 * pad_w - s) / stride_w + 1;
+  if (oh <= 0 || ow <= 0) return HF_ERR_ARG;
+  // (channel counts that are not multiples of 4 run the element-wise gather variant)
+  if (!aligned16(workspace) || (((c % 4) == 0 && (k % 4) == 0) &&
+                                (!aligned16(out) || !aligned16(act) || !aligned16(mat))))
+    return HF_ERR_ALIGN;
+  if (n * h * w * (c > k ? c : k) > 0x7fffffffLL || n * oh * ow * (c > k ? c : k) > 0x7fffffffLL ||
+      k * r * s * c > 0x7fffffffLL)
+    return HF_ERR_ARG;
+  return HF_OK;
+}
+
+}  // namespace
+
+// C linkage comes from hf_pcg.h
+int hf_conv2d_nhwc(int direction, void* out, const void* act, const void* mat, int64_t n,
+                   int64_t h, int64_t w, int64_t c, int64_t k, int64_t r, int64_t s,
+                   int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
+                   int64_t act_ld, void* workspace, int64_t workspace_bytes, void* tickets,
+                   int64_t n_tickets, int target_blocks, int dtype, void* stream) {
+  if (direction < 0 || direction > 2) return HF_ERR_ARG;
+  const int rc = check_common(out, act, mat, workspace, tickets, dtype, n, h, w, c, k, r, s, stride_h,
+                              stride_w, pad_h, pad_w);
+  if (rc) return rc;
+  ConvArgs a;
+  const int64_t blocks = setup(a, direction, out, act, mat, n, h, w, c, k, r, s, stride_h, stride_w, pad_h,
+                               pad_w, act_ld, (float*)workspace, workspace_bytes, (int*)tickets, n_tickets,
+                               target_blocks);
+  if (blocks <= 0) return (int)blocks;
+  if (direction <= 1) hipLaunchKernelGGL(k_conv_nt, dim3((unsigned)blocks), dim3(CT), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_conv_tn, dim3((unsigned)blocks), dim3(CT), 0, (hipStream_t)stream, a);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_conv2d_nhwc_backward(void* dx, void* dw, const void* dy, const void* x, const void* w_t, int64_t n,
+                            int64_t h, int64_t w, int64_t c, int64_t k, int64_t r, int64_t s,
+                            int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
+                            void* workspace, int64_t workspace_bytes, void* tickets, int64_t n_tickets,
+                            int target_blocks, int dtype, void* stream) {
+  if (!dx || !dw) return HF_ERR_ARG;
+  int rc = check_common(dx, dy, w_t, workspace, tickets, dtype, n, h, w, c, k, r, s, stride_h, stride_w,
+                        pad_h, pad_w);
+  if (rc) return rc;
+  if (!x || !aligned16(x) || !aligned16(dw)) return x ? HF_ERR_ALIGN : HF_ERR_ARG;
+  // the two halves get disjoint halves of the scratch (they run concurrently)
+  const int64_t half_ws = (workspace_bytes / 2) & ~(int64_t)15, half_t = n_tickets / 2;
+  ConvArgs d, g;
+  const int64_t bd = setup(d, 1, dx, dy, w_t, n, h, w, c, k, r, s, stride_h, stride_w, pad_h, pad_w, 0,
+                           (float*)workspace, half_ws, (int*)tickets, half_t, target_blocks);
+  if (bd <= 0) return (int)bd;
+  const int64_t bw = setup(g, 2, dw, x, dy, n, h, w, c, k, r, s, stride_h, stride_w, pad_h, pad_w, 0,
+                           (float*)((char*)workspace + half_ws), half_ws, (int*)tickets + half_t, half_t,
+                           target_blocks);
+  if (bw <= 0) return (int)bw;
+  hipLaunchKernelGGL(k_conv_dw, dim3((unsigned)(bd + bw)), dim3(CT), 0, (hipStream_t)stream, d, g, (int)bd);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}

@@ -25,7 +25,7 @@ GPU the HIP kernel is mandatory (``_lib`` raises if the library is missing).
 import torch
 
 from . import _lib
-from .modelprep import first_order_only, tangent_owner
+from .modelprep import consumed_at_once, first_order_only, tangent_owner
 from .utils import vector_to_parameter_list
 
 
@@ -146,10 +146,11 @@ class GGNOperator(_Operator):
                 self._JTu, self._u, grad_outputs=[vs[i] for i in self._used], retain_graph=True
             )
         HJv = self._loss_hessian(Jv)
-        JTHJv = torch.autograd.grad(
-            self.outputs, self.params, grad_outputs=HJv, retain_graph=True, allow_unused=True
-        )
-        return self._finish(JTHJv, out)
+        with consumed_at_once():  # gathered by hf_pack right below
+            JTHJv = torch.autograd.grad(
+                self.outputs, self.params, grad_outputs=HJv, retain_graph=True, allow_unused=True
+            )
+            return self._finish(JTHJv, out)
 
     # -- the same product in two phases, for overlapping the all-reduce with compute --
     def split_point(self, tail_fraction=0.75):
@@ -175,17 +176,19 @@ class GGNOperator(_Operator):
         Hessian, and the adjoint sweep only as far back as ``params[cut]``."""
         self._hjv = self._H_J(v)
         tail = self.params[cut:]
-        g = torch.autograd.grad(self.outputs, tail, grad_outputs=self._hjv, retain_graph=True,
-                                allow_unused=True)
-        flatten_into(g, tail, out=out[offset:], scale=self.weight)
+        with consumed_at_once():
+            g = torch.autograd.grad(self.outputs, tail, grad_outputs=self._hjv, retain_graph=True,
+                                    allow_unused=True)
+            flatten_into(g, tail, out=out[offset:], scale=self.weight)
 
     def phase_head(self, out, cut, offset):
         """``out[:offset]``: the rest of the adjoint sweep (re-walks the tail's data
         gradients, which is cheap next to the all-reduce it hides)."""
         head = self.params[:cut]
-        g = torch.autograd.grad(self.outputs, head, grad_outputs=self._hjv, retain_graph=True,
-                                allow_unused=True)
-        flatten_into(g, head, out=out[:offset], scale=self.weight)
+        with consumed_at_once():
+            g = torch.autograd.grad(self.outputs, head, grad_outputs=self._hjv, retain_graph=True,
+                                    allow_unused=True)
+            flatten_into(g, head, out=out[:offset], scale=self.weight)
 
 
 class HessianOperator(_Operator):

@@ -46,6 +46,7 @@ class _Mode:
     vector = None     # the flat vector that sweep differentiates against
     prefilled = False
     producers = {}    # data_ptr -> (ctx, tensor) of this sweep's fused-layer tangent outputs
+    consume_now = False  # adjoint sweep whose per-parameter results are gathered at once
 
 
 class first_order_only:
@@ -61,6 +62,21 @@ class first_order_only:
 
     def __exit__(self, *exc):
         _Mode.first_order_only = self._old
+        return False
+
+
+class consumed_at_once:
+    """Context manager a curvature operator holds around its adjoint sweep: the
+    per-parameter gradients are gathered into the flat vector before anything else runs, so
+    a conv layer may return its persistent (partly constant-zero) weight-gradient buffer
+    instead of a fresh tensor.  Outside it every backward returns its own tensor."""
+
+    def __enter__(self):
+        self._old = _Mode.consume_now
+        _Mode.consume_now = True
+
+    def __exit__(self, *exc):
+        _Mode.consume_now = self._old
         return False
 
 
@@ -518,6 +534,108 @@ def _bias_grad(gy):
     return gb
 
 
+def _own_conv_ok(x, w, cl, dilation, channels):
+    """The package's implicit-GEMM kernels (``hf_conv2d_nhwc``: one launch, deterministic
+    split-K, dead taps skipped) apply: NHWC fp32 on the GPU, unit dilation, both channel
+    counts multiples of 4.  ``HF_OWN_CONV=0`` keeps MIOpen everywhere."""
+    return (
+        cl and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and list(dilation) == [1, 1]
+        and channels % 4 == 0 and w.shape[0] % 4 == 0 and w.shape[2] * w.shape[3] <= 64
+        and x.numel() < 2**31 and os.environ.get("HF_OWN_CONV", "1") != "0"
+    )
+
+
+def _use_own(mode, kind, rows):
+    """Which implementation runs a convolution of the product whose GEMM view has ``rows``
+    rows (N*OH*OW): the package's one-launch deterministic kernels or MIOpen.
+
+    ``mode`` "own" / "miopen" force one of them (``prepare_model(deterministic=True)`` sets
+    "own"; env ``HF_CONV`` overrides).  "auto" takes the faster one as measured on MI355X
+    INSIDE the ResNet-18 product (bench.py --conv ..., profiles/r02_conv_modes.jsonl): MIOpen,
+    for every layer and direction -- its hand-scheduled split-K kernels plus their zero-fill
+    launch (~11 us per convolution) beat the own one-launch kernels (12-20 us), whose
+    in-launch reduction is a chain of dependent memory round trips (partial tiles out,
+    ticket, acquire, partial tiles in).  A stand-alone micro-benchmark of the same shapes
+    (scripts/conv_kernel_bench.py) favours the own kernels for <= 128 rows; in the product
+    that advantage is gone (operands arrive cold from other XCDs' L2).  kind: "T" tangent,
+    "D" data gradient, "W" weight gradient, "DW" both in one launch, "stem" the tiny-Cin
+    layer; the thresholds stay tunable (``HF_CONV_AUTO``)."""
+    mode = os.environ.get("HF_CONV") or mode or "auto"
+    if mode == "own":
+        return True
+    if mode == "miopen":
+        return False
+    return rows <= _auto_rows().get(kind, 0)
+
+
+_AUTO_DEFAULT = {"T": 0, "D": 0, "W": 0, "DW": 0, "stem": 0}
+
+
+def _auto_rows():
+    """Row thresholds of the "auto" rule per kind (``HF_CONV_AUTO="W:128,DW:32"`` overrides,
+    for tuning); kind "stem" = the tiny-Cin layer (1 = own, 0 = MIOpen)."""
+    spec = os.environ.get("HF_CONV_AUTO")
+    if not spec:
+        return _AUTO_DEFAULT
+    out = dict(_AUTO_DEFAULT)
+    for item in spec.split(","):
+        k, v = item.split(":")
+        out[k.strip()] = int(v)
+    return out
+
+
+def _tiny_cin(x, w, cl):
+    """A layer with so few input channels that one kernel tap holds less than a 16-byte
+    gather (the 1-channel 7x7 stem of the MNIST ResNet): its tangent and weight gradient run
+    as 1x1 products over the im2col of the input, which is constant for a step."""
+    return cl and x.is_cuda and x.dtype == torch.float32 and x.shape[1] < 4 and (
+        x.shape[1] * w.shape[2] * w.shape[3] <= 64) and w.is_contiguous()
+
+
+def _cols_of(ctx, x, w, stride, padding):
+    if getattr(ctx, "cols", None) is None:
+        u = torch.nn.functional.unfold(x.contiguous(), (w.shape[2], w.shape[3]), padding=tuple(padding),
+                                       stride=tuple(stride))
+        ctx.cols = u.transpose(1, 2).contiguous()  # [N, OH*OW, Cin*R*S], channel order (c, r, s) as w.flatten(1)
+    return ctx.cols
+
+
+def _out_hw(x, w, stride, padding):
+    return ((x.shape[2] + 2 * padding[0] - w.shape[2]) // stride[0] + 1,
+            (x.shape[3] + 2 * padding[1] - w.shape[3]) // stride[1] + 1)
+
+
+def _own_conv_forward(xa, wa, stride, padding):
+    """``conv2d(xa, wa)`` for NHWC ``xa`` [N, C, H, W] and ``wa`` [K, C, R, S] (both stored
+    channels-last; C = the channel count both actually hold, e.g. 2*Cin for the tangent
+    operands)."""
+    n, c, h, w_ = xa.shape
+    k, _, r, s = wa.shape
+    oh, ow = _out_hw(xa, wa, stride, padding)
+    out = torch.empty((n, k, oh, ow), dtype=xa.dtype, device=xa.device).contiguous(
+        memory_format=torch.channels_last)
+    return _lib.conv2d_nhwc(0, out, xa, wa, n, h, w_, c, k, r, s, stride, padding)
+
+
+def _own_conv_dgrad(gy, x_shape, wT, r, s, stride, padding):
+    """Data gradient: ``wT`` is the weight stored (I, H, W, O)."""
+    n, c, h, w_ = x_shape
+    k = gy.shape[1]
+    gx = torch.empty((n, c, h, w_), dtype=gy.dtype, device=gy.device).contiguous(
+        memory_format=torch.channels_last)
+    return _lib.conv2d_nhwc(1, gx, gy, wT, n, h, w_, c, k, r, s, stride, padding)
+
+
+def _own_conv_wgrad(gy, xa, w_like, stride, padding, out=None):
+    """Weight gradient in the layout of ``w_like`` (channels-last).  Taps that never meet
+    data are not written: ``out`` must then be a zero-initialised buffer."""
+    n, c, h, w_ = xa.shape
+    k, _, r, s = w_like.shape
+    if out is None:
+        out = torch.zeros_like(w_like)
+    return _lib.conv2d_nhwc(2, out, xa, gy, n, h, w_, c, k, r, s, stride, padding)
+
+
 class _ConvBwd(torch.autograd.Function):
     """(gy; x, w) -> (gx, gw, gb) of a convolution.  Recorded only in
     ``first_order_only`` mode, so the sole derivative ever taken is d/d gy, whose
@@ -533,11 +651,13 @@ class _ConvBwd(torch.autograd.Function):
     the 20 layers of ResNet-18)."""
 
     @staticmethod
-    def forward(ctx, gy, x, w, has_bias, stride, padding, dilation, cl, need_gx=True):
+    def forward(ctx, gy, x, w, has_bias, stride, padding, dilation, cl, need_gx=True, mode=None):
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, w)
         ctx.conf = (stride, padding, dilation, has_bias, cl)
+        ctx.mode = mode
         ctx.cat = None
+        ctx.cols = None
         gy = _fmt(gy, cl)
         c = _point(x, w, padding, dilation, cl)
         if c is not None:
@@ -553,9 +673,15 @@ class _ConvBwd(torch.autograd.Function):
     def backward(ctx, vgx, vgw, vgb):
         x, w = ctx.saved_tensors
         stride, padding, dilation, _, cl = ctx.conf
+        mode = ctx.mode
         c = _point(x, w, padding, dilation, cl)
 
+        oh, ow = _out_hw(x, w, stride, padding)
+        rows = x.shape[0] * oh * ow
+
         def conv(xa, wa, *rest):
+            if _own_conv_ok(xa, wa, cl, dilation, xa.shape[1]) and _use_own(mode, "T", rows):
+                return _own_conv_forward(xa, wa, stride, padding)
             if c is not None:  # a GEMM on the centre tap
                 return (xa.flatten(1) @ wa[:, :, c, c].t()).view(xa.shape[0], wa.shape[0], 1, 1)
             with _miopen_mode(cl):
@@ -563,6 +689,13 @@ class _ConvBwd(torch.autograd.Function):
 
         if vgx is None and vgw is None:
             v_gy = None
+        elif vgx is None and _tiny_cin(x, w, cl) and vgw.is_contiguous() and _use_own(mode, "stem", 1):
+            # 1x1 product over the step's im2col: v_gy[m, k] = sum_j cols[m, j] * v_W[k, j]
+            cols = _cols_of(ctx, x, w, stride, padding)
+            n_, k_, j_ = x.shape[0], w.shape[0], cols.shape[2]
+            v_gy = torch.empty((n_, k_, oh, ow), dtype=x.dtype, device=x.device).contiguous(
+                memory_format=torch.channels_last)
+            _lib.conv2d_nhwc(0, v_gy, cols, vgw, n_ * oh * ow, 1, 1, j_, k_, 1, 1, (1, 1), (0, 0))
         elif vgx is None:
             v_gy = conv(x, _fmt(vgw, cl), None, stride, padding, dilation)
         elif vgw is None:
@@ -589,17 +722,23 @@ class _ConvBwd(torch.autograd.Function):
             v_gy = conv(xcat, wcat, None, stride, padding, dilation)
         if vgb is not None:
             vb = vgb.view(1, -1, 1, 1)
-            v_gy = vb.expand(x.shape[0], -1, 1, 1) if v_gy is None else v_gy + vb
-        return v_gy, None, None, None, None, None, None, None, None
+            if v_gy is None:  # only the bias carries a tangent: constant over the output map
+                v_gy = vb.expand(x.shape[0], -1, *_out_hw(x, w, stride, padding))
+            else:
+                v_gy = v_gy + vb
+        return v_gy, None, None, None, None, None, None, None, None, None
 
 
 class _Conv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding, dilation, cl):
+    def forward(ctx, x, w, b, stride, padding, dilation, cl, mode=None):
         xf, wf = _fmt(x, cl), _fmt(w, cl)
         ctx.save_for_backward(x, w, xf, wf)
         ctx.conf = (stride, padding, dilation, b is not None, cl)
+        ctx.mode = mode
+        ctx.cols = None
         ctx.gw_buf = None
+        ctx.wT = None
         c = _point(xf, wf, padding, dilation, cl)
         if c is not None:
             y = xf.flatten(1) @ wf[:, :, c, c].t()
@@ -614,29 +753,75 @@ class _Conv(torch.autograd.Function):
         need_gx = ctx.needs_input_grad[0]  # False for the first layer of a net
         if _Mode.first_order_only:
             gx, gw, gb = _ConvBwd.apply(gy, xf.detach(), wf.detach(), has_bias, stride, padding,
-                                        dilation, cl, need_gx)
+                                        dilation, cl, need_gx, ctx.mode)
         else:
             # stock call.  Differentiable again (Hessian products, create_graph) when grad
             # mode is on, so then it must see the tracked x, w; a plain first-order sweep
             # (the adjoint pass of every GGN product) uses the layout-converted copies --
             # with the NCHW parameter PyTorch would re-convert the weight on every call
             c = None
+            own = tiny = False
+            mode = ctx.mode
             if torch.is_grad_enabled():
                 xa, wa = x, w
             else:
                 xa, wa = xf, wf
+                own = _own_conv_ok(xf, wf, cl, dilation, xf.shape[1])
+                tiny = (not need_gx) and _tiny_cin(xf, wf, cl) and _use_own(mode, "stem", 1)
                 c = _point(xf, wf, padding, dilation, cl)
-            if c is not None:
-                if ctx.gw_buf is None:  # zero off the centre tap, for good
-                    ctx.gw_buf = torch.zeros_like(wf)
-                gx, gw = _point_backward(gy, xf, wf, c, need_gx, ctx.gw_buf)
-            else:
+            oh, ow = _out_hw(xf, wf, stride, padding)
+            rows = xf.shape[0] * oh * ow
+            own_dw = own and need_gx and _use_own(mode, "DW", rows)
+            own_w = own and not own_dw and _use_own(mode, "W", rows)
+            own_d = own_w and need_gx and _use_own(mode, "D", rows)
+            gx = gw = None
+            if own_dw or own_w:
+                # the package's deterministic one-launch kernels (hf_conv2d_nhwc)
+                gy = _fmt(gy, True)
+                r, s_ = wf.shape[2], wf.shape[3]
+                # taps that only ever meet padding are never written: a zero-filled buffer,
+                # persistent while the results are consumed at once (the product's gather),
+                # fresh otherwise (a caller may retain several gradients of one graph)
+                if _Mode.consume_now:
+                    if ctx.gw_buf is None:
+                        ctx.gw_buf = torch.zeros_like(wf)
+                    gw = ctx.gw_buf
+                else:
+                    gw = torch.zeros_like(wf)
+                if (own_dw or own_d) and ctx.wT is None:  # weight stored (I, H, W, O), once per step
+                    ctx.wT = wf.permute(1, 2, 3, 0).contiguous()
+                if own_dw:
+                    n_, c_, h_, w_ = xf.shape
+                    gx = torch.empty_like(xf)  # channels_last like xf
+                    _lib.conv2d_nhwc_backward(gx, gw, gy, xf, ctx.wT, n_, h_, w_, c_, wf.shape[0], r, s_,
+                                              stride, padding)  # data + weight gradient: ONE launch
+                else:
+                    _own_conv_wgrad(gy, xf, wf, stride, padding, out=gw)
+                    if own_d:
+                        gx = _own_conv_dgrad(gy, xf.shape, ctx.wT, r, s_, stride, padding)
+            elif tiny:
+                # weight gradient of a tiny-Cin layer: gW[k, j] = sum_m gy[m, k] * cols[m, j]
+                cols = _cols_of(ctx, xf, wf, stride, padding)
+                gy = _fmt(gy, True)
+                gw = torch.empty_like(wf)
+                _lib.conv2d_nhwc(2, gw, cols, gy, cols.shape[0] * cols.shape[1], 1, 1, cols.shape[2],
+                                 wf.shape[0], 1, 1, (1, 1), (0, 0))
+            elif c is not None:
+                if _Mode.consume_now:
+                    if ctx.gw_buf is None:  # zero off the centre tap, for good
+                        ctx.gw_buf = torch.zeros_like(wf)
+                    gx, gw = _point_backward(gy, xf, wf, c, need_gx, ctx.gw_buf)
+                else:
+                    gx, gw = _point_backward(gy, xf, wf, c, need_gx)
+            if gw is None or (need_gx and gx is None):
                 with _miopen_mode(cl):
-                    gx, gw, _ = torch.ops.aten.convolution_backward(
+                    g2 = torch.ops.aten.convolution_backward(
                         gy, xa, wa, None, stride, padding, dilation, False, [0] * len(stride), 1,
-                        [need_gx, True, False])
+                        [need_gx and gx is None, gw is None, False])
+                gx = g2[0] if (need_gx and gx is None) else gx
+                gw = g2[1] if gw is None else gw
             gb = _bias_grad(gy) if has_bias else None
-        return gx, gw, gb if has_bias else None, None, None, None, None
+        return gx, gw, gb if has_bias else None, None, None, None, None, None
 
 
 def _conv_forward(self, x):
@@ -647,10 +832,11 @@ def _conv_forward(self, x):
     if not usable:
         return self._hf_stock_forward(x)
     return _Conv.apply(x, self.weight, self.bias, list(self.stride), list(self.padding),
-                       list(self.dilation), bool(getattr(self, "_hf_channels_last", False)))
+                       list(self.dilation), bool(getattr(self, "_hf_channels_last", False)),
+                       getattr(self, "_hf_conv_mode", None))
 
 
-def fuse_conv_tangent(model, channels_last=False):
+def fuse_conv_tangent(model, channels_last=False, conv_mode=None):
     """Patch every plain ``nn.Conv2d`` (groups=1, zero padding) so that, inside a GGN
     product, its tangent map is one convolution (see ``_ConvBwd``).  Forward and
     first-order backward are the stock MIOpen calls.  With ``channels_last`` the
@@ -662,6 +848,7 @@ def fuse_conv_tangent(model, channels_last=False):
     for m in model.modules():
         if type(m) is nn.Conv2d:
             m._hf_channels_last = bool(channels_last)
+            m._hf_conv_mode = conv_mode
             if not hasattr(m, "_hf_stock_forward"):
                 m._hf_stock_forward = m.forward
                 m.forward = types.MethodType(_conv_forward, m)
@@ -688,8 +875,16 @@ def skip_identity_pools(model):
     return count
 
 
-def prepare_model(model, channels_last=False):
+def prepare_model(model, channels_last=False, deterministic=False):
     """All opt-in preparations; returns ``model`` for chaining.
+
+    ``deterministic=True`` (with ``channels_last=True``): every convolution of the curvature
+    product that the package's own kernels can run (fp32 NHWC, unit dilation) does run on
+    them -- one launch each, split-K partial sums combined in a fixed order -- instead of
+    MIOpen's split-K kernels with atomic accumulation.  Two products of the same vector are
+    then bitwise equal (the reference's ``_test_mvp_deterministic``, optimizer.py:414-448,
+    passes exactly); it costs ~20 % of the product's speed on the ResNet-18 workload.  The
+    default ("auto") uses the own kernels only where they are also the faster ones.
 
     ``channels_last=True`` additionally runs the convolution layers, and with them the
     fused BatchNorm kernels, in NHWC: MIOpen's implicit-GEMM kernels then need no layout
@@ -713,7 +908,7 @@ def prepare_model(model, channels_last=False):
 
     configure()  # MIOpen settings the patched layers were validated with (config.py)
     fuse_eval_batchnorm(model)
-    fuse_conv_tangent(model, channels_last=channels_last)
+    fuse_conv_tangent(model, channels_last=channels_last, conv_mode="own" if deterministic else None)
     fuse_residual_blocks(model)
     fuse_bn_relu(model)
     skip_identity_pools(model)

@@ -1,0 +1,116 @@
+"""GPU: the package's implicit-GEMM convolution kernels (``hf_conv2d_nhwc``: fp32 MFMA,
+deterministic split-K, dead taps skipped) against float64 convolutions, through the C ABI.
+
+These kernels replace, inside the curvature product, the three MIOpen calls per conv layer
+that BackPACK's R-op / L-op issue through PyTorch (``/root/reference/hessianfree/
+optimizer.py:461``).  Stated tolerance: fp32 fma-chain accuracy, ``3e-6 * sum|a*b|`` scale
+(max-norm error below 2e-5 of the result's max-norm at the longest reductions here), and
+BITWISE equality of two launches on the same inputs (what MIOpen's split-K kernels with
+atomic accumulation do not give)."""
+
+import pytest
+import torch
+
+from pytorchhessianfree_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+# (N, H, W, C, K, R, S, stride, padding)
+GEOMS = [
+    (32, 7, 7, 64, 64, 3, 3, (1, 1), (1, 1)),      # ResNet-18 layer1
+    (32, 7, 7, 64, 128, 3, 3, (2, 2), (1, 1)),     # layer2.0.conv1 (7 -> 4)
+    (32, 7, 7, 64, 128, 1, 1, (2, 2), (0, 0)),     # layer2.0.downsample
+    (32, 4, 4, 128, 128, 3, 3, (1, 1), (1, 1)),    # layer2
+    (32, 2, 2, 256, 256, 3, 3, (1, 1), (1, 1)),    # layer3: every tap meets data somewhere
+    (32, 2, 2, 256, 512, 3, 3, (2, 2), (1, 1)),    # layer4.0.conv1: 4 of 9 taps live
+    (32, 1, 1, 512, 512, 3, 3, (1, 1), (1, 1)),    # layer4: centre tap only
+    (32, 7, 7, 128, 64, 3, 3, (1, 1), (1, 1)),     # tangent operands: 2*Cin channels
+    (4, 5, 6, 12, 20, 3, 2, (2, 1), (1, 0)),       # ragged everything
+    (2, 9, 9, 8, 100, 5, 5, (1, 1), (2, 2)),       # K not a multiple of the tile
+    (3, 6, 5, 36, 8, 1, 1, (1, 1), (0, 0)),
+    (8, 16, 16, 96, 96, 3, 3, (1, 1), (1, 1)),     # All-CNN-C-like: many tiles, no split needed
+    (1, 3, 3, 4, 4, 3, 3, (1, 1), (0, 0)),         # one output pixel
+    (3, 8, 8, 3, 6, 3, 3, (1, 1), (1, 1)),         # channel counts not multiples of 4: scalar gathers
+    (32 * 196, 1, 1, 49, 64, 1, 1, (1, 1), (0, 0)),  # the stem as a 1x1 product over its im2col
+]
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _reference(x, w, gy, stride, padding):
+    x64, w64, gy64 = x.double().requires_grad_(True), w.double().requires_grad_(True), gy.double()
+    y = torch.nn.functional.conv2d(x64, w64, None, stride, padding)
+    gx, gw = torch.autograd.grad(y, (x64, w64), gy64)
+    return y.detach(), gx, gw
+
+
+@pytest.mark.parametrize("geom", GEOMS, ids=[str(g[:7]) for g in GEOMS])
+def test_three_directions_match_float64(geom):
+    n, h, w_, c, k, r, s, stride, padding = geom
+    gen = torch.Generator(device=DEV).manual_seed(hash(geom) % 2**31)
+    x = _cl(torch.randn(n, c, h, w_, device=DEV, generator=gen))
+    w = _cl(torch.randn(k, c, r, s, device=DEV, generator=gen))
+    oh = (h + 2 * padding[0] - r) // stride[0] + 1
+    ow = (w_ + 2 * padding[1] - s) // stride[1] + 1
+    gy = _cl(torch.randn(n, k, oh, ow, device=DEV, generator=gen))
+    y64, gx64, gw64 = _reference(x, w, gy, stride, padding)
+
+    def rel(a, b):
+        return float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+    for _ in range(2):  # the second round runs on recycled tickets / workspace
+        y = _cl(torch.empty(n, k, oh, ow, device=DEV))
+        _lib.conv2d_nhwc(0, y, x, w, n, h, w_, c, k, r, s, stride, padding)
+        assert rel(y, y64) < 2e-5
+
+        wT = w.permute(1, 2, 3, 0).contiguous()  # (I, H, W, O)
+        gx = _cl(torch.empty(n, c, h, w_, device=DEV))
+        _lib.conv2d_nhwc(1, gx, gy, wT, n, h, w_, c, k, r, s, stride, padding)
+        assert rel(gx, gx64) < 2e-5
+
+        gw = torch.zeros_like(w)
+        _lib.conv2d_nhwc(2, gw, x, gy, n, h, w_, c, k, r, s, stride, padding)
+        assert rel(gw, gw64) < 2e-5
+
+        # data + weight gradient in ONE launch: the same numbers as the two separate launches
+        gx3, gw3 = torch.empty_like(gx), torch.zeros_like(w)
+        _lib.conv2d_nhwc_backward(gx3, gw3, gy, x, wT, n, h, w_, c, k, r, s, stride, padding)
+        assert rel(gx3, gx64) < 2e-5 and rel(gw3, gw64) < 2e-5
+
+        # bitwise repeatable
+        y2, gx2, gw2 = torch.empty_like(y), torch.empty_like(gx), torch.zeros_like(w)
+        _lib.conv2d_nhwc(0, y2, x, w, n, h, w_, c, k, r, s, stride, padding)
+        _lib.conv2d_nhwc(1, gx2, gy, wT, n, h, w_, c, k, r, s, stride, padding)
+        _lib.conv2d_nhwc(2, gw2, x, gy, n, h, w_, c, k, r, s, stride, padding)
+        assert torch.equal(y, y2) and torch.equal(gx, gx2) and torch.equal(gw, gw2)
+
+
+def test_channel_slice_of_a_wider_buffer():
+    """``act_ld``: the gathered tensor is the first-C-channels slice of a wider NHWC buffer."""
+    n, h, w_, c, k = 4, 6, 6, 16, 24
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    wide = _cl(torch.randn(n, 2 * c, h, w_, device=DEV, generator=gen))
+    x = wide[:, :c]
+    w = _cl(torch.randn(k, c, 3, 3, device=DEV, generator=gen))
+    y = _cl(torch.empty(n, k, h, w_, device=DEV))
+    _lib.conv2d_nhwc(0, y, x, w, n, h, w_, c, k, 3, 3, (1, 1), (1, 1), act_ld=2 * c)
+    want = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+    assert float((y.double() - want).abs().max() / want.abs().max()) < 2e-5
+
+
+def test_bad_geometry_is_refused():
+    lib = _lib.load()
+    x = torch.zeros(64, device=DEV)
+    ws, tk = _lib.conv_scratch(x.device)
+    p = _lib.c_void_p
+    # kernel window larger than the padded input
+    rc = lib.hf_conv2d_nhwc(0, p(x.data_ptr()), p(x.data_ptr()), p(x.data_ptr()), 1, 2, 2, 4, 4, 5, 5, 1, 1,
+                            0, 0, 0, p(ws.data_ptr()), ws.numel() * 4, p(tk.data_ptr()), tk.numel(), 0, 0, None)
+    assert rc == -1
+    # float64 is not implemented by these kernels
+    rc = lib.hf_conv2d_nhwc(0, p(x.data_ptr()), p(x.data_ptr()), p(x.data_ptr()), 1, 4, 4, 4, 4, 3, 3, 1, 1,
+                            1, 1, 0, p(ws.data_ptr()), ws.numel() * 4, p(tk.data_ptr()), tk.numel(), 0, 1, None)
+    assert rc == -1

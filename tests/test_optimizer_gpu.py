@@ -825,3 +825,40 @@ def test_channels_last_curvature_path_small_net():
     assert res["gather_exact"] is True
     assert res["kernel_err"] < 1e-6, res  # elementwise parts exact, sums in fp64 then rounded
     assert max(res["errors"]) < 1e-5, res
+
+
+def test_deterministic_mode_products_are_bitwise_repeatable():
+    """``prepare_model(channels_last=True, deterministic=True)``: all convolutions of the
+    product run on the package's one-launch kernels (fixed-order split-K, no atomics), so two
+    products of the same vector are bitwise equal -- eagerly and replayed from a hipGraph --
+    and the reference's ``_test_mvp_deterministic`` (optimizer.py:414-448) passes with
+    ``torch.equal`` instead of ``allclose``.  The result still matches the float64 product of
+    the stock model."""
+    from pytorchhessianfree_amd import modelprep
+
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device=DEV)
+    ref_model, _, _ = tp.resnet18_mnist(batch_size=32, device=DEV)
+    modelprep.prepare_model(model, channels_last=True, deterministic=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    n = sum(p.numel() for p in params)
+    v = torch.randn(n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(11))
+
+    def builder():
+        out = model(x)
+        return curvature.GGNOperator(lossf(out, t), out, params)
+
+    eager = builder()
+    first = eager(v).clone()
+    for _ in range(3):
+        assert torch.equal(eager(v), first)
+    graphed = curvature.GraphedOperator(builder, params=params)
+    g1 = graphed(v).clone()
+    for _ in range(3):
+        assert torch.equal(graphed(v), g1)
+    assert torch.equal(g1, first)  # the same kernels in the same order: replay == eager, bitwise
+
+    ref_model = ref_model.double()
+    rp = [p for p in ref_model.parameters() if p.requires_grad]
+    ro = ref_model(x.double())
+    want = curvature.GGNOperator(lossf(ro, t), ro, rp)(v.double())
+    assert float((first.double() - want).abs().max() / want.abs().max()) < 2e-6
