@@ -496,6 +496,41 @@ def make_acc_step():
     save("acc_step.npz", store)
 
 
+def make_acc_step_distinct():
+    """``acc_step`` with DIFFERENT data for the loss, the gradient and the curvature -- the
+    usage the reference recommends (README.md:147-150; optimizer.py:519-606): loss on
+    chunks [9, 6], gradient on [7, 8], curvature products on the smaller list [5, 4]."""
+    store, index = {}, []
+    sizes = {"loss": (9, 6), "grad": (7, 8), "mvp": (5, 4)}
+    for curv in ("ggn", "hessian"):
+        for reduction in ("mean", "sum"):
+            torch.manual_seed(0)
+            model, _, _ = get_small_nn_testproblem()
+            lossf = torch.nn.MSELoss(reduction=reduction)
+            key = f"{curv}_{reduction}"
+            index.append(key)
+            for k, a in model_arrays(model).items():
+                store[f"{key}/model/{k}"] = a
+            opt = RefHF(model.parameters(), curvature_opt=curv, cg_max_iter=6)
+            for s in range(3):
+                lists = {}
+                for role, ns in sizes.items():
+                    lists[role] = []
+                    for c, n in enumerate(ns):
+                        _, data, _ = get_small_nn_testproblem(N=n)
+                        lists[role].append(data)
+                        store[f"{key}/{role}_inputs/{s}/{c}"] = npy(data[0])
+                        store[f"{key}/{role}_targets/{s}/{c}"] = npy(data[1])
+                quiet(opt.acc_step, model, lossf, lists["loss"], grad_datalist=lists["grad"],
+                      mvp_datalist=lists["mvp"], reduction=reduction)
+                store[f"{key}/params/{s}"] = trainable_vec(model)
+                store[f"{key}/x0/{s}"] = npy(opt.state["x0"])
+            for k, v in state_arrays(opt).items():
+                store[f"{key}/state/{k}"] = v
+    store["index"] = np.array(index)
+    save("acc_step_distinct.npz", store)
+
+
 def make_quadratic():
     """tests/test_optimizer.py:97-155: one undamped Newton step on a quadratic."""
     store, index = {}, []
@@ -529,13 +564,10 @@ def make_quadratic():
 
 if __name__ == "__main__":
     torch.set_num_threads(1)  # reduction order of the reference's dots is then fixed
-    make_cg_linear()
-    make_cg_f64()
-    make_cg_lowrank()
-    make_small_tables()
-    make_curvature()
-    make_step_mwe()
-    make_step_smallnn()
-    make_step_precond()
-    make_acc_step()
-    make_quadratic()
+    makers = [make_cg_linear, make_cg_f64, make_cg_lowrank, make_small_tables, make_curvature,
+              make_step_mwe, make_step_smallnn, make_step_precond, make_acc_step,
+              make_acc_step_distinct, make_quadratic]
+    only = set(sys.argv[1:])  # e.g. `make_golden.py make_acc_step_distinct` regenerates one file
+    for fn in makers:
+        if not only or fn.__name__ in only:
+            fn()

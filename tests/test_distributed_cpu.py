@@ -42,17 +42,27 @@ def _worker(rank, world, port, mode, curv, reduction, outdir):
         from helpers import T, small_nn, trainable_vec
         from oracle import pcg as oracle
 
-        g = load_golden("acc_step.npz")
+        distinct = mode == "acc_distinct"
+        g = load_golden("acc_step_distinct.npz" if distinct else "acc_step.npz")
         key = f"{curv}_{reduction}"
         model = small_nn(g, key)
         lossf = torch.nn.MSELoss(reduction=reduction)
         sizes = [7, 8]
         weight = sizes[rank] / sum(sizes) if reduction == "mean" else 1.0
-        opt = hf.HessianFree(model.parameters(), curvature_opt=curv, cg_max_iter=4,
+        opt = hf.HessianFree(model.parameters(), curvature_opt=curv, cg_max_iter=6 if distinct else 4,
                              process_group=dist.group.WORLD, shard_weight=weight)
         opt._cg = oracle.pcg
         out = []
         for s in range(3):
+            if distinct:  # rank r holds chunk r of each of the three data lists
+                d = {role: [(T(g[f"{key}/{role}_inputs/{s}/{rank}"]), T(g[f"{key}/{role}_targets/{s}/{rank}"]))]
+                     for role in ("loss", "grad", "mvp")}
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    opt.acc_step(model, lossf, d["loss"], grad_datalist=d["grad"], mvp_datalist=d["mvp"],
+                                 reduction=reduction)
+                out.append(trainable_vec(model).numpy().copy())
+                continue
             inputs = T(g[f"{key}/inputs/{s}/{rank}"])
             targets = T(g[f"{key}/targets/{s}/{rank}"])
 
@@ -93,3 +103,23 @@ def test_two_ranks_equal_reference_whole_batch(tmp_path, mode, curv, reduction):
     np.testing.assert_allclose(r0["init_losses"], g[f"{key}/state_step/init_losses"], rtol=1e-5)
     assert r0["num_cg_iters"].tolist() == g[f"{key}/state_step/num_cg_iters"].tolist()
     np.testing.assert_allclose(r0["dampings"], g[f"{key}/state_step/dampings"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("curv,reduction", [("ggn", "mean"), ("hessian", "sum")])
+def test_two_ranks_acc_step_with_distinct_data_lists(tmp_path, curv, reduction):
+    """Every rank passes ITS chunk of the loss / gradient / curvature lists; the result is the
+    reference's single-process ``acc_step`` over the whole lists (README.md:147-150 usage)."""
+    from conftest import load_golden
+
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, "acc_distinct", curv, reduction, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["params"], r1["params"])
+    g = load_golden("acc_step_distinct.npz")
+    key = f"{curv}_{reduction}"
+    for s in range(3):
+        np.testing.assert_allclose(r0["params"][s], g[f"{key}/params/{s}"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(r0["init_losses"], g[f"{key}/state/init_losses"], rtol=1e-5)
+    assert r0["num_cg_iters"].tolist() == g[f"{key}/state/num_cg_iters"].tolist()
+    np.testing.assert_allclose(r0["dampings"], g[f"{key}/state/dampings"], rtol=1e-12)

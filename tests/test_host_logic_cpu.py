@@ -146,6 +146,36 @@ def test_acc_step_trace(curv, reduction, cache):
     check_state(o2, g, key + "/state_acc/", 3)
 
 
+def _distinct_lists(g, key, s, device="cpu"):
+    return {
+        role: [(T(g[f"{key}/{role}_inputs/{s}/{c}"], device), T(g[f"{key}/{role}_targets/{s}/{c}"], device))
+               for c in (0, 1)]
+        for role in ("loss", "grad", "mvp")
+    }
+
+
+@pytest.mark.parametrize("cache", [True, False])
+@pytest.mark.parametrize("curv", ["ggn", "hessian"])
+@pytest.mark.parametrize("reduction", ["mean", "sum"])
+def test_acc_step_with_distinct_loss_grad_and_curvature_data(curv, reduction, cache):
+    """optimizer.py:519-606 / README.md:147-150: loss on chunks [9, 6], gradient on [7, 8],
+    curvature on the smaller [5, 4] -- trace of the real reference (acc_step_distinct.npz)."""
+    g = load_golden("acc_step_distinct.npz")
+    key = f"{curv}_{reduction}"
+    model = small_nn(g, key)
+    lossf = torch.nn.MSELoss(reduction=reduction)
+    opt = make_opt(model.parameters(), curvature_opt=curv, cg_max_iter=6, cache_acc_graphs=cache)
+    for s in range(3):
+        d = _distinct_lists(g, key, s)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            opt.acc_step(model, lossf, d["loss"], grad_datalist=d["grad"], mvp_datalist=d["mvp"],
+                         reduction=reduction)
+        np.testing.assert_allclose(trainable_vec(model).numpy(), g[f"{key}/params/{s}"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(opt.state["x0"].numpy(), g[f"{key}/x0/{s}"], rtol=1e-4, atol=1e-6)
+    check_state(opt, g, key + "/state/", 3)
+
+
 @pytest.mark.parametrize("reduction", ["mean", "sum"])
 @pytest.mark.parametrize("curv", ["ggn", "hessian"])
 def test_test_reduction(curv, reduction):
