@@ -455,13 +455,32 @@ class OverlappedGraphedOperator(GraphedOperator):
             return self.local(v, out)
         if v.data_ptr() != self.input_buffer.data_ptr():
             self.input_buffer.copy_(v)
+        from . import distributed as hfdist
+
         dist, buf = torch.distributed, self.output_buffer
-        self.graph.replay()
-        w_tail = dist.all_reduce(buf[self.offset:], group=self.group, async_op=True)
-        self.graph_head.replay()
-        w_head = dist.all_reduce(buf[: self.offset], group=self.group, async_op=True)
-        w_tail.wait()
-        w_head.wait()
+        tail, head = buf[self.offset:], buf[: self.offset]
+        side_comm = hfdist.side_comm(tail, self.group)
+        if side_comm is not None:
+            # direct RCCL: the tail's all-reduce runs on a side stream with its own
+            # communicator while the head's adjoint sweep replays; the head's all-reduce
+            # follows on the compute stream -- one event hand-off in, one out
+            cur = torch.cuda.current_stream()
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream()
+            self.graph.replay()
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                side_comm.all_reduce_sum(tail)
+            self.graph_head.replay()
+            hfdist.all_reduce_sum(head, self.group)
+            cur.wait_stream(self._side)
+        else:
+            self.graph.replay()
+            w_tail = dist.all_reduce(tail, group=self.group, async_op=True)
+            self.graph_head.replay()
+            w_head = dist.all_reduce(head, group=self.group, async_op=True)
+            w_tail.wait()
+            w_head.wait()
         if out is not None:
             out.copy_(buf)
             return out

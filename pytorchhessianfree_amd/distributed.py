@@ -20,6 +20,7 @@ Both reduce in place and return their argument.
 
 import ctypes
 import os
+import sys
 import warnings
 
 import torch
@@ -40,8 +41,22 @@ class _DirectComm:
         payload = [uid.raw if rank == 0 else None]
         dist.broadcast_object_list(payload, src=dist.get_global_rank(group, 0), group=group)
         self.handle = _lib.c_void_p()
-        _lib.check(lib.hf_comm_create(ctypes.byref(self.handle), payload[0], world, rank),
-                   "hf_comm_create")
+        # RCCL prints a version banner to the C stdout when a communicator is created outside
+        # PyTorch; programs whose stdout is a protocol (bench.py: ONE JSON line) must not see
+        # it: point fd 1 at stderr for the duration and flush the C buffers
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            rc = lib.hf_comm_create(ctypes.byref(self.handle), payload[0], world, rank)
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except Exception:  # noqa: BLE001
+                pass
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        _lib.check(rc, "hf_comm_create")
         self.lib = lib
 
     def all_reduce_sum(self, t):
@@ -78,6 +93,29 @@ def _direct_comm(group):
         torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=group)
         _comms[key] = comm if int(ok.item()) == 1 else None
     return _comms[key]
+
+
+_side_comms = {}
+
+
+def side_comm(t, group):
+    """A SECOND direct communicator of the group, for a collective that runs on a side
+    stream concurrently with one on the compute stream (two collectives in flight on one
+    RCCL communicator are not allowed to overlap).  ``None`` when the direct path is off."""
+    if group is None or not _wants_direct(t, group) or _direct_comm(group) is None:
+        return None
+    key = id(group)
+    if key not in _side_comms:
+        comm = None
+        try:
+            comm = _DirectComm(group)
+        except Exception as exc:  # noqa: BLE001
+            warnings.warn(f"second RCCL communicator unavailable ({exc!r})")
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32,
+                          device=torch.device("cuda", torch.cuda.current_device()))
+        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=group)
+        _side_comms[key] = comm if int(ok.item()) == 1 else None
+    return _side_comms[key]
 
 
 def path_name(t, group):

@@ -62,5 +62,31 @@ for name, kw in [("plain", {}), ("dp", dict(process_group=dist.group.WORLD)),
     runs[name] = [opt.state["init_losses"][0], final, opt.state["num_cg_iters"][0],
                   opt.state["cg_reasons"][0]]
 out["runs"] = runs
+
+# ---- two-graph overlap with the direct communicators (compute stream + side stream) ---------
+from pytorchhessianfree_amd import curvature, distributed as hfdist  # noqa: E402
+
+model, (x, t), lossf = tp.resnet18_mnist(batch_size=8, device=DEV)
+modelprep.prepare_model(model)
+params = [p for p in model.parameters() if p.requires_grad]
+
+
+def builder():
+    o = model(x)
+    return curvature.GGNOperator(lossf(o, t), o, params)
+
+
+single = curvature.GraphedOperator(builder, params=params)
+v = torch.randn(single.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+want = single(v).clone()
+over = curvature.OverlappedGraphedOperator(builder, params=params)
+over.group = dist.group.WORLD
+got = over(v).clone()
+got2 = over(v).clone()
+torch.cuda.synchronize()
+out["overlap_rel_err"] = float((got - want).abs().max() / want.abs().max())
+out["overlap_repeat_rel_err"] = float((got2 - want).abs().max() / want.abs().max())
+out["comm_path"] = hfdist.path_name(want, dist.group.WORLD)
+out["side_comm"] = hfdist.side_comm(want, dist.group.WORLD) is not None
 print("RESULT " + json.dumps(out), flush=True)
 dist.destroy_process_group()
