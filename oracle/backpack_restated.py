@@ -22,8 +22,8 @@ squared individual gradients of the *mean/sum-reduced* loss, i.e. with the
 Parity status: the reference's own tests pin ``Hv`` (test_optimizer.py:97-155,
 one Newton step on a quadratic) and ``SumGradSquared`` (test_preconditioners.py:
 54-99) but NOT ``GGN v`` against an independent truth (SURVEY.md section 8c);
-``tests/test_curvature_cpu.py`` therefore checks this restatement against an
-explicitly materialised ``J^T H_L J``.
+``tests/test_host_logic_cpu.py::test_curvature_products_match_reference_and_explicit_matrices``
+therefore checks this restatement against an explicitly materialised ``J^T H_L J``.
 
 ``install_as_backpack()`` registers this module under the import names the
 reference uses, so that ``tests/golden/make_golden.py`` can import the real

@@ -310,7 +310,9 @@ def fuse_bn_relu(model):
     number of modules patched."""
     count = 0
     for m in model.modules():
-        if type(m) is nn.ReLU and not hasattr(m, "_hf_stock_forward"):
+        # (an in-place ReLU rewrites the BatchNorm output that other consumers may still read;
+        # the fused layer would leave it untouched -- such modules keep their stock forward)
+        if type(m) is nn.ReLU and not m.inplace and not hasattr(m, "_hf_stock_forward"):
             m._hf_stock_forward = m.forward
             m.forward = types.MethodType(_relu_forward, m)
             count += 1
@@ -343,6 +345,35 @@ def _bottleneck_forward(self, x):
     return fused_bn_act(self.bn3, self.conv3(out), res=idt, relu=True, twin=True)
 
 
+def _verified_block_forward(fused):
+    """Wrap a fused block forward: the FIRST call also runs the module's own (stock) forward
+    on the same input and compares.  Recognition is structural (attribute names); a custom
+    block with the same attributes but a different function (squeeze-excite, dropout,
+    stochastic depth, ...) fails the comparison, gets its stock forward back for good and a
+    warning is issued -- the network function is never changed silently."""
+
+    def forward(self, x):
+        y = fused(self, x)
+        # (in training mode the fused layers are the stock ops anyway, and a second stock
+        # forward would update the BatchNorm running statistics twice)
+        if not self._hf_block_verified and not self.training:
+            self._hf_block_verified = True
+            with torch.no_grad():
+                want = self._hf_stock_block_forward(x.detach())
+            scale = float(want.abs().max()) + 1e-30
+            if want.shape != y.shape or not float((want - y.detach()).abs().max()) <= 1e-4 * scale:
+                import warnings
+
+                warnings.warn(
+                    f"{type(self).__name__}: fused residual-block forward does not reproduce the module's "
+                    "own forward; keeping the stock forward for this block")
+                self.forward = self._hf_stock_block_forward
+                return self._hf_stock_block_forward(x)
+        return y
+
+    return forward
+
+
 def _looks_like(block, convs):
     names = [f"conv{i}" for i in range(1, convs + 1)] + [f"bn{i}" for i in range(1, convs + 1)]
     return (
@@ -364,11 +395,14 @@ def fuse_residual_blocks(model):
         if hasattr(m, "_hf_block_patched"):
             continue
         if _looks_like(m, 2):
-            m.forward = types.MethodType(_basic_block_forward, m)
+            fused = _basic_block_forward
         elif _looks_like(m, 3):
-            m.forward = types.MethodType(_bottleneck_forward, m)
+            fused = _bottleneck_forward
         else:
             continue
+        m._hf_stock_block_forward = m.forward
+        m._hf_block_verified = False
+        m.forward = types.MethodType(_verified_block_forward(fused), m)
         m._hf_block_patched = True
         count += 1
     return count

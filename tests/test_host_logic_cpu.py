@@ -434,3 +434,39 @@ def test_modelprep_layout_helpers_on_cpu_tensors():
     assert mp._point(x1, w3, [1, 1], [2, 2], True) is None                      # dilated
     assert mp._point(x1, w2, [1, 1], [1, 1], True) is None                      # even kernel
     assert mp._point(torch.zeros(2, 8, 2, 2), w3, [1, 1], [1, 1], True) is None  # larger map
+
+
+def test_fused_residual_block_is_verified_against_the_modules_own_forward():
+    """A module that merely LOOKS like a torchvision BasicBlock (conv1, bn1, relu, conv2, bn2,
+    downsample) but computes something else must keep its own function: the fused forward is
+    compared with the stock forward on first use and reverted on a mismatch."""
+    from pytorchhessianfree_amd import modelprep
+
+    class LookAlike(torch.nn.Module):
+        def __init__(self, gate):
+            super().__init__()
+            self.conv1 = torch.nn.Conv2d(4, 4, 3, 1, 1, bias=False)
+            self.bn1 = torch.nn.BatchNorm2d(4)
+            self.relu = torch.nn.ReLU()
+            self.conv2 = torch.nn.Conv2d(4, 4, 3, 1, 1, bias=False)
+            self.bn2 = torch.nn.BatchNorm2d(4)
+            self.downsample = None
+            self.gate = gate
+
+        def forward(self, x):
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out))
+            return self.relu(self.gate * out + x)  # gate != 1: not the torchvision function
+
+    torch.manual_seed(0)
+    x = torch.randn(2, 4, 5, 5)
+    for gate, reverted in ((1.0, False), (0.5, True)):
+        block = LookAlike(gate).eval()
+        want = block(x)
+        assert modelprep.fuse_residual_blocks(block) == 1
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = block(x)
+        assert torch.allclose(got, want, atol=1e-6)
+        assert any("fused residual-block forward" in str(m.message) for m in w) == reverted
+        assert torch.allclose(block(x), want, atol=1e-6)  # and on every later call

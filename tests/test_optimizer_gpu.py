@@ -677,6 +677,57 @@ def test_config2_full_step_matches_reference_cpu_path(deterministic):
     assert cos > 0.999, cos
 
 
+def test_train_mode_batchnorm_product_and_solve_match_cpu_oracle():
+    """The reference's ResNet-18 example never calls ``model.eval()``
+    (examples/run_resnet18_mnist.py:14-30): BatchNorm then normalises with BATCH statistics and
+    the GGN couples the samples.  ``prepare_model`` leaves such layers on their stock ops (its
+    fused kernels are for fixed statistics), so this is the plain PyTorch-ROCm autograd path
+    feeding the HIP PCG: product against BackPACK's algorithm on the CPU (oracle) 5e-5, PCG
+    iterates k <= 5 rel-l2 1e-4, same termination reason."""
+    from oracle import backpack_restated as bp
+    from oracle import pcg as oracle
+    from pytorchhessianfree_amd import modelprep
+    from pytorchhessianfree_amd.utils import vector_to_parameter_list
+
+    lam = 1.0
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=16, device="cpu", data_seed=5)
+    model.train()
+    params = list(model.parameters())
+    out = model(x)
+    loss = lossf(out, t)
+    grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, params, retain_graph=True)])
+
+    def mvp(v):
+        Gv = bp.ggn_vector_product_from_plist(loss, out, params, vector_to_parameter_list(v, params))
+        return torch.cat([g.reshape(-1) for g in Gv]).detach()
+
+    v = torch.randn(grad.numel(), generator=torch.Generator().manual_seed(2))
+    want = mvp(v)
+    kw = dict(max_iter=8, martens_conv_crit=True, store_x_at_iters=list(range(9)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ox, om, oreason = oracle.pcg(lambda u: mvp(u) + lam * u, -grad, **kw)
+
+    gm, (gx_, gt_), _ = tp.resnet18_mnist(batch_size=16, device=DEV, data_seed=5)
+    gm.train()
+    modelprep.prepare_model(gm)  # train-mode BatchNorm: the stock layers stay in charge
+    gp = list(gm.parameters())
+    go = gm(gx_)
+    gloss = lossf(go, gt_)
+    ggrad = curvature.flatten_into(torch.autograd.grad(gloss, gp, retain_graph=True), gp)
+    assert float((ggrad.cpu() - grad).norm() / grad.norm()) < 2e-5
+    op = curvature.GGNOperator(gloss, go, gp)
+    got = op(v.to(DEV)).cpu()
+    assert float((got - want).abs().max() / want.abs().max()) < 5e-5
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gx, gmm, greason = hf.cg(hf.DampedCurvature(op, lam), -ggrad, **kw)
+    assert greason == oreason and len(gx) == len(ox)
+    for i in range(1, min(len(gx), 6)):
+        rel = float((gx[i].cpu() - ox[i]).norm() / ox[i].norm())
+        assert rel < 1e-4, (i, rel)
+
+
 def test_allcnnc_hessian_step_with_diag_fisher_preconditioner():
     """BASELINE.json configs[3] shape: All-CNN-C (N = 1 387 108), Hessian curvature,
     diagonal empirical-Fisher preconditioner (exponent 0.75, autograd-style
