@@ -70,6 +70,10 @@ def parse():
                     help="implementation of the product's NHWC convolutions: own = the package's one-launch "
                          "deterministic kernels everywhere, miopen = MIOpen everywhere, auto = the faster one "
                          "per layer as measured (default)")
+    ap.add_argument("--engine", type=int, default=1,
+                    help="1: the fused curvature engine (own deterministic convolutions, BatchNorm fused, "
+                         "split-K slabs summed by the consumer kernel) where the model family is supported; "
+                         "0: the autograd product")
     ap.add_argument("--curvature", default="ggn", choices=["ggn", "hessian"],
                     help="curvature_opt of the reference (optimizer.py:25); hessian = BASELINE.json configs[3]")
     ap.add_argument("--precond", type=int, default=0,
@@ -195,6 +199,8 @@ def main():
     args = parse()
     if args.conv:
         os.environ["HF_CONV"] = args.conv
+    if not args.engine:
+        os.environ["HF_ENGINE"] = "0"
     if args.channels_last < 0:
         args.channels_last = int(args.workload in ("resnet18", "allcnnc"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -238,7 +244,7 @@ def main():
     def make_operator(loss, out, params):
         if hessian:
             return curvature.HessianOperator(loss, params, weight=weight, group=None)
-        return curvature.GGNOperator(loss, out, params, weight=weight, group=None)
+        return curvature.ggn_operator(loss, out, params, weight=weight, group=None)
 
     def build_operator(channels_last, overlap=False):
         model, x, t, lossf = problem(device)
@@ -250,6 +256,7 @@ def main():
             modelprep.fuse_residual_blocks(model)  # relu(bn(.)) / relu(bn(.) + identity) as one layer
             modelprep.fuse_bn_relu(model)          # relu(bn(.)) outside residual blocks (the stem)
             modelprep.skip_identity_pools(model)   # AdaptiveAvgPool2d(1) of a 1x1 map
+            modelprep._install_engine_hooks(model)  # lets curvature.ggn_operator use the fused engine
         params = [p for p in model.parameters() if p.requires_grad]
         # local gradient first (its graph is freed again: nothing may tie the parameters
         # to the default stream while the product is captured, see GraphedOperator)
@@ -435,7 +442,7 @@ def main():
                 "parallelism": f"dp{world} (batch sharded, one all-reduce of 4N bytes per matvec)"
                                + (f"; {world} ranks share {ndev} device(s) over gloo: functional run, not a "
                                   "scaling number" if oversubscribed else ""),
-                "matvec": getattr(op, "mode", "eager autograd")
+                "matvec": getattr(op, "mode", "eager autograd") + " [" + getattr(getattr(op, "op", op), "mode", "") + "]"
                           + ("; eval-BN fused (hf_chan_affine)" if args.fuse_bn else "")
                           + ("; conv tangent fused" if args.fuse_conv else "")
                           + "; convolutions: " + (os.environ.get("HF_CONV") or "auto") + "; " + layout

@@ -169,6 +169,11 @@ int hf_pcg_timing_read(hf_pcg_t* h, double* ms_k1, double* ms_k2, double* ms_k3,
 int hf_pack(void* dst, const void* const* srcs, const int64_t* numels,
             const int64_t* perm, int n_tensors, double scale, int mode, int dtype,
             void* stream);
+/* The same with `splits` (HOST, 2 per tensor, or NULL): {count, stride in elements} when source t
+ * is the sum of `count` split-K slabs (hf_conv2d_nhwc_*_slabs weight gradients). */
+int hf_pack_ex(void* dst, const void* const* srcs, const int64_t* numels, const int64_t* perm,
+               const int64_t* splits, int n_tensors, double scale, int mode, int dtype,
+               void* stream);
 
 /*
  * Multi-tensor scatter for the tangent sweep, the counterpart of hf_pack: tensor t is the
@@ -224,6 +229,32 @@ int hf_chan_affine(void* out, const void* a, const void* x, const void* mean,
                    const void* add, const void* mask_src, int relu_self, int64_t n,
                    int64_t c, int64_t hw, int channels_last, int64_t out_ld, int64_t add_ld,
                    int dtype, void* stream);
+/* hf_chan_affine with operand `a` given as `a_splits` split-K slabs `a_slab` elements apart
+ * (the tangent convolution's partial results, summed here in split order). */
+int hf_chan_affine_ex(void* out, const void* a, const void* x, const void* mean, const void* rstd,
+                      const void* w, const void* q, const void* r, const void* add,
+                      const void* mask_src, int relu_self, int64_t n, int64_t c, int64_t hw,
+                      int channels_last, int64_t out_ld, int64_t add_ld, int a_splits, int64_t a_slab,
+                      int dtype, void* stream);
+/* hf_chan_affine_bwd with both cotangents given as split-K slabs (data gradients of
+ * hf_conv2d_nhwc_backward_slabs), summed in split order while they are loaded; NHWC (or hw == 1).
+ * row_blocks > 1 (NHWC fp32, c % 4 == 0): the rows are shared among `row_blocks` workgroups per
+ * channel column -- c/4 workgroups cannot occupy 256 CUs -- and gw / gb receive `row_blocks`
+ * partial sums each, c elements apart, for hf_pack_ex to add up. */
+int hf_chan_affine_bwd_ex(void* gx, void* gw, void* gb, void* gres, const void* gy, int gy_splits,
+                          int64_t gy_slab, const void* gy2, int gy2_splits, int64_t gy2_slab,
+                          const void* x, const void* mean, const void* rstd, const void* w,
+                          const void* mask_src, int64_t n, int64_t c, int64_t hw, int channels_last,
+                          int row_blocks, int dtype, void* stream);
+/* Elementwise adjoint pre-pass of a fused BatchNorm(+add+ReLU) layer, NHWC [rows, c]:
+ *   g = (sum of gy_a's slabs + sum of gy_b's slabs) * [mask_src > 0];  g_out = g (nullable);
+ *   ga_out = g * w[c]*rstd[c] (nullable): the cotangent of the convolution output that
+ *   hf_conv2d_nhwc_backward* then consumes; the per-channel sums (hf_chan_affine_bwd with
+ *   gx = NULL) are taken of g_out.  gy_b, mask_src, w nullable. */
+int hf_bn_adjoint_pre(void* g_out, void* ga_out, const void* gy_a, int a_splits, int64_t a_slab,
+                      const void* gy_b, int b_splits, int64_t b_slab, const void* mask_src,
+                      const void* w, const void* rstd, int64_t rows, int64_t c, int dtype,
+                      void* stream);
 /* gy2 (nullable): a second cotangent, added to gy first -- the output of a residual block has
  * two consumers (the next block's first convolution and its identity / downsample branch);
  * handing their cotangents over separately saves the addition autograd would issue. */
@@ -258,6 +289,30 @@ int hf_conv2d_nhwc(int direction, void* out, const void* act, const void* mat, i
                    int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
                    int64_t act_ld, void* workspace, int64_t workspace_bytes, void* tickets,
                    int64_t n_tickets, int target_blocks, int dtype, void* stream);
+
+/*
+ * Consumer-side reduction ("slab") variants: split s of the reduction writes its partial result,
+ * in the output's own layout, to out + s*slab_stride and the launch ends there -- no workspace,
+ * tickets or fences; the launch boundary publishes the slabs and the kernel that CONSUMES the
+ * tensor sums them, in split order, in its prologue (hf_chan_affine_ex: operand `a`;
+ * hf_bn_adjoint_pre: both cotangents; hf_pack_ex: sources).  Measured 6-11 us per launch on the
+ * ResNet-18 shapes against 12-20 us with the in-launch reduction.  `hf_conv2d_nhwc_plan`
+ * returns the number of splits the launch will use (>= 1; pure host arithmetic), which the
+ * caller needs to size the slab buffer; pass it back as `splits`.  For direction 2 every slab
+ * must be zero-initialised once if the geometry has taps that never meet data.
+ */
+int hf_conv2d_nhwc_plan(int direction, int64_t n, int64_t h, int64_t w, int64_t c, int64_t k,
+                        int64_t r, int64_t s, int64_t stride_h, int64_t stride_w, int64_t pad_h,
+                        int64_t pad_w, int target_blocks);
+int hf_conv2d_nhwc_slabs(int direction, void* out, const void* act, const void* mat, int64_t n,
+                         int64_t h, int64_t w, int64_t c, int64_t k, int64_t r, int64_t s,
+                         int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
+                         int64_t act_ld, int splits, int64_t slab_stride, int dtype, void* stream);
+int hf_conv2d_nhwc_backward_slabs(void* dx, void* dw, const void* dy, const void* x, const void* w_t,
+                                  int64_t n, int64_t h, int64_t w, int64_t c, int64_t k, int64_t r,
+                                  int64_t s, int64_t stride_h, int64_t stride_w, int64_t pad_h,
+                                  int64_t pad_w, int splits_d, int64_t slab_stride_d, int splits_w,
+                                  int64_t slab_stride_w, int dtype, void* stream);
 
 /* Data gradient AND weight gradient of one layer (directions 1 and 2 above) in ONE launch:
  * both read dY [n,oh,ow,k], neither depends on the other.  dx [n,h,w,c]; dw [k][r][q][c]

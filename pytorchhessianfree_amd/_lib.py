@@ -99,6 +99,22 @@ SIGNATURES = {
                        + [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "hf_conv2d_nhwc_backward": (c_int, [c_void_p] * 5 + [c_int64] * 11
                                 + [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "hf_conv2d_nhwc_plan": (c_int, [c_int] + [c_int64] * 11 + [c_int]),
+    "hf_conv2d_nhwc_slabs": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int64] * 12
+                             + [c_int, c_int64, c_int, c_void_p]),
+    "hf_conv2d_nhwc_backward_slabs": (c_int, [c_void_p] * 5 + [c_int64] * 11
+                                      + [c_int, c_int64, c_int, c_int64, c_int, c_void_p]),
+    "hf_chan_affine_ex": (c_int, [c_void_p] * 10 + [c_int, c_int64, c_int64, c_int64, c_int, c_int64, c_int64,
+                                                     c_int, c_int64, c_int, c_void_p]),
+    "hf_chan_affine_bwd_ex": (c_int, [c_void_p] * 5 + [c_int, c_int64, c_void_p, c_int, c_int64] + [c_void_p] * 5
+                              + [c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "hf_bn_adjoint_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64,
+                                  c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "hf_pack_ex": (
+        c_int,
+        [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64),
+         ctypes.POINTER(c_int64), c_int, c_double, c_int, c_int, c_void_p],
+    ),
     "hf_softmax_ce_hvp": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int64, c_int, c_void_p]),
     "hf_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "hf_comm_create": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_char_p, c_int, c_int]),
@@ -332,3 +348,53 @@ def conv2d_nhwc_backward(dx, dw, dy, x, w_t, n, h, w, c, k, r, s, stride, paddin
             int(os.environ.get("HF_CONV_BLOCKS", "0")), HF_F32, current_stream_ptr(dx.device)),
         "hf_conv2d_nhwc_backward")
     return dx, dw
+
+
+def pack_ex(dst, tensors, perms, splits, scale=1.0):
+    """``pack`` for sources the caller describes itself: ``perms[i] = (I, H*W)`` marks tensor i as
+    stored (O, H, W, I); ``splits[i] = (count, stride)`` makes it the sum of ``count`` split-K
+    slabs ``stride`` elements apart (``hf_pack_ex``).  ``tensors[i]`` is the first slab."""
+    lib = load()
+    require_device_tensor(dst, "dst")
+    n = len(tensors)
+    ptrs = (c_void_p * n)()
+    numels = (c_int64 * n)()
+    perm = (c_int64 * (2 * n))()
+    spl = (c_int64 * (2 * n))()
+    total = 0
+    for i, t in enumerate(tensors):
+        if t.dtype != dst.dtype or t.device != dst.device:
+            raise RuntimeError("pack_ex: dtype/device mismatch")
+        ptrs[i] = t.data_ptr()
+        numels[i] = t.numel()
+        total += t.numel()
+        if i in perms:
+            perm[2 * i], perm[2 * i + 1] = perms[i]
+        spl[2 * i], spl[2 * i + 1] = splits.get(i, (1, 0))
+    if total != dst.numel():
+        raise RuntimeError(f"pack_ex: {total} source elements for a vector of {dst.numel()}")
+    check(
+        lib.hf_pack_ex(c_void_p(dst.data_ptr()), ptrs, numels, perm, spl, n, float(scale), 0,
+                       dtype_code(dst.dtype), current_stream_ptr(dst.device)),
+        "hf_pack_ex")
+    return dst
+
+
+def conv_plan(direction, n, h, w, c, k, r, s, stride, padding):
+    """Number of K-splits a slab-mode launch of this geometry uses (``hf_conv2d_nhwc_plan``)."""
+    sp = load().hf_conv2d_nhwc_plan(int(direction), n, h, w, c, k, r, s, stride[0], stride[1], padding[0],
+                                    padding[1], int(os.environ.get("HF_CONV_BLOCKS", "0")))
+    if sp < 1:
+        check(sp, "hf_conv2d_nhwc_plan")
+    return sp
+
+
+def conv2d_nhwc_slabs(direction, out, act, mat, n, h, w, c, k, r, s, stride, padding, splits, act_ld=0):
+    """Slab-mode launch: ``out`` is [splits, numel] -- slab s receives split s's partial result."""
+    check(
+        load().hf_conv2d_nhwc_slabs(
+            int(direction), c_void_p(out.data_ptr()), c_void_p(act.data_ptr()), c_void_p(mat.data_ptr()),
+            n, h, w, c, k, r, s, stride[0], stride[1], padding[0], padding[1], act_ld, int(splits),
+            out.shape[1], HF_F32, current_stream_ptr(out.device)),
+        "hf_conv2d_nhwc_slabs")
+    return out

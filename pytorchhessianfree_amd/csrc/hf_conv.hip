@@ -67,26 +67,44 @@ struct ConvArgs {
   unsigned char tap_r[MAX_TAPS], tap_s[MAX_TAPS];
   int tiles_m, tiles_n, splits, steps;  // steps = reduction steps in total
   int scalar;          // 1: channel counts not multiples of 4 -> element-wise gathers
+  int shift_h, shift_w;  // log2 of the strides when both are powers of two, else -1
+  int slabs;           // 1: split s writes its partial result, in the output's own layout, to
+  long long slab_stride;  //    out + s*slab_stride; the CONSUMER kernel sums the slabs in its prologue
 };
 
-// pixel index into the gathered tensor for row coordinates (n, y, x) and tap (r, q); -1 = padding
-__device__ __forceinline__ int gather_pixel(const ConvArgs& a, int n, int y, int x, int r, int q) {
+// Pixel index into the gathered tensor for row coordinates (n, y, x) and tap (r, q); `valid` is
+// false for padding.  Branch-free on purpose (selects only): the staging loads must not sit
+// behind per-lane branches, or hipcc stops pipelining them.
+__device__ __forceinline__ int gather_pixel(const ConvArgs& a, int n, int y, int x, int r, int q, bool& valid) {
   int sy, sx;
-  if (!a.dgrad) {
+  bool v = true;
+  if (!a.dgrad) {  // (uniform: a scalar branch)
     sy = y * a.stride_h - a.pad_h + r;
     sx = x * a.stride_w - a.pad_w + q;
   } else {
     const int ty = y + a.pad_h - r, tx = x + a.pad_w - q;
-    if (ty < 0 || tx < 0) return -1;
-    sy = ty / a.stride_h;
-    sx = tx / a.stride_w;
-    if (sy * a.stride_h != ty || sx * a.stride_w != tx) return -1;
+    if (a.shift_h >= 0) { sy = ty >> a.shift_h; sx = tx >> a.shift_w; }  // power-of-two strides
+    else { sy = ty / a.stride_h; sx = tx / a.stride_w; }
+    v = (ty >= 0) & (tx >= 0) & (sy * a.stride_h == ty) & (sx * a.stride_w == tx);
   }
-  if (sy < 0 || sy >= a.sh_ || sx < 0 || sx >= a.sw_) return -1;
-  return (n * a.sh_ + sy) * a.sw_ + sx;
+  v = v & ((unsigned)sy < (unsigned)a.sh_) & ((unsigned)sx < (unsigned)a.sw_);
+  valid = v;
+  return v ? (n * a.sh_ + sy) * a.sw_ + sx : 0;
 }
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// Staging loads the compiler does not see as loads: hipcc schedules the first use of a loaded
+// register right behind the load (and waits there), which serialises the three-deep prefetch
+// ring below.  Issued as inline asm they stay in flight until the matching HF_WAIT_SLOT, whose
+// "+v" operands tie every later use of the registers to the wait (cdna_hip_programming.md
+// section 5.7: count the queue by hand).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gload4(f32x4& dst, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+#define HF_WAIT_SLOT(N, A, B) \
+  asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(A[0]), "+v"(A[1]), "+v"(B[0]), "+v"(B[1]) : : "memory")
 
 // four consecutive floats of which only the first `valid` exist, no alignment assumed
 // (channel counts that are not multiples of 4: the 49-tap im2col of a 1-channel stem)
@@ -105,12 +123,13 @@ __device__ __forceinline__ void finish_tile(const ConvArgs& a, const f32x16& acc
                                             int row0, int col0, int row_lim, int col_lim, int ldc,
                                             int* flag_lds) {
   const int i = lane & 31, h = lane >> 5;
-  if (a.splits == 1) {
+  if (a.splits == 1 || a.slabs) {
+    float* dst = out_tile_base + (a.slabs ? (size_t)split * (size_t)a.slab_stride : 0);
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h, col = wn * 32 + i;
       if (row0 + row < row_lim && col0 + col < col_lim)
-        out_tile_base[(size_t)(row0 + row) * ldc + col0 + col] = acc[reg];
+        dst[(size_t)(row0 + row) * ldc + col0 + col] = acc[reg];
     }
     return;
   }
@@ -171,6 +190,7 @@ __device__ __forceinline__ void finish_tile(const ConvArgs& a, const f32x16& acc
 // ---------------------------------------------------------------------------------
 constexpr int LDS_FLOATS = 2 * 2 * BM * LDK + 4;  // NT: As + Bs (double-buffered) + the last-arriver flag
 
+template <bool SCALAR>
 __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int bid) {
   float (*As)[BM][LDK] = reinterpret_cast<float (*)[BM][LDK]>(lds);
   float (*Bs)[BN][LDK] = reinterpret_cast<float (*)[BN][LDK]>(lds + 2 * BM * LDK);
@@ -207,33 +227,43 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
     brow[u] = a.mat + (size_t)(bok[u] ? j : 0) * RS * a.cs;
   }
 
-  float4 ra[NU], rb[NU];
-  auto fetch = [&](int step) {
+  // Global -> register -> LDS staging with THREE steps of loads in flight: these kernels run
+  // one or two workgroups per CU on operands that the previous launch has just written (cold
+  // in this XCD's L2), so a step is bound by the ~2 us round trip unless several are
+  // outstanding.  LDS stays double-buffered; the register ring is three deep.
+  // (loads are issued UNCONDITIONALLY -- an out-of-range element reads a valid dummy address
+  // and is zeroed when the registers are written to LDS: a branch around a load makes hipcc
+  // drain the whole queue, vmcnt(0), before the next use; cdna_hip_programming.md trap 4c)
+  auto fetch = [&](int step, float4 (&ra)[NU], float4 (&rb)[NU]) -> unsigned {
     const int ti = step / csteps, c = (step - ti * csteps) * BK + 4 * kq;
     const int r = a.tap_r[ti], q = a.tap_s[ti];
     const bool cok = c < a.cs;
+    unsigned ok = 0;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (cok && rn[u] >= 0) {
-        const int pix = gather_pixel(a, rn[u], ry[u], rx[u], r, q);
-        if (pix >= 0) {
-          const float* p = a.src + (size_t)pix * a.cs_ld + c;
-          ra[u] = a.scalar ? ldg4s(p, a.cs - c) : ldg4(p);
-        }
+      bool va;
+      const int pix = gather_pixel(a, rn[u], ry[u], rx[u], r, q, va);
+      va = va & cok & (rn[u] >= 0);
+      const bool vb = cok & bok[u];
+      const float* pa = a.src + (va ? (size_t)pix * a.cs_ld + c : 0);
+      const float* pb = vb ? brow[u] + (size_t)(r * a.S + q) * a.cs + c : a.mat;
+      if (SCALAR) {
+        ra[u] = ldg4s(pa, va ? a.cs - c : 0);
+        rb[u] = ldg4s(pb, vb ? a.cs - c : 0);
+      } else {
+        ra[u] = ldg4(pa);
+        rb[u] = ldg4(pb);
       }
-      if (cok && bok[u]) {
-        const float* p = brow[u] + (size_t)(r * a.S + q) * a.cs + c;
-        rb[u] = a.scalar ? ldg4s(p, a.cs - c) : ldg4(p);
-      }
+      ok |= (va ? 1u : 0u) << (2 * u) | (vb ? 2u : 0u) << (2 * u);
     }
+    return ok;
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, const float4 (&ra)[NU], const float4 (&rb)[NU], unsigned ok) {
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      *reinterpret_cast<float4*>(&As[buf][lr + RPT * u][4 * kq]) = ra[u];
-      *reinterpret_cast<float4*>(&Bs[buf][lr + RPT * u][4 * kq]) = rb[u];
+      *reinterpret_cast<float4*>(&As[buf][lr + RPT * u][4 * kq]) = (ok >> (2 * u)) & 1u ? ra[u] : zero;
+      *reinterpret_cast<float4*>(&Bs[buf][lr + RPT * u][4 * kq]) = (ok >> (2 * u)) & 2u ? rb[u] : zero;
     }
   };
 
@@ -241,29 +271,94 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int i = lane & 31, h = lane >> 5;
-  if (j0 < j1) {
-    fetch(j0);
-    stash(0);
-    __syncthreads();
-    int cur = 0;
-    for (int j = j0; j < j1; ++j) {
-      const bool more = j + 1 < j1;
-      if (more) fetch(j + 1);
-      const float* ap = &As[cur][wm * 32 + i][HK * h];
-      const float* bp = &Bs[cur][wn * 32 + i][HK * h];
-      float av[HK], bv[HK];
+  auto compute = [&](int cur) {
+    const float* ap = &As[cur][wm * 32 + i][HK * h];
+    const float* bp = &Bs[cur][wn * 32 + i][HK * h];
+    float av[HK], bv[HK];
 #pragma unroll
-      for (int v = 0; v < HK / 4; ++v) {
-        *reinterpret_cast<float4*>(av + 4 * v) = *reinterpret_cast<const float4*>(ap + 4 * v);
-        *reinterpret_cast<float4*>(bv + 4 * v) = *reinterpret_cast<const float4*>(bp + 4 * v);
+    for (int v = 0; v < HK / 4; ++v) {
+      *reinterpret_cast<float4*>(av + 4 * v) = *reinterpret_cast<const float4*>(ap + 4 * v);
+      *reinterpret_cast<float4*>(bv + 4 * v) = *reinterpret_cast<const float4*>(bp + 4 * v);
+    }
+#pragma unroll
+    for (int s = 0; s < HK; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+  };
+  static_assert(NU == 2, "the hand-counted prefetch ring assumes 2 + 2 loads per step");
+  const int jl = j1 - 1;
+  int cur = 0;
+  if (!SCALAR) {
+    // hand-counted ring: always three steps (12 loads) in flight; steps beyond the split's range
+    // re-fetch step j1-1 and are never written to LDS, so the count at every wait is 8
+    auto fetch_v = [&](int step, f32x4 (&ra)[NU], f32x4 (&rb)[NU]) -> unsigned {
+      const int ti = step / csteps, c = (step - ti * csteps) * BK + 4 * kq;
+      const int r = a.tap_r[ti], q = a.tap_s[ti];
+      const bool cok = c < a.cs;
+      unsigned ok = 0;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        bool va;
+        const int pix = gather_pixel(a, rn[u], ry[u], rx[u], r, q, va);
+        va = va & cok & (rn[u] >= 0);
+        const bool vb = cok & bok[u];
+        gload4(ra[u], a.src + (va ? (size_t)pix * a.cs_ld + c : 0));
+        gload4(rb[u], vb ? brow[u] + (size_t)(r * a.S + q) * a.cs + c : a.mat);
+        ok |= (va ? 1u : 0u) << (2 * u) | (vb ? 2u : 0u) << (2 * u);
       }
+      return ok;
+    };
+    auto stash_v = [&](int buf, const f32x4 (&ra)[NU], const f32x4 (&rb)[NU], unsigned ok) {
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < HK; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
-      if (more) stash(cur ^ 1);
+      for (int u = 0; u < NU; ++u) {
+        *reinterpret_cast<f32x4*>(&As[buf][lr + RPT * u][4 * kq]) = (ok >> (2 * u)) & 1u ? ra[u] : zero;
+        *reinterpret_cast<f32x4*>(&Bs[buf][lr + RPT * u][4 * kq]) = (ok >> (2 * u)) & 2u ? rb[u] : zero;
+      }
+    };
+    f32x4 a0[NU], b0[NU], a1[NU], b1[NU], a2[NU], b2[NU];
+    unsigned k0 = 0, k1 = 0, k2 = 0;
+    if (j0 < j1) {
+      k0 = fetch_v(j0, a0, b0);
+      k1 = fetch_v(j0 + 1 < j1 ? j0 + 1 : jl, a1, b1);
+      k2 = fetch_v(j0 + 2 < j1 ? j0 + 2 : jl, a2, b2);
+      for (int j = j0; j < j1; j += 3) {
+        HF_WAIT_SLOT(8, a0, b0);
+        stash_v(cur, a0, b0, k0);
+        __syncthreads();
+        k0 = fetch_v(j + 3 < j1 ? j + 3 : jl, a0, b0);
+        compute(cur);
+        cur ^= 1;
+        HF_WAIT_SLOT(8, a1, b1);
+        if (j + 1 < j1) {
+          stash_v(cur, a1, b1, k1);
+          __syncthreads();
+          compute(cur);
+          cur ^= 1;
+        }
+        k1 = fetch_v(j + 4 < j1 ? j + 4 : jl, a1, b1);
+        HF_WAIT_SLOT(8, a2, b2);
+        if (j + 2 < j1) {
+          stash_v(cur, a2, b2, k2);
+          __syncthreads();
+          compute(cur);
+          cur ^= 1;
+        }
+        k2 = fetch_v(j + 5 < j1 ? j + 5 : jl, a2, b2);
+      }
+      HF_WAIT_SLOT(0, a0, b0);  // drain: the registers may be reused from here on
+      HF_WAIT_SLOT(0, a1, b1);
+      HF_WAIT_SLOT(0, a2, b2);
+    }
+  } else {
+    float4 a0[NU], b0[NU];
+    for (int j = j0; j < j1; ++j) {  // element-wise gathers: plain one-step loop
+      const unsigned k0 = fetch(j, a0, b0);
+      stash(cur, a0, b0, k0);
       __syncthreads();
+      compute(cur);
       cur ^= 1;
     }
   }
+  __syncthreads();  // the LDS array is reused below (last-arriver flag)
   finish_tile(a, acc, tile, split, wm, wn, lane, a.out, tile_m * BM, tile_n * BN, a.rows, a.nout, a.ldc,
               &flag);
 }
@@ -274,6 +369,7 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
 // ---------------------------------------------------------------------------------
 static_assert(2 * 2 * BK * LDT + 4 <= LDS_FLOATS, "TN tiles must fit the shared LDS array");
 
+template <bool SCALAR>
 __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int bid) {
   float (*As)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(lds);
   float (*Bs)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(lds + 2 * BK * LDT);
@@ -297,34 +393,37 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
   const bool aok = ka < a.kout, bkok = cb < a.cs;
 
   constexpr int TU = BK / 16;
-  float4 ra[TU], rb[TU];
-  auto fetch = [&](int step) {
+  auto fetch = [&](int step, float4 (&ra)[TU], float4 (&rb)[TU]) -> unsigned {
+    unsigned ok = 0;
 #pragma unroll
     for (int u = 0; u < TU; ++u) {
       const int m = step * BK + kr + 16 * u;
-      ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < a.rows) {
-        if (aok) {
-          const float* p = a.mat + (size_t)m * a.kout + ka;
-          ra[u] = a.scalar ? ldg4s(p, a.kout - ka) : ldg4(p);
-        }
-        if (bkok) {
-          const int xx = m % a.rw, tq = m / a.rw;
-          const int pix = gather_pixel(a, tq / a.rh, tq % a.rh, xx, r, q);
-          if (pix >= 0) {
-            const float* p = a.src + (size_t)pix * a.cs_ld + cb;
-            rb[u] = a.scalar ? ldg4s(p, a.cs - cb) : ldg4(p);
-          }
-        }
+      const bool mok = m < a.rows;
+      const int mm = mok ? m : 0;
+      const int xx = mm % a.rw, tq = mm / a.rw;
+      bool vb;
+      const int pix = gather_pixel(a, tq / a.rh, tq % a.rh, xx, r, q, vb);
+      vb = vb & mok & bkok;
+      const bool va = mok & aok;
+      const float* pa = a.mat + (va ? (size_t)m * a.kout + ka : 0);
+      const float* pb = a.src + (vb ? (size_t)pix * a.cs_ld + cb : 0);
+      if (SCALAR) {
+        ra[u] = ldg4s(pa, va ? a.kout - ka : 0);
+        rb[u] = ldg4s(pb, vb ? a.cs - cb : 0);
+      } else {
+        ra[u] = ldg4(pa);
+        rb[u] = ldg4(pb);
       }
+      ok |= (va ? 1u : 0u) << (2 * u) | (vb ? 2u : 0u) << (2 * u);
     }
+    return ok;
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, const float4 (&ra)[TU], const float4 (&rb)[TU], unsigned ok) {
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int u = 0; u < TU; ++u) {
-      *reinterpret_cast<float4*>(&As[buf][kr + 16 * u][4 * cq]) = ra[u];
-      *reinterpret_cast<float4*>(&Bs[buf][kr + 16 * u][4 * cq]) = rb[u];
+      *reinterpret_cast<float4*>(&As[buf][kr + 16 * u][4 * cq]) = (ok >> (2 * u)) & 1u ? ra[u] : zero;
+      *reinterpret_cast<float4*>(&Bs[buf][kr + 16 * u][4 * cq]) = (ok >> (2 * u)) & 2u ? rb[u] : zero;
     }
   };
 
@@ -332,49 +431,115 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
 #pragma unroll
   for (int x = 0; x < 16; ++x) acc[x] = 0.f;
   const int i = lane & 31, h = lane >> 5;
-  if (j0 < j1) {
-    fetch(j0);
-    stash(0);
-    __syncthreads();
-    int cur = 0;
-    for (int j = j0; j < j1; ++j) {
-      const bool more = j + 1 < j1;
-      if (more) fetch(j + 1);
-      float av[HK], bv[HK];
+  auto compute = [&](int cur) {
+    float av[HK], bv[HK];
 #pragma unroll
-      for (int s = 0; s < HK; ++s) {
-        av[s] = As[cur][HK * h + s][wm * 32 + i];
-        bv[s] = Bs[cur][HK * h + s][wn * 32 + i];
+    for (int s = 0; s < HK; ++s) {
+      av[s] = As[cur][HK * h + s][wm * 32 + i];
+      bv[s] = Bs[cur][HK * h + s][wn * 32 + i];
+    }
+#pragma unroll
+    for (int s = 0; s < HK; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+  };
+  static_assert(TU == 2, "the hand-counted prefetch ring assumes 2 + 2 loads per step");
+  const int jl = j1 - 1;
+  int cur = 0;
+  if (!SCALAR) {
+    auto fetch_v = [&](int step, f32x4 (&ra)[TU], f32x4 (&rb)[TU]) -> unsigned {
+      unsigned ok = 0;
+#pragma unroll
+      for (int u = 0; u < TU; ++u) {
+        const int m = step * BK + kr + 16 * u;
+        const bool mok = m < a.rows;
+        const int mm = mok ? m : 0;
+        const int xx = mm % a.rw, tq = mm / a.rw;
+        bool vb;
+        const int pix = gather_pixel(a, tq / a.rh, tq % a.rh, xx, r, q, vb);
+        vb = vb & mok & bkok;
+        const bool va = mok & aok;
+        gload4(ra[u], a.mat + (va ? (size_t)m * a.kout + ka : 0));
+        gload4(rb[u], a.src + (vb ? (size_t)pix * a.cs_ld + cb : 0));
+        ok |= (va ? 1u : 0u) << (2 * u) | (vb ? 2u : 0u) << (2 * u);
       }
+      return ok;
+    };
+    auto stash_v = [&](int buf, const f32x4 (&ra)[TU], const f32x4 (&rb)[TU], unsigned ok) {
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < HK; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
-      if (more) stash(cur ^ 1);
+      for (int u = 0; u < TU; ++u) {
+        *reinterpret_cast<f32x4*>(&As[buf][kr + 16 * u][4 * cq]) = (ok >> (2 * u)) & 1u ? ra[u] : zero;
+        *reinterpret_cast<f32x4*>(&Bs[buf][kr + 16 * u][4 * cq]) = (ok >> (2 * u)) & 2u ? rb[u] : zero;
+      }
+    };
+    f32x4 a0[TU], b0[TU], a1[TU], b1[TU], a2[TU], b2[TU];
+    unsigned k0 = 0, k1 = 0, k2 = 0;
+    if (j0 < j1) {
+      k0 = fetch_v(j0, a0, b0);
+      k1 = fetch_v(j0 + 1 < j1 ? j0 + 1 : jl, a1, b1);
+      k2 = fetch_v(j0 + 2 < j1 ? j0 + 2 : jl, a2, b2);
+      for (int j = j0; j < j1; j += 3) {
+        HF_WAIT_SLOT(8, a0, b0);
+        stash_v(cur, a0, b0, k0);
+        __syncthreads();
+        k0 = fetch_v(j + 3 < j1 ? j + 3 : jl, a0, b0);
+        compute(cur);
+        cur ^= 1;
+        HF_WAIT_SLOT(8, a1, b1);
+        if (j + 1 < j1) {
+          stash_v(cur, a1, b1, k1);
+          __syncthreads();
+          compute(cur);
+          cur ^= 1;
+        }
+        k1 = fetch_v(j + 4 < j1 ? j + 4 : jl, a1, b1);
+        HF_WAIT_SLOT(8, a2, b2);
+        if (j + 2 < j1) {
+          stash_v(cur, a2, b2, k2);
+          __syncthreads();
+          compute(cur);
+          cur ^= 1;
+        }
+        k2 = fetch_v(j + 5 < j1 ? j + 5 : jl, a2, b2);
+      }
+      HF_WAIT_SLOT(0, a0, b0);
+      HF_WAIT_SLOT(0, a1, b1);
+      HF_WAIT_SLOT(0, a2, b2);
+    }
+  } else {
+    float4 a0[TU], b0[TU];
+    for (int j = j0; j < j1; ++j) {
+      const unsigned k0 = fetch(j, a0, b0);
+      stash(cur, a0, b0, k0);
       __syncthreads();
+      compute(cur);
       cur ^= 1;
     }
   }
+  __syncthreads();
   // output element (k, tap, c) at (k*RS + tap)*cs + c: rows = k, "columns" = c within this tap
   float* base = a.out + (size_t)(r * a.S + q) * a.cs;
   finish_tile(a, acc, tile, split, wm, wn, lane, base, tile_m * BM, c0, a.kout, a.cs, a.R * a.S * a.cs,
               &flag);
 }
 
+template <bool SCALAR>
 __global__ __launch_bounds__(CT) void k_conv_nt(const ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  conv_nt_body(a, lds, blockIdx.x);
+  conv_nt_body<SCALAR>(a, lds, blockIdx.x);
 }
 
+template <bool SCALAR>
 __global__ __launch_bounds__(CT) void k_conv_tn(const ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  conv_tn_body(a, lds, blockIdx.x);
+  conv_tn_body<SCALAR>(a, lds, blockIdx.x);
 }
 
 // Data gradient AND weight gradient of one layer in ONE launch: both read the same dY,
 // neither depends on the other; the first `nblocks_d` workgroups run the NT body.
 __global__ __launch_bounds__(CT) void k_conv_dw(const ConvArgs d, const ConvArgs w, int nblocks_d) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  if ((int)blockIdx.x < nblocks_d) conv_nt_body(d, lds, blockIdx.x);
-  else conv_tn_body(w, lds, blockIdx.x - nblocks_d);
+  if ((int)blockIdx.x < nblocks_d) conv_nt_body<false>(d, lds, blockIdx.x);
+  else conv_tn_body<false>(w, lds, blockIdx.x - nblocks_d);
 }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -395,8 +560,18 @@ namespace {
 // hides (~1.0 us at BK = 32, ~1.5 us at BK = 64; the fp32 MFMA work itself is 0.43 / 0.86 us),
 // a split run pays ~3 us to publish and collect tickets plus ~0.15 us per slab the last
 // arriver sums; workgroups beyond two per CU queue.
-int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_bytes) {
+int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_bytes, bool slabs = false) {
   int64_t best = 1;
+  if (slabs && target_blocks <= 0) {
+    // no in-launch reduction: a split costs only its consumer one more read per element;
+    // split until ~2 workgroups per CU exist or a split is down to 2 steps
+    best = (512 + tiles - 1) / tiles;
+    if (best > steps / 2) best = steps / 2;
+    if (best > 32) best = 32;
+    if (best < 1) best = 1;
+    while (best > 1 && ((steps + best - 1) / best) * (best - 1) >= steps) --best;
+    return (int)best;
+  }
   if (target_blocks > 0) {
     best = (target_blocks + tiles - 1) / tiles;
     if (best > steps / 2) best = steps / 2;
@@ -413,16 +588,27 @@ int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_by
       if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
     }
   }
-  while (best > 1 && best * tiles * BM * BN * (int64_t)sizeof(float) > ws_bytes) --best;
+  while (!slabs && best > 1 && best * tiles * BM * BN * (int64_t)sizeof(float) > ws_bytes) --best;
   while (best > 1 && ((steps + best - 1) / best) * (best - 1) >= steps) --best;
   return (int)best;
 }
 
 // Fill `a` for one direction; returns the number of workgroups (<= 0: error code).
+void launch_one(int direction, const ConvArgs& a, int64_t blocks, hipStream_t stream) {
+  const dim3 grid((unsigned)blocks), block(CT);
+  if (direction <= 1) {
+    if (a.scalar) hipLaunchKernelGGL(k_conv_nt<true>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(k_conv_nt<false>, grid, block, 0, stream, a);
+  } else {
+    if (a.scalar) hipLaunchKernelGGL(k_conv_tn<true>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(k_conv_tn<false>, grid, block, 0, stream, a);
+  }
+}
+
 int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void* mat, int64_t n, int64_t h,
               int64_t w, int64_t c, int64_t k, int64_t r, int64_t s, int64_t stride_h, int64_t stride_w,
               int64_t pad_h, int64_t pad_w, int64_t act_ld, float* ws, int64_t ws_bytes, int* tickets,
-              int64_t n_tickets, int target_blocks) {
+              int64_t n_tickets, int target_blocks, int slab_splits = -1, int64_t slab_stride = 0) {
   const int64_t oh = (h + 2 * pad_h - r) / stride_h + 1, ow = (w + 2 * pad_w - s) / stride_w + 1;
   memset(&a, 0, sizeof(a));
   a.src = (const float*)act;
@@ -432,6 +618,12 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
   a.tickets = tickets;
   a.R = (int)r; a.S = (int)s;
   a.stride_h = (int)stride_h; a.stride_w = (int)stride_w; a.pad_h = (int)pad_h; a.pad_w = (int)pad_w;
+  a.shift_h = a.shift_w = -1;
+  if ((stride_h & (stride_h - 1)) == 0 && (stride_w & (stride_w - 1)) == 0) {
+    a.shift_h = a.shift_w = 0;
+    while ((1 << a.shift_h) < stride_h) ++a.shift_h;
+    while ((1 << a.shift_w) < stride_w) ++a.shift_w;
+  }
   // taps that meet data for at least one output position
   for (int rr = 0; rr < r; ++rr) {
     bool live_r = false;
@@ -470,6 +662,15 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
   }
   a.steps = (int)red_steps;
   const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
+  if (slab_splits >= 0) {  // consumer-side reduction: no workspace, no tickets
+    a.slabs = 1;
+    a.slab_stride = slab_stride;
+    int sp = slab_splits > 0 ? slab_splits : choose_splits(tiles, red_steps, target_blocks, 0, true);
+    if (sp > red_steps) sp = (int)red_steps;
+    while (sp > 1 && ((red_steps + sp - 1) / sp) * (sp - 1) >= red_steps) --sp;
+    a.splits = sp < 1 ? 1 : sp;
+    return tiles * a.splits;
+  }
   if (tiles > n_tickets) return HF_ERR_CAPACITY;
   a.splits = choose_splits(tiles, red_steps, target_blocks, ws_bytes);
   return tiles * a.splits;
@@ -512,8 +713,7 @@ int hf_conv2d_nhwc(int direction, void* out, const void* act, const void* mat, i
                                pad_w, act_ld, (float*)workspace, workspace_bytes, (int*)tickets, n_tickets,
                                target_blocks);
   if (blocks <= 0) return (int)blocks;
-  if (direction <= 1) hipLaunchKernelGGL(k_conv_nt, dim3((unsigned)blocks), dim3(CT), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(k_conv_tn, dim3((unsigned)blocks), dim3(CT), 0, (hipStream_t)stream, a);
+  launch_one(direction, a, blocks, (hipStream_t)stream);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }
@@ -538,6 +738,71 @@ int hf_conv2d_nhwc_backward(void* dx, void* dw, const void* dy, const void* x, c
                            (float*)((char*)workspace + half_ws), half_ws, (int*)tickets + half_t, half_t,
                            target_blocks);
   if (bw <= 0) return (int)bw;
+  if (d.scalar || g.scalar) return HF_ERR_ARG;  // the merged launch has the 16-byte gather variant only
+  hipLaunchKernelGGL(k_conv_dw, dim3((unsigned)(bd + bw)), dim3(CT), 0, (hipStream_t)stream, d, g, (int)bd);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+// ---- consumer-side reduction ("slab") variants ---------------------------------------
+// Split s writes its partial result, in the output's own layout, to out + s*slab_stride and
+// the launch ends there: the kernel that consumes the tensor sums the `splits` slabs in its
+// prologue (hf_chan_affine_ex, hf_bn_adjoint_pre, hf_pack_ex).  No workspace, no tickets, no
+// fences: the launch boundary publishes the slabs.
+int hf_conv2d_nhwc_plan(int direction, int64_t n, int64_t h, int64_t w, int64_t c, int64_t k, int64_t r,
+                        int64_t s, int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
+                        int target_blocks) {
+  if (direction < 0 || direction > 2) return HF_ERR_ARG;
+  if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || k <= 0 || r <= 0 || s <= 0 || stride_h <= 0 || stride_w <= 0 ||
+      pad_h < 0 || pad_w < 0 || r * s > MAX_TAPS)
+    return HF_ERR_ARG;
+  ConvArgs a;
+  float dummy = 0.f;
+  const int64_t blocks = setup(a, direction, &dummy, &dummy, &dummy, n, h, w, c, k, r, s, stride_h, stride_w,
+                               pad_h, pad_w, 0, nullptr, 0, nullptr, 0, target_blocks, 0, 0);
+  if (blocks <= 0) return (int)blocks;
+  return a.splits;
+}
+
+int hf_conv2d_nhwc_slabs(int direction, void* out, const void* act, const void* mat, int64_t n, int64_t h,
+                         int64_t w, int64_t c, int64_t k, int64_t r, int64_t s, int64_t stride_h,
+                         int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t act_ld, int splits,
+                         int64_t slab_stride, int dtype, void* stream) {
+  if (direction < 0 || direction > 2 || splits < 1 || slab_stride < 0) return HF_ERR_ARG;
+  alignas(16) float dummy_ws[4];
+  const int rc = check_common(out, act, mat, dummy_ws, dummy_ws, dtype, n, h, w, c, k, r, s, stride_h, stride_w,
+                              pad_h, pad_w);
+  if (rc) return rc;
+  ConvArgs a;
+  const int64_t blocks = setup(a, direction, out, act, mat, n, h, w, c, k, r, s, stride_h, stride_w, pad_h,
+                               pad_w, act_ld, nullptr, 0, nullptr, 0, 0, splits, slab_stride);
+  if (blocks <= 0) return (int)blocks;
+  if (a.splits != splits) return HF_ERR_ARG;  // ask hf_conv2d_nhwc_plan first
+  launch_one(direction, a, blocks, (hipStream_t)stream);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_conv2d_nhwc_backward_slabs(void* dx, void* dw, const void* dy, const void* x, const void* w_t,
+                                  int64_t n, int64_t h, int64_t w, int64_t c, int64_t k, int64_t r,
+                                  int64_t s, int64_t stride_h, int64_t stride_w, int64_t pad_h,
+                                  int64_t pad_w, int splits_d, int64_t slab_stride_d, int splits_w,
+                                  int64_t slab_stride_w, int dtype, void* stream) {
+  if (!dx || !dw || !x || splits_d < 1 || splits_w < 1) return HF_ERR_ARG;
+  alignas(16) float dummy_ws[4];
+  int rc = check_common(dx, dy, w_t, dummy_ws, dummy_ws, dtype, n, h, w, c, k, r, s, stride_h, stride_w, pad_h,
+                        pad_w);
+  if (rc) return rc;
+  if (!aligned16(x) || !aligned16(dw)) return HF_ERR_ALIGN;
+  ConvArgs d, g;
+  const int64_t bd = setup(d, 1, dx, dy, w_t, n, h, w, c, k, r, s, stride_h, stride_w, pad_h, pad_w, 0, nullptr,
+                           0, nullptr, 0, 0, splits_d, slab_stride_d);
+  if (bd <= 0) return (int)bd;
+  const int64_t bw = setup(g, 2, dw, x, dy, n, h, w, c, k, r, s, stride_h, stride_w, pad_h, pad_w, 0, nullptr, 0,
+                           nullptr, 0, 0, splits_w, slab_stride_w);
+  if (bw <= 0) return (int)bw;
+  if (d.splits != splits_d || g.splits != splits_w) return HF_ERR_ARG;
+  if (d.scalar || g.scalar) return HF_ERR_ARG;  // the merged launch has the 16-byte gather variant only
   hipLaunchKernelGGL(k_conv_dw, dim3((unsigned)(bd + bw)), dim3(CT), 0, (hipStream_t)stream, d, g, (int)bd);
   HF_HIP(hipGetLastError());
   return HF_OK;

@@ -552,7 +552,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_p(
 // ---------------------------------------------------------------------------
 // multi-tensor gather (pointer table passed by value)
 // ---------------------------------------------------------------------------
-constexpr int PACK_MAXT = 96;
+constexpr int PACK_MAXT = 64;   // (the argument struct must stay below the 4 KB kernarg limit)
 constexpr int PACK_CHUNK = BLOCK * 16;  // elements per block
 struct PackArgs {
   const void* src[PACK_MAXT];
@@ -564,6 +564,10 @@ struct PackArgs {
   int perm_I[PACK_MAXT];
   int perm_HW[PACK_MAXT];
   int chunk[PACK_MAXT];  // elements per block of tensor t (a whole number of [I, HW] slabs when tiled)
+  // split-K partial results: the source is the SUM of nsplit[t] arrays, split_stride[t] elements apart
+  // (the weight gradients of hf_conv2d_nhwc_*_slabs: combined here, in split order, while gathering)
+  int nsplit[PACK_MAXT];
+  long long split_stride[PACK_MAXT];
   int nt;
 };
 constexpr int TILE_BYTES = 32768;  // LDS staging of the layout-permuting paths
@@ -586,10 +590,57 @@ __global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackA
     if (a.blk_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
   }
   const T* __restrict__ src = reinterpret_cast<const T*>(a.src[lo]);
+  const int nsp = a.nsplit[lo];
   const long long numel = a.numel[lo];
   const long long j0 = (long long)(blockIdx.x - a.blk_start[lo]) * a.chunk[lo];
   const long long j1 = (j0 + a.chunk[lo] < numel) ? j0 + a.chunk[lo] : numel;
   T* __restrict__ out = dst + a.dst_off[lo];
+  if (nsp > 1) {
+    // source = sum of nsp split-K slabs (the weight gradients of layers whose reduction had to
+    // be split, the BatchNorm adjoint's per-row-block sums); combined in split order.  Walked
+    // in SOURCE order (coalesced loads, 4 elements x 2 slabs in flight per lane: these blocks
+    // are latency-bound), un-permuted on the store side.
+    const long long sps = a.split_stride[lo];
+    const unsigned I = (unsigned)a.perm_I[lo], HW = (unsigned)a.perm_HW[lo], slab = I * HW;
+    constexpr int E = 4;
+    for (long long base = j0 + threadIdx.x; base < j1; base += (long long)BLOCK * E) {
+      T acc[E];
+      long long e[E];
+#pragma unroll
+      for (int k = 0; k < E; ++k) {
+        e[k] = base + (long long)k * BLOCK;
+        acc[k] = e[k] < j1 ? src[e[k]] : (T)0;
+      }
+      int sp = 1;
+      for (; sp + 2 <= nsp; sp += 2) {
+        T t0[E], t1[E];
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+          t0[k] = e[k] < j1 ? src[e[k] + (long long)sp * sps] : (T)0;
+          t1[k] = e[k] < j1 ? src[e[k] + (long long)(sp + 1) * sps] : (T)0;
+        }
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc[k] = (acc[k] + t0[k]) + t1[k];
+      }
+      if (sp < nsp) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc[k] += e[k] < j1 ? src[e[k] + (long long)sp * sps] : (T)0;
+      }
+#pragma unroll
+      for (int k = 0; k < E; ++k) {
+        if (e[k] >= j1) continue;
+        long long j = e[k];
+        if (I > 0) {  // source (o, hw, i) -> destination (o, i, hw)
+          const long long o = j / slab;
+          const unsigned rem = (unsigned)(j - o * slab);
+          const unsigned hw = rem / I, i = rem - hw * I;
+          j = o * slab + (long long)i * HW + hw;
+        }
+        out[j] = pack_op<T, OP>(out[j], acc[k], scale);
+      }
+    }
+    return;
+  }
   if (a.perm_I[lo] > 0) {
     // dst index j = (o*I + i)*HW + hw   <-   src index (o*HW + hw)*I + i
     const unsigned I = (unsigned)a.perm_I[lo], HW = (unsigned)a.perm_HW[lo], slab = I * HW;
@@ -758,7 +809,7 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine(
     const T* __restrict__ mean, const T* __restrict__ rstd, const T* __restrict__ w,
     const T* __restrict__ q, const T* __restrict__ r, const T* __restrict__ add,
     const T* __restrict__ mask_src, int relu_self, I total, I C, I HW, int nhwc, I out_ld,
-    I add_ld) {
+    I add_ld, int a_splits, long long a_slab) {
   // out_ld / add_ld != 0: that operand is the first-C-channels slice of a wider buffer --
   // NHWC: element (row, c) at row*ld + c; NCHW: (n, c, hw) at n*ld + c*HW + hw.
   const I CHW = C * HW;
@@ -766,7 +817,19 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine(
     const I c = (nhwc || HW == 1 ? i : i / HW) % C;  // NHWC: the channel is the fastest index
     const T rs = rstd[c];
     T acc = (T)0;
-    if (a) acc = a[i] * ((w ? w[c] : (T)1) * rs);
+    if (a) {
+      T av = a[i];
+      int sp = 1;
+      for (; sp + 8 <= a_splits; sp += 8) {  // split-K slabs: eight loads in flight, summed in split order
+        T t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t8[u] = a[(long long)(sp + u) * a_slab + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) av += t8[u];
+      }
+      for (; sp < a_splits; ++sp) av += a[(long long)sp * a_slab + i];
+      acc = av * ((w ? w[c] : (T)1) * rs);
+    }
     if (q) acc += ((x[i] - mean[c]) * rs) * q[c];
     if (r) acc += r[c];
     I outer = 0;
@@ -786,7 +849,8 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
     T* __restrict__ gx, T* __restrict__ gw, T* __restrict__ gb, T* __restrict__ gres,
     const T* __restrict__ gy, const T* __restrict__ gy2, const T* __restrict__ x,
     const T* __restrict__ mean, const T* __restrict__ rstd, const T* __restrict__ w,
-    const T* __restrict__ mask_src, I N, I C, I HW) {
+    const T* __restrict__ mask_src, I N, I C, I HW, int s1 = 1, long long l1 = 0, int s2 = 1,
+    long long l2 = 0) {
   __shared__ double lds[2 * WAVES];
   constexpr int GROUPS = BLOCK / TPC;
   const I c = (I)blockIdx.x * GROUPS + threadIdx.x / TPC;
@@ -809,7 +873,11 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
           const I n = HW == 1 ? e : e / HW;
           idx[t] = (n * C + c) * HW + (e - n * HW);
           g[t] = gy[idx[t]];
-          if (gy2) h[t] = gy2[idx[t]];
+          for (int sp = 1; sp < s1; ++sp) g[t] += gy[(long long)sp * l1 + idx[t]];  // split-K slabs
+          if (gy2) {
+            h[t] = gy2[idx[t]];
+            for (int sp = 1; sp < s2; ++sp) h[t] += gy2[(long long)sp * l2 + idx[t]];
+          }
           if (mask_src) m[t] = mask_src[idx[t]];
           if (x) xv[t] = x[idx[t]];
         }
@@ -853,10 +921,16 @@ __global__ __launch_bounds__(BS) void k_chan_affine_bwd_nhwc(
     T* __restrict__ gx, T* __restrict__ gw, T* __restrict__ gb, T* __restrict__ gres,
     const T* __restrict__ gy, const T* __restrict__ gy2, const T* __restrict__ x,
     const T* __restrict__ mean, const T* __restrict__ rstd, const T* __restrict__ w,
-    const T* __restrict__ mask_src, I rows, I C) {
+    const T* __restrict__ mask_src, I rows, I C, int s1 = 1, long long l1 = 0, int s2 = 1,
+    long long l2 = 0, int row_blocks = 1) {
   __shared__ double lds[2 * W * (BS / 64)];
   struct alignas(sizeof(T) * W) Col { T e[W]; };
-  const I c0 = (I)blockIdx.x * W;
+  // row_blocks > 1: block (q, rb) owns channel column q and the rb-th share of the rows and
+  // writes its per-channel partial sums to gw/gb + rb*C (hf_pack_ex adds the shares up)
+  const I cq = (I)blockIdx.x % (C / W), rb = (I)blockIdx.x / (C / W);
+  const I c0 = cq * W;
+  const I rpb = (rows + (I)row_blocks - 1) / (I)row_blocks;
+  const I row_lo = rb * rpb, row_hi = (row_lo + rpb < rows) ? row_lo + rpb : rows;
   T rs[W], mu[W], sc[W];
 #pragma unroll
   for (int k = 0; k < W; ++k) {
@@ -870,15 +944,27 @@ __global__ __launch_bounds__(BS) void k_chan_affine_bwd_nhwc(
   // rows are visited ITER at a time with all loads issued before the first use: these
   // activation-sized kernels are latency-bound, one round trip per 8 rows instead of one each
   constexpr int ITER = 8;
-  for (I r0 = threadIdx.x; r0 < rows; r0 += (I)BS * ITER) {
+  for (I r0 = row_lo + threadIdx.x; r0 < row_hi; r0 += (I)BS * ITER) {
     Col g[ITER], h[ITER], xv[ITER], m[ITER];
 #pragma unroll
     for (int t = 0; t < ITER; ++t) {
       const I r = r0 + (I)t * BS;
-      if (r < rows) {
+      if (r < row_hi) {
         const I idx = r * C + c0;
         g[t] = *reinterpret_cast<const Col*>(gy + idx);
-        if (gy2) h[t] = *reinterpret_cast<const Col*>(gy2 + idx);
+        for (int sp = 1; sp < s1; ++sp) {  // split-K slabs of the cotangent, in split order
+          const Col v = *reinterpret_cast<const Col*>(gy + (long long)sp * l1 + idx);
+#pragma unroll
+          for (int k = 0; k < W; ++k) g[t].e[k] += v.e[k];
+        }
+        if (gy2) {
+          h[t] = *reinterpret_cast<const Col*>(gy2 + idx);
+          for (int sp = 1; sp < s2; ++sp) {
+            const Col v = *reinterpret_cast<const Col*>(gy2 + (long long)sp * l2 + idx);
+#pragma unroll
+            for (int k = 0; k < W; ++k) h[t].e[k] += v.e[k];
+          }
+        }
         if (x) xv[t] = *reinterpret_cast<const Col*>(x + idx);
         if (mask_src) m[t] = *reinterpret_cast<const Col*>(mask_src + idx);
       }
@@ -886,7 +972,7 @@ __global__ __launch_bounds__(BS) void k_chan_affine_bwd_nhwc(
 #pragma unroll
     for (int t = 0; t < ITER; ++t) {
       const I r = r0 + (I)t * BS;
-      if (r < rows) {
+      if (r < row_hi) {
         const I idx = r * C + c0;
         if (gy2) {
 #pragma unroll
@@ -915,8 +1001,36 @@ __global__ __launch_bounds__(BS) void k_chan_affine_bwd_nhwc(
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-      if (gw) gw[c0 + k] = (T)acc[2 * k];
-      if (gb) gb[c0 + k] = (T)acc[2 * k + 1];
+      if (gw) gw[rb * C + c0 + k] = (T)acc[2 * k];
+      if (gb) gb[rb * C + c0 + k] = (T)acc[2 * k + 1];
+    }
+  }
+}
+
+// Adjoint pre-pass of a fused eval-BatchNorm(+add+ReLU) layer in NHWC [rows, C], elementwise:
+//   g  = (sum_s gyA[s] + sum_s gyB[s]) * [mask_src > 0]      (the two consumers' cotangents,
+//                                                              each possibly split-K slabs)
+//   g_out = g (the residual branch's cotangent, and what the per-channel sums are taken of)
+//   ga_out = g * w[c]*rstd[c]                                 (cotangent of the convolution output)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_bn_adjoint_pre(
+    T* __restrict__ g_out, T* __restrict__ ga_out, const T* __restrict__ gyA, int a_splits,
+    long long a_slab, const T* __restrict__ gyB, int b_splits, long long b_slab,
+    const T* __restrict__ mask_src, const T* __restrict__ w, const T* __restrict__ rstd,
+    unsigned total, unsigned C) {
+  for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < total; i += gridDim.x * BLOCK) {
+    T g = gyA[i];
+    for (int sp = 1; sp < a_splits; ++sp) g += gyA[(long long)sp * a_slab + i];
+    if (gyB) {
+      T h = gyB[i];
+      for (int sp = 1; sp < b_splits; ++sp) h += gyB[(long long)sp * b_slab + i];
+      g = g + h;
+    }
+    if (mask_src) g = mask_src[i] > (T)0 ? g : (T)0;
+    if (g_out) g_out[i] = g;
+    if (ga_out) {
+      const unsigned c = i % C;
+      ga_out[i] = g * ((w ? w[c] : (T)1) * rstd[c]);
     }
   }
 }
@@ -1570,7 +1684,8 @@ int hf_pcg_timing_read(hf_pcg_t* h, double* ms_k1, double* ms_k2, double* ms_k3,
 // ---- vector helpers -------------------------------------------------------
 template <typename T>
 static int pack_impl(void* dst, const void* const* srcs, const int64_t* numels,
-                     const int64_t* perm, int nt, double scale, int mode, hipStream_t s) {
+                     const int64_t* perm, const int64_t* splits, int nt, double scale, int mode,
+                     hipStream_t s) {
   int t = 0;
   long long off = 0;
   while (t < nt) {
@@ -1585,13 +1700,20 @@ static int pack_impl(void* dst, const void* const* srcs, const int64_t* numels,
         a.dst_off[k] = off;
         a.numel[k] = numels[t];
         a.chunk[k] = PACK_CHUNK;
+        a.nsplit[k] = 1;
+        if (splits) {
+          if (splits[2 * t] < 1 || (splits[2 * t] > 1 && splits[2 * t + 1] < numels[t])) return HF_ERR_ARG;
+          a.nsplit[k] = (int)splits[2 * t];
+          a.split_stride[k] = splits[2 * t + 1];
+          if (a.nsplit[k] > 1) a.chunk[k] = BLOCK * 4;  // latency-bound blocks: more of them
+        }
         if (perm && perm[2 * t] > 0) {
           const int64_t I = perm[2 * t], HW = perm[2 * t + 1];
           if (HW <= 0 || numels[t] % (I * HW) != 0 || I * HW > 0x7fffffffLL) return HF_ERR_ARG;
           a.perm_I[k] = (int)I;
           a.perm_HW[k] = (int)HW;
           const int64_t slabs = (int64_t)(TILE_BYTES / sizeof(T)) / (I * HW + HW);
-          if (slabs >= 1) a.chunk[k] = (int)(slabs * I * HW);  // LDS-tiled path
+          if (slabs >= 1 && !(splits && splits[2 * t] > 1)) a.chunk[k] = (int)(slabs * I * HW);  // LDS-tiled path
         }
         a.blk_start[k] = blocks;
         blocks += (int)((numels[t] + a.chunk[k] - 1) / a.chunk[k]);
@@ -1614,11 +1736,16 @@ static int pack_impl(void* dst, const void* const* srcs, const int64_t* numels,
 
 int hf_pack(void* dst, const void* const* srcs, const int64_t* numels, const int64_t* perm,
             int n_tensors, double scale, int mode, int dtype, void* stream) {
+  return hf_pack_ex(dst, srcs, numels, perm, nullptr, n_tensors, scale, mode, dtype, stream);
+}
+
+int hf_pack_ex(void* dst, const void* const* srcs, const int64_t* numels, const int64_t* perm,
+               const int64_t* splits, int n_tensors, double scale, int mode, int dtype, void* stream) {
   if (!dst || !srcs || !numels || n_tensors < 0 || (mode != 0 && mode != 1)) return HF_ERR_ARG;
   if (dtype == HF_F32)
-    return pack_impl<float>(dst, srcs, numels, perm, n_tensors, scale, mode, (hipStream_t)stream);
+    return pack_impl<float>(dst, srcs, numels, perm, splits, n_tensors, scale, mode, (hipStream_t)stream);
   if (dtype == HF_F64)
-    return pack_impl<double>(dst, srcs, numels, perm, n_tensors, scale, mode, (hipStream_t)stream);
+    return pack_impl<double>(dst, srcs, numels, perm, splits, n_tensors, scale, mode, (hipStream_t)stream);
   return HF_ERR_ARG;
 }
 
@@ -1722,6 +1849,31 @@ int hf_axpy_out(void* out, const void* a, const void* sv, double alpha, int64_t 
   return HF_OK;
 }
 
+int hf_bn_adjoint_pre(void* g_out, void* ga_out, const void* gy_a, int a_splits, int64_t a_slab,
+                      const void* gy_b, int b_splits, int64_t b_slab, const void* mask_src, const void* w,
+                      const void* rstd, int64_t rows, int64_t c, int dtype, void* stream) {
+  if (!gy_a || (!g_out && !ga_out) || rows <= 0 || c <= 0 || a_splits < 1 || b_splits < 1) return HF_ERR_ARG;
+  if (ga_out && !rstd) return HF_ERR_ARG;
+  if ((a_splits > 1 && a_slab <= 0) || (gy_b && b_splits > 1 && b_slab <= 0)) return HF_ERR_ARG;
+  const long long total = (long long)rows * c;
+  if (total > 0x7fffffffLL) return HF_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == HF_F32)
+    hipLaunchKernelGGL((k_bn_adjoint_pre<float>), dim3(wide_grid(total)), dim3(BLOCK), 0, s, (float*)g_out,
+                       (float*)ga_out, (const float*)gy_a, a_splits, (long long)a_slab, (const float*)gy_b,
+                       b_splits, (long long)b_slab, (const float*)mask_src, (const float*)w, (const float*)rstd,
+                       (unsigned)total, (unsigned)c);
+  else if (dtype == HF_F64)
+    hipLaunchKernelGGL((k_bn_adjoint_pre<double>), dim3(wide_grid(total)), dim3(BLOCK), 0, s, (double*)g_out,
+                       (double*)ga_out, (const double*)gy_a, a_splits, (long long)a_slab, (const double*)gy_b,
+                       b_splits, (long long)b_slab, (const double*)mask_src, (const double*)w,
+                       (const double*)rstd, (unsigned)total, (unsigned)c);
+  else
+    return HF_ERR_ARG;
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
 int hf_softmax_ce_hvp(void* out, const void* p, const void* v, double scale, int64_t rows,
                       int64_t cols, int dtype, void* stream) {
   if (!out || !p || !v || rows <= 0 || cols <= 0 || cols > 0x7fffffffLL || rows > 0x7fffffffLL)
@@ -1744,24 +1896,35 @@ static void launch_chan_affine(hipStream_t s, void* out, const void* a, const vo
                                const void* mean, const void* rstd, const void* w, const void* q,
                                const void* r, const void* add, const void* mask_src,
                                int relu_self, long long total, long long c, long long hw,
-                               int nhwc, long long out_ld, long long add_ld) {
+                               int nhwc, long long out_ld, long long add_ld, int a_splits = 1,
+                               long long a_slab = 0) {
   if (2 * total < 0x7fffffffLL)  // strided operands reach at most 2*total
     hipLaunchKernelGGL((k_chan_affine<T, unsigned>), dim3(wide_grid(total)), dim3(BLOCK), 0, s,
                        (T*)out, (const T*)a, (const T*)x, (const T*)mean, (const T*)rstd,
                        (const T*)w, (const T*)q, (const T*)r, (const T*)add, (const T*)mask_src,
                        relu_self, (unsigned)total, (unsigned)c, (unsigned)hw, nhwc,
-                       (unsigned)out_ld, (unsigned)add_ld);
+                       (unsigned)out_ld, (unsigned)add_ld, a_splits, a_slab);
   else
     hipLaunchKernelGGL((k_chan_affine<T, long long>), dim3(wide_grid(total)), dim3(BLOCK), 0, s,
                        (T*)out, (const T*)a, (const T*)x, (const T*)mean, (const T*)rstd,
                        (const T*)w, (const T*)q, (const T*)r, (const T*)add, (const T*)mask_src,
-                       relu_self, total, c, hw, nhwc, out_ld, add_ld);
+                       relu_self, total, c, hw, nhwc, out_ld, add_ld, a_splits, a_slab);
 }
 
 int hf_chan_affine(void* out, const void* a, const void* x, const void* mean, const void* rstd,
                    const void* w, const void* q, const void* r, const void* add,
                    const void* mask_src, int relu_self, int64_t n, int64_t c, int64_t hw,
                    int channels_last, int64_t out_ld, int64_t add_ld, int dtype, void* stream) {
+  return hf_chan_affine_ex(out, a, x, mean, rstd, w, q, r, add, mask_src, relu_self, n, c, hw, channels_last,
+                           out_ld, add_ld, 1, 0, dtype, stream);
+}
+
+int hf_chan_affine_ex(void* out, const void* a, const void* x, const void* mean, const void* rstd,
+                      const void* w, const void* q, const void* r, const void* add,
+                      const void* mask_src, int relu_self, int64_t n, int64_t c, int64_t hw,
+                      int channels_last, int64_t out_ld, int64_t add_ld, int a_splits, int64_t a_slab,
+                      int dtype, void* stream) {
+  if (a_splits < 1 || (a_splits > 1 && (!a || a_slab <= 0))) return HF_ERR_ARG;
   if (!out || !rstd || n <= 0 || c <= 0 || hw <= 0) return HF_ERR_ARG;
   if (q && (!x || !mean)) return HF_ERR_ARG;
   // a leading dimension is that of a buffer with MORE channels: >= 2x would be the
@@ -1774,10 +1937,10 @@ int hf_chan_affine(void* out, const void* a, const void* x, const void* mean, co
   hipStream_t s = (hipStream_t)stream;
   if (dtype == HF_F32)
     launch_chan_affine<float>(s, out, a, x, mean, rstd, w, q, r, add, mask_src, relu_self, total, c, hw,
-                              channels_last, out_ld, add_ld);
+                              channels_last, out_ld, add_ld, a_splits, a_slab);
   else if (dtype == HF_F64)
     launch_chan_affine<double>(s, out, a, x, mean, rstd, w, q, r, add, mask_src, relu_self, total, c, hw,
-                               channels_last, out_ld, add_ld);
+                               channels_last, out_ld, add_ld, a_splits, a_slab);
   else
     return HF_ERR_ARG;
   HF_HIP(hipGetLastError());
@@ -1788,16 +1951,18 @@ template <typename T>
 static void launch_chan_affine_bwd(hipStream_t s, void* gx, void* gw, void* gb, void* gres,
                                    const void* gy, const void* gy2, const void* x, const void* mean,
                                    const void* rstd, const void* w, const void* mask_src,
-                                   long long n, long long c, long long hw, int nhwc) {
+                                   long long n, long long c, long long hw, int nhwc, int s1 = 1,
+                                   long long l1 = 0, int s2 = 1, long long l2 = 0, int row_blocks = 1) {
   const long long total = n * c * hw;
   if (nhwc && hw > 1) {
     const bool vec = c % 4 == 0 && aligned16(gy) && (!gy2 || aligned16(gy2)) && (!x || aligned16(x)) &&
                      (!mask_src || aligned16(mask_src)) &&
                      (!gx || aligned16(gx)) && (!gres || aligned16(gres)) && sizeof(T) == 4;
 #define HF_BWD_CL(I, W, BS)                                                                        \
-  hipLaunchKernelGGL((k_chan_affine_bwd_nhwc<T, I, W, BS>), dim3((unsigned)(c / W)), dim3(BS), 0, s, \
+  hipLaunchKernelGGL((k_chan_affine_bwd_nhwc<T, I, W, BS>), dim3((unsigned)(c / W * row_blocks)), dim3(BS), 0, s, \
                      (T*)gx, (T*)gw, (T*)gb, (T*)gres, (const T*)gy, (const T*)gy2, (const T*)x,    \
-                     (const T*)mean, (const T*)rstd, (const T*)w, (const T*)mask_src, (I)(n * hw), (I)c)
+                     (const T*)mean, (const T*)rstd, (const T*)w, (const T*)mask_src, (I)(n * hw), (I)c,  \
+                     s1, l1, s2, l2, row_blocks)
     // (512- and 1024-thread blocks for the early layers' tall reductions were measured: no
     // gain; a row-major kernel with a two-level reduction (block partials + last-ticket block)
     // was correct but slower end to end (885 vs 915 matvecs/s): its extra dependent round
@@ -1814,7 +1979,8 @@ static void launch_chan_affine_bwd(hipStream_t s, void* gx, void* gw, void* gb, 
 #define HF_BWD(I, TPC, GRID)                                                                    \
   hipLaunchKernelGGL((k_chan_affine_bwd<T, I, TPC>), dim3((unsigned)(GRID)), dim3(BLOCK), 0, s,  \
                      (T*)gx, (T*)gw, (T*)gb, (T*)gres, (const T*)gy, (const T*)gy2, (const T*)x,  \
-                     (const T*)mean, (const T*)rstd, (const T*)w, (const T*)mask_src, (I)n, (I)c, (I)hw)
+                     (const T*)mean, (const T*)rstd, (const T*)w, (const T*)mask_src, (I)n, (I)c, (I)hw,  \
+                     s1, l1, s2, l2)
   if (total < 0x7fffffffLL) {
     if (small) HF_BWD(unsigned, 64, (c + 3) / 4); else HF_BWD(unsigned, 256, c);
   } else {
@@ -1827,16 +1993,29 @@ int hf_chan_affine_bwd(void* gx, void* gw, void* gb, void* gres, const void* gy,
                        const void* x, const void* mean, const void* rstd, const void* w,
                        const void* mask_src, int64_t n, int64_t c, int64_t hw, int channels_last,
                        int dtype, void* stream) {
-  if (!gy || n <= 0 || c <= 0 || hw <= 0) return HF_ERR_ARG;
+  return hf_chan_affine_bwd_ex(gx, gw, gb, gres, gy, 1, 0, gy2, 1, 0, x, mean, rstd, w, mask_src, n, c, hw,
+                               channels_last, 1, dtype, stream);
+}
+
+int hf_chan_affine_bwd_ex(void* gx, void* gw, void* gb, void* gres, const void* gy, int gy_splits,
+                          int64_t gy_slab, const void* gy2, int gy2_splits, int64_t gy2_slab,
+                          const void* x, const void* mean, const void* rstd, const void* w,
+                          const void* mask_src, int64_t n, int64_t c, int64_t hw, int channels_last,
+                          int row_blocks, int dtype, void* stream) {
+  if (!gy || n <= 0 || c <= 0 || hw <= 0 || gy_splits < 1 || gy2_splits < 1 || row_blocks < 1) return HF_ERR_ARG;
+  // row shares exist in the 16-byte-column NHWC kernel only
+  if (row_blocks > 1 && !(channels_last && hw > 1 && c % 4 == 0 && dtype == HF_F32)) return HF_ERR_ARG;
+  if ((gy_splits > 1 && gy_slab <= 0) || (gy2 && gy2_splits > 1 && gy2_slab <= 0)) return HF_ERR_ARG;
+  if ((gy_splits > 1 || gy2_splits > 1) && !(channels_last || hw == 1)) return HF_ERR_ARG;
   if ((gw && (!x || !mean || !rstd)) || (gx && !rstd)) return HF_ERR_ARG;
   if (!gw) x = nullptr;  // plain per-channel sums (a conv layer's bias gradient)
   hipStream_t s = (hipStream_t)stream;
   if (dtype == HF_F32)
     launch_chan_affine_bwd<float>(s, gx, gw, gb, gres, gy, gy2, x, mean, rstd, w, mask_src, n, c, hw,
-                                  channels_last);
+                                  channels_last, gy_splits, gy_slab, gy2_splits, gy2_slab, row_blocks);
   else if (dtype == HF_F64)
     launch_chan_affine_bwd<double>(s, gx, gw, gb, gres, gy, gy2, x, mean, rstd, w, mask_src, n, c, hw,
-                                   channels_last);
+                                   channels_last, gy_splits, gy_slab, gy2_splits, gy2_slab, row_blocks);
   else
     return HF_ERR_ARG;
   HF_HIP(hipGetLastError());

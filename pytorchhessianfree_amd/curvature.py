@@ -191,6 +191,19 @@ class GGNOperator(_Operator):
             flatten_into(g, head, out=out[:offset], scale=self.weight)
 
 
+def ggn_operator(loss, outputs, params, weight=1.0, group=None):
+    """The GGN operator for ``(loss, outputs)``: the fused curvature engine (engine.py) when
+    ``outputs`` comes from a prepared model of a family it knows (conv - eval-BatchNorm - ReLU
+    units with residual connections, NHWC fp32), else the autograd operator above."""
+    if isinstance(outputs, torch.Tensor) and getattr(outputs, "_hf_model", None) is not None:
+        from .engine import FusedGGNEngine
+
+        eng = FusedGGNEngine.try_build(loss, outputs, list(params), weight=weight, group=group)
+        if eng is not None:
+            return eng
+    return GGNOperator(loss, outputs, params, weight=weight, group=group)
+
+
 class HessianOperator(_Operator):
     """``v -> (d^2 loss / d params^2) v`` (BackPACK's ``hessian_vector_product``,
     optimizer.py:450-455).  ``grad_with_graph`` are the per-parameter gradients

@@ -1,0 +1,500 @@
+"""Fused curvature engine: the GGN product ``v -> J^T H_L J v`` of a prepared ResNet-family
+model (conv - eval-BatchNorm - ReLU units with residual connections, NHWC fp32) by EXPLICIT
+tangent and adjoint sweeps over its layers, issued as direct kernel launches.
+
+Why.  The reference obtains the product from BackPACK's R-op / L-op (optimizer.py:457-462), i.e.
+from autograd; so does ``curvature.GGNOperator``.  On an MI355X that product is bound by the
+NUMBER of dependent launches (~170 x ~6 us for ResNet-18 on 28x28 inputs), and the convolutions
+inside it are MIOpen split-K kernels: a zero-fill launch + a kernel that accumulates with
+atomics (not repeatable).  Here every convolution is ONE launch of the package's implicit-GEMM
+kernels (hf_conv.hip) whose split-K partial results ("slabs") are summed by the kernel that
+CONSUMES them, in its prologue -- the launch boundary publishes them, there is no zero-fill, no
+atomic, no in-launch reduction:
+
+    tangent sweep, per unit :  T-conv([t_x | x], [W | v_W]) -> slabs
+                               BatchNorm tangent (+ residual tangent, ReLU mask) sums the slabs and
+                               writes straight into the next unit's [t_x | x] operand
+    adjoint sweep, per unit :  BatchNorm adjoint: g = mask * (sum of the consumers' cotangent slabs),
+                               g_a = g * w * rstd, per-channel sums      (hf_chan_affine_bwd_ex)
+                               data + weight gradient of the convolution in ONE launch -> slabs
+    once per product        :  hf_unpack_tangent (v_W of all layers), hf_pack_ex (all parameter
+                               gradients, summing the weight-gradient slabs while it gathers)
+
+4 launches per conv-BN unit instead of 8; bitwise repeatable.
+The layer topology is taken from the prepared model's module tree and from the activations its
+patched layers recorded during the step's forward pass (``modelprep`` stores them detached);
+anything the engine does not recognise makes ``try_build`` return ``None`` and the caller uses
+the autograd operator.  The first product of every model signature is compared with that
+operator's product on a random vector.
+"""
+
+import os
+import warnings
+
+import torch
+from torch import nn
+
+from . import _lib
+from .curvature import GGNOperator, _Operator, _all_reduce_sum
+
+_P = _lib.c_void_p
+
+
+def _ptr(t):
+    return _P(t.data_ptr()) if t is not None else None
+
+
+def _same(a, b):
+    """Two records refer to the same activation (records are detached: compare storage)."""
+    return a is not None and b is not None and a.data_ptr() == b.data_ptr() and a.shape == b.shape
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+class _Unit:
+    """conv -> eval-BatchNorm (-> + residual) (-> ReLU)."""
+
+    def __init__(self, name, conv, bn):
+        self.name, self.conv, self.bn = name, conv, bn
+        self.res_unit = None      # downsample unit whose output is added before the activation
+        self.res_identity = False  # ... or the block input itself
+        self.consumers = 0
+
+
+class FusedGGNEngine(_Operator):
+    mode = ("fused curvature engine: own deterministic convolutions (split-K slabs summed by the consumer "
+            "kernel), BatchNorm tangents/adjoints fused, 4 launches per conv-BN unit")
+
+    _verified = set()
+
+    # ------------------------------------------------------------------------------------
+    @classmethod
+    def try_build(cls, loss, outputs, params, weight=1.0, group=None):
+        if os.environ.get("HF_ENGINE", "1") == "0":
+            return None
+        ref = getattr(outputs, "_hf_model", None)
+        model = ref() if ref is not None else None
+        if model is None or not outputs.is_cuda or outputs.dtype != torch.float32 or outputs.dim() != 2:
+            return None
+        try:
+            eng = cls(model, loss, outputs, params, weight, group)
+        except _Unsupported as exc:
+            if os.environ.get("HF_ENGINE_DEBUG"):
+                warnings.warn(f"fused curvature engine not used: {exc}")
+            return None
+        return eng
+
+    def __init__(self, model, loss, outputs, params, weight, group):
+        super().__init__(params, weight, group)
+        self.outputs = outputs
+        self.dev = outputs.device
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        offs, o = [], 0
+        for p in self.params:
+            offs.append(o)
+            o += p.numel()
+        self._offs = offs
+        self._layout(model)
+        self._loss_setup(loss, outputs)
+        self._allocate()
+        self._verify(loss)
+
+    # ---- topology ---------------------------------------------------------------------
+    def _param(self, p):
+        if p is None:
+            return None
+        i = self._index.get(id(p))
+        if i is None:
+            raise _Unsupported("a layer parameter is not among the optimizer's parameters")
+        return i
+
+    def _layout(self, model):
+        need = ("conv1", "bn1", "maxpool", "avgpool", "fc")
+        if not all(isinstance(getattr(model, a, None), nn.Module) for a in need):
+            raise _Unsupported("not a ResNet-family module tree")
+        if hasattr(model, "layers") and isinstance(model.layers, nn.Sequential):
+            blocks = list(model.layers)
+        elif all(hasattr(model, f"layer{i}") for i in range(1, 5)):
+            blocks = [b for i in range(1, 5) for b in getattr(model, f"layer{i}")]
+        else:
+            raise _Unsupported("no block list")
+        x_in = getattr(self.outputs, "_hf_input", None)
+        if x_in is None:
+            raise _Unsupported("no recorded input")
+
+        def io(m, n):
+            rec = getattr(m, "_hf_io", None)
+            if rec is None or len(rec) != n:
+                raise _Unsupported(f"{type(m).__name__} has no record of this forward pass")
+            return rec
+
+        units = []
+
+        def make_unit(name, conv, bn, relu_expected):
+            if type(conv) is not nn.Conv2d or conv.bias is not None or conv.groups != 1:
+                raise _Unsupported(f"{name}: unsupported convolution")
+            if not getattr(conv, "_hf_channels_last", False) or tuple(conv.dilation) != (1, 1):
+                raise _Unsupported(f"{name}: needs prepare_model(channels_last=True)")
+            if bn.training or not isinstance(bn, nn.BatchNorm2d):
+                raise _Unsupported(f"{name}: BatchNorm must be in eval mode")
+            u = _Unit(name, conv, bn)
+            cx, cy = io(conv, 2)
+            bx, bres, by, brelu, rstd = io(bn, 5)
+            if not _same(cy, bx):
+                raise _Unsupported(f"{name}: the BatchNorm does not consume the convolution's output")
+            if brelu != relu_expected:
+                raise _Unsupported(f"{name}: unexpected activation")
+            # identity of activations: the RAW records (a 1-channel stem runs NCHW, its records are
+            # converted below); the kernels get NHWC copies / views
+            u.kx, u.ky, u.rx, u.ry = cx.data_ptr(), by.data_ptr(), cx, by
+            u.x, u.a, u.y, u.relu, u.rstd, u.res = _cl(cx), _cl(cy), _cl(by), brelu, rstd, bres
+            u.pw, u.pg, u.pb = self._param(conv.weight), self._param(bn.weight), self._param(bn.bias)
+            units.append(u)
+            return u
+
+        # stem: conv1 -> bn1 (+ relu, fused by fuse_bn_relu or by a block-style forward) -> maxpool
+        stem = make_unit("stem", model.conv1, model.bn1, True)
+        if not _same(stem.rx, x_in.detach()) or stem.res is not None:
+            raise _Unsupported("stem does not start at the network input")
+        mp_x, mp_y = io(model.maxpool, 2)
+        if not _same(mp_x, stem.ry):
+            raise _Unsupported(f"maxpool does not follow the stem ({tuple(mp_x.shape)} {mp_x.stride()} "
+                               f"{mp_x.data_ptr():x} vs {tuple(stem.y.shape)} {stem.y.stride()} {stem.y.data_ptr():x})")
+        mp = model.maxpool
+        self.stem, self.pool_args = stem, (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode)
+        cur = mp_y
+        self.pool_out, self.pool_key = _cl(mp_y), mp_y.data_ptr()
+        self.blocks = []
+        for bi, b in enumerate(blocks):
+            convs = [n for n in ("conv1", "conv2", "conv3") if isinstance(getattr(b, n, None), nn.Conv2d)]
+            if not getattr(b, "_hf_block_patched", False) or len(convs) < 2 or b.training:
+                raise _Unsupported(f"block {bi}: not a fused residual block")
+            chain, inp = [], cur
+            for k, cn in enumerate(convs):
+                u = make_unit(f"block{bi}.{cn}", getattr(b, cn), getattr(b, "bn" + cn[-1]), True)
+                if not _same(u.rx, inp):
+                    raise _Unsupported(f"block {bi}.{cn}: input is not the previous activation")
+                last = k == len(convs) - 1
+                if (u.res is not None) != last:
+                    raise _Unsupported(f"block {bi}.{cn}: unexpected residual")
+                chain.append(u)
+                inp = u.ry
+            tail = chain[-1]
+            ds = None
+            if b.downsample is not None:
+                d = b.downsample
+                if not (isinstance(d, nn.Sequential) and len(d) == 2):
+                    raise _Unsupported(f"block {bi}: unsupported downsample")
+                ds = make_unit(f"block{bi}.downsample", d[0], d[1], False)
+                if not _same(ds.rx, cur) or ds.res is not None or not _same(tail.res, ds.ry):
+                    raise _Unsupported(f"block {bi}: downsample wiring")
+                tail.res_unit = ds
+            else:
+                if not _same(tail.res, cur):
+                    raise _Unsupported(f"block {bi}: identity wiring")
+                tail.res_identity = True
+            self.blocks.append((chain, ds, cur))
+            cur = tail.ry
+        ap_x, ap_y = io(model.avgpool, 2)
+        if not _same(ap_x, cur):
+            raise _Unsupported("avgpool does not follow the last block")
+        fc = model.fc
+        fc_x, fc_y = io(fc, 2)
+        if fc_x.dim() != 2 or fc_x.shape[0] != cur.shape[0] or fc_x.shape[1] != cur.shape[1]:
+            raise _Unsupported("the classifier does not take the pooled features")
+        if not _same(fc_y, self.outputs.detach()):
+            raise _Unsupported("the network output is not the classifier's output")
+        self.fc, self.feat = fc, fc_x
+        self.pfw, self.pfb = self._param(fc.weight), self._param(fc.bias)
+        self.units = units
+        used = {i for u in units for i in (u.pw, u.pg, u.pb)} | {self.pfw} | ({self.pfb} if self.pfb is not None else set())
+        if used != set(range(len(self.params))):
+            raise _Unsupported("the parameter list has entries the engine's layers do not cover")
+
+    # ---- loss Hessian (same contract as GGNOperator) -------------------------------------
+    def _loss_setup(self, loss, outputs):
+        (self._dl,) = torch.autograd.grad(loss, outputs, create_graph=True, retain_graph=True)
+        self._ce = GGNOperator._closed_form_loss_hessian(self, loss, outputs)
+
+    _loss_hessian = GGNOperator._loss_hessian
+
+    # ---- buffers -------------------------------------------------------------------------
+    def _plan(self, direction, u):
+        n, c, h, w = u.x.shape
+        k, _, r, s = u.conv.weight.shape
+        cin = 2 * c if direction == 0 else c
+        sp = _lib.load().hf_conv2d_nhwc_plan(direction, n, h, w, cin, k, r, s, u.conv.stride[0], u.conv.stride[1],
+                                             u.conv.padding[0], u.conv.padding[1],
+                                             int(os.environ.get("HF_CONV_BLOCKS", "0")))
+        if sp < 1:
+            raise _Unsupported(f"{u.name}: convolution geometry refused ({sp})")
+        return sp
+
+    def _allocate(self):
+        dev, f32 = self.dev, torch.float32
+        xcats = {}
+        self._tangent_slots = {}
+        for u in self.units:
+            n, c, h, w = u.x.shape
+            k, _, r, s = u.conv.weight.shape
+            if u is self.stem:
+                if c * r * s > 256:
+                    raise _Unsupported("stem: too many taps for the im2col formulation")
+                cols = torch.nn.functional.unfold(u.x.contiguous(), (r, s), padding=tuple(u.conv.padding),
+                                                  stride=tuple(u.conv.stride))
+                u.cols = cols.transpose(1, 2).contiguous()  # [N, OH*OW, c*r*s]
+                u.geo = (n * u.cols.shape[1], 1, 1, u.cols.shape[2], k, 1, 1, (1, 1), (0, 0))
+                if not u.conv.weight.is_contiguous():
+                    raise _Unsupported("stem weight layout")
+            else:
+                if c % 4 or k % 4:
+                    raise _Unsupported(f"{u.name}: channel counts must be multiples of 4")
+                u.geo = (n, h, w, c, k, r, s, tuple(u.conv.stride), tuple(u.conv.padding))
+                key = u.kx
+                if key not in xcats:
+                    xc = torch.zeros((n, 2 * c, h, w), dtype=f32, device=dev).contiguous(
+                        memory_format=torch.channels_last)
+                    xc[:, c:].copy_(u.x)
+                    xcats[key] = xc
+                u.xcat = xcats[key]
+                wf = _cl(u.conv.weight.detach())
+                u.wcat = torch.empty((k, 2 * c, r, s), dtype=f32, device=dev).contiguous(
+                    memory_format=torch.channels_last)
+                u.wcat[:, :c].copy_(wf)
+                u.wT = wf.permute(1, 2, 3, 0).contiguous()  # (I, H, W, O)
+                self._tangent_slots[id(u)] = (self._offs[u.pw], u.wcat, c)
+            oh, ow = u.a.shape[2], u.a.shape[3]
+            u.rows, u.cout = n * oh * ow, k
+            # split-K slab buffers
+            if u is self.stem:
+                u.sT = self._plan_stem(0, u)
+                u.sW = self._plan_stem(2, u)
+                u.sD = 0
+            else:
+                u.sT, u.sD, u.sW = self._plan(0, u), self._plan(1, u), self._plan(2, u)
+            u.tbuf = torch.empty((u.sT, u.rows * k), dtype=f32, device=dev)
+            u.wbuf = torch.zeros((u.sW, u.conv.weight.numel()), dtype=f32, device=dev)  # dead taps stay 0
+            if u.sD:
+                u.dbuf = torch.empty((u.sD, u.x.numel()), dtype=f32, device=dev)
+            u.g = torch.empty_like(u.a)    # masked cotangent of the unit's output
+            u.ga = torch.empty_like(u.a)   # cotangent of the convolution output
+            # the BatchNorm adjoint shares the rows among `rb` workgroups per channel column; the
+            # per-channel sums arrive as rb partial rows that hf_pack_ex adds up
+            u.rb = 1
+            if oh * ow > 1 and k % 4 == 0:
+                u.rb = max(1, min(u.rows // 64, -(-256 // (k // 4))))
+            u.gw = torch.empty((u.rb, k), dtype=f32, device=dev)
+            u.gb = torch.empty((u.rb, k), dtype=f32, device=dev)
+        # where each unit's tangent output goes: the [t_x | x] operand of its consumer, else a buffer
+        for u in self.units:
+            xc = xcats.get(u.ky)
+            if xc is not None:
+                c = u.y.shape[1]
+                u.tout, u.tout_ld = xc[:, :c], 2 * c
+            else:
+                u.tout, u.tout_ld = torch.empty_like(u.y), 0
+        self.pool_t = xcats.get(self.pool_key)
+        if self.pool_t is None:
+            raise _Unsupported("nothing consumes the pooled stem output")
+        self.pool_idx = None
+        self._slot_list = list(self._tangent_slots.values())
+
+    def _plan_stem(self, direction, u):
+        n, h, w, c, k, r, s, st, pd = u.geo
+        sp = _lib.load().hf_conv2d_nhwc_plan(direction, n, h, w, c, k, r, s, 1, 1, 0, 0,
+                                             int(os.environ.get("HF_CONV_BLOCKS", "0")))
+        if sp < 1:
+            raise _Unsupported(f"stem geometry refused ({sp})")
+        return sp
+
+    # ---- kernels ---------------------------------------------------------------------------
+    def _conv_slabs(self, direction, out, act, mat, geo, splits, act_ld=0):
+        n, h, w, c, k, r, s, st, pd = geo
+        _lib.check(_lib.load().hf_conv2d_nhwc_slabs(
+            direction, _ptr(out), _ptr(act), _ptr(mat), n, h, w, c, k, r, s, st[0], st[1], pd[0], pd[1], act_ld,
+            splits, out.shape[1] if out.dim() == 2 else 0, _lib.HF_F32, _lib.current_stream_ptr(self.dev)),
+            "hf_conv2d_nhwc_slabs")
+
+    def _bn_tangent(self, u, v, add, add_ld):
+        """t_y = mask * (sum(T slabs) * w*rstd + xhat * v_w + v_b + add), into the consumer's operand."""
+        n, k, oh, ow = u.a.shape
+        vg = v[self._offs[u.pg]: self._offs[u.pg] + k]
+        vb = v[self._offs[u.pb]: self._offs[u.pb] + k]
+        _lib.check(_lib.load().hf_chan_affine_ex(
+            _ptr(u.tout), _ptr(u.tbuf), _ptr(u.a), _ptr(u.bn.running_mean), _ptr(u.rstd), _ptr(u.bn.weight),
+            _ptr(vg), _ptr(vb), _ptr(add), _ptr(u.y) if u.relu else None, 0, n, k, oh * ow, 1, u.tout_ld, add_ld,
+            u.sT, u.tbuf.shape[1], _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_chan_affine_ex")
+
+    def _adjoint_unit(self, u, srcs):
+        """srcs: up to two (tensor, splits, slab_stride) cotangents of the unit's output."""
+        if not 1 <= len(srcs) <= 2:
+            raise RuntimeError(f"{u.name}: {len(srcs)} consumers")
+        (a, sa, la) = srcs[0]
+        (b, sb, lb) = srcs[1] if len(srcs) == 2 else (None, 1, 0)
+        lib, st = _lib.load(), _lib.current_stream_ptr(self.dev)
+        n, k, oh, ow = u.a.shape
+        # g = mask * (sum of both cotangents' slabs) -> u.g; g * w*rstd -> u.ga; per-channel sums
+        _lib.check(lib.hf_chan_affine_bwd_ex(
+            _ptr(u.ga), _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a),
+            _ptr(u.bn.running_mean), _ptr(u.rstd), _ptr(u.bn.weight), _ptr(u.y) if u.relu else None, n, k,
+            oh * ow, 1, u.rb, _lib.HF_F32, st), "hf_chan_affine_bwd_ex")
+        if u is self.stem:
+            self._conv_slabs(2, u.wbuf, u.cols, u.ga, u.geo, u.sW)
+            return
+        n_, h, w, c, k_, r, s, sd, pd = u.geo
+        _lib.check(lib.hf_conv2d_nhwc_backward_slabs(
+            _ptr(u.dbuf), _ptr(u.wbuf), _ptr(u.ga), _ptr(u.x), _ptr(u.wT), n_, h, w, c, k_, r, s, sd[0], sd[1],
+            pd[0], pd[1], u.sD, u.dbuf.shape[1], u.sW, u.wbuf.shape[1], _lib.HF_F32, st),
+            "hf_conv2d_nhwc_backward_slabs")
+
+    # ---- the product -------------------------------------------------------------------------
+    def local(self, v, out=None):
+        if out is None:
+            out = torch.empty(self.n, dtype=torch.float32, device=self.dev)
+        v = v.detach()
+        if not v.is_contiguous():
+            v = v.contiguous()
+        _lib.unpack_tangent(v, self._slot_list)  # v_W halves of all [W | v_W] operands: one launch
+
+        # ---- tangent sweep ------------------------------------------------------------------
+        s = self.stem
+        vw = v[self._offs[s.pw]: self._offs[s.pw] + s.conv.weight.numel()]
+        self._conv_slabs(0, s.tbuf, s.cols, vw, s.geo, s.sT)  # input has no tangent: conv(x, v_W) as 1x1 on im2col
+        self._bn_tangent(s, v, None, 0)
+        ks, st_, pd, dl, cm = self.pool_args
+        if self.pool_idx is None:
+            _, self.pool_idx = torch.nn.functional.max_pool2d(s.y, ks, st_, pd, dl, cm, return_indices=True)
+        c0 = self.pool_out.shape[1]
+        t_pool = s.tout.flatten(2).gather(2, self.pool_idx.flatten(2)).view_as(self.pool_out)
+        self.pool_t[:, :c0].copy_(t_pool)
+        for chain, ds, _x in self.blocks:
+            head = chain[0]
+            if ds is not None:
+                self._conv_slabs(0, ds.tbuf, ds.xcat, ds.wcat, self._tgeo(ds), ds.sT)
+                self._bn_tangent(ds, v, None, 0)
+            for u in chain:
+                self._conv_slabs(0, u.tbuf, u.xcat, u.wcat, self._tgeo(u), u.sT)
+                add, add_ld = None, 0
+                if u.res_unit is not None:
+                    add, add_ld = u.res_unit.tout, u.res_unit.tout_ld
+                elif u.res_identity:
+                    c = head.x.shape[1]
+                    add, add_ld = head.xcat[:, :c], 2 * c
+                self._bn_tangent(u, v, add, add_ld)
+        tail = self.blocks[-1][0][-1]
+        t_last = tail.tout
+        hw = t_last.shape[2] * t_last.shape[3]
+        t_feat = t_last.flatten(1) if hw == 1 else t_last.mean(dim=(2, 3))
+        fw = self.fc.weight
+        nf = fw.numel()
+        v_fw = v[self._offs[self.pfw]: self._offs[self.pfw] + nf].view_as(fw)
+        Jv = t_feat @ fw.detach().t() + self.feat @ v_fw.t()
+        if self.pfb is not None:
+            Jv = Jv + v[self._offs[self.pfb]: self._offs[self.pfb] + fw.shape[0]]
+
+        # ---- loss Hessian ---------------------------------------------------------------------
+        HJv = self._loss_hessian(Jv)
+
+        # ---- adjoint sweep --------------------------------------------------------------------
+        g_fw = HJv.t() @ self.feat
+        g_fb = HJv.sum(0) if self.pfb is not None else None
+        g_feat = HJv @ fw.detach()
+        if hw == 1:
+            g_last = g_feat.view(tail.y.shape)
+        else:
+            g_last = _cl((g_feat / hw).view(g_feat.shape[0], -1, 1, 1).expand(tail.y.shape))
+        incoming = {id(tail): [(g_last, 1, 0)]}
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            chain, ds, _x = self.blocks[bi]
+            head, last = chain[0], chain[-1]
+            for k in range(len(chain) - 1, -1, -1):
+                u = chain[k]
+                self._adjoint_unit(u, incoming.pop(id(u)))
+                if k > 0:
+                    incoming.setdefault(id(chain[k - 1]), []).append((u.dbuf, u.sD, u.dbuf.shape[1]))
+            # the block input receives conv1's data gradient and the residual branch's cotangent
+            srcs = [(head.dbuf, head.sD, head.dbuf.shape[1])]
+            if ds is not None:
+                self._adjoint_unit(ds, [(last.g, 1, 0)])
+                srcs.append((ds.dbuf, ds.sD, ds.dbuf.shape[1]))
+            else:
+                srcs.append((last.g, 1, 0))
+            if bi > 0:
+                incoming[id(self.blocks[bi - 1][0][-1])] = srcs
+            else:
+                pool_srcs = srcs
+        # block 0's input is the pooled stem output: sum its two cotangents, undo the max-pool
+        (a, sa, la), (b, sb, lb) = pool_srcs
+        g_pool = torch.empty_like(self.pool_out)
+        _lib.check(_lib.load().hf_bn_adjoint_pre(
+            _ptr(g_pool), None, _ptr(a), sa, la, _ptr(b), sb, lb, None, None, None,
+            g_pool.numel() // c0, c0, _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_bn_adjoint_pre")
+        g_stem = torch.ops.aten.max_pool2d_with_indices_backward(
+            g_pool, s.y, _pair(ks), _pair(st_ if st_ is not None else ks), _pair(pd), _pair(dl), cm,
+            self.pool_idx)
+        self._adjoint_unit(s, [(_cl(g_stem), 1, 0)])
+
+        # ---- gather all parameter gradients (weight-gradient slabs summed on the way) ---------
+        tensors, perms, splits = self._pack_args()
+        tensors = list(tensors)
+        tensors[self.pfw] = g_fw
+        if self.pfb is not None:
+            tensors[self.pfb] = g_fb
+        _lib.pack_ex(out, tensors, perms, splits, scale=self.weight)
+        return out
+
+    def _pack_args(self):
+        if getattr(self, "_pack", None) is None:
+            tensors, perms, splits = [None] * len(self.params), {}, {}
+            for u in self.units:
+                tensors[u.pw] = u.wbuf[0]
+                if u is not self.stem:
+                    k, c, r, s_ = u.conv.weight.shape
+                    if r * s_ > 1:
+                        perms[u.pw] = (c, r * s_)  # stored (O, H, W, I); 1x1 kernels: already in order
+                if u.sW > 1:
+                    splits[u.pw] = (u.sW, u.wbuf.shape[1])
+                tensors[u.pg], tensors[u.pb] = u.gw[0], u.gb[0]
+                if u.rb > 1:
+                    splits[u.pg] = splits[u.pb] = (u.rb, u.cout)
+            self._pack = (tensors, perms, splits)
+        return self._pack
+
+    def _tgeo(self, u):
+        n, h, w, c, k, r, s, st, pd = u.geo
+        return (n, h, w, 2 * c, k, r, s, st, pd)
+
+    def __call__(self, v, out=None):
+        self.calls += 1
+        return _all_reduce_sum(self.local(v, out), self.group)
+
+    # ---- safety net --------------------------------------------------------------------------
+    def _verify(self, loss):
+        """First product of every model signature against the autograd operator."""
+        policy = os.environ.get("HF_ENGINE_VERIFY", "first")
+        key = (self.n, tuple(tuple(p.shape) for p in self.params), tuple(self.outputs.shape),
+               tuple(self.stem.x.shape), str(self.dev))
+        if policy == "never" or (policy != "always" and key in FusedGGNEngine._verified):
+            return
+        gen = torch.Generator(device=self.dev).manual_seed(4321)
+        v = torch.randn(self.n, device=self.dev, generator=gen)
+        weight, self.weight = self.weight, 1.0
+        try:
+            got = self.local(v).clone()
+        finally:
+            self.weight = weight
+        want = GGNOperator(loss, self.outputs, self.params).local(v)
+        err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
+        if not err < 1e-3:
+            raise _Unsupported(f"engine product differs from the autograd product by {err:.2e}")
+        FusedGGNEngine._verified.add(key)
+
+
+class _Unsupported(Exception):
+    pass
+
+
+def _pair(v):
+    return [v, v] if isinstance(v, int) else list(v)

@@ -274,6 +274,7 @@ def fused_bn_act(bn, x, res=None, relu=False, twin=False):
     BatchNorm on a GPU tensor, the stock ops otherwise.  ``twin``: tag the result with an
     alias (``y._hf_twin``) for its second consumer, see ``_ChanAffine``."""
     if not _bn_usable(bn, x):
+        bn._hf_io = None
         fwd = getattr(bn, "_hf_stock_forward", None) or bn.forward
         y = fwd(x)
         if res is not None:
@@ -281,9 +282,12 @@ def fused_bn_act(bn, x, res=None, relu=False, twin=False):
         return torch.relu(y) if relu else y
     rstd = torch.rsqrt(bn.running_var + bn.eps)
     if not twin:
-        return _ChanAffine.apply(x, bn.weight, bn.bias, bn.running_mean, rstd, res, relu)
+        y = _ChanAffine.apply(x, bn.weight, bn.bias, bn.running_mean, rstd, res, relu)
+        bn._hf_io = (x.detach(), None if res is None else res.detach(), y.detach(), relu, rstd)
+        return y
     y, y2 = _ChanAffine.apply(x, bn.weight, bn.bias, bn.running_mean, rstd, res, relu, True)
     y._hf_twin = y2
+    bn._hf_io = (x.detach(), None if res is None else res.detach(), y.detach(), relu, rstd)
     return y
 
 
@@ -358,8 +362,11 @@ def _verified_block_forward(fused):
         # forward would update the BatchNorm running statistics twice)
         if not self._hf_block_verified and not self.training:
             self._hf_block_verified = True
+            keep = [(m, m._hf_io) for m in self.modules() if getattr(m, "_hf_io", None) is not None]
             with torch.no_grad():
                 want = self._hf_stock_block_forward(x.detach())
+            for m, rec in keep:  # the stock pass must not replace the fused pass's records
+                m._hf_io = rec
             scale = float(want.abs().max()) + 1e-30
             if want.shape != y.shape or not float((want - y.detach()).abs().max()) <= 1e-4 * scale:
                 import warnings
@@ -865,9 +872,13 @@ def _conv_forward(self, x):
     )
     if not usable:
         return self._hf_stock_forward(x)
-    return _Conv.apply(x, self.weight, self.bias, list(self.stride), list(self.padding),
-                       list(self.dilation), bool(getattr(self, "_hf_channels_last", False)),
-                       getattr(self, "_hf_conv_mode", None))
+    y = _Conv.apply(x, self.weight, self.bias, list(self.stride), list(self.padding),
+                    list(self.dilation), bool(getattr(self, "_hf_channels_last", False)),
+                    getattr(self, "_hf_conv_mode", None))
+    # what the curvature engine (engine.py) needs of this step's forward; detached: a record
+    # must not keep an autograd graph (and its stream affinity) alive
+    self._hf_io = (x.detach(), y.detach())
+    return y
 
 
 def fuse_conv_tangent(model, channels_last=False, conv_mode=None):
@@ -909,6 +920,33 @@ def skip_identity_pools(model):
     return count
 
 
+def _record_io(module, inputs, output):
+    x = inputs[0] if inputs else None
+    module._hf_io = (x.detach() if isinstance(x, torch.Tensor) else x,
+                     output.detach() if isinstance(output, torch.Tensor) else output)
+
+
+def _tag_output(module, inputs, output):
+    """Top-level forward hook: the network output remembers which prepared model produced it
+    from which input, so that ``curvature.ggn_operator`` can hand the product to the fused
+    curvature engine (engine.py) when the model is of a family it knows."""
+    if isinstance(output, torch.Tensor):
+        import weakref
+
+        output._hf_model = weakref.ref(module)
+        output._hf_input = inputs[0] if inputs else None
+
+
+def _install_engine_hooks(model):
+    if getattr(model, "_hf_engine_hooks", False):
+        return
+    for m in model.modules():
+        if isinstance(m, (nn.MaxPool2d, nn.AdaptiveAvgPool2d, nn.Linear, nn.Flatten)):
+            m.register_forward_hook(_record_io)
+    model.register_forward_hook(_tag_output)
+    model._hf_engine_hooks = True
+
+
 def prepare_model(model, channels_last=False, deterministic=False):
     """All opt-in preparations; returns ``model`` for chaining.
 
@@ -946,6 +984,7 @@ def prepare_model(model, channels_last=False, deterministic=False):
     fuse_residual_blocks(model)
     fuse_bn_relu(model)
     skip_identity_pools(model)
+    _install_engine_hooks(model)
     return model
 
 

@@ -193,8 +193,8 @@ class HessianFree(torch.optim.Optimizer):
                     loss, self._params_list,
                     grad_with_graph=None if (grads is None or any(g is None for g in grads)) else grads,
                     weight=self.shard_weight, group=self.process_group)
-            return curvature.GGNOperator(loss, outputs, self._params_list,
-                                         weight=self.shard_weight, group=self.process_group)
+            return curvature.ggn_operator(loss, outputs, self._params_list,
+                                          weight=self.shard_weight, group=self.process_group)
 
         if self.graph_matvec and not user_mvp and self.device.type == "cuda":
             mvp = curvature.maybe_graphed(setup, params=self._params_list)

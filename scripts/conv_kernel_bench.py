@@ -50,6 +50,9 @@ def cl(t):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--blocks", type=int, default=0)
+    ap.add_argument("--no-reduce", type=int, default=0,
+                    help="1: also time the slab-mode launches (hf_conv2d_nhwc_slabs: split-K partial results left "
+                         "for the consumer kernel's prologue, as the fused curvature engine runs them)")
     args = ap.parse_args()
     if args.blocks:
         os.environ["HF_CONV_BLOCKS"] = str(args.blocks)
@@ -69,6 +72,17 @@ def main():
         line["D_own"] = timed(lambda: _lib.conv2d_nhwc(1, gx, gy, wT, n, h, w, c, k, r, r, stride, pad))
         line["W_own"] = timed(lambda: _lib.conv2d_nhwc(2, gw, x, gy, n, h, w, c, k, r, r, stride, pad))
         line["DW_own"] = timed(lambda: _lib.conv2d_nhwc_backward(gx, gw, gy, x, wT, n, h, w, c, k, r, r, stride, pad))
+        if args.no_reduce:
+            sT = _lib.conv_plan(0, n, h, w, 2 * c, k, r, r, stride, pad)
+            sD = _lib.conv_plan(1, n, h, w, c, k, r, r, stride, pad)
+            sW = _lib.conv_plan(2, n, h, w, c, k, r, r, stride, pad)
+            ys = torch.empty(sT, y.numel(), device=DEV)
+            gxs = torch.empty(sD, gx.numel(), device=DEV)
+            gws = torch.zeros(sW, gw.numel(), device=DEV)
+            line["splits"] = [sT, sD, sW]
+            line["T_slab"] = timed(lambda: _lib.conv2d_nhwc_slabs(0, ys, x2, w2, n, h, w, 2 * c, k, r, r, stride, pad, sT))
+            line["D_slab"] = timed(lambda: _lib.conv2d_nhwc_slabs(1, gxs, gy, wT, n, h, w, c, k, r, r, stride, pad, sD))
+            line["W_slab"] = timed(lambda: _lib.conv2d_nhwc_slabs(2, gws, x, gy, n, h, w, c, k, r, r, stride, pad, sW))
         line["T_miopen"] = timed(lambda: torch.nn.functional.conv2d(x2, w2, None, stride, pad))
         line["D_miopen"] = timed(lambda: torch.ops.aten.convolution_backward(
             gy, x, wt, None, stride, pad, [1, 1], False, [0, 0], 1, [True, False, False]))
