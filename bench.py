@@ -271,6 +271,7 @@ def main():
             return make_operator(lossf(out, t), out, params)
 
         if args.graph and overlap and not hessian:
+            os.environ["HF_ENGINE"] = "0"  # the two-graph split is a split of the autograd sweeps
             op = curvature.OverlappedGraphedOperator(builder, params=params)
         else:
             op = curvature.maybe_graphed(builder, enable=bool(args.graph), params=params)
@@ -442,7 +443,7 @@ def main():
                 "parallelism": f"dp{world} (batch sharded, one all-reduce of 4N bytes per matvec)"
                                + (f"; {world} ranks share {ndev} device(s) over gloo: functional run, not a "
                                   "scaling number" if oversubscribed else ""),
-                "matvec": getattr(op, "mode", "eager autograd") + " [" + getattr(getattr(op, "op", op), "mode", "") + "]"
+                "matvec": getattr(op, "mode", "eager autograd")
                           + ("; eval-BN fused (hf_chan_affine)" if args.fuse_bn else "")
                           + ("; conv tangent fused" if args.fuse_conv else "")
                           + "; convolutions: " + (os.environ.get("HF_CONV") or "auto") + "; " + layout

@@ -238,9 +238,11 @@ int hf_chan_affine_ex(void* out, const void* a, const void* x, const void* mean,
                       int dtype, void* stream);
 /* hf_chan_affine_bwd with both cotangents given as split-K slabs (data gradients of
  * hf_conv2d_nhwc_backward_slabs), summed in split order while they are loaded; NHWC (or hw == 1).
- * row_blocks > 1 (NHWC fp32, c % 4 == 0): the rows are shared among `row_blocks` workgroups per
- * channel column -- c/4 workgroups cannot occupy 256 CUs -- and gw / gb receive `row_blocks`
- * partial sums each, c elements apart, for hf_pack_ex to add up. */
+ * row_blocks > 1 (NHWC fp32, c % 4 == 0, c <= 1024): a row-major kernel -- `row_blocks`
+ * workgroups each take a share of the rows and ALL channels, reading whole contiguous rows
+ * (the default kernel gives each workgroup one 16-byte channel column of all rows: one cache
+ * line per lane) -- and gw / gb receive `row_blocks` partial sums each, c elements apart, for
+ * hf_pack_ex to add up.  ceil(rows / row_blocks) rows per workgroup; no empty workgroup allowed. */
 int hf_chan_affine_bwd_ex(void* gx, void* gw, void* gb, void* gres, const void* gy, int gy_splits,
                           int64_t gy_slab, const void* gy2, int gy2_splits, int64_t gy2_slab,
                           const void* x, const void* mean, const void* rstd, const void* w,
@@ -299,7 +301,9 @@ int hf_conv2d_nhwc(int direction, void* out, const void* act, const void* mat, i
  * ResNet-18 shapes against 12-20 us with the in-launch reduction.  `hf_conv2d_nhwc_plan`
  * returns the number of splits the launch will use (>= 1; pure host arithmetic), which the
  * caller needs to size the slab buffer; pass it back as `splits`.  For direction 2 every slab
- * must be zero-initialised once if the geometry has taps that never meet data.
+ * must be zero-initialised once if the geometry has taps that never meet data; `out_c` (0 = c)
+ * restricts the output to X's first out_c channels, laid out [k][r][q][out_c] -- X may carry
+ * zero-padding channels that make its rows 16-byte multiples (the 49-tap im2col of a stem).
  */
 int hf_conv2d_nhwc_plan(int direction, int64_t n, int64_t h, int64_t w, int64_t c, int64_t k,
                         int64_t r, int64_t s, int64_t stride_h, int64_t stride_w, int64_t pad_h,
@@ -307,7 +311,8 @@ int hf_conv2d_nhwc_plan(int direction, int64_t n, int64_t h, int64_t w, int64_t 
 int hf_conv2d_nhwc_slabs(int direction, void* out, const void* act, const void* mat, int64_t n,
                          int64_t h, int64_t w, int64_t c, int64_t k, int64_t r, int64_t s,
                          int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
-                         int64_t act_ld, int splits, int64_t slab_stride, int dtype, void* stream);
+                         int64_t act_ld, int64_t out_c, int splits, int64_t slab_stride, int dtype,
+                         void* stream);
 int hf_conv2d_nhwc_backward_slabs(void* dx, void* dw, const void* dy, const void* x, const void* w_t,
                                   int64_t n, int64_t h, int64_t w, int64_t c, int64_t k, int64_t r,
                                   int64_t s, int64_t stride_h, int64_t stride_w, int64_t pad_h,

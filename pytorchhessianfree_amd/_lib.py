@@ -100,7 +100,7 @@ SIGNATURES = {
     "hf_conv2d_nhwc_backward": (c_int, [c_void_p] * 5 + [c_int64] * 11
                                 + [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "hf_conv2d_nhwc_plan": (c_int, [c_int] + [c_int64] * 11 + [c_int]),
-    "hf_conv2d_nhwc_slabs": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int64] * 12
+    "hf_conv2d_nhwc_slabs": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int64] * 13
                              + [c_int, c_int64, c_int, c_void_p]),
     "hf_conv2d_nhwc_backward_slabs": (c_int, [c_void_p] * 5 + [c_int64] * 11
                                       + [c_int, c_int64, c_int, c_int64, c_int, c_void_p]),
@@ -389,12 +389,12 @@ def conv_plan(direction, n, h, w, c, k, r, s, stride, padding):
     return sp
 
 
-def conv2d_nhwc_slabs(direction, out, act, mat, n, h, w, c, k, r, s, stride, padding, splits, act_ld=0):
+def conv2d_nhwc_slabs(direction, out, act, mat, n, h, w, c, k, r, s, stride, padding, splits, act_ld=0, out_c=0):
     """Slab-mode launch: ``out`` is [splits, numel] -- slab s receives split s's partial result."""
     check(
         load().hf_conv2d_nhwc_slabs(
             int(direction), c_void_p(out.data_ptr()), c_void_p(act.data_ptr()), c_void_p(mat.data_ptr()),
-            n, h, w, c, k, r, s, stride[0], stride[1], padding[0], padding[1], act_ld, int(splits),
+            n, h, w, c, k, r, s, stride[0], stride[1], padding[0], padding[1], act_ld, out_c, int(splits),
             out.shape[1], HF_F32, current_stream_ptr(out.device)),
         "hf_conv2d_nhwc_slabs")
     return out

@@ -68,6 +68,7 @@ struct ConvArgs {
   int tiles_m, tiles_n, splits, steps;  // steps = reduction steps in total
   int scalar;          // 1: channel counts not multiples of 4 -> element-wise gathers
   int shift_h, shift_w;  // log2 of the strides when both are powers of two, else -1
+  int out_c;           // W: channels of X that get an output column (<= cs: X may be zero-padded)
   int slabs;           // 1: split s writes its partial result, in the output's own layout, to
   long long slab_stride;  //    out + s*slab_stride; the CONSUMER kernel sums the slabs in its prologue
 };
@@ -517,9 +518,9 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
   }
   __syncthreads();
   // output element (k, tap, c) at (k*RS + tap)*cs + c: rows = k, "columns" = c within this tap
-  float* base = a.out + (size_t)(r * a.S + q) * a.cs;
-  finish_tile(a, acc, tile, split, wm, wn, lane, base, tile_m * BM, c0, a.kout, a.cs, a.R * a.S * a.cs,
-              &flag);
+  float* base = a.out + (size_t)(r * a.S + q) * a.out_c;
+  finish_tile(a, acc, tile, split, wm, wn, lane, base, tile_m * BM, c0, a.kout, a.out_c,
+              a.R * a.S * a.out_c, &flag);
 }
 
 template <bool SCALAR>
@@ -563,9 +564,11 @@ namespace {
 int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_bytes, bool slabs = false) {
   int64_t best = 1;
   if (slabs && target_blocks <= 0) {
-    // no in-launch reduction: a split costs only its consumer one more read per element;
-    // split until ~2 workgroups per CU exist or a split is down to 2 steps
-    best = (512 + tiles - 1) / tiles;
+    // no in-launch reduction: a split costs its consumer one more read per element; split
+    // until one workgroup per CU exists (measured in the ResNet-18 product: 256 beats 384,
+    // 512 and 768 -- the prefetch ring keeps a workgroup with several steps busy) or a split
+    // is down to 2 steps
+    best = (256 + tiles - 1) / tiles;
     if (best > steps / 2) best = steps / 2;
     if (best > 32) best = 32;
     if (best < 1) best = 1;
@@ -647,6 +650,7 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
     a.dgrad = 0; rows = n * oh * ow; a.rh = (int)oh; a.rw = (int)ow; a.sh_ = (int)h; a.sw_ = (int)w;
     a.cs = (int)c; a.kout = (int)k;
   }
+  a.out_c = a.cs;
   a.rows = (int)rows;
   a.cs_ld = (int)(act_ld > 0 ? act_ld : a.cs);
   a.scalar = ((c % 4) || (k % 4) || (a.cs_ld % 4)) ? 1 : 0;
@@ -766,9 +770,10 @@ int hf_conv2d_nhwc_plan(int direction, int64_t n, int64_t h, int64_t w, int64_t 
 
 int hf_conv2d_nhwc_slabs(int direction, void* out, const void* act, const void* mat, int64_t n, int64_t h,
                          int64_t w, int64_t c, int64_t k, int64_t r, int64_t s, int64_t stride_h,
-                         int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t act_ld, int splits,
-                         int64_t slab_stride, int dtype, void* stream) {
+                         int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t act_ld, int64_t out_c,
+                         int splits, int64_t slab_stride, int dtype, void* stream) {
   if (direction < 0 || direction > 2 || splits < 1 || slab_stride < 0) return HF_ERR_ARG;
+  if (out_c < 0 || out_c > c || (out_c && direction != 2)) return HF_ERR_ARG;
   alignas(16) float dummy_ws[4];
   const int rc = check_common(out, act, mat, dummy_ws, dummy_ws, dtype, n, h, w, c, k, r, s, stride_h, stride_w,
                               pad_h, pad_w);
@@ -778,6 +783,7 @@ int hf_conv2d_nhwc_slabs(int direction, void* out, const void* act, const void* 
                                pad_w, act_ld, nullptr, 0, nullptr, 0, 0, splits, slab_stride);
   if (blocks <= 0) return (int)blocks;
   if (a.splits != splits) return HF_ERR_ARG;  // ask hf_conv2d_nhwc_plan first
+  if (out_c) a.out_c = (int)out_c;
   launch_one(direction, a, blocks, (hipStream_t)stream);
   HF_HIP(hipGetLastError());
   return HF_OK;

@@ -819,15 +819,13 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine(
     T acc = (T)0;
     if (a) {
       T av = a[i];
-      int sp = 1;
-      for (; sp + 8 <= a_splits; sp += 8) {  // split-K slabs: eight loads in flight, summed in split order
+      for (int sp = 1; sp < a_splits; sp += 8) {  // split-K slabs: eight loads in flight, summed in split order
         T t8[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t8[u] = a[(long long)(sp + u) * a_slab + i];
+        for (int u = 0; u < 8; ++u) t8[u] = a[(long long)(sp + u < a_splits ? sp + u : 0) * a_slab + i];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) av += t8[u];
+        for (int u = 0; u < 8; ++u) av += sp + u < a_splits ? t8[u] : (T)0;
       }
-      for (; sp < a_splits; ++sp) av += a[(long long)sp * a_slab + i];
       acc = av * ((w ? w[c] : (T)1) * rs);
     }
     if (q) acc += ((x[i] - mean[c]) * rs) * q[c];
@@ -911,6 +909,29 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
   }
 }
 
+// first + slabs 1..n-1 of a W-wide column, eight loads in flight, added in split order
+template <typename T, typename Col, int W>
+__device__ __forceinline__ Col slab_sum(Col first, const T* p, int n, long long stride) {
+  // batches of eight loads, ALL in flight before the first add; the last batch is predicated
+  // instead of a one-by-one tail (a tail of dependent load-add pairs costs a round trip each)
+  for (int sp = 1; sp < n; sp += 8) {
+    Col v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = sp + u < n ? sp + u : 0;  // slab 0 is valid memory; its value is discarded
+      v[u] = *reinterpret_cast<const Col*>(p + (long long)q * stride);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (sp + u < n) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) first.e[k] += v[u].e[k];
+      }
+    }
+  }
+  return first;
+}
+
 // NHWC variant: element (row, c) at row*C + c, row = n*HW + hw.  A block owns W
 // adjacent channels (W = 4: one 16-byte column) and spreads the rows over its 256
 // threads, so the per-channel sums need no cross-block step (deterministic, no
@@ -951,22 +972,22 @@ __global__ __launch_bounds__(BS) void k_chan_affine_bwd_nhwc(
       const I r = r0 + (I)t * BS;
       if (r < row_hi) {
         const I idx = r * C + c0;
+        // every first load is issued before any slab is summed (a sum waits for its loads)
         g[t] = *reinterpret_cast<const Col*>(gy + idx);
-        for (int sp = 1; sp < s1; ++sp) {  // split-K slabs of the cotangent, in split order
-          const Col v = *reinterpret_cast<const Col*>(gy + (long long)sp * l1 + idx);
-#pragma unroll
-          for (int k = 0; k < W; ++k) g[t].e[k] += v.e[k];
-        }
-        if (gy2) {
-          h[t] = *reinterpret_cast<const Col*>(gy2 + idx);
-          for (int sp = 1; sp < s2; ++sp) {
-            const Col v = *reinterpret_cast<const Col*>(gy2 + (long long)sp * l2 + idx);
-#pragma unroll
-            for (int k = 0; k < W; ++k) h[t].e[k] += v.e[k];
-          }
-        }
+        if (gy2) h[t] = *reinterpret_cast<const Col*>(gy2 + idx);
         if (x) xv[t] = *reinterpret_cast<const Col*>(x + idx);
         if (mask_src) m[t] = *reinterpret_cast<const Col*>(mask_src + idx);
+      }
+    }
+    if (s1 > 1 || s2 > 1) {
+#pragma unroll
+      for (int t = 0; t < ITER; ++t) {
+        const I r = r0 + (I)t * BS;
+        if (r < row_hi) {
+          const I idx = r * C + c0;
+          if (s1 > 1) g[t] = slab_sum<T, Col, W>(g[t], gy + idx, s1, l1);  // split-K slabs, in split order
+          if (gy2 && s2 > 1) h[t] = slab_sum<T, Col, W>(h[t], gy2 + idx, s2, l2);
+        }
       }
     }
 #pragma unroll
@@ -1003,6 +1024,90 @@ __global__ __launch_bounds__(BS) void k_chan_affine_bwd_nhwc(
     for (int k = 0; k < W; ++k) {
       if (gw) gw[rb * C + c0 + k] = (T)acc[2 * k];
       if (gb) gb[rb * C + c0 + k] = (T)acc[2 * k + 1];
+    }
+  }
+}
+
+// BatchNorm adjoint, NHWC fp32, ROW-MAJOR thread map: thread (ty, tx) owns the 16-byte channel
+// column tx of rows ty, ty + RP, ... of its block's row share, so that a wave reads whole
+// contiguous rows (the column-per-block kernel above reads 16 bytes every C*4 bytes: one cache
+// line per lane).  Per-channel sums: per thread over its rows, then over ty through LDS in a
+// fixed order; every block writes its partial sums to gw / gb + blockIdx.x*C (hf_pack_ex adds
+// the row shares up).  Cotangents may arrive as split-K slabs.
+__global__ __launch_bounds__(BLOCK) void k_bn_adjoint_rows(
+    float* __restrict__ gx, float* __restrict__ gw, float* __restrict__ gb, float* __restrict__ gres,
+    const float* __restrict__ gy, int s1, long long l1, const float* __restrict__ gy2, int s2, long long l2,
+    const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ w, const float* __restrict__ mask_src, unsigned rows, unsigned C,
+    unsigned rows_per_block) {
+  __shared__ double red[BLOCK * 8];
+  struct alignas(16) Col { float e[4]; };
+  const unsigned quads = C / 4, RP = BLOCK / quads;
+  const unsigned tx = threadIdx.x % quads, ty = threadIdx.x / quads;
+  const unsigned c0 = tx * 4;
+  const bool live = ty < RP;
+  float rs[4], mu[4], sc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    rs[k] = rstd ? rstd[c0 + k] : 1.f;
+    mu[k] = mean ? mean[c0 + k] : 0.f;
+    sc[k] = (w ? w[c0 + k] : 1.f) * rs[k];
+  }
+  double acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+  const unsigned row_lo = blockIdx.x * rows_per_block;
+  const unsigned row_hi = row_lo + rows_per_block < rows ? row_lo + rows_per_block : rows;
+  if (live) {
+    // two rows per pass: their first loads and their slab batches are all in flight together
+    for (unsigned r = row_lo + ty; r < row_hi; r += 2 * RP) {
+      const bool two = r + RP < row_hi;
+      const unsigned idx0 = r * C + c0, idx1 = (two ? r + RP : r) * C + c0;
+      Col g0 = *reinterpret_cast<const Col*>(gy + idx0), g1 = *reinterpret_cast<const Col*>(gy + idx1);
+      Col h0, h1, x0, x1, m0, m1;
+      if (gy2) { h0 = *reinterpret_cast<const Col*>(gy2 + idx0); h1 = *reinterpret_cast<const Col*>(gy2 + idx1); }
+      if (x) { x0 = *reinterpret_cast<const Col*>(x + idx0); x1 = *reinterpret_cast<const Col*>(x + idx1); }
+      if (mask_src) {
+        m0 = *reinterpret_cast<const Col*>(mask_src + idx0);
+        m1 = *reinterpret_cast<const Col*>(mask_src + idx1);
+      }
+      if (s1 > 1) { g0 = slab_sum<float, Col, 4>(g0, gy + idx0, s1, l1); g1 = slab_sum<float, Col, 4>(g1, gy + idx1, s1, l1); }
+      if (gy2 && s2 > 1) {
+        h0 = slab_sum<float, Col, 4>(h0, gy2 + idx0, s2, l2);
+        h1 = slab_sum<float, Col, 4>(h1, gy2 + idx1, s2, l2);
+      }
+      Col o0, o1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float a0 = gy2 ? g0.e[k] + h0.e[k] : g0.e[k], a1 = gy2 ? g1.e[k] + h1.e[k] : g1.e[k];
+        if (mask_src) { a0 = m0.e[k] > 0.f ? a0 : 0.f; a1 = m1.e[k] > 0.f ? a1 : 0.f; }
+        g0.e[k] = a0; g1.e[k] = a1;
+        o0.e[k] = a0 * sc[k]; o1.e[k] = a1 * sc[k];
+        if (x) acc[2 * k] += (double)a0 * (double)(float)((x0.e[k] - mu[k]) * rs[k]);
+        acc[2 * k + 1] += (double)a0;
+        if (two) {
+          if (x) acc[2 * k] += (double)a1 * (double)(float)((x1.e[k] - mu[k]) * rs[k]);
+          acc[2 * k + 1] += (double)a1;
+        }
+      }
+      if (gres) { *reinterpret_cast<Col*>(gres + idx0) = g0; if (two) *reinterpret_cast<Col*>(gres + idx1) = g1; }
+      if (gx) { *reinterpret_cast<Col*>(gx + idx0) = o0; if (two) *reinterpret_cast<Col*>(gx + idx1) = o1; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = live ? acc[k] : 0.0;
+  __syncthreads();
+  if (ty == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      double sum = 0.0;
+      for (unsigned t = 0; t < RP; ++t) sum += red[(t * quads + tx) * 8 + k];  // fixed order over ty
+      acc[k] = sum;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (gw) gw[blockIdx.x * C + c0 + k] = (float)acc[2 * k];
+      if (gb) gb[blockIdx.x * C + c0 + k] = (float)acc[2 * k + 1];
     }
   }
 }
@@ -2003,8 +2108,22 @@ int hf_chan_affine_bwd_ex(void* gx, void* gw, void* gb, void* gres, const void* 
                           const void* mask_src, int64_t n, int64_t c, int64_t hw, int channels_last,
                           int row_blocks, int dtype, void* stream) {
   if (!gy || n <= 0 || c <= 0 || hw <= 0 || gy_splits < 1 || gy2_splits < 1 || row_blocks < 1) return HF_ERR_ARG;
-  // row shares exist in the 16-byte-column NHWC kernel only
-  if (row_blocks > 1 && !(channels_last && hw > 1 && c % 4 == 0 && dtype == HF_F32)) return HF_ERR_ARG;
+  // row shares: the row-major NHWC fp32 kernel
+  if (row_blocks > 1) {
+    if (!(channels_last && c % 4 == 0 && c / 4 <= BLOCK && dtype == HF_F32)) return HF_ERR_ARG;
+    const int64_t rows = n * hw;
+    if (rows * c > 0x7fffffffLL || !aligned16(gy) || (gy2 && !aligned16(gy2)) || (x && !aligned16(x)) ||
+        (mask_src && !aligned16(mask_src)) || (gx && !aligned16(gx)) || (gres && !aligned16(gres)))
+      return HF_ERR_ALIGN;
+    const unsigned rpb = (unsigned)((rows + row_blocks - 1) / row_blocks);
+    hipLaunchKernelGGL(k_bn_adjoint_rows, dim3((unsigned)row_blocks), dim3(BLOCK), 0, (hipStream_t)stream,
+                       (float*)gx, (float*)gw, (float*)gb, (float*)gres, (const float*)gy, gy_splits,
+                       (long long)gy_slab, (const float*)gy2, gy2_splits, (long long)gy2_slab, (const float*)x,
+                       (const float*)mean, (const float*)rstd, (const float*)w, (const float*)mask_src,
+                       (unsigned)rows, (unsigned)c, rpb);
+    HF_HIP(hipGetLastError());
+    return HF_OK;
+  }
   if ((gy_splits > 1 && gy_slab <= 0) || (gy2 && gy2_splits > 1 && gy2_slab <= 0)) return HF_ERR_ARG;
   if ((gy_splits > 1 || gy2_splits > 1) && !(channels_last || hw == 1)) return HF_ERR_ARG;
   if ((gw && (!x || !mean || !rstd)) || (gx && !rstd)) return HF_ERR_ARG;

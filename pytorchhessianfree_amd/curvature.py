@@ -257,7 +257,12 @@ class GraphedOperator:
     that stream and the engine then touches it during capture).
     """
 
-    mode = "hipGraph replay of autograd sweeps + hf_pack"
+    @property
+    def mode(self):
+        inner = getattr(getattr(self, "op", None), "mode", "")
+        if "engine" in inner:
+            return "hipGraph replay of the " + inner
+        return "hipGraph replay of autograd sweeps + hf_pack"
 
     _captured_before = False  # later captures in a process need a single warm-up run
     _streams = {}             # one capture stream per device, shared by all instances
