@@ -600,7 +600,8 @@ def _use_own(mode, kind, rows):
     (scripts/conv_kernel_bench.py) favours the own kernels for <= 128 rows; in the product
     that advantage is gone (operands arrive cold from other XCDs' L2).  kind: "T" tangent,
     "D" data gradient, "W" weight gradient, "DW" both in one launch, "stem" the tiny-Cin
-    layer; the thresholds stay tunable (``HF_CONV_AUTO``)."""
+    layer, "F" the once-per-step forward pass (own kernels: accuracy first); the thresholds stay
+    tunable (``HF_CONV_AUTO``)."""
     mode = os.environ.get("HF_CONV") or mode or "auto"
     if mode == "own":
         return True
@@ -609,7 +610,7 @@ def _use_own(mode, kind, rows):
     return rows <= _auto_rows().get(kind, 0)
 
 
-_AUTO_DEFAULT = {"T": 0, "D": 0, "W": 0, "DW": 0, "stem": 0}
+_AUTO_DEFAULT = {"T": 0, "D": 0, "W": 0, "DW": 0, "stem": 0, "F": 1 << 30}
 
 
 def _auto_rows():
@@ -630,7 +631,7 @@ def _tiny_cin(x, w, cl):
     gather (the 1-channel 7x7 stem of the MNIST ResNet): its tangent and weight gradient run
     as 1x1 products over the im2col of the input, which is constant for a step."""
     return cl and x.is_cuda and x.dtype == torch.float32 and x.shape[1] < 4 and (
-        x.shape[1] * w.shape[2] * w.shape[3] <= 64) and w.is_contiguous()
+        x.shape[1] * w.shape[2] * w.shape[3] <= 256) and w.is_contiguous()
 
 
 def _cols_of(ctx, x, w, stride, padding):
@@ -780,6 +781,23 @@ class _Conv(torch.autograd.Function):
         ctx.cols = None
         ctx.gw_buf = None
         ctx.wT = None
+        # The forward pass of an NHWC layer runs on the package's own kernels by default ("F" in
+        # the auto rule): once per step its speed does not matter, its accuracy does -- the
+        # activations feed every curvature product -- and for shapes without a find-db record
+        # MIOpen's heuristic solver choice was measured to be good to only 1e-4..1e-3 on some
+        # machines (a fresh box with a cold kernel cache), run to run.
+        oh, ow = _out_hw(xf, wf, stride, padding)
+        rows = xf.shape[0] * oh * ow
+        if _own_conv_ok(xf, wf, cl, dilation, xf.shape[1]) and _use_own(mode, "F", rows):
+            y = _own_conv_forward(xf, wf, stride, padding)
+            return y if b is None else y + b.view(1, -1, 1, 1)
+        if _tiny_cin(xf, w, cl) and _use_own(mode, "F", rows):
+            cols = _cols_of(ctx, xf, w, stride, padding)  # 1x1 product over the im2col, (c, r, s) order
+            n_, k_, j_ = xf.shape[0], w.shape[0], cols.shape[2]
+            y = torch.empty((n_, k_, oh, ow), dtype=xf.dtype, device=xf.device).contiguous(
+                memory_format=torch.channels_last)
+            _lib.conv2d_nhwc(0, y, cols, w, n_ * oh * ow, 1, 1, j_, k_, 1, 1, (1, 1), (0, 0))
+            return y if b is None else y + b.view(1, -1, 1, 1)
         c = _point(xf, wf, padding, dilation, cl)
         if c is not None:
             y = xf.flatten(1) @ wf[:, :, c, c].t()

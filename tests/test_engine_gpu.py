@@ -69,7 +69,12 @@ def test_bottleneck_net_engine_product_matches_float64():
     os_ = stock(xs)
     stock_err = float((curvature.GGNOperator(lossf2(os_, ts), os_, ps)(v).double() - want).abs().max()
                       / want.abs().max())
-    assert err < max(2e-5, 3.0 * stock_err), (err, stock_err)
+    worst, off = [], 0
+    for name, p in model.named_parameters():
+        a, b = got[off:off + p.numel()].double(), want[off:off + p.numel()]
+        worst.append((float((a - b).abs().max() / want.abs().max()), name))
+        off += p.numel()
+    assert err < max(2e-5, 3.0 * stock_err), (err, stock_err, sorted(worst, reverse=True)[:5])
 
 
 def test_engine_declines_what_it_does_not_know():

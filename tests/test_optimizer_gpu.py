@@ -769,8 +769,15 @@ def test_resnet18_newton_solve_matches_reference_cpu_path(deterministic):
     from pytorchhessianfree_amd import modelprep
     from pytorchhessianfree_amd.utils import vector_to_parameter_list
 
+    import copy
+
     lam = 1e-3
-    model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=1000)
+    # a batch on which no ReLU input of the float64 model lies within fp32 rounding of zero: two
+    # correct fp32 forward passes (CPU / GPU) may otherwise disagree on one ReLU sign, which alone
+    # moves the gradient by 2e-4 (testproblems.relu_margin; ~every third random batch has one)
+    seed = tp.RESNET18_B32_SEPARATED_SEEDS[0]
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=seed)
+    assert tp.relu_margin(copy.deepcopy(model).double(), x.double()) > 8e-7
     params = list(model.parameters())
     out = model(x)
     loss = lossf(out, t)
@@ -785,7 +792,7 @@ def test_resnet18_newton_solve_matches_reference_cpu_path(deterministic):
         warnings.simplefilter("ignore")
         ox, om, oreason = oracle.pcg(lambda v: mvp(v) + lam * v, -grad, **kw)
 
-    gm, (gx_, gt_), _ = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=1000)
+    gm, (gx_, gt_), _ = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=seed)
     # deterministic: every convolution on the package's own fixed-order kernels (NHWC)
     modelprep.prepare_model(gm, channels_last=deterministic, deterministic=deterministic)
     gp = list(gm.parameters())
