@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 2
+#define HF_ABI_VERSION 3
 
 enum hf_dtype { HF_F32 = 0, HF_F64 = 1 };
 
@@ -170,10 +170,13 @@ int hf_pack(void* dst, const void* const* srcs, const int64_t* numels,
             const int64_t* perm, int n_tensors, double scale, int mode, int dtype,
             void* stream);
 /* The same with `splits` (HOST, 2 per tensor, or NULL): {count, stride in elements} when source t
- * is the sum of `count` split-K slabs (hf_conv2d_nhwc_*_slabs weight gradients). */
+ * is the sum of `count` split-K slabs (hf_conv2d_nhwc_*_slabs weight gradients), and `live` (HOST,
+ * 1 per tensor, or NULL): for a permuted source with H*W <= 16, bit hw set = kernel tap hw can
+ * meet data; the gradients of the other taps (3x3 kernels on 1x1 / 2x2 maps) are structurally
+ * zero and are written as zeros without being read.  0 = read everything. */
 int hf_pack_ex(void* dst, const void* const* srcs, const int64_t* numels, const int64_t* perm,
-               const int64_t* splits, int n_tensors, double scale, int mode, int dtype,
-               void* stream);
+               const int64_t* splits, const int64_t* live, int n_tensors, double scale, int mode,
+               int dtype, void* stream);
 
 /*
  * Multi-tensor scatter for the tangent sweep, the counterpart of hf_pack: tensor t is the
@@ -189,6 +192,12 @@ int hf_pack_ex(void* dst, const void* const* srcs, const int64_t* numels, const 
 int hf_unpack_tangent(const void* src, void* const* dsts, const int64_t* src_offs,
                       const int64_t* numels, const int64_t* slabs, const int64_t* inners,
                       int n_tensors, int dtype, void* stream);
+/* The same with `live` (HOST, 1 per tensor, or NULL; NHWC destinations with H*W <= 16): only the
+ * slices of the taps whose bit is set are copied -- the convolution kernels never read the
+ * others (hf_conv2d_nhwc drops taps that only meet padding).  0 = copy everything. */
+int hf_unpack_tangent_ex(const void* src, void* const* dsts, const int64_t* src_offs,
+                         const int64_t* numels, const int64_t* slabs, const int64_t* inners,
+                         const int64_t* live, int n_tensors, int dtype, void* stream);
 
 /* minv = (diag + damping)^(-exponent)   (preconditioners.py:124, hoisted out of
  * the CG loop). */
@@ -339,6 +348,44 @@ int hf_conv2d_nhwc_backward(void* dx, void* dw, const void* dy, const void* x, c
  */
 int hf_softmax_ce_hvp(void* out, const void* p, const void* v, double scale, int64_t rows,
                       int64_t cols, int dtype, void* stream);
+
+/* ---- max-pool and classifier head inside the GGN product (hf_head.hip) ----------- */
+/*
+ * The remaining non-convolution stages of BackPACK's R-op / L-op sweeps through a ResNet
+ * (optimizer.py:461), each as ONE launch with a fixed summation order; fp32, NHWC.
+ *
+ * hf_maxpool_tangent_nhwc: out[n,oy,ox,c] = t[n, idx[n,oy,ox,c], c] -- the tangent of a max-pool
+ * is the tangent at the window's maximum.  idx: int32 [n,oh,ow,c], flat position y*w + x inside
+ * the (n, c) plane (max_pool2d_with_indices, taken once per Newton step).  out may be the
+ * first-channels slice of a wider NHWC buffer (out_ld floats per pixel, 0 = dense).
+ * Replaced: a gather plus a strided copy.
+ */
+int hf_maxpool_tangent_nhwc(void* out, const void* t, const void* idx, int64_t n, int64_t h, int64_t w,
+                            int64_t oh, int64_t ow, int64_t c, int64_t out_ld, int dtype, void* stream);
+/*
+ * hf_maxpool_adjoint_nhwc: g[n,y,x,c] = sum over the windows whose maximum sits at (y,x) of
+ * (gy_a + gy_b)[n,oy,ox,c], gy_a / gy_b the cotangents from the pooled map's two consumers, each
+ * `splits` slabs `slab` elements apart that are summed in split order (gy_b nullable).  Gather
+ * form: no zero-fill, no atomics.  Replaced: the slab sum, a zero-fill and ATen's
+ * max_pool2d_with_indices_backward (atomic accumulation in NHWC).
+ */
+int hf_maxpool_adjoint_nhwc(void* g, const void* gy_a, int a_splits, int64_t a_slab, const void* gy_b,
+                            int b_splits, int64_t b_slab, const void* idx, int64_t n, int64_t h, int64_t w,
+                            int64_t oh, int64_t ow, int64_t c, int64_t kh, int64_t kw, int64_t stride_h,
+                            int64_t stride_w, int64_t pad_h, int64_t pad_w, int dtype, void* stream);
+/*
+ * hf_linear_ce_head: the classifier head of J^T H_L J v in one launch (one workgroup):
+ *   Jv = t_feat W^T + feat V_W^T + v_b;  HJv = scale * p * (Jv - <p, Jv>) (as hf_softmax_ce_hvp);
+ *   g_feat = HJv W [rows, features];  g_w = HJv^T feat [classes, features];  g_b = sum_rows HJv.
+ * t_feat / feat [rows, features]: tangent and value of the features; w / v_w [classes, features];
+ * v_b, g_b nullable; p = softmax(logits) [rows, classes].  Small heads only: classes <= 64,
+ * features <= 512 and a multiple of 4, (rows*classes + rows*features) floats within 150 KB of
+ * LDS -- returns -1 otherwise (the caller keeps the GEMM path).  Replaced: 4 rocBLAS GEMMs, a
+ * reduction and hf_softmax_ce_hvp.
+ */
+int hf_linear_ce_head(void* g_feat, void* g_w, void* g_b, const void* t_feat, const void* feat, const void* w,
+                      const void* v_w, const void* v_b, const void* p, double scale, int64_t rows,
+                      int64_t features, int64_t classes, int dtype, void* stream);
 
 /* ---- RCCL (resolved at run time from the already-loaded librccl) ----------- */
 typedef struct hf_comm hf_comm_t;

@@ -90,6 +90,10 @@ SIGNATURES = {
         c_int,
         [c_void_p, ctypes.POINTER(c_void_p)] + [ctypes.POINTER(c_int64)] * 4 + [c_int, c_int, c_void_p],
     ),
+    "hf_unpack_tangent_ex": (
+        c_int,
+        [c_void_p, ctypes.POINTER(c_void_p)] + [ctypes.POINTER(c_int64)] * 5 + [c_int, c_int, c_void_p],
+    ),
     "hf_precond_build": (c_int, [c_void_p, c_void_p, c_double, c_double, c_int64, c_int, c_void_p]),
     "hf_axpy_out": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int, c_void_p]),
     "hf_chan_affine": (c_int, [c_void_p] * 10 + [c_int, c_int64, c_int64, c_int64, c_int, c_int64, c_int64,
@@ -113,9 +117,13 @@ SIGNATURES = {
     "hf_pack_ex": (
         c_int,
         [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64),
-         ctypes.POINTER(c_int64), c_int, c_double, c_int, c_int, c_void_p],
+         ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), c_int, c_double, c_int, c_int, c_void_p],
     ),
     "hf_softmax_ce_hvp": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int64, c_int, c_void_p]),
+    "hf_maxpool_tangent_nhwc": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int64] * 7 + [c_int, c_void_p]),
+    "hf_maxpool_adjoint_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_void_p]
+                                + [c_int64] * 12 + [c_int, c_void_p]),
+    "hf_linear_ce_head": (c_int, [c_void_p] * 9 + [c_double, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "hf_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "hf_comm_create": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_char_p, c_int, c_int]),
     "hf_comm_destroy": (c_int, [c_void_p]),
@@ -150,7 +158,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.hf_abi_version() != 2:
+    if lib.hf_abi_version() != 3:
         raise RuntimeError("libhfpcg.so ABI version mismatch")
     _lib = lib
     return lib
@@ -232,8 +240,10 @@ def unpack_tangent(v, slots):
     require_device_tensor(v, "v")
     n = len(slots)
     dsts = (c_void_p * n)()
-    offs, numels, slabs, inners = ((c_int64 * n)() for _ in range(4))
-    for k, (off, buf, cin) in enumerate(slots):
+    offs, numels, slabs, inners, live = ((c_int64 * n)() for _ in range(5))
+    for k, slot in enumerate(slots):
+        off, buf, cin = slot[:3]
+        live[k] = slot[3] if len(slot) > 3 else 0  # bit mask of the kernel taps that meet data (0 = all)
         if buf.dtype != v.dtype or buf.device != v.device or buf.dim() != 4 or buf.shape[1] != 2 * cin:
             raise RuntimeError("unpack_tangent: buffer does not match")
         hw = buf.shape[2] * buf.shape[3]
@@ -250,11 +260,11 @@ def unpack_tangent(v, slots):
         if off < 0 or off + numels[k] > v.numel():
             raise RuntimeError("unpack_tangent: slice outside the vector")
     check(
-        lib.hf_unpack_tangent(
-            c_void_p(v.data_ptr()), dsts, offs, numels, slabs, inners, n, dtype_code(v.dtype),
+        lib.hf_unpack_tangent_ex(
+            c_void_p(v.data_ptr()), dsts, offs, numels, slabs, inners, live, n, dtype_code(v.dtype),
             current_stream_ptr(v.device),
         ),
-        "hf_unpack_tangent",
+        "hf_unpack_tangent_ex",
     )
 
 
@@ -350,10 +360,11 @@ def conv2d_nhwc_backward(dx, dw, dy, x, w_t, n, h, w, c, k, r, s, stride, paddin
     return dx, dw
 
 
-def pack_ex(dst, tensors, perms, splits, scale=1.0):
+def pack_ex(dst, tensors, perms, splits, scale=1.0, live=None):
     """``pack`` for sources the caller describes itself: ``perms[i] = (I, H*W)`` marks tensor i as
     stored (O, H, W, I); ``splits[i] = (count, stride)`` makes it the sum of ``count`` split-K
-    slabs ``stride`` elements apart (``hf_pack_ex``).  ``tensors[i]`` is the first slab."""
+    slabs ``stride`` elements apart (``hf_pack_ex``); ``live[i]`` = bit mask of the kernel taps
+    whose gradients are not structurally zero.  ``tensors[i]`` is the first slab."""
     lib = load()
     require_device_tensor(dst, "dst")
     n = len(tensors)
@@ -361,6 +372,7 @@ def pack_ex(dst, tensors, perms, splits, scale=1.0):
     numels = (c_int64 * n)()
     perm = (c_int64 * (2 * n))()
     spl = (c_int64 * (2 * n))()
+    lv = (c_int64 * n)()
     total = 0
     for i, t in enumerate(tensors):
         if t.dtype != dst.dtype or t.device != dst.device:
@@ -371,10 +383,11 @@ def pack_ex(dst, tensors, perms, splits, scale=1.0):
         if i in perms:
             perm[2 * i], perm[2 * i + 1] = perms[i]
         spl[2 * i], spl[2 * i + 1] = splits.get(i, (1, 0))
+        lv[i] = (live or {}).get(i, 0)
     if total != dst.numel():
         raise RuntimeError(f"pack_ex: {total} source elements for a vector of {dst.numel()}")
     check(
-        lib.hf_pack_ex(c_void_p(dst.data_ptr()), ptrs, numels, perm, spl, n, float(scale), 0,
+        lib.hf_pack_ex(c_void_p(dst.data_ptr()), ptrs, numels, perm, spl, lv, n, float(scale), 0,
                        dtype_code(dst.dtype), current_stream_ptr(dst.device)),
         "hf_pack_ex")
     return dst

@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SRC = os.path.join(HERE, "hf_pcg.hip")
 SRC_CONV = os.path.join(HERE, "hf_conv.hip")
-SOURCES = [SRC, SRC_CONV]
+SRC_HEAD = os.path.join(HERE, "hf_head.hip")
+SOURCES = [SRC, SRC_CONV, SRC_HEAD]
 HDR = os.path.join(ROOT, "include", "hf_pcg.h")
 OUT = os.path.join(HERE, "libhfpcg.so")
 

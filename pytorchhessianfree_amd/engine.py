@@ -268,11 +268,12 @@ class FusedGGNEngine(_Operator):
                     xcats[key] = xc
                 u.xcat = xcats[key]
                 wf = _cl(u.conv.weight.detach())
-                u.wcat = torch.empty((k, 2 * c, r, s), dtype=f32, device=dev).contiguous(
-                    memory_format=torch.channels_last)
+                u.wcat = torch.zeros((k, 2 * c, r, s), dtype=f32, device=dev).contiguous(
+                    memory_format=torch.channels_last)  # (slices of taps that never meet data stay 0)
                 u.wcat[:, :c].copy_(wf)
                 u.wT = wf.permute(1, 2, 3, 0).contiguous()  # (I, H, W, O)
-                self._tangent_slots[id(u)] = (self._offs[u.pw], u.wcat, c)
+                u.live = _live_taps(h, w, r, s, u.conv.stride, u.conv.padding)
+                self._tangent_slots[id(u)] = (self._offs[u.pw], u.wcat, c, u.live)
             oh, ow = u.a.shape[2], u.a.shape[3]
             u.rows, u.cout = n * oh * ow, k
             # split-K slab buffers
@@ -294,7 +295,8 @@ class FusedGGNEngine(_Operator):
             if k % 4 == 0 and k // 4 <= 256 and u.rows >= 64:
                 # row-major adjoint kernel: ~32 workgroups, each reading whole contiguous rows
                 rp = 256 // (k // 4)
-                per = max(2 * rp, -(-u.rows // 32))
+                tgt = int(os.environ.get("HF_BN_ROW_BLOCKS", "32"))
+                per = max(int(os.environ.get("HF_BN_ROW_PASSES", "2")) * rp, -(-u.rows // tgt))
                 u.rb = -(-u.rows // per)
                 if u.rb < 2:
                     u.rb = 1
@@ -311,7 +313,7 @@ class FusedGGNEngine(_Operator):
         self.pool_t = xcats.get(self.pool_key)
         if self.pool_t is None:
             raise _Unsupported("nothing consumes the pooled stem output")
-        self.pool_idx = None
+        self.pool_idx = self.pool_idx32 = None
         self._slot_list = list(self._tangent_slots.values())
 
     def _plan_stem(self, direction, geo):
@@ -379,9 +381,21 @@ class FusedGGNEngine(_Operator):
         ks, st_, pd, dl, cm = self.pool_args
         if self.pool_idx is None:
             _, self.pool_idx = torch.nn.functional.max_pool2d(s.y, ks, st_, pd, dl, cm, return_indices=True)
+            # own one-launch pooling kernels (hf_head.hip): NHWC int32 positions, unit dilation
+            self.pool_idx32 = None
+            if _pair(dl) == [1, 1] and os.environ.get("HF_ENGINE_POOL", "1") != "0":
+                self.pool_idx32 = self.pool_idx.permute(0, 2, 3, 1).contiguous().to(torch.int32)
+                self._g_stem = torch.empty_like(s.y)
         c0 = self.pool_out.shape[1]
-        t_pool = s.tout.flatten(2).gather(2, self.pool_idx.flatten(2)).view_as(self.pool_out)
-        self.pool_t[:, :c0].copy_(t_pool)
+        pn, _, ph, pw = s.y.shape
+        poh, pow_ = self.pool_out.shape[2], self.pool_out.shape[3]
+        if self.pool_idx32 is not None:
+            _lib.check(_lib.load().hf_maxpool_tangent_nhwc(
+                _ptr(self.pool_t), _ptr(s.tout), _ptr(self.pool_idx32), pn, ph, pw, poh, pow_, c0, 2 * c0,
+                _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_maxpool_tangent_nhwc")
+        else:
+            t_pool = s.tout.flatten(2).gather(2, self.pool_idx.flatten(2)).view_as(self.pool_out)
+            self.pool_t[:, :c0].copy_(t_pool)
         for chain, ds, _x in self.blocks:
             head = chain[0]
             if ds is not None:
@@ -399,23 +413,35 @@ class FusedGGNEngine(_Operator):
         tail = self.blocks[-1][0][-1]
         t_last = tail.tout
         hw = t_last.shape[2] * t_last.shape[3]
-        t_feat = t_last.flatten(1) if hw == 1 else t_last.mean(dim=(2, 3))
         fw = self.fc.weight
         nf = fw.numel()
         v_fw = v[self._offs[self.pfw]: self._offs[self.pfw] + nf].view_as(fw)
-        if self.pfb is not None:
-            Jv = torch.addmm(v[self._offs[self.pfb]: self._offs[self.pfb] + fw.shape[0]], t_feat, fw.detach().t())
+        v_fb = None if self.pfb is None else v[self._offs[self.pfb]: self._offs[self.pfb] + fw.shape[0]]
+        if self._head_fused(hw, v_fw):
+            # classifier head in ONE launch: logits' tangent, softmax-CE Hessian, the three gradients
+            g_feat, g_fw, g_fb = self._head_bufs
+            _lib.check(_lib.load().hf_linear_ce_head(
+                _ptr(g_feat), _ptr(g_fw), _ptr(g_fb) if self.pfb is not None else None, _ptr(t_last),
+                _ptr(self.feat), _ptr(fw), _ptr(v_fw), _ptr(v_fb), _ptr(self._ce[0]), float(self._ce[1]),
+                g_feat.shape[0], g_feat.shape[1], fw.shape[0], _lib.HF_F32,
+                _lib.current_stream_ptr(self.dev)), "hf_linear_ce_head")
+            if self.pfb is None:
+                g_fb = None
         else:
-            Jv = t_feat @ fw.detach().t()
-        Jv = torch.addmm(Jv, self.feat, v_fw.t())
+            t_feat = t_last.flatten(1) if hw == 1 else t_last.mean(dim=(2, 3))
+            if self.pfb is not None:
+                Jv = torch.addmm(v_fb, t_feat, fw.detach().t())
+            else:
+                Jv = t_feat @ fw.detach().t()
+            Jv = torch.addmm(Jv, self.feat, v_fw.t())
 
-        # ---- loss Hessian ---------------------------------------------------------------------
-        HJv = self._loss_hessian(Jv)
+            # ---- loss Hessian -----------------------------------------------------------------
+            HJv = self._loss_hessian(Jv)
 
-        # ---- adjoint sweep --------------------------------------------------------------------
-        g_fw = HJv.t() @ self.feat
-        g_fb = HJv.sum(0) if self.pfb is not None else None
-        g_feat = HJv @ fw.detach()
+            # ---- adjoint sweep ----------------------------------------------------------------
+            g_fw = HJv.t() @ self.feat
+            g_fb = HJv.sum(0) if self.pfb is not None else None
+            g_feat = HJv @ fw.detach()
         if hw == 1:
             g_last = g_feat.view(tail.y.shape)
         else:
@@ -442,14 +468,23 @@ class FusedGGNEngine(_Operator):
                 pool_srcs = srcs
         # block 0's input is the pooled stem output: sum its two cotangents, undo the max-pool
         (a, sa, la), (b, sb, lb) = pool_srcs
-        g_pool = torch.empty_like(self.pool_out)
-        _lib.check(_lib.load().hf_bn_adjoint_pre(
-            _ptr(g_pool), None, _ptr(a), sa, la, _ptr(b), sb, lb, None, None, None,
-            g_pool.numel() // c0, c0, _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_bn_adjoint_pre")
-        g_stem = torch.ops.aten.max_pool2d_with_indices_backward(
-            g_pool, s.y, _pair(ks), _pair(st_ if st_ is not None else ks), _pair(pd), _pair(dl), cm,
-            self.pool_idx)
-        self._adjoint_unit(s, [(_cl(g_stem), 1, 0)])
+        if self.pool_idx32 is not None:
+            # slab sums of both cotangents and the max-pool adjoint (gather form) in one launch
+            g_stem = self._g_stem
+            (kh, kw), (sh, sw), (pph, ppw) = _pair(ks), _pair(st_ if st_ is not None else ks), _pair(pd)
+            _lib.check(_lib.load().hf_maxpool_adjoint_nhwc(
+                _ptr(g_stem), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(self.pool_idx32), pn, ph, pw, poh, pow_,
+                c0, kh, kw, sh, sw, pph, ppw, _lib.HF_F32, _lib.current_stream_ptr(self.dev)),
+                "hf_maxpool_adjoint_nhwc")
+        else:
+            g_pool = torch.empty_like(self.pool_out)
+            _lib.check(_lib.load().hf_bn_adjoint_pre(
+                _ptr(g_pool), None, _ptr(a), sa, la, _ptr(b), sb, lb, None, None, None,
+                g_pool.numel() // c0, c0, _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_bn_adjoint_pre")
+            g_stem = _cl(torch.ops.aten.max_pool2d_with_indices_backward(
+                g_pool, s.y, _pair(ks), _pair(st_ if st_ is not None else ks), _pair(pd), _pair(dl), cm,
+                self.pool_idx))
+        self._adjoint_unit(s, [(g_stem, 1, 0)])
 
         # ---- gather all parameter gradients (weight-gradient slabs summed on the way) ---------
         tensors, perms, splits = self._pack_args()
@@ -457,18 +492,42 @@ class FusedGGNEngine(_Operator):
         tensors[self.pfw] = g_fw
         if self.pfb is not None:
             tensors[self.pfb] = g_fb
-        _lib.pack_ex(out, tensors, perms, splits, scale=self.weight)
+        _lib.pack_ex(out, tensors, perms, splits, scale=self.weight, live=self._pack_live)
         return out
+
+    def _head_fused(self, hw, v_fw):
+        """Whether ``hf_linear_ce_head`` applies: closed-form softmax-CE Hessian, a 1x1 final map
+        (the pooling is then the identity), a small dense head, 16-byte aligned operands."""
+        ok = getattr(self, "_head_ok", None)
+        if ok is None:
+            fw = self.fc.weight
+            k, f = fw.shape
+            ok = (
+                os.environ.get("HF_ENGINE_HEAD", "1") != "0" and self._ce is not None and hw == 1
+                and fw.is_contiguous() and fw.dtype == torch.float32 and k <= 64 and f <= 512 and f % 4 == 0
+                and self.feat.is_contiguous() and tuple(self.feat.shape) == (self.outputs.shape[0], f)
+                and (self.outputs.shape[0] * (k + f) + 4) * 4 <= 150 * 1024
+                and self._offs[self.pfw] % 4 == 0 and self._ce[0].is_contiguous()
+            )
+            if ok:
+                b = self.outputs.shape[0]
+                kw = dict(dtype=torch.float32, device=self.dev)
+                self._head_bufs = (torch.empty((b, f), **kw), torch.empty((k, f), **kw), torch.empty((k,), **kw))
+            self._head_ok = ok
+        return ok and v_fw.data_ptr() % 16 == 0
 
     def _pack_args(self):
         if getattr(self, "_pack", None) is None:
             tensors, perms, splits = [None] * len(self.params), {}, {}
+            self._pack_live = {}
             for u in self.units:
                 tensors[u.pw] = u.wbuf[0]
                 if u is not self.stem:
                     k, c, r, s_ = u.conv.weight.shape
                     if r * s_ > 1:
                         perms[u.pw] = (c, r * s_)  # stored (O, H, W, I); 1x1 kernels: already in order
+                        if u.live:
+                            self._pack_live[u.pw] = u.live
                 if u.sW > 1:
                     splits[u.pw] = (u.sW, u.wbuf.shape[1])
                 tensors[u.pg], tensors[u.pb] = u.gw[0], u.gb[0]
@@ -513,3 +572,18 @@ class _Unsupported(Exception):
 
 def _pair(v):
     return [v, v] if isinstance(v, int) else list(v)
+
+
+def _live_taps(h, w, r, s, stride, padding):
+    """Bit mask (bit ``i*s + j``) of the kernel taps that meet data at some output position; 0 when
+    all do or the mask does not fit the kernels' 16 bits.  The rule ``hf_conv2d_nhwc`` drops taps
+    by: a 3x3 kernel on a 1x1 map only ever uses its centre tap, the other 8/9 of the layer's
+    weight tangent / weight gradient are never read / structurally zero."""
+    if r * s > 16 or os.environ.get("HF_ENGINE_LIVE", "1") == "0":
+        return 0
+    oh = (h + 2 * padding[0] - r) // stride[0] + 1
+    ow = (w + 2 * padding[1] - s) // stride[1] + 1
+    rows = [any(0 <= o * stride[0] - padding[0] + i < h for o in range(oh)) for i in range(r)]
+    cols = [any(0 <= o * stride[1] - padding[1] + j < w for o in range(ow)) for j in range(s)]
+    mask = sum(1 << (i * s + j) for i in range(r) for j in range(s) if rows[i] and cols[j])
+    return 0 if mask == (1 << (r * s)) - 1 else mask

@@ -112,3 +112,139 @@ def test_step_with_engine_graph_and_data_parallel_weight():
     assert f0 < i0 and f1 < i1
     assert n0 == n1 and abs(f0 - f1) <= 1e-5 * abs(f0)
     assert float((p0 - p1).abs().max()) <= 1e-5 * float(p0.abs().max())
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("geom", [(32, 64, 14, 14, 3, 2, 1), (3, 8, 9, 7, 2, 2, 0), (2, 12, 10, 10, 3, 1, 1),
+                                  (2, 4, 7, 7, 3, 3, 1)])
+def test_maxpool_kernels_match_autograd(geom):
+    """``hf_maxpool_tangent_nhwc`` / ``hf_maxpool_adjoint_nhwc`` (one launch each, gather form, slab
+    sums of two cotangents) against ATen's max-pool JVP / backward in float64."""
+    from pytorchhessianfree_amd import _lib
+
+    n, c, h, w, k, s, p = geom
+    gen = torch.Generator(device=DEV).manual_seed(sum(geom))
+    x = _cl(torch.randn(n, c, h, w, device=DEV, generator=gen))
+    y, idx = torch.nn.functional.max_pool2d(x, k, s, p, return_indices=True)
+    oh, ow = y.shape[2], y.shape[3]
+    idx32 = idx.permute(0, 2, 3, 1).contiguous().to(torch.int32)
+    lib, st = _lib.load(), _lib.current_stream_ptr(x.device)
+    P = _lib.c_void_p
+
+    t = _cl(torch.randn(n, c, h, w, device=DEV, generator=gen))
+    wide = _cl(torch.zeros(n, 2 * c, oh, ow, device=DEV))
+    _lib.check(lib.hf_maxpool_tangent_nhwc(P(wide.data_ptr()), P(t.data_ptr()), P(idx32.data_ptr()), n, h, w, oh, ow,
+                                           c, 2 * c, _lib.HF_F32, st), "tangent")
+    want = t.flatten(2).gather(2, idx.flatten(2)).view_as(y)
+    assert torch.equal(wide[:, :c], want) and float(wide[:, c:].abs().max()) == 0.0
+
+    # adjoint: 3 slabs of one cotangent + 1 of the other
+    a = torch.randn(3, n, oh, ow, c, device=DEV, generator=gen)
+    b = torch.randn(1, n, oh, ow, c, device=DEV, generator=gen)
+    g = _cl(torch.empty(n, c, h, w, device=DEV))
+    _lib.check(lib.hf_maxpool_adjoint_nhwc(
+        P(g.data_ptr()), P(a.data_ptr()), 3, a[0].numel(), P(b.data_ptr()), 1, 0, P(idx32.data_ptr()), n, h, w, oh, ow,
+        c, k, k, s, s, p, p, _lib.HF_F32, st), "adjoint")
+    gy = (a.double().sum(0) + b[0].double()).permute(0, 3, 1, 2)
+    x64 = x.double().requires_grad_(True)
+    (want,) = torch.autograd.grad(torch.nn.functional.max_pool2d(x64, k, s, p), x64, gy)
+    assert float((g.double() - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    g2 = torch.empty_like(g)
+    _lib.check(lib.hf_maxpool_adjoint_nhwc(
+        P(g2.data_ptr()), P(a.data_ptr()), 3, a[0].numel(), P(b.data_ptr()), 1, 0, P(idx32.data_ptr()), n, h, w, oh, ow,
+        c, k, k, s, s, p, p, _lib.HF_F32, st), "adjoint")
+    assert torch.equal(g, g2)
+
+
+@pytest.mark.parametrize("shape", [(32, 512, 10, True), (5, 64, 3, False), (16, 256, 64, True), (7, 260, 11, True)])
+def test_linear_ce_head_kernel_matches_float64(shape):
+    """``hf_linear_ce_head``: logits' tangent, softmax-CE Hessian and the head's three gradients in
+    one launch, against the same chain in float64 (stated tolerance 2e-6 of each result's max)."""
+    from pytorchhessianfree_amd import _lib
+
+    b, f, k, bias = shape
+    gen = torch.Generator(device=DEV).manual_seed(b + f + k)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=gen)
+    t_feat, feat, w, v_w, v_b, logits = r(b, f), r(b, f).abs(), r(k, f) / f**0.5, r(k, f), r(k), r(b, k)
+    p = torch.softmax(logits, 1)
+    scale = 1.0 / b
+    g_feat, g_w, g_b = torch.empty(b, f, device=DEV), torch.empty(k, f, device=DEV), torch.empty(k, device=DEV)
+    P = _lib.c_void_p
+    rc = _lib.load().hf_linear_ce_head(
+        P(g_feat.data_ptr()), P(g_w.data_ptr()), P(g_b.data_ptr()) if bias else None, P(t_feat.data_ptr()),
+        P(feat.data_ptr()), P(w.data_ptr()), P(v_w.data_ptr()), P(v_b.data_ptr()) if bias else None, P(p.data_ptr()),
+        scale, b, f, k, _lib.HF_F32, _lib.current_stream_ptr(feat.device))
+    assert rc == 0
+    d = lambda t: t.double()
+    jv = d(t_feat) @ d(w).t() + d(feat) @ d(v_w).t() + (d(v_b) if bias else 0.0)
+    hjv = scale * d(p) * (jv - (d(p) * jv).sum(1, keepdim=True))
+    for got, want in ((g_feat, hjv @ d(w)), (g_w, hjv.t() @ d(feat))) + (((g_b, hjv.sum(0)),) if bias else ()):
+        assert float((got.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+def test_linear_ce_head_refuses_large_heads():
+    from pytorchhessianfree_amd import _lib
+
+    x = torch.zeros(16, device=DEV)
+    P = _lib.c_void_p
+    a = P(x.data_ptr())
+    lib = _lib.load()
+    assert lib.hf_linear_ce_head(a, a, a, a, a, a, a, a, a, 1.0, 4, 2048, 10, _lib.HF_F32, None) == -1   # features
+    assert lib.hf_linear_ce_head(a, a, a, a, a, a, a, a, a, 1.0, 4, 512, 1000, _lib.HF_F32, None) == -1  # classes
+    assert lib.hf_linear_ce_head(a, a, a, a, a, a, a, a, a, 1.0, 512, 512, 10, _lib.HF_F32, None) == -1  # LDS
+
+
+def test_pack_and_unpack_skip_structurally_zero_taps():
+    """``live`` masks of ``hf_pack_ex`` / ``hf_unpack_tangent_ex``: the slices of kernel taps that
+    never meet data (3x3 kernel on a 1x1 map: 8 of 9) are not read -- same vector as without the
+    mask when those gradient entries are zero, which they structurally are."""
+    from pytorchhessianfree_amd import _lib
+    from pytorchhessianfree_amd.engine import _live_taps
+
+    assert _live_taps(1, 1, 3, 3, (1, 1), (1, 1)) == 1 << 4           # centre tap only
+    assert _live_taps(2, 2, 3, 3, (2, 2), (1, 1)) == 0b110110000       # layer4.0.conv1: taps (1..2, 1..2)
+    assert _live_taps(2, 2, 3, 3, (1, 1), (1, 1)) == 0                 # every tap meets data somewhere
+    assert _live_taps(7, 7, 3, 3, (1, 1), (1, 1)) == 0
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    k, c = 24, 16
+    masks = {0: 1 << 4, 2: 0b110110000}
+    # three weight gradients stored (O, H, W, I) = channels_last [O, I, 3, 3]; #1 has no dead taps
+    grads, splits = [], {}
+    for i in range(3):
+        nsp = (1, 3, 2)[i]
+        g = torch.randn(nsp, k, 3, 3, c, device=DEV, generator=gen)
+        m = masks.get(i)
+        if m is not None:
+            dead = torch.tensor([not (m >> t) & 1 for t in range(9)], device=DEV).view(3, 3)
+            g[:, :, dead] = 0.0
+        grads.append(g)
+        if nsp > 1:
+            splits[i] = (nsp, g[0].numel())
+    n = sum(g[0].numel() for g in grads)
+    perms = {i: (c, 9) for i in range(3)}
+    firsts = [g[0].reshape(-1) for g in grads]
+    plain = _lib.pack_ex(torch.empty(n, device=DEV), firsts, perms, splits, scale=0.5)
+    # poison the dead slices: with the mask they must not be read
+    for i, m in masks.items():
+        dead = torch.tensor([not (m >> t) & 1 for t in range(9)], device=DEV).view(3, 3)
+        grads[i][:, :, dead] = float("nan")
+    masked = _lib.pack_ex(torch.empty(n, device=DEV), firsts, perms, splits, scale=0.5, live=masks)
+    assert torch.equal(plain, masked)
+    want = torch.cat([0.5 * g.sum(0).permute(0, 3, 1, 2).reshape(-1) for g in
+                      [torch.nan_to_num(g, nan=0.0) for g in grads]])
+    assert float((masked - want).abs().max()) <= 1e-6
+
+    # unpack: only live slices are written
+    v = torch.randn(2 * k * c * 9 + 5, device=DEV, generator=gen)
+    bufs = [torch.full((k, 2 * c, 3, 3), 7.0, device=DEV).contiguous(memory_format=torch.channels_last)
+            for _ in range(2)]
+    _lib.unpack_tangent(v, [(5, bufs[0], c, 1 << 4), (5 + k * c * 9, bufs[1], c, 0)])
+    src0 = v[5:5 + k * c * 9].view(k, c, 3, 3)
+    assert torch.equal(bufs[0][:, c:, 1, 1], src0[:, :, 1, 1])
+    rest = bufs[0][:, c:].clone()
+    rest[:, :, 1, 1] = 7.0
+    assert float((rest - 7.0).abs().max()) == 0.0 and float((bufs[0][:, :c] - 7.0).abs().max()) == 0.0
+    assert torch.equal(bufs[1][:, c:], v[5 + k * c * 9:].view(k, c, 3, 3))

@@ -751,8 +751,8 @@ def test_allcnnc_hessian_step_with_diag_fisher_preconditioner():
     assert opt.state["num_cg_iters"][0] >= 1
 
 
-@pytest.mark.parametrize("deterministic", [False, True])
-def test_resnet18_newton_solve_matches_reference_cpu_path(deterministic):
+@pytest.mark.parametrize("mode", ["nchw", "deterministic", "engine"])
+def test_resnet18_newton_solve_matches_reference_cpu_path(mode):
     """BASELINE.json configs[1] end to end: the damped GGN PCG solve of the
     ResNet-18-sized problem (N = 11 175 370, batch 32, CE-mean, eval-mode BN) on the
     GPU -- fused layers, hipGraph matvec, HIP PCG kernels -- against the reference's
@@ -763,7 +763,13 @@ def test_resnet18_newton_solve_matches_reference_cpu_path(deterministic):
     moves by a few iterations from run to run because MIOpen's split-K weight-
     gradient kernels accumulate with atomics); same termination reason, iteration
     count +-12 (Martens' stagnation test is the most sensitive quantity: observed
-    34..41 on the GPU against 35 on the CPU); final step direction cosine > 0.995."""
+    34..41 on the GPU against 35 on the CPU); final step direction cosine > 0.995.
+
+    Modes: "nchw" = prepared model, MIOpen convolutions (atomics: +-12 iterations);
+    "deterministic" = autograd sweeps on the package's own convolution kernels;
+    "engine" = the fused curvature engine (what ``prepare_model(channels_last=True)`` + the
+    optimizer use by default).  The last two are bitwise repeatable: iteration count +-2."""
+    deterministic = mode != "nchw"
     from oracle import backpack_restated as bp
     from oracle import pcg as oracle
     from pytorchhessianfree_amd import modelprep
@@ -794,16 +800,19 @@ def test_resnet18_newton_solve_matches_reference_cpu_path(deterministic):
 
     gm, (gx_, gt_), _ = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=seed)
     # deterministic: every convolution on the package's own fixed-order kernels (NHWC)
-    modelprep.prepare_model(gm, channels_last=deterministic, deterministic=deterministic)
+    modelprep.prepare_model(gm, channels_last=deterministic, deterministic=(mode == "deterministic"))
     gp = list(gm.parameters())
     ggrad = curvature.flatten_into(torch.autograd.grad(lossf(gm(gx_), gt_), gp), gp)
     assert float((ggrad.cpu() - grad).norm() / grad.norm()) < 5e-6
 
     def builder():
         o = gm(gx_)
+        if mode == "engine":
+            return curvature.ggn_operator(lossf(o, gt_), o, gp)
         return curvature.GGNOperator(lossf(o, gt_), o, gp)
 
     op = curvature.maybe_graphed(builder, params=gp)
+    assert ("engine" in op.mode) == (mode == "engine")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         gx, gmm, greason = hf.cg(hf.DampedCurvature(op, lam), -ggrad, **kw)
