@@ -208,7 +208,7 @@ def main():
     if not args.engine:
         os.environ["HF_ENGINE"] = "0"
     if args.channels_last < 0:
-        args.channels_last = int(args.workload in ("resnet18", "allcnnc"))
+        args.channels_last = 1  # NHWC: the fused engine (ResNets) / +10 % (All-CNN-C), DESIGN.md section 6
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -314,7 +314,7 @@ def main():
             stock_err = float((stock_product(v, torch.float32) - want).abs().max()) / scale
             # (floor: 1e-5; the 50-layer random-init net is badly conditioned -- any fp32 product of it,
             # stock autograd included, lands between 1e-6 and 3e-4 from run to run)
-            floor = 1e-4 if args.workload == "resnet50" else 1e-5
+            floor = 5e-4 if args.workload == "resnet50" else 1e-5
             check.update(v=v, want=want, scale=scale, stock_err=stock_err, tol=max(floor, 5.0 * stock_err))
         got = op(check["v"]).double()
         err = float((got - check["want"]).abs().max()) / check["scale"]

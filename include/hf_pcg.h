@@ -378,9 +378,9 @@ int hf_maxpool_adjoint_nhwc(void* g, const void* gy_a, int a_splits, int64_t a_s
  *   Jv = t_feat W^T + feat V_W^T + v_b;  HJv = scale * p * (Jv - <p, Jv>) (as hf_softmax_ce_hvp);
  *   g_feat = HJv W [rows, features];  g_w = HJv^T feat [classes, features];  g_b = sum_rows HJv.
  * t_feat / feat [rows, features]: tangent and value of the features; w / v_w [classes, features];
- * v_b, g_b nullable; p = softmax(logits) [rows, classes].  Small heads only: classes <= 64,
- * features <= 512 and a multiple of 4, (rows*classes + rows*features) floats within 150 KB of
- * LDS -- returns -1 otherwise (the caller keeps the GEMM path).  Replaced: 4 rocBLAS GEMMs, a
+ * v_b, g_b nullable; p = softmax(logits) [rows, classes].  Small heads only: rows <= 64, classes
+ * <= 64, features <= 512 and a multiple of 4, (2*classes + rows)*features + rows*classes floats
+ * within 150 KB of LDS -- returns -1 otherwise (the caller keeps the GEMM path).  Replaced: 4 rocBLAS GEMMs, a
  * reduction and hf_softmax_ce_hvp.
  */
 int hf_linear_ce_head(void* g_feat, void* g_w, void* g_b, const void* t_feat, const void* feat, const void* w,

@@ -77,16 +77,97 @@ __global__ __launch_bounds__(HB) void k_maxpool_adjoint(float* __restrict__ g, c
   g[i] = acc;
 }
 
+// The same for windows that overlap at most 2x2 (kernel <= 2*stride: the 3x3 / stride-2 pool of a
+// ResNet stem) and at most MAXS slabs per cotangent, arranged for latency: ONE round of position
+// loads (4 windows), then ONE round of slab loads for every matching window -- all of them issued
+// before the first addition (the loop nest above waits window by window: 5 dependent round
+// trips, 13 us for a 400 K-element map; this form: 2).  Same summation order.
+constexpr int POOL_MAXS = 16;
+
+__global__ __launch_bounds__(HB) void k_maxpool_adjoint_2x2(float* __restrict__ g, const float* __restrict__ A,
+                                                            int a_splits, long long a_slab,
+                                                            const float* __restrict__ B, int b_splits,
+                                                            long long b_slab, const int* __restrict__ idx,
+                                                            unsigned total, unsigned C, PoolGeo q) {
+  const unsigned i = blockIdx.x * HB + threadIdx.x;
+  if (i >= total) return;
+  const unsigned c = i % C;
+  unsigned pix = i / C;
+  const int x = pix % q.W; pix /= q.W;
+  const int y = pix % q.H;
+  const int n = pix / q.H;
+  const int self = y * q.W + x;
+  int oy0 = y + q.ph - q.kh + 1; oy0 = oy0 > 0 ? (oy0 + q.sh - 1) / q.sh : 0;
+  int oy1 = (y + q.ph) / q.sh;   oy1 = oy1 < q.OH - 1 ? oy1 : q.OH - 1;
+  int ox0 = x + q.pw - q.kw + 1; ox0 = ox0 > 0 ? (ox0 + q.sw - 1) / q.sw : 0;
+  int ox1 = (x + q.pw) / q.sw;   ox1 = ox1 < q.OW - 1 ? ox1 : q.OW - 1;
+  size_t o[4];
+  bool m[4];
+  int id[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int oy = oy0 + (w >> 1), ox = ox0 + (w & 1);
+    m[w] = oy <= oy1 && ox <= ox1;
+    o[w] = m[w] ? ((size_t)(n * q.OH + oy) * q.OW + ox) * C + c : (size_t)c;  // (a valid address either way)
+    id[w] = idx[o[w]];
+  }
+  float va[4][POOL_MAXS], vb[4][POOL_MAXS];
+  const float* __restrict__ Bq = B ? B : A;   // (no second cotangent: its loads alias the first, unused)
+  const int b_eff = B ? b_splits : 1;
+  // all four match flags are COMPUTED before the first window is entered (the empty asm pins
+  // them): a wait for a position inside the window blocks would have to cover the blocks' own
+  // loads as well, the counter being in-order
+  int mi[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    mi[w] = (m[w] && id[w] == self) ? 1 : 0;
+    asm volatile("" : "+v"(mi[w]));
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    m[w] = mi[w] != 0;
+    if (m[w]) {  // loads only: nothing below waits before all four windows have issued theirs
+      // (slab index clamped instead of a branch per slab -- the surplus loads repeat the last slab
+      // and are never added --: branches made hipcc wait between the loads)
+#pragma unroll
+      for (int s = 0; s < POOL_MAXS; ++s) {
+        va[w][s] = A[(size_t)(s < a_splits ? s : a_splits - 1) * a_slab + o[w]];
+        vb[w][s] = Bq[(size_t)(s < b_eff ? s : b_eff - 1) * b_slab + o[w]];
+      }
+    }
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (!m[w]) continue;
+    float v = va[w][0];
+#pragma unroll
+    for (int s = 1; s < POOL_MAXS; ++s)
+      if (s < a_splits) v += va[w][s];
+    if (B) {
+      float u = vb[w][0];
+#pragma unroll
+      for (int s = 1; s < POOL_MAXS; ++s)
+        if (s < b_splits) u += vb[w][s];
+      v = v + u;
+    }
+    acc += v;
+  }
+  g[i] = acc;
+}
+
 // ---------------------------------------------------------------------------------------
 // Classifier head of the GGN product in one launch (one workgroup, 16 waves):
 //   Jv   = t_feat W^T + feat V_W^T + v_b          tangent of the logits        [B, K]
 //   HJv  = scale * p * (Jv - <p, Jv>)             softmax-CE Hessian, row-wise [B, K]
 //   g_feat = HJv W    [B, F],   g_W = HJv^T feat  [K, F],   g_b = sum_b HJv    [K]
-// A wave owns a row b: the row's two feature vectors stay in registers while it walks the K
-// classes; the cross-row sums (g_W, g_b) run after a barrier on HJv / feat in LDS, rows in
-// order.  Sized for small heads (K <= 64, F <= 512: 120 VGPRs at 16 waves; feat + HJv fit LDS).
+// One round of global loads: W, V_W and feat go to LDS, every wave keeps the feature tangents of
+// its rows in registers; everything after the barrier reads LDS (a single workgroup that went
+// back to L2 for every class was measured at 26 us: twelve dependent round trips).  A wave
+// owns rows b, b+16, ...; the cross-row sums (g_W, g_b) run after a second barrier, rows in
+// order.  Sized for small heads (K <= 64, F <= 512, everything within 150 KB of LDS).
 // ---------------------------------------------------------------------------------------
-constexpr int HEAD_T = 1024, HEAD_W = HEAD_T / 64, KB = 5;
+constexpr int HEAD_T = 1024, HEAD_W = HEAD_T / 64, HEAD_ROWS = 4;  // rows per wave kept in registers
 
 template <int CH>  // float4 chunks per lane: F <= 256*CH
 __global__ __launch_bounds__(HEAD_T) void k_linear_ce_head(
@@ -95,81 +176,76 @@ __global__ __launch_bounds__(HEAD_T) void k_linear_ce_head(
     const float* __restrict__ VW, const float* __restrict__ vb, const float* __restrict__ p, float scale,
     int B, int F, int K) {
   extern __shared__ float lds[];
-  float* s_h = lds;                 // [B][K]
-  float* s_feat = lds + ((B * K + 3) & ~3);  // [B][F], 16-byte aligned
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int F4 = F >> 2;
-  for (int b = wave; b < B; b += HEAD_W) {
-    float4 tf[CH], ff[CH];
+  float4* s_w = reinterpret_cast<float4*>(lds);   // [K][F]
+  float4* s_vw = s_w + K * F4;                    // [K][F]
+  float4* s_feat = s_vw + K * F4;                 // [B][F]
+  float* s_h = reinterpret_cast<float*>(s_feat + B * F4);  // [B][K]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // ---- the only round of global loads ----
+  for (int e = threadIdx.x; e < K * F4; e += HEAD_T) {
+    s_w[e] = reinterpret_cast<const float4*>(W)[e];
+    s_vw[e] = reinterpret_cast<const float4*>(VW)[e];
+  }
+  for (int e = threadIdx.x; e < B * F4; e += HEAD_T) s_feat[e] = reinterpret_cast<const float4*>(feat)[e];
+  float4 tf[HEAD_ROWS][CH];
+  float pk[HEAD_ROWS];
+#pragma unroll
+  for (int q = 0; q < HEAD_ROWS; ++q) {
+    const int b = wave + HEAD_W * q;
+    pk[q] = (b < B && lane < K) ? p[(size_t)b * K + lane] : 0.f;
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
       const int j = lane + 64 * u;
-      tf[u] = ff[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j < F4) {
-        tf[u] = reinterpret_cast<const float4*>(t_feat + (size_t)b * F)[j];
-        ff[u] = reinterpret_cast<const float4*>(feat + (size_t)b * F)[j];
-        reinterpret_cast<float4*>(s_feat + (size_t)b * F)[j] = ff[u];
-      }
+      tf[q][u] = (b < B && j < F4) ? reinterpret_cast<const float4*>(t_feat + (size_t)b * F)[j]
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // logits' tangent, KB classes per pass: all loads of a pass are issued before the first use
-    // (clamped row index instead of a branch, so that nothing serialises them)
-    float jv = 0.f;  // lane k keeps Jv[b][k] (K <= 64)
-    for (int k0 = 0; k0 < K; k0 += KB) {
-      float4 w[KB][CH], v[KB][CH];
+  }
+  const float bias = (vb && lane < K) ? vb[lane] : 0.f;
+  __syncthreads();
+  // ---- per row: logits' tangent, loss Hessian, data gradient (LDS only) ----
 #pragma unroll
-      for (int q = 0; q < KB; ++q) {
-        const int k = k0 + q < K ? k0 + q : K - 1;
+  for (int q = 0; q < HEAD_ROWS; ++q) {
+    const int b = wave + HEAD_W * q;
+    if (b >= B) break;
+    float4 ff[CH];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          const int j = lane + 64 * u < F4 ? lane + 64 * u : 0;
-          w[q][u] = reinterpret_cast<const float4*>(W + (size_t)k * F)[j];
-          v[q][u] = reinterpret_cast<const float4*>(VW + (size_t)k * F)[j];
+    for (int u = 0; u < CH; ++u) {
+      const int j = lane + 64 * u;
+      ff[u] = j < F4 ? s_feat[b * F4 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float jv = 0.f;  // lane k keeps Jv[b][k]
+    for (int k = 0; k < K; ++k) {
+      float part = 0.f;
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int j = lane + 64 * u;
+        if (j < F4) {
+          const float4 w = s_w[k * F4 + j], v = s_vw[k * F4 + j];
+          part += tf[q][u].x * w.x + tf[q][u].y * w.y + tf[q][u].z * w.z + tf[q][u].w * w.w;
+          part += ff[u].x * v.x + ff[u].y * v.y + ff[u].z * v.z + ff[u].w * v.w;
         }
       }
 #pragma unroll
-      for (int q = 0; q < KB; ++q) {
-        float part = 0.f;
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          if (lane + 64 * u < F4) {
-            part += tf[u].x * w[q][u].x + tf[u].y * w[q][u].y + tf[u].z * w[q][u].z + tf[u].w * w[q][u].w;
-            part += ff[u].x * v[q][u].x + ff[u].y * v[q][u].y + ff[u].z * v[q][u].z + ff[u].w * v[q][u].w;
-          }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-        if (lane == k0 + q && k0 + q < K) jv = part + (vb ? vb[k0 + q] : 0.f);
-      }
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+      if (lane == k) jv = part + bias;
     }
-    // softmax-CE Hessian on the row: lanes 0..K-1 hold Jv, the dot product in fp64
-    const float pk = lane < K ? p[(size_t)b * K + lane] : 0.f;
-    double d = (double)pk * (double)jv;
+    double d = (double)pk[q] * (double)jv;  // <p, Jv> in fp64, as hf_softmax_ce_hvp
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
-    const float h = scale * (pk * (jv - (float)d));
+    const float h = scale * (pk[q] * (jv - (float)d));
     if (lane < K) s_h[b * K + lane] = h;
-    // data gradient of the row: g_feat[b, :] = sum_k h_k W[k, :]
     float4 acc[CH];
 #pragma unroll
     for (int u = 0; u < CH; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k0 = 0; k0 < K; k0 += KB) {
-      float4 w[KB][CH];
+    for (int k = 0; k < K; ++k) {
+      const float hk = __shfl(h, k, 64);
 #pragma unroll
-      for (int q = 0; q < KB; ++q) {
-        const int k = k0 + q < K ? k0 + q : K - 1;
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          const int j = lane + 64 * u < F4 ? lane + 64 * u : 0;
-          w[q][u] = reinterpret_cast<const float4*>(W + (size_t)k * F)[j];
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < KB; ++q) {
-        const float hk = k0 + q < K ? __shfl(h, k0 + q, 64) : 0.f;
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-          acc[u].x += hk * w[q][u].x; acc[u].y += hk * w[q][u].y;
-          acc[u].z += hk * w[q][u].z; acc[u].w += hk * w[q][u].w;
+      for (int u = 0; u < CH; ++u) {
+        const int j = lane + 64 * u;
+        if (j < F4) {
+          const float4 w = s_w[k * F4 + j];
+          acc[u].x += hk * w.x; acc[u].y += hk * w.y; acc[u].z += hk * w.z; acc[u].w += hk * w.w;
         }
       }
     }
@@ -180,13 +256,13 @@ __global__ __launch_bounds__(HEAD_T) void k_linear_ce_head(
     }
   }
   __syncthreads();
-  // weight / bias gradient: sums over the rows, in row order
+  // ---- weight / bias gradient: sums over the rows, in row order ----
   for (int e = threadIdx.x; e < K * F4; e += HEAD_T) {
     const int k = e / F4, j = e % F4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int b = 0; b < B; ++b) {
       const float hb = s_h[b * K + k];
-      const float4 f = reinterpret_cast<const float4*>(s_feat + (size_t)b * F)[j];
+      const float4 f = s_feat[b * F4 + j];
       s.x += hb * f.x; s.y += hb * f.y; s.z += hb * f.z; s.w += hb * f.w;
     }
     reinterpret_cast<float4*>(g_w + (size_t)k * F)[j] = s;
@@ -226,10 +302,17 @@ int hf_maxpool_adjoint_nhwc(void* g, const void* gy_a, int a_splits, int64_t a_s
   const int64_t total = n * h * w * c;
   if (total >= (1LL << 31)) return -1;
   PoolGeo q{(int)h, (int)w, (int)oh, (int)ow, (int)kh, (int)kw, (int)stride_h, (int)stride_w, (int)pad_h, (int)pad_w};
-  hipLaunchKernelGGL(k_maxpool_adjoint, dim3((unsigned)((total + HB - 1) / HB)), dim3(HB), 0,
-                     (hipStream_t)stream, (float*)g, (const float*)gy_a, a_splits, (long long)a_slab,
-                     (const float*)gy_b, b_splits, (long long)b_slab, (const int*)idx, (unsigned)total,
-                     (unsigned)c, q);
+  const bool small = kh <= 2 * stride_h && kw <= 2 * stride_w && a_splits <= POOL_MAXS && b_splits <= POOL_MAXS;
+  if (small)
+    hipLaunchKernelGGL(k_maxpool_adjoint_2x2, dim3((unsigned)((total + HB - 1) / HB)), dim3(HB), 0,
+                       (hipStream_t)stream, (float*)g, (const float*)gy_a, a_splits, (long long)a_slab,
+                       (const float*)gy_b, b_splits, (long long)b_slab, (const int*)idx, (unsigned)total,
+                       (unsigned)c, q);
+  else
+    hipLaunchKernelGGL(k_maxpool_adjoint, dim3((unsigned)((total + HB - 1) / HB)), dim3(HB), 0,
+                       (hipStream_t)stream, (float*)g, (const float*)gy_a, a_splits, (long long)a_slab,
+                       (const float*)gy_b, b_splits, (long long)b_slab, (const int*)idx, (unsigned)total,
+                       (unsigned)c, q);
   return (int)hipGetLastError();
 }
 
@@ -237,9 +320,11 @@ int hf_linear_ce_head(void* g_feat, void* g_w, void* g_b, const void* t_feat, co
                       const void* v_w, const void* v_b, const void* p, double scale, int64_t rows,
                       int64_t features, int64_t classes, int dtype, void* stream) {
   if (dtype != HF_F32 || !g_feat || !g_w || !t_feat || !feat || !w || !v_w || !p) return -1;
-  if (rows < 1 || classes < 1 || classes > 64 || features < 4 || features % 4 || features > 512) return -1;
-  const size_t lds = (size_t)(((rows * classes + 3) & ~3LL) + rows * features) * sizeof(float);
-  if (lds > 150 * 1024) return -1;  // feat + HJv must fit the CU's LDS
+  if (rows < 1 || rows > HEAD_W * HEAD_ROWS || classes < 1 || classes > 64 || features < 4 || features % 4 ||
+      features > 512)
+    return -1;
+  const size_t lds = (size_t)(2 * classes * features + rows * features + rows * classes) * sizeof(float);
+  if (lds > 150 * 1024) return -1;  // W, V_W, feat and HJv must fit the CU's LDS
   if (!al16(g_feat) || !al16(g_w) || !al16(t_feat) || !al16(feat) || !al16(w) || !al16(v_w)) return -1;
   const int ch = (int)((features / 4 + 63) / 64);
   hipStream_t s = (hipStream_t)stream;

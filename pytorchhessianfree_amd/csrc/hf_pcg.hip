@@ -649,6 +649,35 @@ __global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackA
     }
     return;
   }
+  if (a.perm_I[lo] > 0 && a.live[lo] != 0) {
+    // mostly structural zeros (a 3x3 kernel on a 1x1 map: 8 of 9 entries): walk the DESTINATION
+    // in 16-byte vectors, fetch only the live entries (dst (o, i, hw) <- src (o, hw, i)); no LDS
+    // staging, no barrier -- the block is a stream of vector stores
+    const unsigned I = (unsigned)a.perm_I[lo], HW = (unsigned)a.perm_HW[lo], slab = I * HW;
+    const unsigned live = a.live[lo];
+    const bool al = (((uintptr_t)(out + j0)) & 15) == 0;
+    for (long long j = j0 + (long long)threadIdx.x * W; j < j1; j += (long long)BLOCK * W) {
+      VU<T> v;
+#pragma unroll
+      for (int c = 0; c < W; ++c) {
+        const long long jj = j + c;
+        const long long o = jj / slab;
+        const unsigned rem = (unsigned)(jj - o * slab);
+        const unsigned i = rem / HW, hw = rem - i * HW;
+        v.e[c] = (jj < j1 && ((live >> hw) & 1u)) ? src[o * slab + (long long)hw * I + i] : (T)0;
+      }
+      if (OP == 0 && al && j + W <= j1) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) v.e[c] = pack_op<T, OP>((T)0, v.e[c], scale);
+        *reinterpret_cast<V*>(out + j) = v.v;
+      } else {
+#pragma unroll
+        for (int c = 0; c < W; ++c)
+          if (j + c < j1) out[j + c] = pack_op<T, OP>(out[j + c], v.e[c], scale);
+      }
+    }
+    return;
+  }
   if (a.perm_I[lo] > 0) {
     // dst index j = (o*I + i)*HW + hw   <-   src index (o*HW + hw)*I + i
     const unsigned I = (unsigned)a.perm_I[lo], HW = (unsigned)a.perm_HW[lo], slab = I * HW;
@@ -658,27 +687,23 @@ __global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackA
       // against bank conflicts), write the permuted order contiguously
       __shared__ T tile[TILE];
       const unsigned len = (unsigned)(j1 - j0);
-      const unsigned live = a.live[lo] ? a.live[lo] : 0xffffffffu;
       for (unsigned t = threadIdx.x; t < len; t += BLOCK) {
         const unsigned row = t / I;  // (o_local*HW + hw)
-        if ((live >> (row % HW)) & 1u) tile[row * (I + 1) + (t - row * I)] = src[j0 + t];
+        tile[row * (I + 1) + (t - row * I)] = src[j0 + t];
       }
       __syncthreads();
       for (unsigned t = threadIdx.x; t < len; t += BLOCK) {
         const unsigned ol = t / slab, rem = t - ol * slab;
         const unsigned i = rem / HW, hw = rem - i * HW;
-        const T v = ((live >> hw) & 1u) ? tile[(ol * HW + hw) * (I + 1) + i] : (T)0;
-        out[j0 + t] = pack_op<T, OP>(out[j0 + t], v, scale);
+        out[j0 + t] = pack_op<T, OP>(out[j0 + t], tile[(ol * HW + hw) * (I + 1) + i], scale);
       }
       return;
     }
-    const unsigned live = a.live[lo] ? a.live[lo] : 0xffffffffu;
     for (long long j = j0 + threadIdx.x; j < j1; j += BLOCK) {
       const long long o = j / slab;
       const unsigned rem = (unsigned)(j - o * slab);
       const unsigned i = rem / HW, hw = rem - i * HW;
-      const T v = ((live >> hw) & 1u) ? src[o * slab + (long long)hw * I + i] : (T)0;
-      out[j] = pack_op<T, OP>(out[j], v, scale);
+      out[j] = pack_op<T, OP>(out[j], src[o * slab + (long long)hw * I + i], scale);
     }
     return;
   }
@@ -1835,7 +1860,8 @@ static int pack_impl(void* dst, const void* const* srcs, const int64_t* numels,
           a.perm_HW[k] = (int)HW;
           if (live && live[t] > 0 && HW <= 16) a.live[k] = (unsigned short)(live[t] & ((1 << HW) - 1));
           const int64_t slabs = (int64_t)(TILE_BYTES / sizeof(T)) / (I * HW + HW);
-          if (slabs >= 1 && !(splits && splits[2 * t] > 1)) a.chunk[k] = (int)(slabs * I * HW);  // LDS-tiled path
+          if (slabs >= 1 && !(splits && splits[2 * t] > 1) && a.live[k] == 0)
+            a.chunk[k] = (int)(slabs * I * HW);  // LDS-tiled path
         }
         a.blk_start[k] = blocks;
         blocks += (int)((numels[t] + a.chunk[k] - 1) / a.chunk[k]);

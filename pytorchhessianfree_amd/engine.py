@@ -293,10 +293,12 @@ class FusedGGNEngine(_Operator):
             # per-channel sums arrive as rb partial rows that hf_pack_ex adds up
             u.rb = 1
             if k % 4 == 0 and k // 4 <= 256 and u.rows >= 64:
-                # row-major adjoint kernel: ~32 workgroups, each reading whole contiguous rows
+                # row-major adjoint kernel: ~64 workgroups, each reading whole contiguous rows, one
+                # pass of the row loop where the map is small enough (measured on the ResNet-18
+                # bench: 32 workgroups x 2 passes 1124, 64 x 1 1150, 128 x 1 the same, 256 x 1 1138)
                 rp = 256 // (k // 4)
-                tgt = int(os.environ.get("HF_BN_ROW_BLOCKS", "32"))
-                per = max(int(os.environ.get("HF_BN_ROW_PASSES", "2")) * rp, -(-u.rows // tgt))
+                tgt = int(os.environ.get("HF_BN_ROW_BLOCKS", "64"))
+                per = max(int(os.environ.get("HF_BN_ROW_PASSES", "1")) * rp, -(-u.rows // tgt))
                 u.rb = -(-u.rows // per)
                 if u.rb < 2:
                     u.rb = 1
@@ -506,7 +508,8 @@ class FusedGGNEngine(_Operator):
                 os.environ.get("HF_ENGINE_HEAD", "1") != "0" and self._ce is not None and hw == 1
                 and fw.is_contiguous() and fw.dtype == torch.float32 and k <= 64 and f <= 512 and f % 4 == 0
                 and self.feat.is_contiguous() and tuple(self.feat.shape) == (self.outputs.shape[0], f)
-                and (self.outputs.shape[0] * (k + f) + 4) * 4 <= 150 * 1024
+                and self.outputs.shape[0] <= 64
+                and ((2 * k + self.outputs.shape[0]) * f + self.outputs.shape[0] * k) * 4 <= 150 * 1024
                 and self._offs[self.pfw] % 4 == 0 and self._ce[0].is_contiguous()
             )
             if ok:

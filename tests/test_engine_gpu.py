@@ -159,7 +159,7 @@ def test_maxpool_kernels_match_autograd(geom):
     assert torch.equal(g, g2)
 
 
-@pytest.mark.parametrize("shape", [(32, 512, 10, True), (5, 64, 3, False), (16, 256, 64, True), (7, 260, 11, True)])
+@pytest.mark.parametrize("shape", [(32, 512, 10, True), (5, 64, 3, False), (16, 256, 40, True), (7, 260, 11, True), (64, 128, 5, True)])
 def test_linear_ce_head_kernel_matches_float64(shape):
     """``hf_linear_ce_head``: logits' tangent, softmax-CE Hessian and the head's three gradients in
     one launch, against the same chain in float64 (stated tolerance 2e-6 of each result's max)."""
@@ -194,7 +194,8 @@ def test_linear_ce_head_refuses_large_heads():
     lib = _lib.load()
     assert lib.hf_linear_ce_head(a, a, a, a, a, a, a, a, a, 1.0, 4, 2048, 10, _lib.HF_F32, None) == -1   # features
     assert lib.hf_linear_ce_head(a, a, a, a, a, a, a, a, a, 1.0, 4, 512, 1000, _lib.HF_F32, None) == -1  # classes
-    assert lib.hf_linear_ce_head(a, a, a, a, a, a, a, a, a, 1.0, 512, 512, 10, _lib.HF_F32, None) == -1  # LDS
+    assert lib.hf_linear_ce_head(a, a, a, a, a, a, a, a, a, 1.0, 65, 512, 10, _lib.HF_F32, None) == -1    # rows
+    assert lib.hf_linear_ce_head(a, a, a, a, a, a, a, a, a, 1.0, 64, 512, 64, _lib.HF_F32, None) == -1    # LDS
 
 
 def test_pack_and_unpack_skip_structurally_zero_taps():
