@@ -346,20 +346,32 @@ def main():
             for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"),
                              ("MASTER_PORT", "29517")):
                 os.environ.setdefault(key, val)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(args.backend)
+        # (gloo and RCCL print connection banners on fd 1: stdout carries the ONE JSON line only)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(args.backend)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         group = dist.group.WORLD
         world = dist.get_world_size(group)  # what the backend reports is what gets printed
-        # one-off timing of THE collective of this path: the 4N-byte all-reduce
+        # one-off timing of THE collective of this path: the operator's own reduction of a product
+        # (all-reduce of the 4N-byte vector; the engine moves only the entries that can be non-zero)
         probe = torch.zeros(n, device=device)
+        op.group = group
         for _ in range(3):
-            hfdist.all_reduce_sum(probe, group)
+            op.reduce(probe)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(10):
-            hfdist.all_reduce_sum(probe, group)
+            op.reduce(probe)
         torch.cuda.synchronize()
         tt = torch.tensor([(time.perf_counter() - t0) / 10 * 1e3], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)  # one number, one decision, on every rank
@@ -449,7 +461,8 @@ def main():
                             f"damping {args.damping}, eval-mode BN, CE-mean"
                             + (f" + L2 {l2:g}" if l2 > 0 else "") + ", x0=0, tol=0"
                             + (", diag empirical-Fisher preconditioner ^-0.75 (per-sample autograd)" if M is not None else ""),
-                "parallelism": f"dp{world} (batch sharded, one all-reduce of 4N bytes per matvec)"
+                "parallelism": f"dp{world} (batch sharded, one all-reduce per matvec: the 4N-byte vector, or only its "
+                               "entries that can be non-zero with the fused engine -- config.allreduce.bytes)"
                                + (f"; {world} ranks share {ndev} device(s) over gloo: functional run, not a "
                                   "scaling number" if oversubscribed else ""),
                 "matvec": getattr(op, "mode", "eager autograd")
@@ -463,7 +476,8 @@ def main():
                               else "product, then K1, K2, K3 as separate launches"),
                 "termination": reason,
                 "allreduce": None if allreduce_ms is None else {
-                    "path": comm_path, "bytes": 4 * n, "ms": allreduce_ms,
+                    "path": comm_path, "bytes": int(getattr(getattr(op, "op", op), "reduce_bytes", 4 * n)),
+                    "ms": allreduce_ms,
                     "overlap_two_graphs": bool(args.overlap)},
             },
             "cg_iters_per_s": world * args.steps * iters_done / dt,

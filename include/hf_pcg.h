@@ -374,18 +374,21 @@ int hf_maxpool_adjoint_nhwc(void* g, const void* gy_a, int a_splits, int64_t a_s
                             int64_t oh, int64_t ow, int64_t c, int64_t kh, int64_t kw, int64_t stride_h,
                             int64_t stride_w, int64_t pad_h, int64_t pad_w, int dtype, void* stream);
 /*
- * hf_linear_ce_head: the classifier head of J^T H_L J v in one launch (one workgroup):
+ * hf_linear_ce_head: the classifier head of J^T H_L J v in one launch (one workgroup per 4 rows):
  *   Jv = t_feat W^T + feat V_W^T + v_b;  HJv = scale * p * (Jv - <p, Jv>) (as hf_softmax_ce_hvp);
  *   g_feat = HJv W [rows, features];  g_w = HJv^T feat [classes, features];  g_b = sum_rows HJv.
  * t_feat / feat [rows, features]: tangent and value of the features; w / v_w [classes, features];
- * v_b, g_b nullable; p = softmax(logits) [rows, classes].  Small heads only: rows <= 64, classes
- * <= 64, features <= 512 and a multiple of 4, (2*classes + rows)*features + rows*classes floats
- * within 150 KB of LDS -- returns -1 otherwise (the caller keeps the GEMM path).  Replaced: 4 rocBLAS GEMMs, a
- * reduction and hf_softmax_ce_hvp.
+ * v_b, g_b nullable; p = softmax(logits) [rows, classes].  g_w and g_b are written as
+ * hf_linear_ce_head_slabs(rows) PARTIAL sums (one per workgroup, classes*features resp. classes
+ * elements apart) that hf_pack_ex adds up (`splits`), like split-K weight gradients.  Small heads
+ * only: classes <= 64, features <= 512 and a multiple of 4, (2*classes + 4)*features floats within
+ * 64 KB of LDS -- returns -1 otherwise (the caller keeps the GEMM path).  Replaced: 4 rocBLAS
+ * GEMMs, a reduction and hf_softmax_ce_hvp.
  */
 int hf_linear_ce_head(void* g_feat, void* g_w, void* g_b, const void* t_feat, const void* feat, const void* w,
                       const void* v_w, const void* v_b, const void* p, double scale, int64_t rows,
                       int64_t features, int64_t classes, int dtype, void* stream);
+int hf_linear_ce_head_slabs(int64_t rows);
 
 /* ---- RCCL (resolved at run time from the already-loaded librccl) ----------- */
 typedef struct hf_comm hf_comm_t;

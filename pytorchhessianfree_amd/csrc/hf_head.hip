@@ -77,97 +77,21 @@ __global__ __launch_bounds__(HB) void k_maxpool_adjoint(float* __restrict__ g, c
   g[i] = acc;
 }
 
-// The same for windows that overlap at most 2x2 (kernel <= 2*stride: the 3x3 / stride-2 pool of a
-// ResNet stem) and at most MAXS slabs per cotangent, arranged for latency: ONE round of position
-// loads (4 windows), then ONE round of slab loads for every matching window -- all of them issued
-// before the first addition (the loop nest above waits window by window: 5 dependent round
-// trips, 13 us for a 400 K-element map; this form: 2).  Same summation order.
-constexpr int POOL_MAXS = 16;
-
-__global__ __launch_bounds__(HB) void k_maxpool_adjoint_2x2(float* __restrict__ g, const float* __restrict__ A,
-                                                            int a_splits, long long a_slab,
-                                                            const float* __restrict__ B, int b_splits,
-                                                            long long b_slab, const int* __restrict__ idx,
-                                                            unsigned total, unsigned C, PoolGeo q) {
-  const unsigned i = blockIdx.x * HB + threadIdx.x;
-  if (i >= total) return;
-  const unsigned c = i % C;
-  unsigned pix = i / C;
-  const int x = pix % q.W; pix /= q.W;
-  const int y = pix % q.H;
-  const int n = pix / q.H;
-  const int self = y * q.W + x;
-  int oy0 = y + q.ph - q.kh + 1; oy0 = oy0 > 0 ? (oy0 + q.sh - 1) / q.sh : 0;
-  int oy1 = (y + q.ph) / q.sh;   oy1 = oy1 < q.OH - 1 ? oy1 : q.OH - 1;
-  int ox0 = x + q.pw - q.kw + 1; ox0 = ox0 > 0 ? (ox0 + q.sw - 1) / q.sw : 0;
-  int ox1 = (x + q.pw) / q.sw;   ox1 = ox1 < q.OW - 1 ? ox1 : q.OW - 1;
-  size_t o[4];
-  bool m[4];
-  int id[4];
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const int oy = oy0 + (w >> 1), ox = ox0 + (w & 1);
-    m[w] = oy <= oy1 && ox <= ox1;
-    o[w] = m[w] ? ((size_t)(n * q.OH + oy) * q.OW + ox) * C + c : (size_t)c;  // (a valid address either way)
-    id[w] = idx[o[w]];
-  }
-  float va[4][POOL_MAXS], vb[4][POOL_MAXS];
-  const float* __restrict__ Bq = B ? B : A;   // (no second cotangent: its loads alias the first, unused)
-  const int b_eff = B ? b_splits : 1;
-  // all four match flags are COMPUTED before the first window is entered (the empty asm pins
-  // them): a wait for a position inside the window blocks would have to cover the blocks' own
-  // loads as well, the counter being in-order
-  int mi[4];
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    mi[w] = (m[w] && id[w] == self) ? 1 : 0;
-    asm volatile("" : "+v"(mi[w]));
-  }
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    m[w] = mi[w] != 0;
-    if (m[w]) {  // loads only: nothing below waits before all four windows have issued theirs
-      // (slab index clamped instead of a branch per slab -- the surplus loads repeat the last slab
-      // and are never added --: branches made hipcc wait between the loads)
-#pragma unroll
-      for (int s = 0; s < POOL_MAXS; ++s) {
-        va[w][s] = A[(size_t)(s < a_splits ? s : a_splits - 1) * a_slab + o[w]];
-        vb[w][s] = Bq[(size_t)(s < b_eff ? s : b_eff - 1) * b_slab + o[w]];
-      }
-    }
-  }
-  float acc = 0.f;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    if (!m[w]) continue;
-    float v = va[w][0];
-#pragma unroll
-    for (int s = 1; s < POOL_MAXS; ++s)
-      if (s < a_splits) v += va[w][s];
-    if (B) {
-      float u = vb[w][0];
-#pragma unroll
-      for (int s = 1; s < POOL_MAXS; ++s)
-        if (s < b_splits) u += vb[w][s];
-      v = v + u;
-    }
-    acc += v;
-  }
-  g[i] = acc;
-}
-
 // ---------------------------------------------------------------------------------------
-// Classifier head of the GGN product in one launch (one workgroup, 16 waves):
+// Classifier head of the GGN product in one launch:
 //   Jv   = t_feat W^T + feat V_W^T + v_b          tangent of the logits        [B, K]
 //   HJv  = scale * p * (Jv - <p, Jv>)             softmax-CE Hessian, row-wise [B, K]
 //   g_feat = HJv W    [B, F],   g_W = HJv^T feat  [K, F],   g_b = sum_b HJv    [K]
-// One round of global loads: W, V_W and feat go to LDS, every wave keeps the feature tangents of
-// its rows in registers; everything after the barrier reads LDS (a single workgroup that went
-// back to L2 for every class was measured at 26 us: twelve dependent round trips).  A wave
-// owns rows b, b+16, ...; the cross-row sums (g_W, g_b) run after a second barrier, rows in
-// order.  Sized for small heads (K <= 64, F <= 512, everything within 150 KB of LDS).
+// One workgroup per HEAD_R rows, one wave per row.  ONE round of global loads: W and V_W go to
+// LDS, every wave keeps its row's features and feature tangents in registers; everything after
+// the barrier reads LDS.  The sums over the rows (g_W, g_b) are left to the consumer: workgroup
+// g writes the partial sums of ITS rows to slab g, hf_pack_ex adds the slabs up in order (as
+// it does for split-K weight gradients).  Measured on the way here: a single workgroup that went
+// back to L2 for every class 26 us (twelve dependent round trips); a single workgroup with
+// everything in LDS 19-20 us (2.7 MB of LDS reads through ONE CU's 128 B/clk); this form spreads
+// them over ceil(B / HEAD_R) CUs.
 // ---------------------------------------------------------------------------------------
-constexpr int HEAD_T = 1024, HEAD_W = HEAD_T / 64, HEAD_ROWS = 4;  // rows per wave kept in registers
+constexpr int HEAD_R = 4, HEAD_T = 64 * HEAD_R, KB = 5;
 
 template <int CH>  // float4 chunks per lane: F <= 256*CH
 __global__ __launch_bounds__(HEAD_T) void k_linear_ce_head(
@@ -179,76 +103,87 @@ __global__ __launch_bounds__(HEAD_T) void k_linear_ce_head(
   const int F4 = F >> 2;
   float4* s_w = reinterpret_cast<float4*>(lds);   // [K][F]
   float4* s_vw = s_w + K * F4;                    // [K][F]
-  float4* s_feat = s_vw + K * F4;                 // [B][F]
-  float* s_h = reinterpret_cast<float*>(s_feat + B * F4);  // [B][K]
+  float4* s_feat = s_vw + K * F4;                 // [HEAD_R][F]
+  float* s_h = reinterpret_cast<float*>(s_feat + HEAD_R * F4);  // [HEAD_R][K]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * HEAD_R + wave;
+  const bool row = b < B;
   // ---- the only round of global loads ----
   for (int e = threadIdx.x; e < K * F4; e += HEAD_T) {
     s_w[e] = reinterpret_cast<const float4*>(W)[e];
     s_vw[e] = reinterpret_cast<const float4*>(VW)[e];
   }
-  for (int e = threadIdx.x; e < B * F4; e += HEAD_T) s_feat[e] = reinterpret_cast<const float4*>(feat)[e];
-  float4 tf[HEAD_ROWS][CH];
-  float pk[HEAD_ROWS];
+  float4 tf[CH], ff[CH];
 #pragma unroll
-  for (int q = 0; q < HEAD_ROWS; ++q) {
-    const int b = wave + HEAD_W * q;
-    pk[q] = (b < B && lane < K) ? p[(size_t)b * K + lane] : 0.f;
-#pragma unroll
-    for (int u = 0; u < CH; ++u) {
-      const int j = lane + 64 * u;
-      tf[q][u] = (b < B && j < F4) ? reinterpret_cast<const float4*>(t_feat + (size_t)b * F)[j]
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int u = 0; u < CH; ++u) {
+    const int j = lane + 64 * u;
+    tf[u] = ff[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row && j < F4) {
+      tf[u] = reinterpret_cast<const float4*>(t_feat + (size_t)b * F)[j];
+      ff[u] = reinterpret_cast<const float4*>(feat + (size_t)b * F)[j];
     }
+    if (j < F4) s_feat[wave * F4 + j] = ff[u];  // (zeros for a row past the end)
   }
+  const float pk = (row && lane < K) ? p[(size_t)b * K + lane] : 0.f;
   const float bias = (vb && lane < K) ? vb[lane] : 0.f;
   __syncthreads();
-  // ---- per row: logits' tangent, loss Hessian, data gradient (LDS only) ----
+  // ---- the row: logits' tangent, KB classes per pass (their wave reductions interleave) ----
+  float jv = 0.f;  // lane k keeps Jv[b][k]
+  for (int k0 = 0; k0 < K; k0 += KB) {
+    float part[KB];
 #pragma unroll
-  for (int q = 0; q < HEAD_ROWS; ++q) {
-    const int b = wave + HEAD_W * q;
-    if (b >= B) break;
-    float4 ff[CH];
-#pragma unroll
-    for (int u = 0; u < CH; ++u) {
-      const int j = lane + 64 * u;
-      ff[u] = j < F4 ? s_feat[b * F4 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float jv = 0.f;  // lane k keeps Jv[b][k]
-    for (int k = 0; k < K; ++k) {
-      float part = 0.f;
+    for (int r = 0; r < KB; ++r) {
+      const int k = k0 + r < K ? k0 + r : K - 1;  // (clamped: the surplus sums are discarded)
+      float p0 = 0.f, p1 = 0.f;
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
         const int j = lane + 64 * u;
         if (j < F4) {
           const float4 w = s_w[k * F4 + j], v = s_vw[k * F4 + j];
-          part += tf[q][u].x * w.x + tf[q][u].y * w.y + tf[q][u].z * w.z + tf[q][u].w * w.w;
-          part += ff[u].x * v.x + ff[u].y * v.y + ff[u].z * v.z + ff[u].w * v.w;
+          // (explicit fma: the file is built with -ffp-contract=off)
+          p0 = fmaf(tf[u].x, w.x, p0); p1 = fmaf(tf[u].y, w.y, p1);
+          p0 = fmaf(tf[u].z, w.z, p0); p1 = fmaf(tf[u].w, w.w, p1);
+          p0 = fmaf(ff[u].x, v.x, p0); p1 = fmaf(ff[u].y, v.y, p1);
+          p0 = fmaf(ff[u].z, v.z, p0); p1 = fmaf(ff[u].w, v.w, p1);
         }
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-      if (lane == k) jv = part + bias;
+      part[r] = p0 + p1;
     }
-    double d = (double)pk[q] * (double)jv;  // <p, Jv> in fp64, as hf_softmax_ce_hvp
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
-    const float h = scale * (pk[q] * (jv - (float)d));
-    if (lane < K) s_h[b * K + lane] = h;
-    float4 acc[CH];
+    for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-    for (int u = 0; u < CH; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < K; ++k) {
-      const float hk = __shfl(h, k, 64);
+      for (int r = 0; r < KB; ++r) part[r] += __shfl_xor(part[r], off, 64);
+    }
+#pragma unroll
+    for (int r = 0; r < KB; ++r)
+      if (lane == k0 + r && k0 + r < K) jv = part[r] + bias;
+  }
+  double d = (double)pk * (double)jv;  // <p, Jv> in fp64, as hf_softmax_ce_hvp
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+  const float h = row ? scale * (pk * (jv - (float)d)) : 0.f;
+  if (lane < K) s_h[wave * K + lane] = h;
+  // ---- the row's data gradient ----
+  float4 acc[CH];
+#pragma unroll
+  for (int u = 0; u < CH; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k0 = 0; k0 < K; k0 += KB) {
+#pragma unroll
+    for (int r = 0; r < KB; ++r) {
+      const int k = k0 + r < K ? k0 + r : K - 1;
+      const float hk = k0 + r < K ? __shfl(h, k, 64) : 0.f;
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
         const int j = lane + 64 * u;
         if (j < F4) {
           const float4 w = s_w[k * F4 + j];
-          acc[u].x += hk * w.x; acc[u].y += hk * w.y; acc[u].z += hk * w.z; acc[u].w += hk * w.w;
+          acc[u].x = fmaf(hk, w.x, acc[u].x); acc[u].y = fmaf(hk, w.y, acc[u].y);
+          acc[u].z = fmaf(hk, w.z, acc[u].z); acc[u].w = fmaf(hk, w.w, acc[u].w);
         }
       }
     }
+  }
+  if (row) {
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
       const int j = lane + 64 * u;
@@ -256,21 +191,24 @@ __global__ __launch_bounds__(HEAD_T) void k_linear_ce_head(
     }
   }
   __syncthreads();
-  // ---- weight / bias gradient: sums over the rows, in row order ----
+  // ---- this workgroup's share of the weight / bias gradient (its rows, in order) -> slab ----
+  float* gw = g_w + (size_t)blockIdx.x * K * F;
   for (int e = threadIdx.x; e < K * F4; e += HEAD_T) {
     const int k = e / F4, j = e % F4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int b = 0; b < B; ++b) {
-      const float hb = s_h[b * K + k];
-      const float4 f = s_feat[b * F4 + j];
-      s.x += hb * f.x; s.y += hb * f.y; s.z += hb * f.z; s.w += hb * f.w;
+#pragma unroll
+    for (int r = 0; r < HEAD_R; ++r) {
+      const float hb = s_h[r * K + k];
+      const float4 f = s_feat[r * F4 + j];
+      s.x = fmaf(hb, f.x, s.x); s.y = fmaf(hb, f.y, s.y); s.z = fmaf(hb, f.z, s.z); s.w = fmaf(hb, f.w, s.w);
     }
-    reinterpret_cast<float4*>(g_w + (size_t)k * F)[j] = s;
+    reinterpret_cast<float4*>(gw)[e] = s;
   }
   if (g_b && threadIdx.x < K) {
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += s_h[b * K + threadIdx.x];
-    g_b[threadIdx.x] = s;
+#pragma unroll
+    for (int r = 0; r < HEAD_R; ++r) s += s_h[r * K + threadIdx.x];
+    g_b[(size_t)blockIdx.x * K + threadIdx.x] = s;
   }
 }
 
@@ -302,17 +240,13 @@ int hf_maxpool_adjoint_nhwc(void* g, const void* gy_a, int a_splits, int64_t a_s
   const int64_t total = n * h * w * c;
   if (total >= (1LL << 31)) return -1;
   PoolGeo q{(int)h, (int)w, (int)oh, (int)ow, (int)kh, (int)kw, (int)stride_h, (int)stride_w, (int)pad_h, (int)pad_w};
-  const bool small = kh <= 2 * stride_h && kw <= 2 * stride_w && a_splits <= POOL_MAXS && b_splits <= POOL_MAXS;
-  if (small)
-    hipLaunchKernelGGL(k_maxpool_adjoint_2x2, dim3((unsigned)((total + HB - 1) / HB)), dim3(HB), 0,
-                       (hipStream_t)stream, (float*)g, (const float*)gy_a, a_splits, (long long)a_slab,
-                       (const float*)gy_b, b_splits, (long long)b_slab, (const int*)idx, (unsigned)total,
-                       (unsigned)c, q);
-  else
-    hipLaunchKernelGGL(k_maxpool_adjoint, dim3((unsigned)((total + HB - 1) / HB)), dim3(HB), 0,
-                       (hipStream_t)stream, (float*)g, (const float*)gy_a, a_splits, (long long)a_slab,
-                       (const float*)gy_b, b_splits, (long long)b_slab, (const int*)idx, (unsigned)total,
-                       (unsigned)c, q);
+  // (a variant that issued the slab loads of all matching windows before the first addition --
+  // two dependent round trips instead of five -- was measured slower, 17.7 vs 13.4 us: 138 VGPRs
+  // and 32 loads per match instead of 11)
+  hipLaunchKernelGGL(k_maxpool_adjoint, dim3((unsigned)((total + HB - 1) / HB)), dim3(HB), 0,
+                     (hipStream_t)stream, (float*)g, (const float*)gy_a, a_splits, (long long)a_slab,
+                     (const float*)gy_b, b_splits, (long long)b_slab, (const int*)idx, (unsigned)total,
+                     (unsigned)c, q);
   return (int)hipGetLastError();
 }
 
@@ -320,34 +254,25 @@ int hf_linear_ce_head(void* g_feat, void* g_w, void* g_b, const void* t_feat, co
                       const void* v_w, const void* v_b, const void* p, double scale, int64_t rows,
                       int64_t features, int64_t classes, int dtype, void* stream) {
   if (dtype != HF_F32 || !g_feat || !g_w || !t_feat || !feat || !w || !v_w || !p) return -1;
-  if (rows < 1 || rows > HEAD_W * HEAD_ROWS || classes < 1 || classes > 64 || features < 4 || features % 4 ||
-      features > 512)
+  if (rows < 1 || rows > 4096 || classes < 1 || classes > 64 || features < 4 || features % 4 || features > 512)
     return -1;
-  const size_t lds = (size_t)(2 * classes * features + rows * features + rows * classes) * sizeof(float);
-  if (lds > 150 * 1024) return -1;  // W, V_W, feat and HJv must fit the CU's LDS
+  const size_t lds = (size_t)(2 * classes * features + HEAD_R * features + HEAD_R * classes) * sizeof(float);
+  if (lds > 64 * 1024) return -1;  // W, V_W and the workgroup's rows must fit the default LDS allowance
   if (!al16(g_feat) || !al16(g_w) || !al16(t_feat) || !al16(feat) || !al16(w) || !al16(v_w)) return -1;
   const int ch = (int)((features / 4 + 63) / 64);
+  const unsigned groups = (unsigned)((rows + HEAD_R - 1) / HEAD_R);
   hipStream_t s = (hipStream_t)stream;
-  // (the attribute is raised once per variant and never during a later stream capture: the
-  // engine's first, eager product comes before any capture)
-  static size_t lds_allowed[3] = {0, 0, 0};
-#define HF_HEAD(CH)                                                                                         \
-  do {                                                                                                      \
-    if (lds > lds_allowed[CH]) {                                                                            \
-      hipError_t e_ = hipFuncSetAttribute((const void*)k_linear_ce_head<CH>,                                \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);          \
-      if (e_ != hipSuccess) return (int)e_;                                                                 \
-      lds_allowed[CH] = 150 * 1024;                                                                         \
-    }                                                                                                       \
-    hipLaunchKernelGGL((k_linear_ce_head<CH>), dim3(1), dim3(HEAD_T), lds, s, (float*)g_feat, (float*)g_w,  \
-                       (float*)g_b, (const float*)t_feat, (const float*)feat, (const float*)w,              \
-                       (const float*)v_w, (const float*)v_b, (const float*)p, (float)scale, (int)rows,      \
-                       (int)features, (int)classes);                                                        \
-  } while (0)
+#define HF_HEAD(CH)                                                                                        \
+  hipLaunchKernelGGL((k_linear_ce_head<CH>), dim3(groups), dim3(HEAD_T), lds, s, (float*)g_feat,           \
+                     (float*)g_w, (float*)g_b, (const float*)t_feat, (const float*)feat, (const float*)w,  \
+                     (const float*)v_w, (const float*)v_b, (const float*)p, (float)scale, (int)rows,       \
+                     (int)features, (int)classes)
   if (ch <= 1) HF_HEAD(1);
   else HF_HEAD(2);
 #undef HF_HEAD
   return (int)hipGetLastError();
 }
+
+int hf_linear_ce_head_slabs(int64_t rows) { return rows < 1 ? 0 : (int)((rows + HEAD_R - 1) / HEAD_R); }
 
 }  // extern "C"

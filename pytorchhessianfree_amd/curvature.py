@@ -74,9 +74,14 @@ class _Operator:
         """This rank's weighted partial product (no communication)."""
         raise NotImplementedError
 
+    def reduce(self, t, group=None):
+        """In-place sum of a local product over the ranks (``group`` defaults to the operator's
+        own); operators that know more about the vector may move fewer bytes (the engine)."""
+        return _all_reduce_sum(t, self.group if group is None else group)
+
     def __call__(self, v, out=None):
         self.calls += 1
-        return _all_reduce_sum(self.local(v, out), self.group)
+        return self.reduce(self.local(v, out))
 
 
 class GGNOperator(_Operator):
@@ -327,6 +332,9 @@ class GraphedOperator:
         self.graph.replay()
 
     def reduce(self, t):
+        inner = getattr(self.op, "reduce", None)  # (the captured operator's own rule, if it has one)
+        if inner is not None:
+            return inner(t, self.group)
         return _all_reduce_sum(t, self.group)
 
     _verified = set()  # signatures whose first capture in this process was checked
@@ -390,7 +398,7 @@ class GraphedOperator:
 
     def __call__(self, v, out=None):
         self.calls += 1
-        return _all_reduce_sum(self.local(v, out), self.group)
+        return self.reduce(self.local(v, out))
 
 
 class OverlappedGraphedOperator(GraphedOperator):

@@ -17,10 +17,14 @@ atomic, no in-launch reduction:
     adjoint sweep, per unit :  BatchNorm adjoint: g = mask * (sum of the consumers' cotangent slabs),
                                g_a = g * w * rstd, per-channel sums      (hf_chan_affine_bwd_ex)
                                data + weight gradient of the convolution in ONE launch -> slabs
-    once per product        :  hf_unpack_tangent (v_W of all layers), hf_pack_ex (all parameter
-                               gradients, summing the weight-gradient slabs while it gathers)
+    once per product        :  hf_unpack_tangent_ex (v_W of all layers), hf_maxpool_tangent_nhwc,
+                               hf_linear_ce_head (logits' tangent, loss Hessian, the head's three
+                               gradients), hf_maxpool_adjoint_nhwc, hf_pack_ex (all parameter
+                               gradients, summing the weight-gradient slabs while it gathers);
+                               slices of kernel taps that never meet data are skipped throughout
 
-4 launches per conv-BN unit instead of 8; bitwise repeatable.
+4 launches per conv-BN unit instead of 8, 85 per product of ResNet-18; bitwise repeatable.  Under
+data parallelism only the entries of the product that can be non-zero are all-reduced (``reduce``).
 The layer topology is taken from the prepared model's module tree and from the activations its
 patched layers recorded during the step's forward pass (``modelprep`` stores them detached);
 anything the engine does not recognise makes ``try_build`` return ``None`` and the caller uses
@@ -491,9 +495,17 @@ class FusedGGNEngine(_Operator):
         # ---- gather all parameter gradients (weight-gradient slabs summed on the way) ---------
         tensors, perms, splits = self._pack_args()
         tensors = list(tensors)
-        tensors[self.pfw] = g_fw
-        if self.pfb is not None:
-            tensors[self.pfb] = g_fb
+        if g_fw.dim() == 3:  # the head kernel's per-workgroup partial sums: slabs for hf_pack_ex
+            splits = dict(splits)
+            tensors[self.pfw] = g_fw[0]
+            splits[self.pfw] = (g_fw.shape[0], g_fw[0].numel())
+            if self.pfb is not None:
+                tensors[self.pfb] = g_fb[0]
+                splits[self.pfb] = (g_fb.shape[0], g_fb.shape[1])
+        else:
+            tensors[self.pfw] = g_fw
+            if self.pfb is not None:
+                tensors[self.pfb] = g_fb
         _lib.pack_ex(out, tensors, perms, splits, scale=self.weight, live=self._pack_live)
         return out
 
@@ -508,14 +520,15 @@ class FusedGGNEngine(_Operator):
                 os.environ.get("HF_ENGINE_HEAD", "1") != "0" and self._ce is not None and hw == 1
                 and fw.is_contiguous() and fw.dtype == torch.float32 and k <= 64 and f <= 512 and f % 4 == 0
                 and self.feat.is_contiguous() and tuple(self.feat.shape) == (self.outputs.shape[0], f)
-                and self.outputs.shape[0] <= 64
-                and ((2 * k + self.outputs.shape[0]) * f + self.outputs.shape[0] * k) * 4 <= 150 * 1024
+                and self.outputs.shape[0] <= 4096 and ((2 * k + 4) * f + 4 * k) * 4 <= 64 * 1024
                 and self._offs[self.pfw] % 4 == 0 and self._ce[0].is_contiguous()
             )
             if ok:
                 b = self.outputs.shape[0]
+                g = _lib.load().hf_linear_ce_head_slabs(b)  # partial sums per workgroup, added up by hf_pack_ex
                 kw = dict(dtype=torch.float32, device=self.dev)
-                self._head_bufs = (torch.empty((b, f), **kw), torch.empty((k, f), **kw), torch.empty((k,), **kw))
+                self._head_bufs = (torch.empty((b, f), **kw), torch.empty((g, k, f), **kw),
+                                   torch.empty((g, k), **kw))
             self._head_ok = ok
         return ok and v_fw.data_ptr() % 16 == 0
 
@@ -545,7 +558,50 @@ class FusedGGNEngine(_Operator):
 
     def __call__(self, v, out=None):
         self.calls += 1
-        return _all_reduce_sum(self.local(v, out), self.group)
+        return self.reduce(self.local(v, out))
+
+    # ---- data parallelism: only the entries that can be non-zero travel ----------------------
+    def _live_index(self):
+        """Positions (int32) of the product's entries that are not structurally zero -- the weight
+        slices of kernel taps that never meet data are zero on every rank (``_live_taps``) --, or
+        ``None`` when (almost) everything is live.  ResNet-18 on 28x28 inputs: 4.3 M of 11.2 M."""
+        if not hasattr(self, "_live_idx"):
+            self._live_idx = None
+            masked = [u for u in self.units if u is not self.stem and getattr(u, "live", 0)]
+            dead = 0
+            for u in masked:
+                rs = u.conv.weight.shape[2] * u.conv.weight.shape[3]
+                dead += u.conv.weight.numel() // rs * (rs - bin(u.live).count("1"))
+            if masked and dead >= 0.2 * self.n and self.n < 2**31 and os.environ.get("HF_COMPACT_ALLREDUCE", "1") != "0":
+                keep = torch.ones(self.n, dtype=torch.bool, device=self.dev)
+                for u in masked:
+                    k, c, r, s_ = u.conv.weight.shape
+                    taps = torch.tensor([(u.live >> t) & 1 for t in range(r * s_)], dtype=torch.bool, device=self.dev)
+                    off = self._offs[u.pw]
+                    keep[off: off + k * c * r * s_] = taps.repeat(k * c)  # parameter order (o, i, tap)
+                self._live_idx = torch.nonzero(keep).flatten().to(torch.int32)
+                self._compact = torch.empty(self._live_idx.numel(), dtype=torch.float32, device=self.dev)
+        return self._live_idx
+
+    @property
+    def reduce_bytes(self):
+        idx = self._live_index()
+        return 4 * (self.n if idx is None else idx.numel())
+
+    def reduce(self, t, group=None):
+        """Sum of the local products over the ranks.  The structurally-zero entries are zero on
+        every rank, so only the live ones are gathered into a compact vector, all-reduced and
+        scattered back (17 MB instead of 44.7 MB per product on the ResNet-18 workload)."""
+        group = self.group if group is None else group
+        if group is None:
+            return t
+        idx = self._live_index()
+        if idx is None or t.dtype != torch.float32 or t.numel() != self.n or not t.is_contiguous():
+            return _all_reduce_sum(t, group)
+        torch.index_select(t, 0, idx, out=self._compact)
+        _all_reduce_sum(self._compact, group)
+        t.index_put_((idx,), self._compact)
+        return t
 
     # ---- safety net --------------------------------------------------------------------------
     def _verify(self, loss):
