@@ -199,6 +199,19 @@ int hf_unpack_tangent_ex(const void* src, void* const* dsts, const int64_t* src_
                          const int64_t* numels, const int64_t* slabs, const int64_t* inners,
                          const int64_t* live, int n_tensors, int dtype, void* stream);
 
+/*
+ * Data-parallel products (the `result += N * mb_result` of optimizer.py:677-684, across GPUs): the
+ * entries of a curvature product that are structurally zero on EVERY rank -- conv-weight slices of
+ * kernel taps that never meet data -- need not travel.  hf_live_copy gathers the other entries
+ * of the flat vector `full` into `compact` (scatter = 0) or writes them back (scatter = 1); the
+ * all-reduce runs on `compact`.  The vector is described as n_segments <= 24 consecutive segments
+ * (HOST arrays): full_offs[i] = start in the full vector, counts[i] = elements IN THE FULL VECTOR,
+ * periods[i] = 0 for a dense segment, else H*W <= 16 of a weight [O, I, H, W] whose live taps are
+ * the bits of masks[i].  Compact order = segment order, inside a masked segment (o, i, live tap).
+ */
+int hf_live_copy(void* full, void* compact, int scatter, const int64_t* full_offs, const int64_t* counts,
+                 const int64_t* periods, const int64_t* masks, int n_segments, int dtype, void* stream);
+
 /* minv = (diag + damping)^(-exponent)   (preconditioners.py:124, hoisted out of
  * the CG loop). */
 int hf_precond_build(void* minv, const void* diag, double damping,

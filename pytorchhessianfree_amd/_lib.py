@@ -94,6 +94,7 @@ SIGNATURES = {
         c_int,
         [c_void_p, ctypes.POINTER(c_void_p)] + [ctypes.POINTER(c_int64)] * 5 + [c_int, c_int, c_void_p],
     ),
+    "hf_live_copy": (c_int, [c_void_p, c_void_p, c_int] + [ctypes.POINTER(c_int64)] * 4 + [c_int, c_int, c_void_p]),
     "hf_precond_build": (c_int, [c_void_p, c_void_p, c_double, c_double, c_int64, c_int, c_void_p]),
     "hf_axpy_out": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int, c_void_p]),
     "hf_chan_affine": (c_int, [c_void_p] * 10 + [c_int, c_int64, c_int64, c_int64, c_int, c_int64, c_int64,

@@ -797,6 +797,42 @@ __global__ __launch_bounds__(BLOCK) void k_unpack_tangent(const T* __restrict__ 
   }
 }
 
+// Compaction of a flat parameter-space vector to its entries that can be non-zero, and back
+// (data-parallel products: only those travel through the all-reduce).  The vector is a sequence
+// of segments: dense ones, and conv weights [O, I, H*W] of which only the kernel taps in `mask`
+// are live (period HW, nl = popcount(mask) live entries per period, pos[] their tap indices).
+constexpr int LIVE_MAXS = 24;
+struct LiveSegs {
+  long long full_off[LIVE_MAXS];
+  long long comp_off[LIVE_MAXS + 1];  // compact offsets; [ns] = total
+  int hw[LIVE_MAXS];                  // 0: dense
+  int nl[LIVE_MAXS];
+  unsigned char pos[LIVE_MAXS][16];
+  int ns;
+};
+
+// SCATTER = false: comp[k] = full[index(k)];  true: full[index(k)] = comp[k]
+template <typename T, bool SCATTER>
+__global__ __launch_bounds__(BLOCK) void k_live_copy(T* __restrict__ full, T* __restrict__ comp,
+                                                     const LiveSegs a, long long total) {
+  for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < total; k += (long long)gridDim.x * BLOCK) {
+    int lo = 0, hi = a.ns;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (a.comp_off[mid] <= k) lo = mid; else hi = mid;
+    }
+    const long long r = k - a.comp_off[lo];
+    long long f = a.full_off[lo];
+    if (a.hw[lo] == 0) {
+      f += r;
+    } else {
+      const long long g = r / a.nl[lo];
+      f += g * a.hw[lo] + a.pos[lo][(int)(r - g * a.nl[lo])];
+    }
+    if (SCATTER) full[f] = comp[k]; else comp[k] = full[f];
+  }
+}
+
 // minv = (diag + damping)^(-exponent)
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_precond_build(T* __restrict__ minv,
@@ -1970,6 +2006,52 @@ int hf_unpack_tangent_ex(const void* src, void* const* dsts, const int64_t* src_
   if (dtype == HF_F64)
     return unpack_impl<double>(src, dsts, src_offs, numels, slabs, inners, live, n_tensors, (hipStream_t)stream);
   return HF_ERR_ARG;
+}
+
+int hf_live_copy(void* full, void* compact, int scatter, const int64_t* full_offs, const int64_t* counts,
+                 const int64_t* periods, const int64_t* masks, int n_segments, int dtype, void* stream) {
+  if (!full || !compact || !full_offs || !counts || !periods || !masks || n_segments < 1 ||
+      n_segments > LIVE_MAXS)
+    return HF_ERR_ARG;
+  LiveSegs a;
+  memset(&a, 0, sizeof(a));
+  long long total = 0;
+  for (int i = 0; i < n_segments; ++i) {
+    if (full_offs[i] < 0 || counts[i] < 1 || periods[i] < 0 || periods[i] > 16) return HF_ERR_ARG;
+    a.full_off[i] = full_offs[i];
+    a.comp_off[i] = total;
+    a.hw[i] = (int)periods[i];
+    if (periods[i] == 0) {
+      a.nl[i] = 1;
+      total += counts[i];
+    } else {
+      // counts[i] = elements of the weight tensor in the FULL vector (a whole number of periods)
+      if (counts[i] % periods[i] != 0) return HF_ERR_ARG;
+      int nl = 0;
+      for (int t = 0; t < (int)periods[i]; ++t)
+        if ((masks[i] >> t) & 1) a.pos[i][nl++] = (unsigned char)t;
+      if (nl < 1) return HF_ERR_ARG;
+      a.nl[i] = nl;
+      total += counts[i] / periods[i] * nl;
+    }
+  }
+  a.comp_off[n_segments] = total;
+  a.ns = n_segments;
+  long long blocks = (total + (long long)BLOCK * 4 - 1) / ((long long)BLOCK * 4);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == HF_F32) {
+    if (scatter) hipLaunchKernelGGL((k_live_copy<float, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (float*)full, (float*)compact, a, total);
+    else hipLaunchKernelGGL((k_live_copy<float, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (float*)full, (float*)compact, a, total);
+  } else if (dtype == HF_F64) {
+    if (scatter) hipLaunchKernelGGL((k_live_copy<double, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (double*)full, (double*)compact, a, total);
+    else hipLaunchKernelGGL((k_live_copy<double, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (double*)full, (double*)compact, a, total);
+  } else {
+    return HF_ERR_ARG;
+  }
+  HF_HIP(hipGetLastError());
+  return HF_OK;
 }
 
 int hf_precond_build(void* minv, const void* diag, double damping, double exponent, int64_t n,

@@ -561,47 +561,62 @@ class FusedGGNEngine(_Operator):
         return self.reduce(self.local(v, out))
 
     # ---- data parallelism: only the entries that can be non-zero travel ----------------------
-    def _live_index(self):
-        """Positions (int32) of the product's entries that are not structurally zero -- the weight
-        slices of kernel taps that never meet data are zero on every rank (``_live_taps``) --, or
-        ``None`` when (almost) everything is live.  ResNet-18 on 28x28 inputs: 4.3 M of 11.2 M."""
-        if not hasattr(self, "_live_idx"):
-            self._live_idx = None
-            masked = [u for u in self.units if u is not self.stem and getattr(u, "live", 0)]
-            dead = 0
-            for u in masked:
-                rs = u.conv.weight.shape[2] * u.conv.weight.shape[3]
-                dead += u.conv.weight.numel() // rs * (rs - bin(u.live).count("1"))
-            if masked and dead >= 0.2 * self.n and self.n < 2**31 and os.environ.get("HF_COMPACT_ALLREDUCE", "1") != "0":
-                keep = torch.ones(self.n, dtype=torch.bool, device=self.dev)
-                for u in masked:
-                    k, c, r, s_ = u.conv.weight.shape
-                    taps = torch.tensor([(u.live >> t) & 1 for t in range(r * s_)], dtype=torch.bool, device=self.dev)
-                    off = self._offs[u.pw]
-                    keep[off: off + k * c * r * s_] = taps.repeat(k * c)  # parameter order (o, i, tap)
-                self._live_idx = torch.nonzero(keep).flatten().to(torch.int32)
-                self._compact = torch.empty(self._live_idx.numel(), dtype=torch.float32, device=self.dev)
-        return self._live_idx
+    def _live_segments(self):
+        """Description of the product's entries that are not structurally zero for ``hf_live_copy``
+        -- the weight slices of kernel taps that never meet data are zero on every rank
+        (``_live_taps``) --, or ``None`` when (almost) everything is live.  ResNet-18 on 28x28
+        inputs: 4.3 M of 11.2 M entries."""
+        if not hasattr(self, "_live_segs"):
+            self._live_segs = None
+            masked = {u.pw: u for u in self.units if u is not self.stem and getattr(u, "live", 0)}
+            segs, dead, run_start = [], 0, None  # (full offset, count in the full vector, period, mask)
+            for i, p in enumerate(self.params):
+                off = self._offs[i]
+                if i in masked:
+                    if run_start is not None:
+                        segs.append((run_start, off - run_start, 0, 0))
+                        run_start = None
+                    u = masked[i]
+                    rs = p.shape[2] * p.shape[3]
+                    segs.append((off, p.numel(), rs, u.live))
+                    dead += p.numel() // rs * (rs - bin(u.live).count("1"))
+                elif run_start is None:
+                    run_start = off
+            if run_start is not None:
+                segs.append((run_start, self.n - run_start, 0, 0))
+            if (masked and dead >= 0.2 * self.n and len(segs) <= 24
+                    and os.environ.get("HF_COMPACT_ALLREDUCE", "1") != "0"):
+                arr = lambda col: (_lib.c_int64 * len(segs))(*[sg[col] for sg in segs])
+                self._live_segs = (arr(0), arr(1), arr(2), arr(3), len(segs))
+                self._compact = torch.empty(self.n - dead, dtype=torch.float32, device=self.dev)
+        return self._live_segs
+
+    def _live_copy(self, full, scatter):
+        offs, counts, periods, masks, ns = self._live_segs
+        _lib.check(_lib.load().hf_live_copy(_ptr(full), _ptr(self._compact), int(scatter), offs, counts, periods,
+                                            masks, ns, _lib.HF_F32, _lib.current_stream_ptr(self.dev)),
+                   "hf_live_copy")
 
     @property
     def reduce_bytes(self):
-        idx = self._live_index()
-        return 4 * (self.n if idx is None else idx.numel())
+        return 4 * (self.n if self._live_segments() is None else self._compact.numel())
 
     def reduce(self, t, group=None):
         """Sum of the local products over the ranks.  The structurally-zero entries are zero on
-        every rank, so only the live ones are gathered into a compact vector, all-reduced and
-        scattered back (17 MB instead of 44.7 MB per product on the ResNet-18 workload)."""
+        every rank, so only the live ones are gathered into a compact vector (``hf_live_copy``),
+        all-reduced and scattered back (17 MB instead of 44.7 MB per product on the ResNet-18
+        workload)."""
         group = self.group if group is None else group
         if group is None:
             return t
-        idx = self._live_index()
-        if idx is None or t.dtype != torch.float32 or t.numel() != self.n or not t.is_contiguous():
+        if (self._live_segments() is None or t.dtype != torch.float32 or t.numel() != self.n
+                or not t.is_contiguous() or not t.is_cuda):
             return _all_reduce_sum(t, group)
-        torch.index_select(t, 0, idx, out=self._compact)
+        self._live_copy(t, False)
         _all_reduce_sum(self._compact, group)
-        t.index_put_((idx,), self._compact)
+        self._live_copy(t, True)
         return t
+
 
     # ---- safety net --------------------------------------------------------------------------
     def _verify(self, loss):

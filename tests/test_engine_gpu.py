@@ -251,3 +251,33 @@ def test_pack_and_unpack_skip_structurally_zero_taps():
     rest[:, :, 1, 1] = 7.0
     assert float((rest - 7.0).abs().max()) == 0.0 and float((bufs[0][:, :c] - 7.0).abs().max()) == 0.0
     assert torch.equal(bufs[1][:, c:], v[5 + k * c * 9:].view(k, c, 3, 3))
+
+
+def test_live_copy_gathers_and_scatters_the_live_entries():
+    """``hf_live_copy``: dense segments and conv-weight segments with a live-tap mask, against
+    indexing with an explicit boolean mask; scatter restores exactly the gathered entries."""
+    from pytorchhessianfree_amd import _lib
+
+    gen = torch.Generator(device=DEV).manual_seed(21)
+    # [dense 37 | weight 6x5x(3x3), centre tap | dense 11 | weight 4x3x(3x3), 4 taps | dense 5]
+    segs = [(0, 37, 0, 0), (37, 270, 9, 1 << 4), (307, 11, 0, 0), (318, 108, 9, 0b110110000), (426, 5, 0, 0)]
+    n = 431
+    keep = torch.ones(n, dtype=torch.bool, device=DEV)
+    for off, cnt, per, mask in segs:
+        if per:
+            taps = torch.tensor([(mask >> t) & 1 for t in range(per)], dtype=torch.bool, device=DEV)
+            keep[off:off + cnt] = taps.repeat(cnt // per)
+    full = torch.randn(n, device=DEV, generator=gen)
+    m = int(keep.sum())
+    comp = torch.full((m,), -1.0, device=DEV)
+    arr = lambda c: (_lib.c_int64 * len(segs))(*[s[c] for s in segs])
+    P = _lib.c_void_p
+    st = _lib.current_stream_ptr(full.device)
+    lib = _lib.load()
+    assert lib.hf_live_copy(P(full.data_ptr()), P(comp.data_ptr()), 0, arr(0), arr(1), arr(2), arr(3), len(segs),
+                            _lib.HF_F32, st) == 0
+    assert torch.equal(comp, full[keep])
+    target, doubled = torch.zeros(n, device=DEV), 2 * comp
+    assert lib.hf_live_copy(P(target.data_ptr()), P(doubled.data_ptr()), 1, arr(0), arr(1), arr(2), arr(3),
+                            len(segs), _lib.HF_F32, st) == 0
+    assert torch.equal(target[keep], 2 * full[keep]) and float(target[~keep].abs().max()) == 0.0
