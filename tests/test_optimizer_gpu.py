@@ -644,7 +644,9 @@ def test_config2_full_step_matches_reference_cpu_path(deterministic):
 
     runs = {}
     for device in ("cpu", DEV):
-        model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device=device, data_seed=1000)
+        # (a batch without a ReLU input within fp32 rounding of zero: testproblems.relu_margin)
+        model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device=device,
+                                                 data_seed=tp.RESNET18_B32_SEPARATED_SEEDS[0])
         if device != "cpu":
             modelprep.prepare_model(model, channels_last=deterministic, deterministic=deterministic)
         before = trainable_vec(model).clone()
