@@ -27,6 +27,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "hf_pcg.h"
@@ -561,6 +562,16 @@ namespace {
 // hides (~1.0 us at BK = 32, ~1.5 us at BK = 64; the fp32 MFMA work itself is 0.43 / 0.86 us),
 // a split run pays ~3 us to publish and collect tickets plus ~0.15 us per slab the last
 // arriver sums; workgroups beyond two per CU queue.
+inline int64_t hf_env_cap() {  // tuning knob, default measured on the ResNet-18 bench
+  static int64_t cap = 0;
+  if (cap == 0) {
+    const char* e = getenv("HF_CONV_FEW_TILES_CAP");
+    cap = e ? atoll(e) : 96;
+    if (cap < 1) cap = 32;
+  }
+  return cap;
+}
+
 int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_bytes, bool slabs = false) {
   int64_t best = 1;
   if (slabs && target_blocks <= 0) {
@@ -570,7 +581,10 @@ int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_by
     // is down to 2 steps
     best = (256 + tiles - 1) / tiles;
     if (best > steps / 2) best = steps / 2;
-    if (best > 32) best = 32;
+    // (one or two output tiles -- the stem's weight gradient: 6272 rows into a 64 x 52 matrix --
+    // would leave most of the chip idle at 32 splits)
+    const int64_t cap = tiles <= 2 ? hf_env_cap() : 32;
+    if (best > cap) best = cap;
     if (best < 1) best = 1;
     while (best > 1 && ((steps + best - 1) / best) * (best - 1) >= steps) --best;
     return (int)best;
