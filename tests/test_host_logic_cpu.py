@@ -470,3 +470,39 @@ def test_fused_residual_block_is_verified_against_the_modules_own_forward():
         assert torch.allclose(got, want, atol=1e-6)
         assert any("fused residual-block forward" in str(m.message) for m in w) == reverted
         assert torch.allclose(block(x), want, atol=1e-6)  # and on every later call
+
+
+def test_live_taps_match_a_brute_force_convolution():
+    """``engine._live_taps``: a kernel tap is live iff the weight gradient of an all-ones problem is
+    non-zero there (what ``hf_conv2d_nhwc`` skips, what pack / unpack / the compact all-reduce
+    leave out) -- against a brute-force weight gradient on the CPU."""
+    from pytorchhessianfree_amd.engine import _live_taps
+
+    for h, w, r, s, stride, pad in [(1, 1, 3, 3, (1, 1), (1, 1)), (2, 2, 3, 3, (2, 2), (1, 1)),
+                                    (2, 2, 3, 3, (1, 1), (1, 1)), (7, 7, 3, 3, (1, 1), (1, 1)),
+                                    (3, 1, 3, 3, (1, 1), (1, 1)), (4, 4, 1, 1, (2, 2), (0, 0)),
+                                    (2, 3, 4, 4, (2, 1), (1, 2)), (1, 1, 5, 5, (1, 1), (2, 2))]:
+        x = torch.ones(1, 1, h, w)
+        wgt = torch.ones(1, 1, r, s, requires_grad=True)
+        y = torch.nn.functional.conv2d(x, wgt, None, stride, pad)
+        (gw,) = torch.autograd.grad(y.sum(), wgt)
+        want = sum(1 << (i * s + j) for i in range(r) for j in range(s) if gw[0, 0, i, j] != 0)
+        got = _live_taps(h, w, r, s, stride, pad)
+        if r * s > 16:
+            assert got == 0  # does not fit the kernels' 16-bit masks: everything is copied
+        else:
+            assert got == (0 if want == (1 << (r * s)) - 1 else want), (h, w, r, s, stride, pad)
+
+
+def test_relu_margin_reports_the_smallest_relu_input():
+    from pytorchhessianfree_amd import testproblems as tp
+
+    net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.ReLU(), torch.nn.Linear(4, 2), torch.nn.ReLU()).double()
+    x = torch.randn(5, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(2))
+    z1 = net[0](x)
+    z2 = net[2](torch.relu(z1))
+    want = min(float(z1.abs().min()), float(z2.abs().min()))
+    assert tp.relu_margin(net, x) == want
+    # the seeds the parity tests and bench.py draw their ResNet-18 batches from
+    model, (xb, _), _ = tp.resnet18_mnist(batch_size=32, data_seed=tp.RESNET18_B32_SEPARATED_SEEDS[0])
+    assert tp.relu_margin(model.double(), xb.double()) > 8e-7
