@@ -270,6 +270,32 @@ int hf_chan_affine_bwd_ex(void* gx, void* gw, void* gb, void* gres, const void* 
                           const void* x, const void* mean, const void* rstd, const void* w,
                           const void* mask_src, int64_t n, int64_t c, int64_t hw, int channels_last,
                           int row_blocks, int dtype, void* stream);
+/* TWO independent layers in one launch (a residual block's first BatchNorm and its downsample
+ * branch's, whose inputs come out of one grouped convolution launch): the arguments of
+ * hf_chan_affine_ex resp. hf_chan_affine_bwd_ex (row_blocks >= 2) per problem; NHWC fp32 only. */
+typedef struct hf_affine_problem {
+  void* out;
+  const void *a, *x, *mean, *rstd, *w, *q, *r, *add, *mask_src;
+  int relu_self;
+  int64_t n, c, hw, out_ld, add_ld;
+  int a_splits;
+  int64_t a_slab;
+} hf_affine_problem;
+int hf_chan_affine_pair(const hf_affine_problem* problems /* [2] */, int dtype, void* stream);
+typedef struct hf_bn_adjoint_problem {
+  void *gx, *gw, *gb, *gres;
+  const void* gy;
+  int gy_splits;
+  int64_t gy_slab;
+  const void* gy2;
+  int gy2_splits;
+  int64_t gy2_slab;
+  const void *x, *mean, *rstd, *w, *mask_src;
+  int64_t n, c, hw;
+  int row_blocks;
+} hf_bn_adjoint_problem;
+int hf_chan_affine_bwd_pair(const hf_bn_adjoint_problem* problems /* [2] */, int dtype, void* stream);
+
 /* Elementwise adjoint pre-pass of a fused BatchNorm(+add+ReLU) layer, NHWC [rows, c]:
  *   g = (sum of gy_a's slabs + sum of gy_b's slabs) * [mask_src > 0];  g_out = g (nullable);
  *   ga_out = g * w[c]*rstd[c] (nullable): the cotangent of the convolution output that
@@ -340,6 +366,22 @@ int hf_conv2d_nhwc_backward_slabs(void* dx, void* dw, const void* dy, const void
                                   int64_t s, int64_t stride_h, int64_t stride_w, int64_t pad_h,
                                   int64_t pad_w, int splits_d, int64_t slab_stride_d, int splits_w,
                                   int64_t slab_stride_w, int dtype, void* stream);
+
+/* Up to 4 independent slab-mode convolutions in ONE launch (any mix of directions; 16-byte gather
+ * variant only: channel counts multiples of 4).  Each problem is what hf_conv2d_nhwc_slabs takes.
+ * The curvature engine groups the two tangent convolutions that read a residual block's input (its
+ * first convolution and its downsample branch), and the data + weight gradients of both layers. */
+typedef struct hf_conv_problem {
+  int direction;            /* 0 forward / tangent, 1 data gradient, 2 weight gradient */
+  void* out;
+  const void* act;
+  const void* mat;
+  int64_t n, h, w, c, k, r, s, stride_h, stride_w, pad_h, pad_w;
+  int64_t act_ld, out_c;
+  int splits;
+  int64_t slab_stride;
+} hf_conv_problem;
+int hf_conv2d_nhwc_group_slabs(const hf_conv_problem* problems, int n_problems, int dtype, void* stream);
 
 /* Data gradient AND weight gradient of one layer (directions 1 and 2 above) in ONE launch:
  * both read dY [n,oh,ow,k], neither depends on the other.  dx [n,h,w,c]; dw [k][r][q][c]

@@ -107,6 +107,9 @@ SIGNATURES = {
     "hf_conv2d_nhwc_plan": (c_int, [c_int] + [c_int64] * 11 + [c_int]),
     "hf_conv2d_nhwc_slabs": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int64] * 13
                              + [c_int, c_int64, c_int, c_void_p]),
+    "hf_conv2d_nhwc_group_slabs": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "hf_chan_affine_pair": (c_int, [c_void_p, c_int, c_void_p]),
+    "hf_chan_affine_bwd_pair": (c_int, [c_void_p, c_int, c_void_p]),
     "hf_conv2d_nhwc_backward_slabs": (c_int, [c_void_p] * 5 + [c_int64] * 11
                                       + [c_int, c_int64, c_int, c_int64, c_int, c_void_p]),
     "hf_chan_affine_ex": (c_int, [c_void_p] * 10 + [c_int, c_int64, c_int64, c_int64, c_int, c_int64, c_int64,
@@ -393,6 +396,48 @@ def pack_ex(dst, tensors, perms, splits, scale=1.0, live=None):
                        dtype_code(dst.dtype), current_stream_ptr(dst.device)),
         "hf_pack_ex")
     return dst
+
+
+class AffineProblem(ctypes.Structure):
+    """``hf_affine_problem`` of include/hf_pcg.h."""
+
+    _fields_ = ([("out", c_void_p)] + [(nm, c_void_p) for nm in ("a", "x", "mean", "rstd", "w", "q", "r", "add",
+                                                                   "mask_src")]
+                + [("relu_self", c_int)] + [(nm, c_int64) for nm in ("n", "c", "hw", "out_ld", "add_ld")]
+                + [("a_splits", c_int), ("a_slab", c_int64)])
+
+
+class BnAdjointProblem(ctypes.Structure):
+    """``hf_bn_adjoint_problem`` of include/hf_pcg.h."""
+
+    _fields_ = ([(nm, c_void_p) for nm in ("gx", "gw", "gb", "gres", "gy")] + [("gy_splits", c_int), ("gy_slab", c_int64),
+                                                                                 ("gy2", c_void_p), ("gy2_splits", c_int),
+                                                                                 ("gy2_slab", c_int64)]
+                + [(nm, c_void_p) for nm in ("x", "mean", "rstd", "w", "mask_src")]
+                + [(nm, c_int64) for nm in ("n", "c", "hw")] + [("row_blocks", c_int)])
+
+
+class ConvProblem(ctypes.Structure):
+    """``hf_conv_problem`` of include/hf_pcg.h."""
+
+    _fields_ = [("direction", c_int), ("out", c_void_p), ("act", c_void_p), ("mat", c_void_p)] + [
+        (name, c_int64) for name in ("n", "h", "w", "c", "k", "r", "s", "stride_h", "stride_w", "pad_h", "pad_w",
+                                     "act_ld", "out_c")] + [("splits", c_int), ("slab_stride", c_int64)]
+
+
+def conv_group_slabs(problems, device):
+    """One launch for up to 4 slab-mode convolutions; ``problems``: tuples ``(direction, out, act, mat,
+    (n, h, w, c, k, r, s, stride, padding), splits, act_ld, out_c)`` with ``out`` a [splits, ...] buffer."""
+    arr = (ConvProblem * len(problems))()
+    for q, (direction, out, act, mat, geo, splits, act_ld, out_c) in zip(arr, problems):
+        n, h, w, c, k, r, s, st, pd = geo
+        q.direction, q.out, q.act, q.mat = int(direction), out.data_ptr(), act.data_ptr(), mat.data_ptr()
+        q.n, q.h, q.w, q.c, q.k, q.r, q.s = n, h, w, c, k, r, s
+        q.stride_h, q.stride_w, q.pad_h, q.pad_w = st[0], st[1], pd[0], pd[1]
+        q.act_ld, q.out_c, q.splits = act_ld, out_c, splits
+        q.slab_stride = out.shape[1] if out.dim() == 2 else 0
+    check(load().hf_conv2d_nhwc_group_slabs(ctypes.cast(arr, c_void_p), len(problems), HF_F32,
+                                            current_stream_ptr(device)), "hf_conv2d_nhwc_group_slabs")
 
 
 def conv_plan(direction, n, h, w, c, k, r, s, stride, padding):

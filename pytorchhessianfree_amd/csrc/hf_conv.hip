@@ -544,6 +544,27 @@ __global__ __launch_bounds__(CT) void k_conv_dw(const ConvArgs d, const ConvArgs
   else conv_tn_body<false>(w, lds, blockIdx.x - nblocks_d);
 }
 
+// Up to GROUP_MAX independent convolutions (any mix of directions) in ONE launch: workgroups
+// [start[p], start[p+1]) run problem p.  The curvature engine uses it where two layers read the
+// same tensor (a residual block's first convolution and its downsample branch): one launch for
+// both tangent convolutions, one for both layers' data + weight gradients.
+constexpr int GROUP_MAX = 4;
+struct GroupArgs {
+  ConvArgs a[GROUP_MAX];
+  int tn[GROUP_MAX];       // 1: weight gradient (TN body), 0: forward / data gradient (NT body)
+  int start[GROUP_MAX + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(CT) void k_conv_group(const GroupArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  int p = 0;
+  while (p + 1 < g.n && (int)blockIdx.x >= g.start[p + 1]) ++p;  // (uniform)
+  const int local = (int)blockIdx.x - g.start[p];
+  if (g.tn[p]) conv_tn_body<false>(g.a[p], lds, local);
+  else conv_nt_body<false>(g.a[p], lds, local);
+}
+
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
@@ -824,6 +845,38 @@ int hf_conv2d_nhwc_backward_slabs(void* dx, void* dw, const void* dy, const void
   if (d.splits != splits_d || g.splits != splits_w) return HF_ERR_ARG;
   if (d.scalar || g.scalar) return HF_ERR_ARG;  // the merged launch has the 16-byte gather variant only
   hipLaunchKernelGGL(k_conv_dw, dim3((unsigned)(bd + bw)), dim3(CT), 0, (hipStream_t)stream, d, g, (int)bd);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_conv2d_nhwc_group_slabs(const hf_conv_problem* problems, int n_problems, int dtype, void* stream) {
+  if (!problems || n_problems < 1 || n_problems > GROUP_MAX) return HF_ERR_ARG;
+  GroupArgs q;  // (~1.2 KB, passed to the kernel by value)
+  memset(&q, 0, sizeof(q));
+  int64_t total = 0;
+  alignas(16) float dummy_ws[4];
+  for (int i = 0; i < n_problems; ++i) {
+    const hf_conv_problem& pr = problems[i];
+    if (pr.direction < 0 || pr.direction > 2 || pr.splits < 1 || pr.slab_stride < 0) return HF_ERR_ARG;
+    if (pr.out_c < 0 || pr.out_c > pr.c || (pr.out_c && pr.direction != 2)) return HF_ERR_ARG;
+    const int rc = check_common(pr.out, pr.act, pr.mat, dummy_ws, dummy_ws, dtype, pr.n, pr.h, pr.w, pr.c, pr.k,
+                                pr.r, pr.s, pr.stride_h, pr.stride_w, pr.pad_h, pr.pad_w);
+    if (rc) return rc;
+    const int64_t blocks = setup(q.a[i], pr.direction, pr.out, pr.act, pr.mat, pr.n, pr.h, pr.w, pr.c, pr.k, pr.r,
+                                 pr.s, pr.stride_h, pr.stride_w, pr.pad_h, pr.pad_w, pr.act_ld, nullptr, 0,
+                                 nullptr, 0, 0, pr.splits, pr.slab_stride);
+    if (blocks <= 0) return (int)blocks;
+    if (q.a[i].splits != pr.splits) return HF_ERR_ARG;  // ask hf_conv2d_nhwc_plan first
+    if (q.a[i].scalar) return HF_ERR_ARG;               // the grouped launch has the 16-byte gather variant only
+    if (pr.out_c) q.a[i].out_c = (int)pr.out_c;
+    q.tn[i] = pr.direction == 2;
+    q.start[i] = (int)total;
+    total += blocks;
+    if (total > 0x7fffffffLL) return HF_ERR_ARG;
+  }
+  q.start[n_problems] = (int)total;
+  q.n = n_problems;
+  hipLaunchKernelGGL(k_conv_group, dim3((unsigned)total), dim3(CT), 0, (hipStream_t)stream, q);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }

@@ -881,16 +881,16 @@ __global__ __launch_bounds__(BLOCK) void k_axpy_out(T* out, const T* a, const T*
 // I = unsigned (tensors < 2^31 elements: 32-bit index arithmetic, the per-element
 // division is what these tiny kernels spend their time on) or long long.
 template <typename T, typename I>
-__global__ __launch_bounds__(BLOCK) void k_chan_affine(
+__device__ __forceinline__ void chan_affine_body(
     T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ x,
     const T* __restrict__ mean, const T* __restrict__ rstd, const T* __restrict__ w,
     const T* __restrict__ q, const T* __restrict__ r, const T* __restrict__ add,
     const T* __restrict__ mask_src, int relu_self, I total, I C, I HW, int nhwc, I out_ld,
-    I add_ld, int a_splits, long long a_slab) {
+    I add_ld, int a_splits, long long a_slab, I bid, I nblocks) {
   // out_ld / add_ld != 0: that operand is the first-C-channels slice of a wider buffer --
   // NHWC: element (row, c) at row*ld + c; NCHW: (n, c, hw) at n*ld + c*HW + hw.
   const I CHW = C * HW;
-  for (I i = (I)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (I)gridDim.x * BLOCK) {
+  for (I i = bid * BLOCK + threadIdx.x; i < total; i += nblocks * BLOCK) {
     const I c = (nhwc || HW == 1 ? i : i / HW) % C;  // NHWC: the channel is the fastest index
     const T rs = rstd[c];
     T acc = (T)0;
@@ -914,6 +914,39 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine(
     else if (mask_src) acc = mask_src[i] > (T)0 ? acc : (T)0;
     out[out_ld ? i + outer * (out_ld - (nhwc ? C : CHW)) : i] = acc;
   }
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(BLOCK) void k_chan_affine(
+    T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ x,
+    const T* __restrict__ mean, const T* __restrict__ rstd, const T* __restrict__ w,
+    const T* __restrict__ q, const T* __restrict__ r, const T* __restrict__ add,
+    const T* __restrict__ mask_src, int relu_self, I total, I C, I HW, int nhwc, I out_ld,
+    I add_ld, int a_splits, long long a_slab) {
+  chan_affine_body<T, I>(out, a, x, mean, rstd, w, q, r, add, mask_src, relu_self, total, C, HW, nhwc, out_ld,
+                         add_ld, a_splits, a_slab, (I)blockIdx.x, (I)gridDim.x);
+}
+
+// Two independent layers (a residual block's first BatchNorm and its downsample branch's) in ONE
+// launch: the first `blocks_a` workgroups run problem A.  fp32, 32-bit indices.
+struct AffArgs {
+  float* out;
+  const float *a, *x, *mean, *rstd, *w, *q, *r, *add, *mask_src;
+  int relu_self;
+  unsigned total, C, HW;
+  int nhwc;
+  unsigned out_ld, add_ld;
+  int a_splits;
+  long long a_slab;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_chan_affine_pair(const AffArgs A, const AffArgs B, unsigned blocks_a) {
+  const bool first = blockIdx.x < blocks_a;
+  const AffArgs& p = first ? A : B;
+  chan_affine_body<float, unsigned>(p.out, p.a, p.x, p.mean, p.rstd, p.w, p.q, p.r, p.add, p.mask_src, p.relu_self,
+                                    p.total, p.C, p.HW, p.nhwc, p.out_ld, p.add_ld, p.a_splits, p.a_slab,
+                                    first ? blockIdx.x : blockIdx.x - blocks_a,
+                                    first ? blocks_a : gridDim.x - blocks_a);
 }
 
 // One channel per GROUP of TPC threads (TPC = 64: one wave per channel, 4 channels
@@ -1111,13 +1144,12 @@ __global__ __launch_bounds__(BS) void k_chan_affine_bwd_nhwc(
 // line per lane).  Per-channel sums: per thread over its rows, then over ty through LDS in a
 // fixed order; every block writes its partial sums to gw / gb + blockIdx.x*C (hf_pack_ex adds
 // the row shares up).  Cotangents may arrive as split-K slabs.
-__global__ __launch_bounds__(BLOCK) void k_bn_adjoint_rows(
+__device__ __forceinline__ void bn_adjoint_rows_body(
     float* __restrict__ gx, float* __restrict__ gw, float* __restrict__ gb, float* __restrict__ gres,
     const float* __restrict__ gy, int s1, long long l1, const float* __restrict__ gy2, int s2, long long l2,
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ w, const float* __restrict__ mask_src, unsigned rows, unsigned C,
-    unsigned rows_per_block) {
-  __shared__ double red[BLOCK * 8];
+    unsigned rows_per_block, unsigned bid, double* red) {
   struct alignas(16) Col { float e[4]; };
   const unsigned quads = C / 4, RP = BLOCK / quads;
   const unsigned tx = threadIdx.x % quads, ty = threadIdx.x / quads;
@@ -1133,7 +1165,7 @@ __global__ __launch_bounds__(BLOCK) void k_bn_adjoint_rows(
   double acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.0;
-  const unsigned row_lo = blockIdx.x * rows_per_block;
+  const unsigned row_lo = bid * rows_per_block;
   const unsigned row_hi = row_lo + rows_per_block < rows ? row_lo + rows_per_block : rows;
   if (live) {
     // two rows per pass: their first loads and their slab batches are all in flight together
@@ -1183,10 +1215,43 @@ __global__ __launch_bounds__(BLOCK) void k_bn_adjoint_rows(
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (gw) gw[blockIdx.x * C + c0 + k] = (float)acc[2 * k];
-      if (gb) gb[blockIdx.x * C + c0 + k] = (float)acc[2 * k + 1];
+      if (gw) gw[bid * C + c0 + k] = (float)acc[2 * k];
+      if (gb) gb[bid * C + c0 + k] = (float)acc[2 * k + 1];
     }
   }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_bn_adjoint_rows(
+    float* __restrict__ gx, float* __restrict__ gw, float* __restrict__ gb, float* __restrict__ gres,
+    const float* __restrict__ gy, int s1, long long l1, const float* __restrict__ gy2, int s2, long long l2,
+    const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ w, const float* __restrict__ mask_src, unsigned rows, unsigned C,
+    unsigned rows_per_block) {
+  __shared__ double red[BLOCK * 8];
+  bn_adjoint_rows_body(gx, gw, gb, gres, gy, s1, l1, gy2, s2, l2, x, mean, rstd, w, mask_src, rows, C,
+                       rows_per_block, blockIdx.x, red);
+}
+
+// Two independent layers' adjoints in ONE launch (see k_chan_affine_pair).
+struct BnAdjArgs {
+  float *gx, *gw, *gb, *gres;
+  const float* gy;
+  int s1;
+  long long l1;
+  const float* gy2;
+  int s2;
+  long long l2;
+  const float *x, *mean, *rstd, *w, *mask_src;
+  unsigned rows, C, rows_per_block;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_bn_adjoint_rows_pair(const BnAdjArgs A, const BnAdjArgs B,
+                                                                unsigned blocks_a) {
+  __shared__ double red[BLOCK * 8];
+  const bool first = blockIdx.x < blocks_a;
+  const BnAdjArgs& p = first ? A : B;
+  bn_adjoint_rows_body(p.gx, p.gw, p.gb, p.gres, p.gy, p.s1, p.l1, p.gy2, p.s2, p.l2, p.x, p.mean, p.rstd, p.w,
+                       p.mask_src, p.rows, p.C, p.rows_per_block, first ? blockIdx.x : blockIdx.x - blocks_a, red);
 }
 
 // Adjoint pre-pass of a fused eval-BatchNorm(+add+ReLU) layer in NHWC [rows, C], elementwise:
@@ -2184,6 +2249,58 @@ int hf_chan_affine_ex(void* out, const void* a, const void* x, const void* mean,
                                channels_last, out_ld, add_ld, a_splits, a_slab);
   else
     return HF_ERR_ARG;
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_chan_affine_pair(const hf_affine_problem* problems, int dtype, void* stream) {
+  if (!problems || dtype != HF_F32) return HF_ERR_ARG;
+  AffArgs q[2];
+  unsigned blocks[2];
+  for (int i = 0; i < 2; ++i) {
+    const hf_affine_problem& p = problems[i];
+    if (p.a_splits < 1 || (p.a_splits > 1 && (!p.a || p.a_slab <= 0))) return HF_ERR_ARG;
+    if (!p.out || !p.rstd || p.n <= 0 || p.c <= 0 || p.hw <= 0 || (p.q && (!p.x || !p.mean))) return HF_ERR_ARG;
+    const int64_t dense = p.c;  // NHWC
+    if ((p.out_ld && p.out_ld < dense) || (p.add_ld && (p.add_ld < dense || !p.add)) ||
+        p.out_ld > 0x3fffffffLL || p.add_ld > 0x3fffffffLL)
+      return HF_ERR_ARG;
+    const long long total = (long long)p.n * p.c * p.hw;
+    if (2 * total >= 0x7fffffffLL) return HF_ERR_ARG;
+    q[i] = AffArgs{(float*)p.out, (const float*)p.a, (const float*)p.x, (const float*)p.mean,
+                   (const float*)p.rstd, (const float*)p.w, (const float*)p.q, (const float*)p.r,
+                   (const float*)p.add, (const float*)p.mask_src, p.relu_self, (unsigned)total, (unsigned)p.c,
+                   (unsigned)p.hw, 1, (unsigned)p.out_ld, (unsigned)p.add_ld, p.a_splits, (long long)p.a_slab};
+    blocks[i] = (unsigned)wide_grid(total);
+  }
+  hipLaunchKernelGGL(k_chan_affine_pair, dim3(blocks[0] + blocks[1]), dim3(BLOCK), 0, (hipStream_t)stream, q[0],
+                     q[1], blocks[0]);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_chan_affine_bwd_pair(const hf_bn_adjoint_problem* problems, int dtype, void* stream) {
+  if (!problems || dtype != HF_F32) return HF_ERR_ARG;
+  BnAdjArgs q[2];
+  unsigned blocks[2];
+  for (int i = 0; i < 2; ++i) {
+    const hf_bn_adjoint_problem& p = problems[i];
+    if (!p.gy || p.n <= 0 || p.c <= 0 || p.hw <= 0 || p.gy_splits < 1 || p.gy2_splits < 1 || p.row_blocks < 2)
+      return HF_ERR_ARG;
+    if (!(p.c % 4 == 0 && p.c / 4 <= BLOCK)) return HF_ERR_ARG;
+    const int64_t rows = p.n * p.hw;
+    if (rows * p.c > 0x7fffffffLL || !aligned16(p.gy) || (p.gy2 && !aligned16(p.gy2)) || (p.x && !aligned16(p.x)) ||
+        (p.mask_src && !aligned16(p.mask_src)) || (p.gx && !aligned16(p.gx)) || (p.gres && !aligned16(p.gres)))
+      return HF_ERR_ALIGN;
+    const unsigned rpb = (unsigned)((rows + p.row_blocks - 1) / p.row_blocks);
+    q[i] = BnAdjArgs{(float*)p.gx, (float*)p.gw, (float*)p.gb, (float*)p.gres, (const float*)p.gy, p.gy_splits,
+                     (long long)p.gy_slab, (const float*)p.gy2, p.gy2_splits, (long long)p.gy2_slab,
+                     (const float*)p.x, (const float*)p.mean, (const float*)p.rstd, (const float*)p.w,
+                     (const float*)p.mask_src, (unsigned)rows, (unsigned)p.c, rpb};
+    blocks[i] = (unsigned)p.row_blocks;
+  }
+  hipLaunchKernelGGL(k_bn_adjoint_rows_pair, dim3(blocks[0] + blocks[1]), dim3(BLOCK), 0, (hipStream_t)stream,
+                     q[0], q[1], blocks[0]);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }

@@ -348,8 +348,45 @@ class FusedGGNEngine(_Operator):
             _ptr(vg), _ptr(vb), _ptr(add), _ptr(u.y) if u.relu else None, 0, n, k, oh * ow, 1, u.tout_ld, add_ld,
             u.sT, u.tbuf.shape[1], _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_chan_affine_ex")
 
+    def _bn_tangent_pair(self, u1, u2, v):
+        """The BatchNorm tangents of two units without residual input in ONE launch."""
+        arr = (_lib.AffineProblem * 2)()
+        for q, u in zip(arr, (u1, u2)):
+            n, k, oh, ow = u.a.shape
+            q.out, q.a, q.x = u.tout.data_ptr(), u.tbuf.data_ptr(), u.a.data_ptr()
+            q.mean, q.rstd, q.w = u.bn.running_mean.data_ptr(), u.rstd.data_ptr(), u.bn.weight.data_ptr()
+            q.q = v.data_ptr() + 4 * self._offs[u.pg]
+            q.r = v.data_ptr() + 4 * self._offs[u.pb]
+            q.add, q.mask_src, q.relu_self = None, (u.y.data_ptr() if u.relu else None), 0
+            q.n, q.c, q.hw, q.out_ld, q.add_ld = n, k, oh * ow, u.tout_ld, 0
+            q.a_splits, q.a_slab = u.sT, u.tbuf.shape[1]
+        _lib.check(_lib.load().hf_chan_affine_pair(_lib.ctypes.cast(arr, _lib.c_void_p), _lib.HF_F32,
+                                                   _lib.current_stream_ptr(self.dev)), "hf_chan_affine_pair")
+
+    def _bn_adjoint_pair(self, u1, srcs1, u2, srcs2):
+        """The BatchNorm adjoints of two units (row-major kernel) in ONE launch."""
+        arr = (_lib.BnAdjointProblem * 2)()
+        for q, u, srcs in zip(arr, (u1, u2), (srcs1, srcs2)):
+            if not 1 <= len(srcs) <= 2:
+                raise RuntimeError(f"{u.name}: {len(srcs)} consumers")
+            (a, sa, la) = srcs[0]
+            (b, sb, lb) = srcs[1] if len(srcs) == 2 else (None, 1, 0)
+            n, k, oh, ow = u.a.shape
+            q.gx, q.gw, q.gb, q.gres = u.ga.data_ptr(), u.gw.data_ptr(), u.gb.data_ptr(), u.g.data_ptr()
+            q.gy, q.gy_splits, q.gy_slab = a.data_ptr(), sa, la
+            q.gy2, q.gy2_splits, q.gy2_slab = (None if b is None else b.data_ptr()), sb, lb
+            q.x, q.mean, q.rstd, q.w = u.a.data_ptr(), u.bn.running_mean.data_ptr(), u.rstd.data_ptr(), u.bn.weight.data_ptr()
+            q.mask_src = u.y.data_ptr() if u.relu else None
+            q.n, q.c, q.hw, q.row_blocks = n, k, oh * ow, u.rb
+        _lib.check(_lib.load().hf_chan_affine_bwd_pair(_lib.ctypes.cast(arr, _lib.c_void_p), _lib.HF_F32,
+                                                       _lib.current_stream_ptr(self.dev)), "hf_chan_affine_bwd_pair")
+
     def _adjoint_unit(self, u, srcs):
         """srcs: up to two (tensor, splits, slab_stride) cotangents of the unit's output."""
+        self._bn_adjoint(u, srcs)
+        self._conv_adjoint(u)
+
+    def _bn_adjoint(self, u, srcs):
         if not 1 <= len(srcs) <= 2:
             raise RuntimeError(f"{u.name}: {len(srcs)} consumers")
         (a, sa, la) = srcs[0]
@@ -361,6 +398,10 @@ class FusedGGNEngine(_Operator):
             _ptr(u.ga), _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a),
             _ptr(u.bn.running_mean), _ptr(u.rstd), _ptr(u.bn.weight), _ptr(u.y) if u.relu else None, n, k,
             oh * ow, 1, u.rb, _lib.HF_F32, st), "hf_chan_affine_bwd_ex")
+
+    def _conv_adjoint(self, u):
+        """Data + weight gradient of the unit's convolution from ``u.ga``, one launch."""
+        lib, st = _lib.load(), _lib.current_stream_ptr(self.dev)
         if u is self.stem:
             self._conv_slabs(2, u.wbuf, u.cols_pad, u.ga, u.geo_w, u.sW, out_c=u.jcols)
             return
@@ -402,13 +443,31 @@ class FusedGGNEngine(_Operator):
         else:
             t_pool = s.tout.flatten(2).gather(2, self.pool_idx.flatten(2)).view_as(self.pool_out)
             self.pool_t[:, :c0].copy_(t_pool)
+        group = self._grouping()
         for chain, ds, _x in self.blocks:
             head = chain[0]
-            if ds is not None:
+            if ds is not None and group:
+                # the downsample branch and the block's first convolution read the same operand:
+                # both tangent convolutions in ONE launch
+                _lib.conv_group_slabs([(0, ds.tbuf, ds.xcat, ds.wcat, self._tgeo(ds), ds.sT, 0, 0),
+                                       (0, head.tbuf, head.xcat, head.wcat, self._tgeo(head), head.sT, 0, 0)],
+                                      self.dev)
+                paired = head.res_unit is None and not head.res_identity and len(chain) > 1
+                if paired:  # ... and both BatchNorm tangents in one
+                    self._bn_tangent_pair(ds, head, v)
+                else:
+                    self._bn_tangent(ds, v, None, 0)
+            elif ds is not None:
+                paired = False
                 self._conv_slabs(0, ds.tbuf, ds.xcat, ds.wcat, self._tgeo(ds), ds.sT)
                 self._bn_tangent(ds, v, None, 0)
+            else:
+                paired = False
             for u in chain:
-                self._conv_slabs(0, u.tbuf, u.xcat, u.wcat, self._tgeo(u), u.sT)
+                if u is head and paired:
+                    continue
+                if not (u is head and ds is not None and group):
+                    self._conv_slabs(0, u.tbuf, u.xcat, u.wcat, self._tgeo(u), u.sT)
                 add, add_ld = None, 0
                 if u.res_unit is not None:
                     add, add_ld = u.res_unit.tout, u.res_unit.tout_ld
@@ -458,13 +517,27 @@ class FusedGGNEngine(_Operator):
             head, last = chain[0], chain[-1]
             for k in range(len(chain) - 1, -1, -1):
                 u = chain[k]
-                self._adjoint_unit(u, incoming.pop(id(u)))
+                if k == 0 and ds is not None and group:
+                    # both BatchNorm adjoints, then the data + weight gradients of the block's first
+                    # convolution AND of its downsample branch in ONE launch (four problems)
+                    if u.rb > 1 and ds.rb > 1:
+                        self._bn_adjoint_pair(u, incoming.pop(id(u)), ds, [(last.g, 1, 0)])
+                    else:
+                        self._bn_adjoint(u, incoming.pop(id(u)))
+                        self._bn_adjoint(ds, [(last.g, 1, 0)])
+                    _lib.conv_group_slabs(
+                        [(1, u.dbuf, u.ga, u.wT, u.geo, u.sD, 0, 0), (2, u.wbuf, u.x, u.ga, u.geo, u.sW, 0, 0),
+                         (1, ds.dbuf, ds.ga, ds.wT, ds.geo, ds.sD, 0, 0), (2, ds.wbuf, ds.x, ds.ga, ds.geo, ds.sW, 0, 0)],
+                        self.dev)
+                else:
+                    self._adjoint_unit(u, incoming.pop(id(u)))
                 if k > 0:
                     incoming.setdefault(id(chain[k - 1]), []).append((u.dbuf, u.sD, u.dbuf.shape[1]))
             # the block input receives conv1's data gradient and the residual branch's cotangent
             srcs = [(head.dbuf, head.sD, head.dbuf.shape[1])]
             if ds is not None:
-                self._adjoint_unit(ds, [(last.g, 1, 0)])
+                if not group:
+                    self._adjoint_unit(ds, [(last.g, 1, 0)])
                 srcs.append((ds.dbuf, ds.sD, ds.dbuf.shape[1]))
             else:
                 srcs.append((last.g, 1, 0))
@@ -508,6 +581,9 @@ class FusedGGNEngine(_Operator):
                 tensors[self.pfb] = g_fb
         _lib.pack_ex(out, tensors, perms, splits, scale=self.weight, live=self._pack_live)
         return out
+
+    def _grouping(self):
+        return os.environ.get("HF_ENGINE_GROUP", "1") != "0"
 
     def _head_fused(self, hw, v_fw):
         """Whether ``hf_linear_ce_head`` applies: closed-form softmax-CE Hessian, a 1x1 final map
