@@ -23,7 +23,8 @@ atomic, no in-launch reduction:
                                gradients, summing the weight-gradient slabs while it gathers);
                                slices of kernel taps that never meet data are skipped throughout
 
-4 launches per conv-BN unit instead of 8, 85 per product of ResNet-18; bitwise repeatable.  Under
+4 launches per conv-BN unit instead of 8 -- 2 where a block's first convolution and its downsample
+branch share their launches (grouped kernels) --, 74 per product of ResNet-18; bitwise repeatable.  Under
 data parallelism only the entries of the product that can be non-zero are all-reduced (``reduce``).
 The layer topology is taken from the prepared model's module tree and from the activations its
 patched layers recorded during the step's forward pass (``modelprep`` stores them detached);

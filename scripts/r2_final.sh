@@ -1,9 +1,9 @@
 # round 2 measurement session (PMC traffic is taken separately: scripts/r2_pmc.sh)
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r2final3; mkdir -p $O
+O=gpurun_out/r2final4; mkdir -p $O
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_engine_gpu.py tests/test_distributed_gpu.py -q -p no:cacheprovider 2>&1 | grep -v amdgpu.ids | tail -3
+timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -v amdgpu.ids | tail -3
 timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k_$$ -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/$O/prof_bench.json 2> $R/$O/prof_bench.err)
 f=$(find /tmp/prof_k_$$ -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_full.csv

@@ -1,6 +1,6 @@
 # rocprofv3 per-kernel summary of the bench command (fresh output directory: boxes may be reused)
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r2final3; mkdir -p $O
+O=gpurun_out/r2final4; mkdir -p $O
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 D=/tmp/prof_k_$$; rm -rf $D

@@ -281,3 +281,75 @@ def test_live_copy_gathers_and_scatters_the_live_entries():
     assert lib.hf_live_copy(P(target.data_ptr()), P(doubled.data_ptr()), 1, arr(0), arr(1), arr(2), arr(3),
                             len(segs), _lib.HF_F32, st) == 0
     assert torch.equal(target[keep], 2 * full[keep]) and float(target[~keep].abs().max()) == 0.0
+
+
+def test_grouped_launches_equal_the_single_ones_bitwise():
+    """``hf_conv2d_nhwc_group_slabs`` (4 convolutions of different directions in one launch),
+    ``hf_chan_affine_pair`` and ``hf_chan_affine_bwd_pair`` write exactly what the corresponding
+    single launches write."""
+    from pytorchhessianfree_amd import _lib
+
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    r_ = lambda *s: torch.randn(*s, device=DEV, generator=gen)
+    n, h, w_, c, k = 8, 7, 7, 64, 128
+    x = _cl(r_(n, c, h, w_))
+    w3 = _cl(r_(k, c, 3, 3))
+    w1 = _cl(r_(k, c, 1, 1))
+    geo3 = (n, h, w_, c, k, 3, 3, (2, 2), (1, 1))   # a block's first convolution ...
+    geo1 = (n, h, w_, c, k, 1, 1, (2, 2), (0, 0))   # ... and its downsample branch: both 7 -> 4
+    gy = _cl(r_(n, k, 4, 4))
+    w3T, w1T = w3.permute(1, 2, 3, 0).contiguous(), w1.permute(1, 2, 3, 0).contiguous()
+    probs = [(0, geo3, x, w3, n * 16 * k), (0, geo1, x, w1, n * 16 * k), (1, geo3, gy, w3T, x.numel()),
+             (2, geo1, x, gy, w1.numel())]
+    singles, grouped, group_args = [], [], []
+    for d, geo, act, mat, numel in probs:
+        sp = _lib.conv_plan(d, *geo[:7], geo[7], geo[8])
+        a, b = torch.zeros(sp, numel, device=DEV), torch.zeros(sp, numel, device=DEV)
+        _lib.conv2d_nhwc_slabs(d, a, act, mat, *geo[:7], geo[7], geo[8], sp)
+        singles.append(a)
+        grouped.append(b)
+        group_args.append((d, b, act, mat, geo, sp, 0, 0))
+    _lib.conv_group_slabs(group_args, x.device)
+    for a, b in zip(singles, grouped):
+        assert torch.equal(a, b)
+
+    # BatchNorm tangent / adjoint pairs against the single launches
+    lib, st, P = _lib.load(), _lib.current_stream_ptr(x.device), _lib.c_void_p
+    rows, chans = (n * 16, n * 16), (128, 64)
+    aff, adj = (_lib.AffineProblem * 2)(), (_lib.BnAdjointProblem * 2)()
+    keep, want_t, want_a = [], [], []
+    for q, qa, rws, ch in zip(aff, adj, rows, chans):
+        slabs = r_(3, rws * ch)
+        xx, yy, mean, rstd, wt, vq, vr = r_(rws, ch), r_(rws, ch), r_(ch), r_(ch).abs() + 0.5, r_(ch), r_(ch), r_(ch)
+        out1, out2 = torch.empty(rws, ch, device=DEV), torch.empty(rws, ch, device=DEV)
+        keep += [slabs, xx, yy, mean, rstd, wt, vq, vr, out1, out2]
+        _lib.check(lib.hf_chan_affine_ex(P(out1.data_ptr()), P(slabs.data_ptr()), P(xx.data_ptr()), P(mean.data_ptr()),
+                                         P(rstd.data_ptr()), P(wt.data_ptr()), P(vq.data_ptr()), P(vr.data_ptr()), None,
+                                         P(yy.data_ptr()), 0, rws, ch, 1, 1, 0, 0, 3, rws * ch, _lib.HF_F32, st), "single")
+        q.out, q.a, q.x, q.mean, q.rstd, q.w = (t.data_ptr() for t in (out2, slabs, xx, mean, rstd, wt))
+        q.q, q.r, q.add, q.mask_src, q.relu_self = vq.data_ptr(), vr.data_ptr(), None, yy.data_ptr(), 0
+        q.n, q.c, q.hw, q.out_ld, q.add_ld, q.a_splits, q.a_slab = rws, ch, 1, 0, 0, 3, rws * ch
+        want_t.append((out1, out2))
+        rb = 8
+        outs1 = [torch.empty(rws, ch, device=DEV), torch.empty(rb, ch, device=DEV), torch.empty(rb, ch, device=DEV),
+                 torch.empty(rws, ch, device=DEV)]
+        outs2 = [torch.empty_like(t) for t in outs1]
+        g2 = r_(rws, ch)
+        keep += outs1 + outs2 + [g2]
+        _lib.check(lib.hf_chan_affine_bwd_ex(*(P(t.data_ptr()) for t in outs1), P(slabs.data_ptr()), 3, rws * ch,
+                                             P(g2.data_ptr()), 1, 0, P(xx.data_ptr()), P(mean.data_ptr()),
+                                             P(rstd.data_ptr()), P(wt.data_ptr()), P(yy.data_ptr()), rws, ch, 1, 1, rb,
+                                             _lib.HF_F32, st), "single bwd")
+        qa.gx, qa.gw, qa.gb, qa.gres = (t.data_ptr() for t in outs2)
+        qa.gy, qa.gy_splits, qa.gy_slab = slabs.data_ptr(), 3, rws * ch
+        qa.gy2, qa.gy2_splits, qa.gy2_slab = g2.data_ptr(), 1, 0
+        qa.x, qa.mean, qa.rstd, qa.w, qa.mask_src = (t.data_ptr() for t in (xx, mean, rstd, wt, yy))
+        qa.n, qa.c, qa.hw, qa.row_blocks = rws, ch, 1, rb
+        want_a.append((outs1, outs2))
+    _lib.check(lib.hf_chan_affine_pair(_lib.ctypes.cast(aff, P), _lib.HF_F32, st), "pair")
+    _lib.check(lib.hf_chan_affine_bwd_pair(_lib.ctypes.cast(adj, P), _lib.HF_F32, st), "pair bwd")
+    for a, b in want_t:
+        assert torch.equal(a, b)
+    for o1, o2 in want_a:
+        for a, b in zip(o1, o2):
+            assert torch.equal(a, b)
