@@ -70,7 +70,8 @@ class _Unit:
 
 class FusedGGNEngine(_Operator):
     mode = ("fused curvature engine: own deterministic convolutions (split-K slabs summed by the consumer "
-            "kernel), BatchNorm tangents/adjoints fused, 4 launches per conv-BN unit")
+            "kernel), BatchNorm tangents/adjoints fused, 4 launches per conv-BN unit, downsample branches grouped "
+            "with their block's first convolution")
 
     _verified = set()
 
