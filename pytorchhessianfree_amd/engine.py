@@ -421,12 +421,17 @@ class FusedGGNEngine(_Operator):
         if not v.is_contiguous():
             v = v.contiguous()
         _lib.unpack_tangent(v, self._slot_list)  # v_W halves of all [W | v_W] operands: one launch
+        self._tangent_stem(v)
+        self._tangent_blocks(v)
+        g_last, g_fw, g_fb = self._head(v)
+        pool_srcs = self._adjoint_blocks(g_last)
+        self._adjoint_stem(pool_srcs)
+        return self._gather(out, g_fw, g_fb)
 
-        # ---- tangent sweep ------------------------------------------------------------------
+    # ---- tangent sweep -------------------------------------------------------------------------
+    def _pool_geometry(self):
+        """(n, h, w, oh, ow, c) of the stem's max-pool; takes the window maxima's positions on first use."""
         s = self.stem
-        vw = v[self._offs[s.pw]: self._offs[s.pw] + s.conv.weight.numel()]
-        self._conv_slabs(0, s.tbuf, s.cols, vw, s.geo, s.sT)  # input has no tangent: conv(x, v_W) as 1x1 on im2col
-        self._bn_tangent(s, v, None, 0)
         ks, st_, pd, dl, cm = self.pool_args
         if self.pool_idx is None:
             _, self.pool_idx = torch.nn.functional.max_pool2d(s.y, ks, st_, pd, dl, cm, return_indices=True)
@@ -435,9 +440,15 @@ class FusedGGNEngine(_Operator):
             if _pair(dl) == [1, 1] and os.environ.get("HF_ENGINE_POOL", "1") != "0":
                 self.pool_idx32 = self.pool_idx.permute(0, 2, 3, 1).contiguous().to(torch.int32)
                 self._g_stem = torch.empty_like(s.y)
-        c0 = self.pool_out.shape[1]
         pn, _, ph, pw = s.y.shape
-        poh, pow_ = self.pool_out.shape[2], self.pool_out.shape[3]
+        return pn, ph, pw, self.pool_out.shape[2], self.pool_out.shape[3], self.pool_out.shape[1]
+
+    def _tangent_stem(self, v):
+        s = self.stem
+        vw = v[self._offs[s.pw]: self._offs[s.pw] + s.conv.weight.numel()]
+        self._conv_slabs(0, s.tbuf, s.cols, vw, s.geo, s.sT)  # input has no tangent: conv(x, v_W) as 1x1 on im2col
+        self._bn_tangent(s, v, None, 0)
+        pn, ph, pw, poh, pow_, c0 = self._pool_geometry()
         if self.pool_idx32 is not None:
             _lib.check(_lib.load().hf_maxpool_tangent_nhwc(
                 _ptr(self.pool_t), _ptr(s.tout), _ptr(self.pool_idx32), pn, ph, pw, poh, pow_, c0, 2 * c0,
@@ -445,9 +456,12 @@ class FusedGGNEngine(_Operator):
         else:
             t_pool = s.tout.flatten(2).gather(2, self.pool_idx.flatten(2)).view_as(self.pool_out)
             self.pool_t[:, :c0].copy_(t_pool)
+
+    def _tangent_blocks(self, v):
         group = self._grouping()
         for chain, ds, _x in self.blocks:
             head = chain[0]
+            paired = False
             if ds is not None and group:
                 # the downsample branch and the block's first convolution read the same operand:
                 # both tangent convolutions in ONE launch
@@ -460,11 +474,8 @@ class FusedGGNEngine(_Operator):
                 else:
                     self._bn_tangent(ds, v, None, 0)
             elif ds is not None:
-                paired = False
                 self._conv_slabs(0, ds.tbuf, ds.xcat, ds.wcat, self._tgeo(ds), ds.sT)
                 self._bn_tangent(ds, v, None, 0)
-            else:
-                paired = False
             for u in chain:
                 if u is head and paired:
                     continue
@@ -477,6 +488,10 @@ class FusedGGNEngine(_Operator):
                     c = head.x.shape[1]
                     add, add_ld = head.xcat[:, :c], 2 * c
                 self._bn_tangent(u, v, add, add_ld)
+
+    # ---- classifier head: logits' tangent, loss Hessian, the head's gradients ----------------------
+    def _head(self, v):
+        """Returns the cotangent of the last unit's output and the head's weight / bias gradients."""
         tail = self.blocks[-1][0][-1]
         t_last = tail.tout
         hw = t_last.shape[2] * t_last.shape[3]
@@ -485,7 +500,7 @@ class FusedGGNEngine(_Operator):
         v_fw = v[self._offs[self.pfw]: self._offs[self.pfw] + nf].view_as(fw)
         v_fb = None if self.pfb is None else v[self._offs[self.pfb]: self._offs[self.pfb] + fw.shape[0]]
         if self._head_fused(hw, v_fw):
-            # classifier head in ONE launch: logits' tangent, softmax-CE Hessian, the three gradients
+            # ONE launch: logits' tangent, softmax-CE Hessian, the three gradients
             g_feat, g_fw, g_fb = self._head_bufs
             _lib.check(_lib.load().hf_linear_ce_head(
                 _ptr(g_feat), _ptr(g_fw), _ptr(g_fb) if self.pfb is not None else None, _ptr(t_last),
@@ -501,11 +516,7 @@ class FusedGGNEngine(_Operator):
             else:
                 Jv = t_feat @ fw.detach().t()
             Jv = torch.addmm(Jv, self.feat, v_fw.t())
-
-            # ---- loss Hessian -----------------------------------------------------------------
             HJv = self._loss_hessian(Jv)
-
-            # ---- adjoint sweep ----------------------------------------------------------------
             g_fw = HJv.t() @ self.feat
             g_fb = HJv.sum(0) if self.pfb is not None else None
             g_feat = HJv @ fw.detach()
@@ -513,7 +524,15 @@ class FusedGGNEngine(_Operator):
             g_last = g_feat.view(tail.y.shape)
         else:
             g_last = _cl((g_feat / hw).view(g_feat.shape[0], -1, 1, 1).expand(tail.y.shape))
+        return g_last, g_fw, g_fb
+
+    # ---- adjoint sweep -------------------------------------------------------------------------
+    def _adjoint_blocks(self, g_last):
+        """Walks the blocks backwards; returns the two cotangents of the pooled stem output."""
+        group = self._grouping()
+        tail = self.blocks[-1][0][-1]
         incoming = {id(tail): [(g_last, 1, 0)]}
+        pool_srcs = None
         for bi in range(len(self.blocks) - 1, -1, -1):
             chain, ds, _x = self.blocks[bi]
             head, last = chain[0], chain[-1]
@@ -547,7 +566,14 @@ class FusedGGNEngine(_Operator):
                 incoming[id(self.blocks[bi - 1][0][-1])] = srcs
             else:
                 pool_srcs = srcs
-        # block 0's input is the pooled stem output: sum its two cotangents, undo the max-pool
+        return pool_srcs
+
+    def _adjoint_stem(self, pool_srcs):
+        """Block 0's input is the pooled stem output: sum its two cotangents, undo the max-pool,
+        then the stem's own adjoint."""
+        s = self.stem
+        ks, st_, pd, dl, cm = self.pool_args
+        pn, ph, pw, poh, pow_, c0 = self._pool_geometry()
         (a, sa, la), (b, sb, lb) = pool_srcs
         if self.pool_idx32 is not None:
             # slab sums of both cotangents and the max-pool adjoint (gather form) in one launch
@@ -567,7 +593,8 @@ class FusedGGNEngine(_Operator):
                 self.pool_idx))
         self._adjoint_unit(s, [(g_stem, 1, 0)])
 
-        # ---- gather all parameter gradients (weight-gradient slabs summed on the way) ---------
+    def _gather(self, out, g_fw, g_fb):
+        """All parameter gradients into the flat vector (weight-gradient slabs summed on the way)."""
         tensors, perms, splits = self._pack_args()
         tensors = list(tensors)
         if g_fw.dim() == 3:  # the head kernel's per-workgroup partial sums: slabs for hf_pack_ex
