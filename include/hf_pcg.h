@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 3
+#define HF_ABI_VERSION 4
 
 enum hf_dtype { HF_F32 = 0, HF_F64 = 1 };
 
@@ -198,6 +198,14 @@ int hf_unpack_tangent(const void* src, void* const* dsts, const int64_t* src_off
 int hf_unpack_tangent_ex(const void* src, void* const* dsts, const int64_t* src_offs,
                          const int64_t* numels, const int64_t* slabs, const int64_t* inners,
                          const int64_t* live, int n_tensors, int dtype, void* stream);
+/* The same scatter with a per-tensor choice of the half it fills (`halves`, HOST, or NULL = all 1):
+ * 1 = the v_W half (above), 0 = the W half -- dst[(o*HW + hw)*2I + i] resp. dst[o*2*slab + r].  The
+ * persistent curvature engine refreshes the W halves of all [W | v_W] operands from the flat
+ * parameter vector with ONE launch per trial point theta0 + alpha*step (optimizer.py:288-294), where
+ * the reference re-binds every parameter (utils.py:8-38) and PyTorch re-converts every NCHW weight. */
+int hf_unpack_weights(const void* src, void* const* dsts, const int64_t* src_offs,
+                      const int64_t* numels, const int64_t* slabs, const int64_t* inners,
+                      const int64_t* live, const int64_t* halves, int n_tensors, int dtype, void* stream);
 
 /*
  * Data-parallel products (the `result += N * mb_result` of optimizer.py:677-684, across GPUs): the
@@ -296,6 +304,21 @@ typedef struct hf_bn_adjoint_problem {
 } hf_bn_adjoint_problem;
 int hf_chan_affine_bwd_pair(const hf_bn_adjoint_problem* problems /* [2] */, int dtype, void* stream);
 
+/*
+ * Forward pass of conv -> (eval-BatchNorm | bias) (+ residual) (+ ReLU) from the convolution's split-K
+ * slabs, NHWC fp32 [rows = n*hw, c] -- what the reference evaluates by `forward()` for the loss
+ * and for every trial point of LM damping / CG-backtracking / line search (optimizer.py:216-229,
+ * :288-294); the persistent curvature engine replays it on its own static buffers:
+ *   s     = sum over `splits` slabs of a (split order);         a_out = s (nullable)
+ *   t     = rstd ? ((s - mean[c])*rstd[c])*w[c] : s;  t += b[c] (nullable);  t += res (nullable)
+ *   y     = relu ? max(t, 0) : t   -> y (dense, nullable) and y2 (nullable; pixel stride y2_ld >= c:
+ *           the x half of the consumer's [t_x | x] operand)
+ * res_ld: pixel stride of res (0 = dense).  Same rounding sequence as hf_chan_affine's forward.
+ */
+int hf_bn_forward(void* y, void* y2, int64_t y2_ld, void* a_out, const void* a, int splits, int64_t slab_stride,
+                  const void* mean, const void* rstd, const void* w, const void* b, const void* res,
+                  int64_t res_ld, int relu, int64_t rows, int64_t c, int dtype, void* stream);
+
 /* Elementwise adjoint pre-pass of a fused BatchNorm(+add+ReLU) layer, NHWC [rows, c]:
  *   g = (sum of gy_a's slabs + sum of gy_b's slabs) * [mask_src > 0];  g_out = g (nullable);
  *   ga_out = g * w[c]*rstd[c] (nullable): the cotangent of the convolution output that
@@ -352,6 +375,9 @@ int hf_conv2d_nhwc(int direction, void* out, const void* act, const void* mat, i
  * must be zero-initialised once if the geometry has taps that never meet data; `out_c` (0 = c)
  * restricts the output to X's first out_c channels, laid out [k][r][q][out_c] -- X may carry
  * zero-padding channels that make its rows 16-byte multiples (the 49-tap im2col of a stem).
+ * `mat_ld` (directions 0 and 1; 0 = c resp. k): floats between consecutive taps of `mat`, when `mat`
+ * is the first-channels slice of a wider [rows][r][q][mat_ld] buffer -- the forward pass of the
+ * curvature engine reads the W half of the tangent sweep's [W | v_W] operand in place.
  */
 int hf_conv2d_nhwc_plan(int direction, int64_t n, int64_t h, int64_t w, int64_t c, int64_t k,
                         int64_t r, int64_t s, int64_t stride_h, int64_t stride_w, int64_t pad_h,
@@ -359,8 +385,8 @@ int hf_conv2d_nhwc_plan(int direction, int64_t n, int64_t h, int64_t w, int64_t 
 int hf_conv2d_nhwc_slabs(int direction, void* out, const void* act, const void* mat, int64_t n,
                          int64_t h, int64_t w, int64_t c, int64_t k, int64_t r, int64_t s,
                          int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
-                         int64_t act_ld, int64_t out_c, int splits, int64_t slab_stride, int dtype,
-                         void* stream);
+                         int64_t act_ld, int64_t mat_ld, int64_t out_c, int splits, int64_t slab_stride,
+                         int dtype, void* stream);
 int hf_conv2d_nhwc_backward_slabs(void* dx, void* dw, const void* dy, const void* x, const void* w_t,
                                   int64_t n, int64_t h, int64_t w, int64_t c, int64_t k, int64_t r,
                                   int64_t s, int64_t stride_h, int64_t stride_w, int64_t pad_h,
@@ -380,6 +406,7 @@ typedef struct hf_conv_problem {
   int64_t act_ld, out_c;
   int splits;
   int64_t slab_stride;
+  int64_t mat_ld;           /* see hf_conv2d_nhwc_slabs; 0 = dense */
 } hf_conv_problem;
 int hf_conv2d_nhwc_group_slabs(const hf_conv_problem* problems, int n_problems, int dtype, void* stream);
 
@@ -417,6 +444,17 @@ int hf_softmax_ce_hvp(void* out, const void* p, const void* v, double scale, int
  */
 int hf_maxpool_tangent_nhwc(void* out, const void* t, const void* idx, int64_t n, int64_t h, int64_t w,
                             int64_t oh, int64_t ow, int64_t c, int64_t out_ld, int dtype, void* stream);
+/*
+ * hf_maxpool_forward_nhwc: out[n,oy,ox,c] = max over the window, idx[n,oy,ox,c] = its flat position
+ * y*w + x (first maximum in window scan order, NaN wins -- ATen's max_pool2d_with_indices rule).
+ * out (dense, nullable) and out2 (nullable, pixel stride out2_ld) receive the same values.  The
+ * persistent curvature engine's own forward pass (positions are taken on every forward instead of
+ * once per step by ATen).
+ */
+int hf_maxpool_forward_nhwc(void* out, void* out2, int64_t out2_ld, void* idx, const void* x, int64_t n,
+                            int64_t h, int64_t w, int64_t oh, int64_t ow, int64_t c, int64_t kh, int64_t kw,
+                            int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w, int dtype,
+                            void* stream);
 /*
  * hf_maxpool_adjoint_nhwc: g[n,y,x,c] = sum over the windows whose maximum sits at (y,x) of
  * (gy_a + gy_b)[n,oy,ox,c], gy_a / gy_b the cotangents from the pooled map's two consumers, each

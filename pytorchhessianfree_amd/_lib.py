@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HF_PCG_LIB") or os.path.join(_HERE, "csrc", "libhfpcg.so")
 
 HF_F32, HF_F64 = 0, 1
+ABI_VERSION = 4
 HF_M_NONE, HF_M_DIAG, HF_M_EXTERNAL = 0, 1, 2
 REASONS = {
     1: "Convergence (Martens)",
@@ -94,6 +95,14 @@ SIGNATURES = {
         c_int,
         [c_void_p, ctypes.POINTER(c_void_p)] + [ctypes.POINTER(c_int64)] * 5 + [c_int, c_int, c_void_p],
     ),
+    "hf_unpack_weights": (
+        c_int,
+        [c_void_p, ctypes.POINTER(c_void_p)] + [ctypes.POINTER(c_int64)] * 6 + [c_int, c_int, c_void_p],
+    ),
+    "hf_bn_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64] + [c_void_p] * 5
+                      + [c_int64, c_int, c_int64, c_int64, c_int, c_void_p]),
+    "hf_maxpool_forward_nhwc": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p] + [c_int64] * 12
+                                + [c_int, c_void_p]),
     "hf_live_copy": (c_int, [c_void_p, c_void_p, c_int] + [ctypes.POINTER(c_int64)] * 4 + [c_int, c_int, c_void_p]),
     "hf_precond_build": (c_int, [c_void_p, c_void_p, c_double, c_double, c_int64, c_int, c_void_p]),
     "hf_axpy_out": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int, c_void_p]),
@@ -105,7 +114,7 @@ SIGNATURES = {
     "hf_conv2d_nhwc_backward": (c_int, [c_void_p] * 5 + [c_int64] * 11
                                 + [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "hf_conv2d_nhwc_plan": (c_int, [c_int] + [c_int64] * 11 + [c_int]),
-    "hf_conv2d_nhwc_slabs": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int64] * 13
+    "hf_conv2d_nhwc_slabs": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int64] * 14
                              + [c_int, c_int64, c_int, c_void_p]),
     "hf_conv2d_nhwc_group_slabs": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "hf_chan_affine_pair": (c_int, [c_void_p, c_int, c_void_p]),
@@ -163,7 +172,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.hf_abi_version() != 3:
+    if lib.hf_abi_version() != ABI_VERSION:
         raise RuntimeError("libhfpcg.so ABI version mismatch")
     _lib = lib
     return lib
@@ -236,8 +245,9 @@ def pack(dst, tensors, scale=1.0, mode=0):
     return dst
 
 
-def unpack_tangent(v, slots):
-    """Scatter weight-shaped slices of the flat vector ``v`` into the ``v_W`` halves of
+def unpack_tangent(v, slots, half=1):
+    """Scatter weight-shaped slices of the flat vector ``v`` into the ``v_W`` halves
+    (``half=1``) or the ``W`` halves (``half=0``: ``v`` is the parameter vector) of
     the tangent convolutions' weight buffers, all layers in one launch.  ``slots`` is
     a list of ``(offset into v, buffer [O, 2I, H, W], I)``; the buffer is NCHW-contiguous
     or channels_last."""
@@ -245,8 +255,9 @@ def unpack_tangent(v, slots):
     require_device_tensor(v, "v")
     n = len(slots)
     dsts = (c_void_p * n)()
-    offs, numels, slabs, inners, live = ((c_int64 * n)() for _ in range(5))
+    offs, numels, slabs, inners, live, halves = ((c_int64 * n)() for _ in range(6))
     for k, slot in enumerate(slots):
+        halves[k] = 1 if half else 0
         off, buf, cin = slot[:3]
         live[k] = slot[3] if len(slot) > 3 else 0  # bit mask of the kernel taps that meet data (0 = all)
         if buf.dtype != v.dtype or buf.device != v.device or buf.dim() != 4 or buf.shape[1] != 2 * cin:
@@ -265,11 +276,11 @@ def unpack_tangent(v, slots):
         if off < 0 or off + numels[k] > v.numel():
             raise RuntimeError("unpack_tangent: slice outside the vector")
     check(
-        lib.hf_unpack_tangent_ex(
-            c_void_p(v.data_ptr()), dsts, offs, numels, slabs, inners, live, n, dtype_code(v.dtype),
+        lib.hf_unpack_weights(
+            c_void_p(v.data_ptr()), dsts, offs, numels, slabs, inners, live, halves, n, dtype_code(v.dtype),
             current_stream_ptr(v.device),
         ),
-        "hf_unpack_tangent_ex",
+        "hf_unpack_weights",
     )
 
 
@@ -422,14 +433,17 @@ class ConvProblem(ctypes.Structure):
 
     _fields_ = [("direction", c_int), ("out", c_void_p), ("act", c_void_p), ("mat", c_void_p)] + [
         (name, c_int64) for name in ("n", "h", "w", "c", "k", "r", "s", "stride_h", "stride_w", "pad_h", "pad_w",
-                                     "act_ld", "out_c")] + [("splits", c_int), ("slab_stride", c_int64)]
+                                     "act_ld", "out_c")] + [("splits", c_int), ("slab_stride", c_int64),
+                                                            ("mat_ld", c_int64)]
 
 
 def conv_group_slabs(problems, device):
     """One launch for up to 4 slab-mode convolutions; ``problems``: tuples ``(direction, out, act, mat,
     (n, h, w, c, k, r, s, stride, padding), splits, act_ld, out_c)`` with ``out`` a [splits, ...] buffer."""
     arr = (ConvProblem * len(problems))()
-    for q, (direction, out, act, mat, geo, splits, act_ld, out_c) in zip(arr, problems):
+    for q, prob in zip(arr, problems):
+        direction, out, act, mat, geo, splits, act_ld, out_c = prob[:8]
+        q.mat_ld = prob[8] if len(prob) > 8 else 0
         n, h, w, c, k, r, s, st, pd = geo
         q.direction, q.out, q.act, q.mat = int(direction), out.data_ptr(), act.data_ptr(), mat.data_ptr()
         q.n, q.h, q.w, q.c, q.k, q.r, q.s = n, h, w, c, k, r, s
@@ -449,12 +463,13 @@ def conv_plan(direction, n, h, w, c, k, r, s, stride, padding):
     return sp
 
 
-def conv2d_nhwc_slabs(direction, out, act, mat, n, h, w, c, k, r, s, stride, padding, splits, act_ld=0, out_c=0):
+def conv2d_nhwc_slabs(direction, out, act, mat, n, h, w, c, k, r, s, stride, padding, splits, act_ld=0, out_c=0,
+                      mat_ld=0):
     """Slab-mode launch: ``out`` is [splits, numel] -- slab s receives split s's partial result."""
     check(
         load().hf_conv2d_nhwc_slabs(
             int(direction), c_void_p(out.data_ptr()), c_void_p(act.data_ptr()), c_void_p(mat.data_ptr()),
-            n, h, w, c, k, r, s, stride[0], stride[1], padding[0], padding[1], act_ld, out_c, int(splits),
+            n, h, w, c, k, r, s, stride[0], stride[1], padding[0], padding[1], act_ld, mat_ld, out_c, int(splits),
             out.shape[1], HF_F32, current_stream_ptr(out.device)),
         "hf_conv2d_nhwc_slabs")
     return out

@@ -29,9 +29,14 @@ def cg_efficient_backtracking(f, steps_list, verbose=False):
         print("\nBacktracking cg-iterations...")
     seen = {}
     best_val, best_idx = float("inf"), None
-    for idx in range(len(steps_list) - 1, -1, -1):
-        if steps_list[idx] is None:
-            continue
+    # ``f.prefetch`` (the optimizer's graph-replayed evaluation): candidates are enqueued two at a
+    # time, so a pair of loss values costs ONE device->host read; the early exit below is unchanged
+    # (at most one evaluation is wasted when the walk stops)
+    prefetch = getattr(f, "prefetch", None)
+    order = [idx for idx in range(len(steps_list) - 1, -1, -1) if steps_list[idx] is not None]
+    for pos, idx in enumerate(order):
+        if prefetch is not None:
+            prefetch([(steps_list[i], 1.0) for i in order[pos:pos + 2]])
         val = f(steps_list[idx])
         seen[idx] = val
         if val < best_val:

@@ -61,6 +61,8 @@ struct ConvArgs {
   int rh, rw;          // spatial extent the row index decodes over (F/W: OH,OW; D: H,W)
   int sh_, sw_;        // spatial extent of the gathered tensor (F/W: H,W; D: OH,OW)
   int cs, cs_ld;       // channels gathered per pixel, pixel stride of src
+  int mat_ld;          // NT: floats between consecutive taps of `mat` (>= cs: `mat` may be the first-channels
+                       //     slice of a wider [Nout][RS][mat_ld] buffer -- the W half of a [W | v_W] operand)
   int nout, ldc;       // output columns (F: K, D: C, W: unused), output row stride
   int kout;            // W: number of dY channels (output rows of dW)
   int R, S, stride_h, stride_w, pad_h, pad_w;
@@ -226,7 +228,7 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
   for (int u = 0; u < NU; ++u) {
     const int j = tile_n * BN + lr + RPT * u;
     bok[u] = j < a.nout;
-    brow[u] = a.mat + (size_t)(bok[u] ? j : 0) * RS * a.cs;
+    brow[u] = a.mat + (size_t)(bok[u] ? j : 0) * RS * a.mat_ld;
   }
 
   // Global -> register -> LDS staging with THREE steps of loads in flight: these kernels run
@@ -248,7 +250,7 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
       va = va & cok & (rn[u] >= 0);
       const bool vb = cok & bok[u];
       const float* pa = a.src + (va ? (size_t)pix * a.cs_ld + c : 0);
-      const float* pb = vb ? brow[u] + (size_t)(r * a.S + q) * a.cs + c : a.mat;
+      const float* pb = vb ? brow[u] + (size_t)(r * a.S + q) * a.mat_ld + c : a.mat;
       if (SCALAR) {
         ra[u] = ldg4s(pa, va ? a.cs - c : 0);
         rb[u] = ldg4s(pb, vb ? a.cs - c : 0);
@@ -303,7 +305,7 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
         va = va & cok & (rn[u] >= 0);
         const bool vb = cok & bok[u];
         gload4(ra[u], a.src + (va ? (size_t)pix * a.cs_ld + c : 0));
-        gload4(rb[u], vb ? brow[u] + (size_t)(r * a.S + q) * a.cs + c : a.mat);
+        gload4(rb[u], vb ? brow[u] + (size_t)(r * a.S + q) * a.mat_ld + c : a.mat);
         ok |= (va ? 1u : 0u) << (2 * u) | (vb ? 2u : 0u) << (2 * u);
       }
       return ok;
@@ -646,7 +648,8 @@ void launch_one(int direction, const ConvArgs& a, int64_t blocks, hipStream_t st
 int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void* mat, int64_t n, int64_t h,
               int64_t w, int64_t c, int64_t k, int64_t r, int64_t s, int64_t stride_h, int64_t stride_w,
               int64_t pad_h, int64_t pad_w, int64_t act_ld, float* ws, int64_t ws_bytes, int* tickets,
-              int64_t n_tickets, int target_blocks, int slab_splits = -1, int64_t slab_stride = 0) {
+              int64_t n_tickets, int target_blocks, int slab_splits = -1, int64_t slab_stride = 0,
+              int64_t mat_ld = 0) {
   const int64_t oh = (h + 2 * pad_h - r) / stride_h + 1, ow = (w + 2 * pad_w - s) / stride_w + 1;
   memset(&a, 0, sizeof(a));
   a.src = (const float*)act;
@@ -688,8 +691,9 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
   a.out_c = a.cs;
   a.rows = (int)rows;
   a.cs_ld = (int)(act_ld > 0 ? act_ld : a.cs);
-  a.scalar = ((c % 4) || (k % 4) || (a.cs_ld % 4)) ? 1 : 0;
-  if (a.cs_ld < a.cs) return HF_ERR_ARG;
+  a.mat_ld = (int)(mat_ld > 0 ? mat_ld : a.cs);
+  a.scalar = ((c % 4) || (k % 4) || (a.cs_ld % 4) || (a.mat_ld % 4)) ? 1 : 0;
+  if (a.cs_ld < a.cs || a.mat_ld < a.cs || (mat_ld > 0 && direction == 2)) return HF_ERR_ARG;
   if (direction <= 1) {
     a.tiles_m = (int)((rows + BM - 1) / BM);
     a.tiles_n = (a.nout + BN - 1) / BN;
@@ -710,8 +714,9 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
     a.splits = sp < 1 ? 1 : sp;
     return tiles * a.splits;
   }
-  if (tiles > n_tickets) return HF_ERR_CAPACITY;
-  a.splits = choose_splits(tiles, red_steps, target_blocks, ws_bytes);
+  // more output tiles than ticket counters (large batches / maps): such a launch fills the chip
+  // without a K split, and an unsplit launch draws no tickets
+  a.splits = tiles > n_tickets ? 1 : choose_splits(tiles, red_steps, target_blocks, ws_bytes);
   return tiles * a.splits;
 }
 
@@ -805,9 +810,9 @@ int hf_conv2d_nhwc_plan(int direction, int64_t n, int64_t h, int64_t w, int64_t 
 
 int hf_conv2d_nhwc_slabs(int direction, void* out, const void* act, const void* mat, int64_t n, int64_t h,
                          int64_t w, int64_t c, int64_t k, int64_t r, int64_t s, int64_t stride_h,
-                         int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t act_ld, int64_t out_c,
-                         int splits, int64_t slab_stride, int dtype, void* stream) {
-  if (direction < 0 || direction > 2 || splits < 1 || slab_stride < 0) return HF_ERR_ARG;
+                         int64_t stride_w, int64_t pad_h, int64_t pad_w, int64_t act_ld, int64_t mat_ld,
+                         int64_t out_c, int splits, int64_t slab_stride, int dtype, void* stream) {
+  if (direction < 0 || direction > 2 || splits < 1 || slab_stride < 0 || mat_ld < 0) return HF_ERR_ARG;
   if (out_c < 0 || out_c > c || (out_c && direction != 2)) return HF_ERR_ARG;
   alignas(16) float dummy_ws[4];
   const int rc = check_common(out, act, mat, dummy_ws, dummy_ws, dtype, n, h, w, c, k, r, s, stride_h, stride_w,
@@ -815,7 +820,7 @@ int hf_conv2d_nhwc_slabs(int direction, void* out, const void* act, const void* 
   if (rc) return rc;
   ConvArgs a;
   const int64_t blocks = setup(a, direction, out, act, mat, n, h, w, c, k, r, s, stride_h, stride_w, pad_h,
-                               pad_w, act_ld, nullptr, 0, nullptr, 0, 0, splits, slab_stride);
+                               pad_w, act_ld, nullptr, 0, nullptr, 0, 0, splits, slab_stride, mat_ld);
   if (blocks <= 0) return (int)blocks;
   if (a.splits != splits) return HF_ERR_ARG;  // ask hf_conv2d_nhwc_plan first
   if (out_c) a.out_c = (int)out_c;
@@ -857,14 +862,14 @@ int hf_conv2d_nhwc_group_slabs(const hf_conv_problem* problems, int n_problems, 
   alignas(16) float dummy_ws[4];
   for (int i = 0; i < n_problems; ++i) {
     const hf_conv_problem& pr = problems[i];
-    if (pr.direction < 0 || pr.direction > 2 || pr.splits < 1 || pr.slab_stride < 0) return HF_ERR_ARG;
+    if (pr.direction < 0 || pr.direction > 2 || pr.splits < 1 || pr.slab_stride < 0 || pr.mat_ld < 0) return HF_ERR_ARG;
     if (pr.out_c < 0 || pr.out_c > pr.c || (pr.out_c && pr.direction != 2)) return HF_ERR_ARG;
     const int rc = check_common(pr.out, pr.act, pr.mat, dummy_ws, dummy_ws, dtype, pr.n, pr.h, pr.w, pr.c, pr.k,
                                 pr.r, pr.s, pr.stride_h, pr.stride_w, pr.pad_h, pr.pad_w);
     if (rc) return rc;
     const int64_t blocks = setup(q.a[i], pr.direction, pr.out, pr.act, pr.mat, pr.n, pr.h, pr.w, pr.c, pr.k, pr.r,
                                  pr.s, pr.stride_h, pr.stride_w, pr.pad_h, pr.pad_w, pr.act_ld, nullptr, 0,
-                                 nullptr, 0, 0, pr.splits, pr.slab_stride);
+                                 nullptr, 0, 0, pr.splits, pr.slab_stride, pr.mat_ld);
     if (blocks <= 0) return (int)blocks;
     if (q.a[i].splits != pr.splits) return HF_ERR_ARG;  // ask hf_conv2d_nhwc_plan first
     if (q.a[i].scalar) return HF_ERR_ARG;               // the grouped launch has the 16-byte gather variant only

@@ -77,6 +77,34 @@ __global__ __launch_bounds__(HB) void k_maxpool_adjoint(float* __restrict__ g, c
   g[i] = acc;
 }
 
+// max-pool, forward with positions (ATen's rule: first maximum in scan order, NaN wins)
+__global__ __launch_bounds__(HB) void k_maxpool_forward(float* __restrict__ out, float* __restrict__ out2,
+                                                        unsigned out2_ld, int* __restrict__ idx,
+                                                        const float* __restrict__ x, unsigned total, unsigned C,
+                                                        PoolGeo q) {
+  const unsigned i = blockIdx.x * HB + threadIdx.x;
+  if (i >= total) return;
+  const unsigned c = i % C;
+  unsigned pix = i / C;
+  const unsigned opix = pix;
+  const int ox = pix % q.OW; pix /= q.OW;
+  const int oy = pix % q.OH;
+  const int n = pix / q.OH;
+  int y0 = oy * q.sh - q.ph, x0 = ox * q.sw - q.pw;
+  const int y1 = y0 + q.kh < q.H ? y0 + q.kh : q.H, x1 = x0 + q.kw < q.W ? x0 + q.kw : q.W;
+  y0 = y0 > 0 ? y0 : 0; x0 = x0 > 0 ? x0 : 0;
+  float best = -__builtin_inff();
+  int bi = y0 * q.W + x0;
+  for (int yy = y0; yy < y1; ++yy)
+    for (int xx = x0; xx < x1; ++xx) {
+      const float v = x[((size_t)(n * q.H + yy) * q.W + xx) * C + c];
+      if (v > best || v != v) { best = v; bi = yy * q.W + xx; }
+    }
+  if (out) out[i] = best;
+  if (out2) out2[(size_t)opix * out2_ld + c] = best;
+  idx[i] = bi;
+}
+
 // ---------------------------------------------------------------------------------------
 // Classifier head of the GGN product in one launch:
 //   Jv   = t_feat W^T + feat V_W^T + v_b          tangent of the logits        [B, K]
@@ -228,6 +256,23 @@ int hf_maxpool_tangent_nhwc(void* out, const void* t, const void* idx, int64_t n
   hipLaunchKernelGGL(k_maxpool_tangent, dim3((unsigned)((total + HB - 1) / HB)), dim3(HB), 0,
                      (hipStream_t)stream, (float*)out, (const float*)t, (const int*)idx, (unsigned)total,
                      (unsigned)c, (unsigned)out_ld, (unsigned)(oh * ow), (unsigned)(h * w));
+  return (int)hipGetLastError();
+}
+
+int hf_maxpool_forward_nhwc(void* out, void* out2, int64_t out2_ld, void* idx, const void* x, int64_t n,
+                            int64_t h, int64_t w, int64_t oh, int64_t ow, int64_t c, int64_t kh, int64_t kw,
+                            int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w, int dtype,
+                            void* stream) {
+  if (dtype != HF_F32 || !idx || !x || (!out && !out2) || n < 1 || c < 1 || oh < 1 || ow < 1) return -1;
+  if (kh < 1 || kw < 1 || stride_h < 1 || stride_w < 1 || pad_h < 0 || pad_w < 0) return -1;
+  const int64_t total = n * oh * ow * c;
+  if (total >= (1LL << 31) || n * h * w * c >= (1LL << 31)) return -1;
+  if (out2 && out2_ld < c) return -1;
+  if (n * oh * ow * (out2 ? out2_ld : c) >= (1LL << 31)) return -1;
+  PoolGeo q{(int)h, (int)w, (int)oh, (int)ow, (int)kh, (int)kw, (int)stride_h, (int)stride_w, (int)pad_h, (int)pad_w};
+  hipLaunchKernelGGL(k_maxpool_forward, dim3((unsigned)((total + HB - 1) / HB)), dim3(HB), 0,
+                     (hipStream_t)stream, (float*)out, (float*)out2, (unsigned)out2_ld, (int*)idx,
+                     (const float*)x, (unsigned)total, (unsigned)c, q);
   return (int)hipGetLastError();
 }
 

@@ -738,6 +738,7 @@ struct UnpackArgs {
   int inner[PACK_MAXT];  // 0 (NCHW) or I (NHWC)
   int chunk[PACK_MAXT];  // elements per block
   unsigned short live[PACK_MAXT];  // NHWC, HW <= 16: taps whose slices are copied (0 = all), see PackArgs
+  unsigned char half[PACK_MAXT];   // 1: the v_W half of the [W | v_W] operand, 0: the W half
   int nt;
 };
 
@@ -755,21 +756,23 @@ __global__ __launch_bounds__(BLOCK) void k_unpack_tangent(const T* __restrict__ 
   const long long j0 = (long long)(blockIdx.x - a.blk_start[lo]) * a.chunk[lo];
   const long long j1 = (j0 + a.chunk[lo] < numel) ? j0 + a.chunk[lo] : numel;
   const unsigned slab = (unsigned)a.slab[lo], I = (unsigned)a.inner[lo];
+  const unsigned half = a.half[lo];
   constexpr int W = VecOf<T>::W;
   typedef typename VecOf<T>::type V;
   const bool al = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
-  if (I == 0) {  // dst[o*2*slab + slab + r] = src[o*slab + r]
+  if (I == 0) {  // dst[o*2*slab + half*slab + r] = src[o*slab + r]
     if (al && slab % W == 0) {
       for (long long j = j0 + (long long)threadIdx.x * W; j < j1; j += (long long)BLOCK * W) {
         const long long o = j / slab;
-        *reinterpret_cast<V*>(dst + j + (o + 1) * slab) = *reinterpret_cast<const V*>(src + j);
+        *reinterpret_cast<V*>(dst + j + (o + half) * slab) = *reinterpret_cast<const V*>(src + j);
       }
     } else {
-      for (long long j = j0 + threadIdx.x; j < j1; j += BLOCK) dst[j + (j / slab + 1) * slab] = src[j];
+      for (long long j = j0 + threadIdx.x; j < j1; j += BLOCK) dst[j + (j / slab + half) * slab] = src[j];
     }
     return;
   }
-  // destination order d = (o*HW + hw)*I + i  ->  dst[(o*HW + hw)*2I + I + i] = src[(o*I + i)*HW + hw]
+  dst += half ? I : 0;  // column offset inside the 2I-wide rows
+  // destination order d = (o*HW + hw)*I + i  ->  dst[(o*HW + hw)*2I + half*I + i] = src[(o*I + i)*HW + hw]
   const unsigned HW = slab / I;
   const unsigned live = a.live[lo] ? a.live[lo] : 0xffffffffu;
   if (al && I % W == 0) {
@@ -783,7 +786,7 @@ __global__ __launch_bounds__(BLOCK) void k_unpack_tangent(const T* __restrict__ 
       VU<T> v;
 #pragma unroll
       for (int c = 0; c < W; ++c) v.e[c] = s[(long long)c * HW];
-      *reinterpret_cast<V*>(dst + row * 2 * I + I + i) = v.v;
+      *reinterpret_cast<V*>(dst + row * 2 * I + i) = v.v;
     }
   } else {
     for (long long d = j0 + threadIdx.x; d < j1; d += BLOCK) {
@@ -792,7 +795,7 @@ __global__ __launch_bounds__(BLOCK) void k_unpack_tangent(const T* __restrict__ 
       const long long o = row / HW;
       const unsigned hw = (unsigned)(row - o * HW);
       if (!((live >> hw) & 1u)) continue;
-      dst[row * 2 * I + I + i] = src[o * slab + (long long)i * HW + hw];
+      dst[row * 2 * I + i] = src[o * slab + (long long)i * HW + hw];
     }
   }
 }
@@ -1279,6 +1282,35 @@ __global__ __launch_bounds__(BLOCK) void k_bn_adjoint_pre(
       const unsigned c = i % C;
       ga_out[i] = g * ((w ? w[c] : (T)1) * rstd[c]);
     }
+  }
+}
+
+// Forward of conv -> (eval-BatchNorm | bias) (+ residual) (+ ReLU) from the convolution's split-K slabs,
+// NHWC [rows, C]; one element per thread (activation-sized, latency-bound).  The rounding sequence
+// is chan_affine_body's forward: ((s - mean)*rstd)*w, + b, + res.
+__global__ __launch_bounds__(BLOCK) void k_bn_forward(
+    float* __restrict__ y, float* __restrict__ y2, unsigned y2_ld, float* __restrict__ a_out,
+    const float* __restrict__ a, int splits, long long slab, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ w, const float* __restrict__ b,
+    const float* __restrict__ res, unsigned res_ld, int relu, unsigned total, unsigned C) {
+  for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < total; i += gridDim.x * BLOCK) {
+  const unsigned c = i % C, row = i / C;
+  float av = a[i];
+  for (int sp = 1; sp < splits; sp += 8) {  // eight slabs in flight, summed in split order
+    float t8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t8[u] = a[(long long)(sp + u < splits ? sp + u : 0) * slab + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) av += sp + u < splits ? t8[u] : 0.f;
+  }
+  if (a_out) a_out[i] = av;
+  float t = av;
+  if (rstd) t = ((av - mean[c]) * rstd[c]) * w[c];
+  if (b) t += b[c];
+  if (res) t += res[res_ld ? (size_t)row * res_ld + c : i];
+  if (relu) t = t > 0.f ? t : 0.f;
+  if (y) y[i] = t;
+  if (y2) y2[(size_t)row * y2_ld + c] = t;
   }
 }
 
@@ -2020,7 +2052,7 @@ static int small_grid(int64_t n) {
 template <typename T>
 static int unpack_impl(const void* src, void* const* dsts, const int64_t* src_offs,
                        const int64_t* numels, const int64_t* slabs, const int64_t* inners,
-                       const int64_t* live, int nt, hipStream_t s) {
+                       const int64_t* live, const int64_t* halves, int nt, hipStream_t s) {
   int t = 0;
   while (t < nt) {
     UnpackArgs a;
@@ -2040,6 +2072,7 @@ static int unpack_impl(const void* src, void* const* dsts, const int64_t* src_of
         a.inner[k] = (int)I;
         if (live && live[t] > 0 && I > 0 && slab / I <= 16)
           a.live[k] = (unsigned short)(live[t] & ((1 << (slab / I)) - 1));
+        a.half[k] = (unsigned char)((halves && halves[t] == 0) ? 0 : 1);
         a.chunk[k] = PACK_CHUNK;  // (an LDS-tiled NHWC variant measured slower: 30.9 vs 24.5 us)
         a.blk_start[k] = blocks;
         blocks += (int)((numels[t] + a.chunk[k] - 1) / a.chunk[k]);
@@ -2065,11 +2098,19 @@ int hf_unpack_tangent(const void* src, void* const* dsts, const int64_t* src_off
 int hf_unpack_tangent_ex(const void* src, void* const* dsts, const int64_t* src_offs,
                          const int64_t* numels, const int64_t* slabs, const int64_t* inners,
                          const int64_t* live, int n_tensors, int dtype, void* stream) {
+  return hf_unpack_weights(src, dsts, src_offs, numels, slabs, inners, live, nullptr, n_tensors, dtype, stream);
+}
+
+int hf_unpack_weights(const void* src, void* const* dsts, const int64_t* src_offs,
+                      const int64_t* numels, const int64_t* slabs, const int64_t* inners,
+                      const int64_t* live, const int64_t* halves, int n_tensors, int dtype, void* stream) {
   if (!src || !dsts || !src_offs || !numels || !slabs || !inners || n_tensors < 0) return HF_ERR_ARG;
   if (dtype == HF_F32)
-    return unpack_impl<float>(src, dsts, src_offs, numels, slabs, inners, live, n_tensors, (hipStream_t)stream);
+    return unpack_impl<float>(src, dsts, src_offs, numels, slabs, inners, live, halves, n_tensors,
+                              (hipStream_t)stream);
   if (dtype == HF_F64)
-    return unpack_impl<double>(src, dsts, src_offs, numels, slabs, inners, live, n_tensors, (hipStream_t)stream);
+    return unpack_impl<double>(src, dsts, src_offs, numels, slabs, inners, live, halves, n_tensors,
+                               (hipStream_t)stream);
   return HF_ERR_ARG;
 }
 
@@ -2176,6 +2217,24 @@ int hf_bn_adjoint_pre(void* g_out, void* ga_out, const void* gy_a, int a_splits,
                        (const double*)rstd, (unsigned)total, (unsigned)c);
   else
     return HF_ERR_ARG;
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_bn_forward(void* y, void* y2, int64_t y2_ld, void* a_out, const void* a, int splits, int64_t slab_stride,
+                  const void* mean, const void* rstd, const void* w, const void* b, const void* res,
+                  int64_t res_ld, int relu, int64_t rows, int64_t c, int dtype, void* stream) {
+  if (dtype != HF_F32 || !a || (!y && !y2) || rows <= 0 || c <= 0 || splits < 1) return HF_ERR_ARG;
+  if (splits > 1 && slab_stride < rows * c) return HF_ERR_ARG;
+  if (rstd && (!mean || !w)) return HF_ERR_ARG;
+  if ((y2 && y2_ld < c) || (res && res_ld && res_ld < c)) return HF_ERR_ARG;
+  const long long total = (long long)rows * c;
+  const long long widest = (long long)rows * (y2_ld > res_ld ? (y2_ld > c ? y2_ld : c) : (res_ld > c ? res_ld : c));
+  if (total > 0x7fffffffLL || widest > 0x7fffffffLL || y2_ld > 0x3fffffffLL || res_ld > 0x3fffffffLL) return HF_ERR_ARG;
+  hipLaunchKernelGGL(k_bn_forward, dim3(wide_grid(total)), dim3(BLOCK), 0, (hipStream_t)stream, (float*)y,
+                     (float*)y2, (unsigned)y2_ld, (float*)a_out, (const float*)a, splits, (long long)slab_stride,
+                     (const float*)mean, (const float*)rstd, (const float*)w, (const float*)b, (const float*)res,
+                     (unsigned)res_ld, relu, (unsigned)total, (unsigned)c);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }

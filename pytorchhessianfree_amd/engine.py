@@ -66,6 +66,7 @@ class _Unit:
         self.res_unit = None      # downsample unit whose output is added before the activation
         self.res_identity = False  # ... or the block input itself
         self.consumers = 0
+        self.src = None           # what the convolution reads: "input", "pool" or the producing unit
 
 
 class FusedGGNEngine(_Operator):
@@ -87,8 +88,13 @@ class FusedGGNEngine(_Operator):
         try:
             eng = cls(model, loss, outputs, params, weight, group)
         except _Unsupported as exc:
-            if os.environ.get("HF_ENGINE_DEBUG"):
+            # (a model the engine does not cover is the normal case: quiet unless asked;
+            # a product that FAILED its check is always reported)
+            if os.environ.get("HF_ENGINE_DEBUG") or getattr(exc, "loud", False):
                 warnings.warn(f"fused curvature engine not used: {exc}")
+            return None
+        except RuntimeError as exc:  # a kernel refused its arguments (alignment, size limits ...)
+            warnings.warn(f"fused curvature engine not used: {exc}")
             return None
         return eng
 
@@ -103,9 +109,19 @@ class FusedGGNEngine(_Operator):
             o += p.numel()
         self._offs = offs
         self._layout(model)
-        self._loss_setup(loss, outputs)
         self._allocate()
+        # own forward pass on the engine's static buffers; it must reproduce the model's output
+        self.set_batch(getattr(outputs, "_hf_input").detach(), None)
+        self.refresh_weights(transposed=True)
+        self.forward_own()
+        want = outputs.detach()
+        err = float((self.logits - want).abs().max() / want.abs().max().clamp_min(1e-30))
+        if not err < 1e-4:
+            raise _Unsupported(f"the engine's forward pass differs from the model's output by {err:.2e}")
+        self._loss_setup(loss, outputs)
         self._verify(loss)
+        if self.loss_spec is not None:
+            self.outputs = None  # nothing of the step's autograd graph stays alive in the engine
 
     # ---- topology ---------------------------------------------------------------------
     def _param(self, p):
@@ -164,6 +180,8 @@ class FusedGGNEngine(_Operator):
         stem = make_unit("stem", model.conv1, model.bn1, True)
         if not _same(stem.rx, x_in.detach()) or stem.res is not None:
             raise _Unsupported("stem does not start at the network input")
+        stem.src = "input"
+        self.model_ref, self._in_shape = model, tuple(x_in.shape)
         mp_x, mp_y = io(model.maxpool, 2)
         if not _same(mp_x, stem.ry):
             raise _Unsupported(f"maxpool does not follow the stem ({tuple(mp_x.shape)} {mp_x.stride()} "
@@ -173,6 +191,7 @@ class FusedGGNEngine(_Operator):
         cur = mp_y
         self.pool_out, self.pool_key = _cl(mp_y), mp_y.data_ptr()
         self.blocks = []
+        prev = "pool"  # producer of the current block input
         for bi, b in enumerate(blocks):
             convs = [n for n in ("conv1", "conv2", "conv3") if isinstance(getattr(b, n, None), nn.Conv2d)]
             if not getattr(b, "_hf_block_patched", False) or len(convs) < 2 or b.training:
@@ -185,6 +204,7 @@ class FusedGGNEngine(_Operator):
                 last = k == len(convs) - 1
                 if (u.res is not None) != last:
                     raise _Unsupported(f"block {bi}.{cn}: unexpected residual")
+                u.src = chain[-1] if chain else prev
                 chain.append(u)
                 inp = u.ry
             tail = chain[-1]
@@ -197,12 +217,14 @@ class FusedGGNEngine(_Operator):
                 if not _same(ds.rx, cur) or ds.res is not None or not _same(tail.res, ds.ry):
                     raise _Unsupported(f"block {bi}: downsample wiring")
                 tail.res_unit = ds
+                ds.src = prev
             else:
                 if not _same(tail.res, cur):
                     raise _Unsupported(f"block {bi}: identity wiring")
                 tail.res_identity = True
             self.blocks.append((chain, ds, cur))
             cur = tail.ry
+            prev = tail
         ap_x, ap_y = io(model.avgpool, 2)
         if not _same(ap_x, cur):
             raise _Unsupported("avgpool does not follow the last block")
@@ -223,14 +245,150 @@ class FusedGGNEngine(_Operator):
     def _loss_setup(self, loss, outputs):
         (self._dl,) = torch.autograd.grad(loss, outputs, create_graph=True, retain_graph=True)
         self._ce = GGNOperator._closed_form_loss_hessian(self, loss, outputs)
+        # a plain softmax cross-entropy (checked numerically above): the engine can then evaluate
+        # loss, probabilities and d loss / d logits itself, on its own forward pass -- which is what
+        # lets ONE engine serve many steps and trial points (``session.EngineSession``)
+        self.loss_spec = None
+        if self._ce is not None:
+            spec = ce_loss_spec(loss, outputs)
+            if spec is not None:
+                self.loss_spec = spec
+                self.set_targets(spec["targets"])
+                self._loss_head()
+                self._ce = (self._p, self._ce[1])  # the static buffer the own forward pass refreshes
+                self._dl = None                     # (nothing of this step's autograd graph is kept)
+
+    # ---- own forward pass ------------------------------------------------------------------
+    def set_batch(self, x, targets=None):
+        """A new input batch of the same shape (and its targets): static input, the stem's im2col."""
+        if tuple(x.shape) != tuple(self.x_in.shape):
+            raise RuntimeError("engine: input shape changed")
+        self.x_in.copy_(x)
+        s = self.stem
+        cols = torch.nn.functional.unfold(self.x_in.contiguous(), tuple(s.conv.kernel_size),
+                                          padding=tuple(s.conv.padding), stride=tuple(s.conv.stride))
+        s.cols.copy_(cols.transpose(1, 2))
+        s.cols_pad[:, :, :s.jcols].copy_(s.cols)
+        for u in self.units:  # eval-mode statistics are constants -- unless somebody retrained them
+            if u.bn.running_var._version != u.rstd_version:
+                torch.rsqrt(u.bn.running_var + u.bn.eps, out=u.rstd)
+                u.rstd_version = u.bn.running_var._version
+        if targets is not None:
+            self.set_targets(targets)
+
+    def set_targets(self, targets):
+        if getattr(self, "_targets", None) is None:
+            self._targets = torch.empty_like(targets)
+            self._onehot = torch.zeros_like(self.logits)
+        self._targets.copy_(targets)
+        k = self.logits.shape[1]
+        # class indices outside [0, K) (an ``ignore_index``) are not covered by the closed forms: the
+        # flag is read back by the caller together with the loss value (no extra sync)
+        self.bad_targets = ((self._targets < 0) | (self._targets >= k)).any()
+        self._onehot.zero_()
+        self._onehot.scatter_(1, self._targets.clamp(0, k - 1).view(-1, 1), 1.0)
+
+    def refresh_weights(self, transposed=False):
+        """The W halves of all [W | v_W] operands from the CURRENT parameters (one scatter launch
+        when the parameters are views of one flat vector); ``transposed``: also the (I, H, W, O)
+        copies the data-gradient convolutions read (once per step; trial points need only W)."""
+        flat = self._flat_params
+        if flat is not None and flat.data_ptr() == self.params[0].data_ptr():
+            _lib.unpack_tangent(flat, self._slot_list, half=0)
+        else:
+            for u in self.units:
+                if u is not self.stem:
+                    c = u.x.shape[1]
+                    u.wcat[:, :c].copy_(self.params[u.pw].detach())
+        if transposed:
+            for u in self.units:
+                if u is not self.stem:
+                    u.wT.copy_(self.params[u.pw].detach().permute(1, 2, 3, 0))
+
+    def _bn_forward(self, u, splits):
+        n, k, oh, ow = u.a.shape
+        res = u.res
+        _lib.check(_lib.load().hf_bn_forward(
+            _ptr(u.y), _ptr(u.yout2), 2 * k if u.yout2 is not None else 0, _ptr(u.a), _ptr(u.tbuf), splits,
+            u.tbuf.shape[1], _ptr(u.bn.running_mean), _ptr(u.rstd), _ptr(u.bn.weight), _ptr(u.bn.bias),
+            _ptr(res), 0, 1 if u.relu else 0, n * oh * ow, k, _lib.HF_F32, _lib.current_stream_ptr(self.dev)),
+            "hf_bn_forward")
+
+    def _conv_forward(self, u):
+        n, h, w, c, k, r, s, st, pd = u.geo
+        self._conv_slabs(0, u.tbuf, u.x, u.wcat, u.geo, u.sF, mat_ld=2 * c)
+
+    def forward_own(self):
+        """The network's forward pass on the engine's static buffers, own kernels only: every
+        activation lands where the sweeps read it (dense output = ReLU mask / weight-gradient operand
+        / residual, and the x half of the consumer's [t_x | x] operand), max-pool positions, logits
+        and -- for a softmax cross-entropy -- probabilities and the loss value."""
+        s = self.stem
+        self._conv_slabs(0, s.tbuf, s.cols, s.conv.weight.detach(), s.geo, s.sF)
+        self._bn_forward(s, s.sF)
+        ks, st_, pd, _dl, _cm = self.pool_args
+        pn, ph, pw, poh, pow_, c0 = self._pool_geometry()
+        (kh, kw), (sh, sw), (pph, ppw) = _pair(ks), _pair(st_ if st_ is not None else ks), _pair(pd)
+        _lib.check(_lib.load().hf_maxpool_forward_nhwc(
+            _ptr(self.pool_out), _ptr(self.pool_t[:, c0:]), 2 * c0, _ptr(self.pool_idx32), _ptr(s.y), pn, ph, pw,
+            poh, pow_, c0, kh, kw, sh, sw, pph, ppw, _lib.HF_F32, _lib.current_stream_ptr(self.dev)),
+            "hf_maxpool_forward_nhwc")
+        for chain, ds, _x in self.blocks:
+            if ds is not None:
+                self._conv_forward(ds)
+                self._bn_forward(ds, ds.sF)
+            for u in chain:
+                self._conv_forward(u)
+                self._bn_forward(u, u.sF)
+        tail = self.blocks[-1][0][-1]
+        if self._head_hw > 1:
+            torch.mean(tail.y, dim=(2, 3), out=self.feat)
+        fw = self.fc.weight.detach()
+        if self.pfb is not None:
+            torch.addmm(self.fc.bias.detach(), self.feat, fw.t(), out=self.logits)
+        else:
+            torch.mm(self.feat, fw.t(), out=self.logits)
+        if getattr(self, "loss_spec", None) is not None:
+            self._loss_head()
+        return self.logits
+
+    def _loss_head(self):
+        """Softmax probabilities and the cross-entropy value of the current logits (the reference's
+        ``forward()[0]``, optimizer.py:216-229; same ATen ops as ``F.cross_entropy``)."""
+        torch.softmax(self.logits, 1, out=self._p)
+        lsm = torch.log_softmax(self.logits, 1)
+        self.loss_buf.copy_(torch.nn.functional.nll_loss(lsm, self._targets, reduction=self.loss_spec["reduction"]))
+
+    def gradient(self, out=None):
+        """``weight * d loss / d params`` of the softmax cross-entropy by ONE adjoint sweep of the
+        engine (the gradient the reference takes with ``torch.autograd.grad``, optimizer.py:231-234),
+        on the activations of the last ``forward_own``."""
+        if self.loss_spec is None:
+            raise RuntimeError("engine.gradient needs a softmax cross-entropy loss")
+        if out is None:
+            out = torch.empty(self.n, dtype=torch.float32, device=self.dev)
+        g = (self._p - self._onehot) * self._ce[1]  # d loss / d logits
+        fw = self.fc.weight.detach()
+        g_fw = g.t() @ self.feat
+        g_fb = g.sum(0) if self.pfb is not None else None
+        g_feat = g @ fw
+        pool_srcs = self._adjoint_blocks(self._feature_cotangent(g_feat))
+        self._adjoint_stem(pool_srcs)
+        return self._gather(out, g_fw, g_fb)
+
+    def _feature_cotangent(self, g_feat):
+        tail = self.blocks[-1][0][-1]
+        if self._head_hw == 1:
+            return g_feat.view(tail.y.shape)
+        return _cl((g_feat / self._head_hw).view(g_feat.shape[0], -1, 1, 1).expand(tail.y.shape))
 
     _loss_hessian = GGNOperator._loss_hessian
 
     # ---- buffers -------------------------------------------------------------------------
-    def _plan(self, direction, u):
+    def _plan(self, direction, u, forward=False):
         n, c, h, w = u.x.shape
         k, _, r, s = u.conv.weight.shape
-        cin = 2 * c if direction == 0 else c
+        cin = 2 * c if (direction == 0 and not forward) else c
         sp = _lib.load().hf_conv2d_nhwc_plan(direction, n, h, w, cin, k, r, s, u.conv.stride[0], u.conv.stride[1],
                                              u.conv.padding[0], u.conv.padding[1],
                                              int(os.environ.get("HF_CONV_BLOCKS", "0")))
@@ -239,7 +397,29 @@ class FusedGGNEngine(_Operator):
         return sp
 
     def _allocate(self):
+        """Every buffer the sweeps touch is owned by the engine and STATIC: the activations are
+        recomputed in place by ``forward_own`` (own kernels), so one engine -- and the hipGraphs
+        captured over it -- can serve every Newton step and every trial point of a step."""
         dev, f32 = self.dev, torch.float32
+        cl = torch.channels_last
+
+        def nhwc(shape):
+            return torch.empty(shape, dtype=f32, device=dev).contiguous(memory_format=cl)
+
+        self.x_in = nhwc(self._in_shape)
+        self.pool_out = nhwc(self.pool_out.shape)
+        for u in self.units:
+            u.a, u.y = nhwc(u.a.shape), nhwc(u.y.shape)
+            u.rstd = torch.rsqrt(u.bn.running_var + u.bn.eps)
+            u.rstd_version = u.bn.running_var._version
+        for u in self.units:  # the convolution's input IS its producer's output buffer
+            u.x = self.x_in if u.src == "input" else self.pool_out if u.src == "pool" else u.src.y
+            if u.res_unit is not None:
+                u.res = u.res_unit.y
+            elif u.res_identity:
+                u.res = self.blocks[[c[-1] for c, _, _ in self.blocks].index(u)][0][0].x
+            else:
+                u.res = None
         xcats = {}
         self._tangent_slots = {}
         for u in self.units:
@@ -248,17 +428,15 @@ class FusedGGNEngine(_Operator):
             if u is self.stem:
                 if c * r * s > 256:
                     raise _Unsupported("stem: too many taps for the im2col formulation")
-                cols = torch.nn.functional.unfold(u.x.contiguous(), (r, s), padding=tuple(u.conv.padding),
-                                                  stride=tuple(u.conv.stride))
-                u.cols = cols.transpose(1, 2).contiguous()  # [N, OH*OW, c*r*s]
-                u.geo = (n * u.cols.shape[1], 1, 1, u.cols.shape[2], k, 1, 1, (1, 1), (0, 0))
+                oh, ow = u.a.shape[2], u.a.shape[3]
+                j = c * r * s
+                u.cols = torch.empty((n, oh * ow, j), dtype=f32, device=dev)  # [N, OH*OW, c*r*s]
+                u.geo = (n * oh * ow, 1, 1, j, k, 1, 1, (1, 1), (0, 0))
                 # the weight gradient reads the im2col with rows padded to 16-byte multiples (zero
                 # channels): 16-byte gathers instead of element-wise ones (28 -> 11 us for the 49-tap stem)
-                j = u.cols.shape[2]
                 jp = -(-j // 4) * 4
-                u.cols_pad = torch.zeros((u.cols.shape[0], u.cols.shape[1], jp), dtype=f32, device=dev)
-                u.cols_pad[:, :, :j].copy_(u.cols)
-                u.geo_w = (n * u.cols.shape[1], 1, 1, jp, k, 1, 1, (1, 1), (0, 0))
+                u.cols_pad = torch.zeros((n, oh * ow, jp), dtype=f32, device=dev)
+                u.geo_w = (n * oh * ow, 1, 1, jp, k, 1, 1, (1, 1), (0, 0))
                 u.jcols = j
                 if not u.conv.weight.is_contiguous():
                     raise _Unsupported("stem weight layout")
@@ -266,30 +444,26 @@ class FusedGGNEngine(_Operator):
                 if c % 4 or k % 4:
                     raise _Unsupported(f"{u.name}: channel counts must be multiples of 4")
                 u.geo = (n, h, w, c, k, r, s, tuple(u.conv.stride), tuple(u.conv.padding))
-                key = u.kx
+                key = id(u.x)
                 if key not in xcats:
-                    xc = torch.zeros((n, 2 * c, h, w), dtype=f32, device=dev).contiguous(
-                        memory_format=torch.channels_last)
-                    xc[:, c:].copy_(u.x)
-                    xcats[key] = xc
+                    xcats[key] = torch.zeros((n, 2 * c, h, w), dtype=f32, device=dev).contiguous(memory_format=cl)
                 u.xcat = xcats[key]
-                wf = _cl(u.conv.weight.detach())
-                u.wcat = torch.zeros((k, 2 * c, r, s), dtype=f32, device=dev).contiguous(
-                    memory_format=torch.channels_last)  # (slices of taps that never meet data stay 0)
-                u.wcat[:, :c].copy_(wf)
-                u.wT = wf.permute(1, 2, 3, 0).contiguous()  # (I, H, W, O)
+                # [W | v_W]; slices of taps that never meet data stay 0
+                u.wcat = torch.zeros((k, 2 * c, r, s), dtype=f32, device=dev).contiguous(memory_format=cl)
+                u.wT = torch.empty((c, r, s, k), dtype=f32, device=dev)  # (I, H, W, O)
                 u.live = _live_taps(h, w, r, s, u.conv.stride, u.conv.padding)
                 self._tangent_slots[id(u)] = (self._offs[u.pw], u.wcat, c, u.live)
             oh, ow = u.a.shape[2], u.a.shape[3]
             u.rows, u.cout = n * oh * ow, k
             # split-K slab buffers
             if u is self.stem:
-                u.sT = self._plan_stem(0, u.geo)
+                u.sT = u.sF = self._plan_stem(0, u.geo)
                 u.sW = self._plan_stem(2, u.geo_w)
                 u.sD = 0
             else:
                 u.sT, u.sD, u.sW = self._plan(0, u), self._plan(1, u), self._plan(2, u)
-            u.tbuf = torch.empty((u.sT, u.rows * k), dtype=f32, device=dev)
+                u.sF = self._plan(0, u, forward=True)
+            u.tbuf = torch.empty((max(u.sT, u.sF), u.rows * k), dtype=f32, device=dev)
             u.wbuf = torch.zeros((u.sW, u.conv.weight.numel()), dtype=f32, device=dev)  # dead taps stay 0
             if u.sD:
                 u.dbuf = torch.empty((u.sD, u.x.numel()), dtype=f32, device=dev)
@@ -310,19 +484,39 @@ class FusedGGNEngine(_Operator):
                     u.rb = 1
             u.gw = torch.empty((u.rb, k), dtype=f32, device=dev)
             u.gb = torch.empty((u.rb, k), dtype=f32, device=dev)
-        # where each unit's tangent output goes: the [t_x | x] operand of its consumer, else a buffer
+        # where each unit's output goes besides its own dense buffer: the [t_x | x] operand of its
+        # consumer -- the tangent into the first half, the value (forward pass) into the second
         for u in self.units:
-            xc = xcats.get(u.ky)
+            xc = xcats.get(id(u.y))
+            c = u.y.shape[1]
             if xc is not None:
-                c = u.y.shape[1]
-                u.tout, u.tout_ld = xc[:, :c], 2 * c
+                u.tout, u.tout_ld, u.yout2 = xc[:, :c], 2 * c, xc[:, c:]
             else:
-                u.tout, u.tout_ld = torch.empty_like(u.y), 0
-        self.pool_t = xcats.get(self.pool_key)
+                u.tout, u.tout_ld, u.yout2 = torch.empty_like(u.y), 0, None
+        self.pool_t = xcats.get(id(self.pool_out))
         if self.pool_t is None:
             raise _Unsupported("nothing consumes the pooled stem output")
-        self.pool_idx = self.pool_idx32 = None
+        if _pair(self.pool_args[3]) != [1, 1] or self.pool_args[4]:
+            raise _Unsupported("max-pool with dilation / ceil_mode")
+        self.pool_idx32 = torch.empty(tuple(self.pool_out.permute(0, 2, 3, 1).shape), dtype=torch.int32, device=dev)
+        self._g_stem = torch.empty_like(self.stem.y)
         self._slot_list = list(self._tangent_slots.values())
+        # classifier head
+        tail = self.blocks[-1][0][-1]
+        n, k = tail.y.shape[0], tail.y.shape[1]
+        self._head_hw = tail.y.shape[2] * tail.y.shape[3]
+        if self._head_hw == 1:
+            self.feat = tail.y.permute(0, 2, 3, 1).reshape(n, k)  # a view: NHWC with a 1x1 map is [n, k]
+            if self.feat.data_ptr() != tail.y.data_ptr():
+                raise _Unsupported("feature view")
+        else:
+            self.feat = torch.empty((n, k), dtype=f32, device=dev)
+        self.logits = torch.empty((n, self.fc.weight.shape[0]), dtype=f32, device=dev)
+        self._p = torch.empty_like(self.logits)
+        self.loss_buf = torch.zeros((), dtype=f32, device=dev)
+        # the parameters as ONE flat vector, when they are consecutive views of one (the optimizer's
+        # arena): every W half is then refreshed by a single scatter launch
+        self._flat_params = _flat_view(self.params, self.n)
 
     def _plan_stem(self, direction, geo):
         n, h, w, c, k, r, s, st, pd = geo
@@ -333,11 +527,11 @@ class FusedGGNEngine(_Operator):
         return sp
 
     # ---- kernels ---------------------------------------------------------------------------
-    def _conv_slabs(self, direction, out, act, mat, geo, splits, act_ld=0, out_c=0):
+    def _conv_slabs(self, direction, out, act, mat, geo, splits, act_ld=0, out_c=0, mat_ld=0):
         n, h, w, c, k, r, s, st, pd = geo
         _lib.check(_lib.load().hf_conv2d_nhwc_slabs(
             direction, _ptr(out), _ptr(act), _ptr(mat), n, h, w, c, k, r, s, st[0], st[1], pd[0], pd[1], act_ld,
-            out_c, splits, out.shape[1] if out.dim() == 2 else 0, _lib.HF_F32,
+            mat_ld, out_c, splits, out.shape[1] if out.dim() == 2 else 0, _lib.HF_F32,
             _lib.current_stream_ptr(self.dev)), "hf_conv2d_nhwc_slabs")
 
     def _bn_tangent(self, u, v, add, add_ld):
@@ -430,17 +624,8 @@ class FusedGGNEngine(_Operator):
 
     # ---- tangent sweep -------------------------------------------------------------------------
     def _pool_geometry(self):
-        """(n, h, w, oh, ow, c) of the stem's max-pool; takes the window maxima's positions on first use."""
-        s = self.stem
-        ks, st_, pd, dl, cm = self.pool_args
-        if self.pool_idx is None:
-            _, self.pool_idx = torch.nn.functional.max_pool2d(s.y, ks, st_, pd, dl, cm, return_indices=True)
-            # own one-launch pooling kernels (hf_head.hip): NHWC int32 positions, unit dilation
-            self.pool_idx32 = None
-            if _pair(dl) == [1, 1] and os.environ.get("HF_ENGINE_POOL", "1") != "0":
-                self.pool_idx32 = self.pool_idx.permute(0, 2, 3, 1).contiguous().to(torch.int32)
-                self._g_stem = torch.empty_like(s.y)
-        pn, _, ph, pw = s.y.shape
+        """(n, h, w, oh, ow, c) of the stem's max-pool (window maxima's positions: ``forward_own``)."""
+        pn, _, ph, pw = self.stem.y.shape
         return pn, ph, pw, self.pool_out.shape[2], self.pool_out.shape[3], self.pool_out.shape[1]
 
     def _tangent_stem(self, v):
@@ -449,13 +634,9 @@ class FusedGGNEngine(_Operator):
         self._conv_slabs(0, s.tbuf, s.cols, vw, s.geo, s.sT)  # input has no tangent: conv(x, v_W) as 1x1 on im2col
         self._bn_tangent(s, v, None, 0)
         pn, ph, pw, poh, pow_, c0 = self._pool_geometry()
-        if self.pool_idx32 is not None:
-            _lib.check(_lib.load().hf_maxpool_tangent_nhwc(
-                _ptr(self.pool_t), _ptr(s.tout), _ptr(self.pool_idx32), pn, ph, pw, poh, pow_, c0, 2 * c0,
-                _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_maxpool_tangent_nhwc")
-        else:
-            t_pool = s.tout.flatten(2).gather(2, self.pool_idx.flatten(2)).view_as(self.pool_out)
-            self.pool_t[:, :c0].copy_(t_pool)
+        _lib.check(_lib.load().hf_maxpool_tangent_nhwc(
+            _ptr(self.pool_t), _ptr(s.tout), _ptr(self.pool_idx32), pn, ph, pw, poh, pow_, c0, 2 * c0,
+            _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_maxpool_tangent_nhwc")
 
     def _tangent_blocks(self, v):
         group = self._grouping()
@@ -520,11 +701,7 @@ class FusedGGNEngine(_Operator):
             g_fw = HJv.t() @ self.feat
             g_fb = HJv.sum(0) if self.pfb is not None else None
             g_feat = HJv @ fw.detach()
-        if hw == 1:
-            g_last = g_feat.view(tail.y.shape)
-        else:
-            g_last = _cl((g_feat / hw).view(g_feat.shape[0], -1, 1, 1).expand(tail.y.shape))
-        return g_last, g_fw, g_fb
+        return self._feature_cotangent(g_feat), g_fw, g_fb
 
     # ---- adjoint sweep -------------------------------------------------------------------------
     def _adjoint_blocks(self, g_last):
@@ -575,22 +752,13 @@ class FusedGGNEngine(_Operator):
         ks, st_, pd, dl, cm = self.pool_args
         pn, ph, pw, poh, pow_, c0 = self._pool_geometry()
         (a, sa, la), (b, sb, lb) = pool_srcs
-        if self.pool_idx32 is not None:
-            # slab sums of both cotangents and the max-pool adjoint (gather form) in one launch
-            g_stem = self._g_stem
-            (kh, kw), (sh, sw), (pph, ppw) = _pair(ks), _pair(st_ if st_ is not None else ks), _pair(pd)
-            _lib.check(_lib.load().hf_maxpool_adjoint_nhwc(
-                _ptr(g_stem), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(self.pool_idx32), pn, ph, pw, poh, pow_,
-                c0, kh, kw, sh, sw, pph, ppw, _lib.HF_F32, _lib.current_stream_ptr(self.dev)),
-                "hf_maxpool_adjoint_nhwc")
-        else:
-            g_pool = torch.empty_like(self.pool_out)
-            _lib.check(_lib.load().hf_bn_adjoint_pre(
-                _ptr(g_pool), None, _ptr(a), sa, la, _ptr(b), sb, lb, None, None, None,
-                g_pool.numel() // c0, c0, _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_bn_adjoint_pre")
-            g_stem = _cl(torch.ops.aten.max_pool2d_with_indices_backward(
-                g_pool, s.y, _pair(ks), _pair(st_ if st_ is not None else ks), _pair(pd), _pair(dl), cm,
-                self.pool_idx))
+        # slab sums of both cotangents and the max-pool adjoint (gather form) in one launch
+        g_stem = self._g_stem
+        (kh, kw), (sh, sw), (pph, ppw) = _pair(ks), _pair(st_ if st_ is not None else ks), _pair(pd)
+        _lib.check(_lib.load().hf_maxpool_adjoint_nhwc(
+            _ptr(g_stem), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(self.pool_idx32), pn, ph, pw, poh, pow_,
+            c0, kh, kw, sh, sw, pph, ppw, _lib.HF_F32, _lib.current_stream_ptr(self.dev)),
+            "hf_maxpool_adjoint_nhwc")
         self._adjoint_unit(s, [(g_stem, 1, 0)])
 
     def _gather(self, out, g_fw, g_fb):
@@ -624,12 +792,12 @@ class FusedGGNEngine(_Operator):
             ok = (
                 os.environ.get("HF_ENGINE_HEAD", "1") != "0" and self._ce is not None and hw == 1
                 and fw.is_contiguous() and fw.dtype == torch.float32 and k <= 64 and f <= 512 and f % 4 == 0
-                and self.feat.is_contiguous() and tuple(self.feat.shape) == (self.outputs.shape[0], f)
-                and self.outputs.shape[0] <= 4096 and ((2 * k + 4) * f + 4 * k) * 4 <= 64 * 1024
+                and self.feat.is_contiguous() and tuple(self.feat.shape) == (self.logits.shape[0], f)
+                and self.logits.shape[0] <= 4096 and ((2 * k + 4) * f + 4 * k) * 4 <= 64 * 1024
                 and self._offs[self.pfw] % 4 == 0 and self._ce[0].is_contiguous()
             )
             if ok:
-                b = self.outputs.shape[0]
+                b = self.logits.shape[0]
                 g = _lib.load().hf_linear_ce_head_slabs(b)  # partial sums per workgroup, added up by hf_pack_ex
                 kw = dict(dtype=torch.float32, device=self.dev)
                 self._head_bufs = (torch.empty((b, f), **kw), torch.empty((g, k, f), **kw),
@@ -724,11 +892,18 @@ class FusedGGNEngine(_Operator):
 
 
     # ---- safety net --------------------------------------------------------------------------
+    # relative max-norm distance to the autograd product above which the engine is refused; fp32
+    # products of the shipped workloads agree to ~1e-6.  Deep, badly conditioned nets (the random-init
+    # ResNet-50) scatter more for EVERY fp32 implementation: callers that have measured what stock
+    # fp32 autograd achieves against float64 (bench.py) raise it to max(1e-5, 5 x that error)
+    verify_tol = float(os.environ.get("HF_ENGINE_VERIFY_TOL", "1e-5"))
+
     def _verify(self, loss):
-        """First product of every model signature against the autograd operator."""
+        """First product of every (model, shape) signature against the autograd operator."""
         policy = os.environ.get("HF_ENGINE_VERIFY", "first")
-        key = (self.n, tuple(tuple(p.shape) for p in self.params), tuple(self.outputs.shape),
-               tuple(self.stem.x.shape), str(self.dev))
+        key = (id(self.model_ref), tuple(type(m).__name__ for m in self.model_ref.modules()), self.n,
+               tuple(tuple(p.shape) for p in self.params), tuple(self.logits.shape), tuple(self.stem.x.shape),
+               str(self.dev))
         if policy == "never" or (policy != "always" and key in FusedGGNEngine._verified):
             return
         gen = torch.Generator(device=self.dev).manual_seed(4321)
@@ -740,8 +915,11 @@ class FusedGGNEngine(_Operator):
             self.weight = weight
         want = GGNOperator(loss, self.outputs, self.params).local(v)
         err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
-        if not err < 1e-3:
-            raise _Unsupported(f"engine product differs from the autograd product by {err:.2e}")
+        if not err < FusedGGNEngine.verify_tol:
+            exc = _Unsupported(f"engine product differs from the autograd product by {err:.2e} "
+                               f"(tolerance {FusedGGNEngine.verify_tol:.1e}); using the autograd operator")
+            exc.loud = True
+            raise exc
         FusedGGNEngine._verified.add(key)
 
 
@@ -749,8 +927,55 @@ class _Unsupported(Exception):
     pass
 
 
+def ce_loss_spec(loss, outputs, check_values=True):
+    """``{"reduction", "targets"}`` if ``loss`` is ``F.cross_entropy(outputs, targets)`` with class-index
+    targets, no class weights, no label smoothing and no ignored target -- read off the autograd
+    graph (``NllLossBackward0 <- LogSoftmaxBackward0 <- outputs``) --, else ``None``."""
+    fn = loss.grad_fn
+    try:
+        if fn is None or fn.name() != "NllLossBackward0" or outputs.dim() != 2:
+            return None
+        lsm = fn.next_functions[0][0]
+        if lsm is None or lsm.name() != "LogSoftmaxBackward0" or lsm._saved_dim not in (1, -1):
+            return None
+        if lsm.next_functions[0][0] is not outputs.grad_fn or outputs.grad_fn is None:
+            return None
+        if fn._saved_weight is not None:
+            return None
+        reduction = {1: "mean", 2: "sum"}.get(fn._saved_reduction)
+        targets = fn._saved_target
+        if reduction is None or targets.dim() != 1 or targets.dtype != torch.int64:
+            return None
+        # (two host syncs: at engine construction only; a later step with an ignored / negative
+        # target shows up as a loss value the session does not reproduce)
+        if check_values and (bool((targets == fn._saved_ignore_index).any()) or bool((targets < 0).any())):
+            return None
+    except AttributeError:
+        return None
+    return {"reduction": reduction, "targets": targets.detach()}
+
+
 def _pair(v):
     return [v, v] if isinstance(v, int) else list(v)
+
+
+def _flat_view(params, n):
+    """The parameters as one flat fp32 vector if they are consecutive, contiguous views of one
+    storage in list order (``utils.ParameterArena``), else ``None``."""
+    p0 = params[0]
+    if p0.dtype != torch.float32 or not p0.is_cuda:
+        return None
+    base, off = p0.data_ptr(), 0
+    for p in params:
+        if not p.is_contiguous() or p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+            return None
+        off += p.numel()
+    try:
+        if p0.untyped_storage().nbytes() < 4 * (p0.storage_offset() + n) or base % 16:
+            return None
+        return p0.detach().as_strided((n,), (1,), p0.storage_offset())
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def _live_taps(h, w, r, s, stride, padding):

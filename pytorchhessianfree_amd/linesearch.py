@@ -30,6 +30,9 @@ def simple_linesearch(f, f_grad_0, step, init_alpha=1.0, beta=0.8, c=1e-2, max_i
         raise ValueError(f"Invalid c = {c}")
     say = print if verbose else (lambda *a: None)
     value_at = _evaluator(f, step)
+    prefetch = getattr(f, "prefetch", None)  # graph-replayed evaluation: enqueue without a host sync
+    if prefetch is not None:
+        prefetch([(step, 0.0), (step, init_alpha)])
 
     say("\nStarting line search...")
     base = float(value_at(0.0))
@@ -49,6 +52,8 @@ def simple_linesearch(f, f_grad_0, step, init_alpha=1.0, beta=0.8, c=1e-2, max_i
             say(f"Significant improvement for alpha = {alpha:.6f}")
             return alpha, trial
         alpha *= beta
+        if prefetch is not None:  # this candidate and the next: one read-back for two values
+            prefetch([(step, alpha), (step, alpha * beta)])
         trial = value_at(alpha)
         tries += 1
 

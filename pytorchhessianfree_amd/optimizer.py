@@ -103,6 +103,10 @@ class HessianFree(torch.optim.Optimizer):
         self._acc_counts = {}           # id(datalist) -> samples over all ranks (per acc_step)
         self._arena = None
         self._cg = cg  # the HIP PCG; tests swap in the CPU oracle to check host logic
+        # persistent engine session (session.py): one engine + graphs for all steps
+        self._session = None
+        self._session_failures = 0
+        self._session_off = False
 
     # ------------------------------------------------------------------------
     # helpers
@@ -196,14 +200,22 @@ class HessianFree(torch.optim.Optimizer):
             return curvature.ggn_operator(loss, outputs, self._params_list,
                                           weight=self.shard_weight, group=self.process_group)
 
-        if self.graph_matvec and not user_mvp and self.device.type == "cuda":
-            mvp = curvature.maybe_graphed(setup, params=self._params_list)
+        sess = None
+        if (self.graph_matvec and not user_mvp and not user_grad and curvature_opt == "ggn"
+                and self.device.type == "cuda" and not self._session_off and self._cg is cg):
+            sess, init_loss = self._session_step(forward)
+        if sess is not None:
+            mvp = sess
+            grad = self._reduce_vector(sess.gradient())
         else:
-            op = setup()
-            mvp = mvp if user_mvp else op
-        if not user_grad:
-            grad = holder["grad"]
-        init_loss = self._reduce_scalar(holder["loss"].item())
+            if self.graph_matvec and not user_mvp and self.device.type == "cuda":
+                mvp = curvature.maybe_graphed(setup, params=self._params_list)
+            else:
+                op = setup()
+                mvp = mvp if user_mvp else op
+            if not user_grad:
+                grad = holder["grad"]
+            init_loss = self._reduce_scalar(holder["loss"].item())
         self._log(f"\nInitial loss = {init_loss:.6f}")
         state["init_losses"].append(init_loss)
 
@@ -233,22 +245,33 @@ class HessianFree(torch.optim.Optimizer):
         # ---- target function on the flat arena (optimizer.py:288-294) -----------
         params_vec = arena.snapshot()
 
-        @torch.no_grad()
-        def trial(step, alpha):
-            if alpha == 0.0:
-                arena.theta.copy_(params_vec)
-            else:
-                arena.write(params_vec, step, alpha)
-            return self._reduce_scalar(forward()[0].item())
+        if sess is not None:
+            # trial points as graph replays on the session's static buffers, values cached and
+            # read back in batches (what follows calls tfunc exactly as the reference does)
+            trials = _SessionTrials(self, sess, arena, params_vec)
+            trial, prefetch = trials.value, trials.prefetch
+        else:
+            prefetch = None
+
+            @torch.no_grad()
+            def trial(step, alpha):
+                if alpha == 0.0:
+                    arena.theta.copy_(params_vec)
+                else:
+                    arena.write(params_vec, step, alpha)
+                return self._reduce_scalar(forward()[0].item())
 
         def tfunc(step):
             return trial(step, 1.0)
 
         tfunc.scaled = trial
+        tfunc.prefetch = prefetch
 
         # ---- Levenberg-Marquardt damping (optimizer.py:299-306) ----------------
         assert x_iters[0] is not None and x_iters[-1] is not None
         if self.adapt_damping:
+            if prefetch is not None:
+                prefetch([(x_iters[0], 1.0), (x_iters[-1], 1.0)])  # both values with one read-back
             self._adapt_damping(
                 f_0=tfunc(x_iters[0]), f_step=tfunc(x_iters[-1]),
                 m_0=m_iters[0], m_step=m_iters[-1],
@@ -287,6 +310,59 @@ class HessianFree(torch.optim.Optimizer):
         return final_loss
 
     # ------------------------------------------------------------------------
+    def _session_step(self, forward):
+        """Start a step on the persistent engine session (session.py), creating it on first use.
+        Runs the caller's ``forward()`` ONCE: its loss value is the step's initial loss and must be
+        reproduced by the session's own forward pass; its autograd graph names the targets.  Returns
+        ``(session, initial loss)`` or ``(None, None)`` -- then the generic path runs (and after
+        repeated failures the session is not tried again)."""
+        sess, a, b = self._session_step_local(forward)
+        if self.process_group is not None:
+            # one decision for all ranks: the session path and the generic path issue different
+            # collectives, so a rank whose session was refused takes every rank with it
+            ok = torch.tensor([1 if sess is not None else 0], dtype=torch.int32, device=self.device)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
+            if int(ok.item()) == 0:
+                if sess is not None:
+                    self._session, self._session_off = None, True
+                return None, None
+        if sess is None:
+            return None, None
+        sess.base_loss = self._reduce_scalar(b)
+        return sess, self._reduce_scalar(a)
+
+    def _session_step_local(self, forward):
+        from .session import EngineSession
+
+        loss, outputs = forward()
+        if not isinstance(outputs, torch.Tensor) or loss.grad_fn is None:
+            self._session_off = True
+            return None, None, None
+        sess = self._session
+        args = (loss, outputs, self._params_list, self.shard_weight, self.process_group)
+        spec = sess.accepts(*args) if sess is not None else None
+        if spec is None:
+            self._session = sess = None
+            if getattr(outputs, "_hf_model", None) is not None:
+                sess = EngineSession.try_create(*args)
+            spec = sess.accepts(*args) if sess is not None else None
+            if spec is None:
+                self._session_failures += 1
+                if self._session_failures >= 2:
+                    self._session_off = True
+                return None, None, None
+            self._session = sess
+        own = sess.begin_step(outputs, spec)
+        a, b, bad = torch.stack([loss.detach().float().reshape(()), own.reshape(()),
+                                 sess.engine.bad_targets.float().reshape(())]).tolist()
+        if bad or not abs(a - b) <= 1e-5 * max(1.0, abs(a)):
+            warn(f"persistent engine session: its forward pass gives loss {b!r}, `forward()` gives {a!r}; "
+                 "using the generic path from now on")
+            self._session, self._session_off = None, True
+            return None, None, None
+        self._session_failures = 0
+        return sess, a, b
+
     def _test_forward_determinisitc(self, forward):
         """Two forward passes must agree (optimizer.py:365-412); warns otherwise."""
         self._log("\nTest deterministic behavior of `forward`...")
@@ -564,3 +640,53 @@ class HessianFree(torch.optim.Optimizer):
         return diag_EF_preconditioner(model, loss_func, inputs, targets, reduction,
                                       damping=self._group["damping"], exponent=exponent,
                                       use_backpack=use_backpack)
+
+
+class _SessionTrials:
+    """``tfunc`` of optimizer.py:288-294 on a persistent engine session: a trial point
+    ``theta0 + alpha*step`` is one ``hf_axpy_out`` launch on the flat arena plus ONE graph launch
+    (weights into kernel layout, forward pass, loss); the loss stays in a device array until a value
+    is needed, so that several trial points cost one device->host read.  Values are cached per
+    (step vector, alpha): LM damping, CG-backtracking and the line search ask for some points more
+    than once (the last CG iterate; the back-tracked step at ``alpha = 1``; the base point)."""
+
+    def __init__(self, opt, sess, arena, params_vec):
+        self.opt, self.sess, self.arena, self.base = opt, sess, arena, params_vec
+        self.cache = {(0, 0.0): sess.base_loss}  # alpha = 0: the loss at theta0 (this step's forward replay)
+        self.pending = []
+
+    @staticmethod
+    def _key(step, alpha):
+        return (0, 0.0) if alpha == 0.0 else (step.data_ptr(), float(alpha))
+
+    @torch.no_grad()
+    def prefetch(self, points):
+        """Enqueue the evaluation of ``[(step, alpha), ...]`` (no host synchronisation)."""
+        for step, alpha in points:
+            key = self._key(step, alpha)
+            if step is None or key in self.cache or any(k == key for k, _ in self.pending):
+                continue
+            if len(self.pending) >= self.sess.losses.numel():
+                self.flush()
+            self.arena.write(self.base, step, alpha)
+            self.sess.forward_loss(len(self.pending))
+            self.pending.append((key, len(self.pending)))
+
+    def flush(self):
+        if not self.pending:
+            return
+        vals = self.sess.losses[: len(self.pending)]
+        opt = self.opt
+        if opt.process_group is not None:  # weighted sum over the ranks' shards, all values at once
+            vals = vals.double() * opt.shard_weight
+            torch.distributed.all_reduce(vals, group=opt.process_group)
+        for (key, _), val in zip(self.pending, vals.tolist()):
+            self.cache[key] = val
+        self.pending = []
+
+    def value(self, step, alpha):
+        key = self._key(step, alpha)
+        if key not in self.cache:
+            self.prefetch([(step, alpha)])
+            self.flush()
+        return self.cache[key]

@@ -1,0 +1,197 @@
+"""A persistent Newton-step session: ONE fused curvature engine and FOUR hipGraphs that serve every
+``HessianFree.step()`` of a training run (reference ``optimizer.py:126-363``).
+
+What the reference (and this package's generic path) redoes on every step:
+
+* builds the autograd graph of ``forward()`` and differentiates it for the gradient
+  (optimizer.py:216-234);
+* sets up the curvature product from that graph (optimizer.py:237-247) -- here: engine construction,
+  capture of the product graph, instantiation of the per-iteration PCG graph: ~13 ms per step;
+* evaluates ``forward()`` eagerly for every trial point of the Levenberg-Marquardt rule,
+  CG-backtracking and the line search (``tfunc``, optimizer.py:288-294: ~8 forward passes of
+  ~2.4 ms of host time each on the ResNet-18 workload, a device->host sync each).
+
+The engine's buffers are static and its own forward pass (``FusedGGNEngine.forward_own``) refills
+them in place, so the session captures, ONCE:
+
+    G_wT     the (I, H, W, O) weight copies of the data-gradient convolutions      (per step)
+    G_fwd    W halves of all [W | v_W] operands <- theta, forward pass, softmax, loss   (per step
+             and per trial point: ``theta = theta0 + alpha*step`` is one ``hf_axpy_out`` launch
+             on the optimizer's flat arena, then ONE graph launch; losses stay on the device until
+             a phase needs them)
+    G_grad   the gradient by one adjoint sweep of the engine                        (per step)
+    G_prod   the GGN product ``input_buffer -> output_buffer``                      (per PCG iteration,
+             cloned by ``cg()`` into its one-launch iteration graph, which also survives)
+
+Per step the host then issues a handful of graph launches plus the user's own ``forward()`` once:
+its loss value must agree with the session's (a model / loss the session does not reproduce makes the
+optimizer fall back to the generic path), and its autograd graph tells the session the targets.
+Supported: models the engine covers (prepared ResNet families, NHWC fp32, eval-mode BatchNorm) with
+a plain softmax cross-entropy loss.
+"""
+
+import os
+
+import torch
+
+from . import _lib
+from .curvature import GraphedOperator
+from .engine import FusedGGNEngine, ce_loss_spec
+
+
+class EngineSession:
+    mode = ("persistent session: hipGraph replay of the " + FusedGGNEngine.mode
+            + "; engine, product graph and PCG iteration graph kept across steps, forward pass / "
+              "gradient / trial losses as graph replays on static buffers")
+
+    # ------------------------------------------------------------------------------------
+    @classmethod
+    def try_create(cls, loss, outputs, params, weight=1.0, group=None):
+        """A session for the model that produced ``outputs`` (``None`` if the engine does not cover
+        it or the loss is not a plain softmax cross-entropy)."""
+        if os.environ.get("HF_SESSION", "1") == "0" or not torch.cuda.is_available():
+            return None
+        if ce_loss_spec(loss, outputs) is None:
+            return None
+        holder = {}
+
+        def builder():
+            holder["eng"] = FusedGGNEngine.try_build(loss, outputs, list(params), weight=weight, group=group)
+            return holder["eng"]
+
+        sess = cls.__new__(cls)
+        try:
+            sess._build(builder, params)
+        except _NoEngine:
+            return None
+        return sess
+
+    def _build(self, builder, params):
+        cur = torch.cuda.current_stream()
+        dev = torch.cuda.current_device()
+        if dev not in GraphedOperator._streams:
+            GraphedOperator._streams[dev] = torch.cuda.Stream()
+        self.stream = GraphedOperator._streams[dev]
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            with torch.enable_grad():
+                eng = builder()
+            if eng is None or eng.loss_spec is None:
+                cur.wait_stream(self.stream)
+                raise _NoEngine()
+            self.op = self.engine = eng
+            self.n, self.group, self.params = eng.n, eng.group, eng.params
+            self.weight = eng.weight
+            f32 = dict(dtype=torch.float32, device=eng.dev)
+            self.input_buffer = torch.zeros(self.n, **f32)
+            self.output_buffer = torch.empty(self.n, **f32)
+            self.grad_buffer = torch.empty(self.n, **f32)
+            self.losses = torch.zeros(64, **f32)
+            # warm-up of everything that will be captured (allocator, lazy initialisations)
+            eng.refresh_weights(transposed=True)
+            eng.forward_own()
+            eng.gradient(self.grad_buffer)
+            eng.local(self.input_buffer, out=self.output_buffer)
+        self.stream.synchronize()
+        with torch.no_grad():
+            self.g_wT = self._capture(lambda: eng.refresh_weights(transposed=True))
+            self.g_fwd = self._capture(lambda: (eng.refresh_weights(), eng.forward_own()))
+            self.g_grad = self._capture(lambda: eng.gradient(self.grad_buffer))
+            self.graph = self._capture(lambda: eng.local(self.input_buffer, out=self.output_buffer), keep=True)
+        cur.wait_stream(self.stream)
+        torch.cuda.synchronize()
+        self.calls = 0
+        self.steps = 0
+        self._cache = {}
+        self._signature = self._signature_of(eng)
+
+    def _capture(self, fn, keep=False):
+        g = torch.cuda.CUDAGraph(keep_graph=True) if keep else torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=self.stream):
+            fn()
+        if keep:
+            g.instantiate()
+        return g
+
+    # ---- validity ------------------------------------------------------------------------
+    @staticmethod
+    def _signature_of(eng):
+        return (id(eng.model_ref), tuple(id(p) for p in eng.params), tuple(eng.x_in.shape), eng.weight,
+                eng.loss_spec["reduction"])
+
+    def accepts(self, loss, outputs, params, weight, group):
+        """The step that produced ``(loss, outputs)`` is one this session reproduces: same model
+        object, parameters, input shape, rank weight and loss structure.  Returns the loss
+        description (reduction, targets) or ``None``."""
+        eng = self.engine
+        ref = getattr(outputs, "_hf_model", None)
+        model = ref() if ref is not None else None
+        x = getattr(outputs, "_hf_input", None)
+        if model is not eng.model_ref or x is None or model.training or group is not self.group:
+            return None
+        if tuple(x.shape) != tuple(eng.x_in.shape) or x.dtype != torch.float32 or x.device != eng.x_in.device:
+            return None
+        if len(params) != len(eng.params) or any(a is not b for a, b in zip(params, eng.params)):
+            return None
+        if float(weight) != eng.weight or eng._flat_params is None:
+            return None
+        if eng._flat_params.data_ptr() != eng.params[0].data_ptr():
+            return None  # the parameters moved (arena rebuilt): a fresh session is needed
+        spec = ce_loss_spec(loss, outputs, check_values=False)
+        if spec is None or spec["reduction"] != eng.loss_spec["reduction"]:
+            return None
+        if tuple(spec["targets"].shape) != tuple(eng._targets.shape):
+            return None
+        return spec
+
+    # ---- per step ------------------------------------------------------------------------
+    def begin_step(self, outputs, spec):
+        """New batch + current parameters: refresh every static buffer of the engine (input, im2col,
+        weights in kernel layout, activations, ReLU masks, pooling positions, probabilities) and
+        return the session's own loss value as a 0-dim device tensor."""
+        eng = self.engine
+        with torch.no_grad():
+            eng.set_batch(getattr(outputs, "_hf_input").detach(), spec["targets"])
+            self.g_wT.replay()
+            self.g_fwd.replay()
+        self._cache = {}
+        self.steps += 1
+        return eng.loss_buf
+
+    def gradient(self):
+        """``weight * grad`` at the parameters of the last forward replay (static buffer)."""
+        self.g_grad.replay()
+        return self.grad_buffer
+
+    def forward_loss(self, slot):
+        """Forward pass at the CURRENT parameters; the loss goes to ``losses[slot]`` (device)."""
+        self.g_fwd.replay()
+        self.losses[slot].copy_(self.engine.loss_buf)
+        return self.losses[slot]
+
+    # ---- operator interface of cg() (see curvature.GraphedOperator) -------------------------
+    def raw_graph(self):
+        return self.graph.raw_cuda_graph()
+
+    def replay_local(self):
+        self.graph.replay()
+
+    def reduce(self, t):
+        return self.engine.reduce(t, self.group)
+
+    def local(self, v, out=None):
+        if v.data_ptr() != self.input_buffer.data_ptr():
+            self.input_buffer.copy_(v)
+        self.graph.replay()
+        if out is not None:
+            out.copy_(self.output_buffer)
+            return out
+        return self.output_buffer
+
+    def __call__(self, v, out=None):
+        self.calls += 1
+        return self.reduce(self.local(v, out))
+
+
+class _NoEngine(Exception):
+    pass

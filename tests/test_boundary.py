@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
         assert name in _lib.SIGNATURES, f"{name} is declared but not bound in _lib.py"
-    assert lib.hf_abi_version() == 3
+    assert lib.hf_abi_version() == _lib.ABI_VERSION
     assert lib.hf_error_string(-2).decode().startswith("hf:")
 
 
