@@ -45,6 +45,8 @@ def parse():
                     help="Tikhonov damping; 1e-3 keeps all 250 iterations numerically alive "
                          "(with 1.0 this random-init problem converges to fp32 round-off in ~15)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-step-timing", action="store_true",
+                    help="skip the `step_ms` leg (complete default HessianFree.step() calls)")
     ap.add_argument("--cpu-iters", type=int, default=120)
     ap.add_argument("--graph", type=int, default=1, help="replay the matvec as a hipGraph if possible")
     ap.add_argument("--fuse-bn", type=int, default=1,
@@ -87,9 +89,9 @@ def parse():
 
 def launch_ranks(args):
     """``python bench.py --gpus N`` without a launcher: start N rank processes (one per
-    GPU) and relay rank 0's JSON line.  The parent never touches the GPU
-    (``device_count`` does not initialise it), so nothing is re-exec'ed after a HIP
-    call.  With fewer devices than ranks (a 1-GPU box) the ranks share devices and
+    GPU) and relay rank 0's JSON line.  The parent only counts devices and starts the ranks as
+    fresh child processes (nothing is exec'ed over a process that has touched the GPU).
+    With fewer devices than ranks (a 1-GPU box) the ranks share devices and
     talk over gloo -- a functional check of the multi-rank path, not a scaling number."""
     import socket
     import subprocess
@@ -105,8 +107,26 @@ def launch_ranks(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rcs = [p.wait() for p in procs]
-    raise SystemExit(max(abs(rc) for rc in rcs))
+    # poll: a rank that dies (out of memory, a failed check) would leave the others waiting in
+    # their next collective for good -- end them and report the failure
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() not in (None, 0):
+                rc = abs(p.returncode)
+        if rc:
+            time.sleep(2.0)  # (let the failing rank's siblings print what they have)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    raise SystemExit(rc or max(abs(p.returncode or 0) for p in procs))
 
 
 def build_problem(args, device, rank):
@@ -198,6 +218,53 @@ def cpu_baseline(args):
                   f"batch-{args.batch} problem, {dt:.1f} s",
         "cg_iters_per_s": (len(xs) - 1) / dt,
         "host_logical_cores": os.cpu_count(),
+    }
+
+
+def full_step_timing(args, device, n_steps=8, warmup=2):
+    """Wall time of complete default ``HessianFree.step()`` calls (optimizer.py:126-363: forward,
+    gradient, PCG to Martens' criterion, LM damping, CG-backtracking, line search, update) on the
+    same workload, a fresh synthetic batch per step -- the persistent engine session where the model
+    family is covered.  Reported beside the headline as ``step_ms``."""
+    import pytorchhessianfree_amd as hf
+    from pytorchhessianfree_amd import modelprep
+    from pytorchhessianfree_amd import testproblems as tp
+
+    make = {"resnet18": tp.resnet18_mnist, "allcnnc": tp.allcnnc_cifar100,
+            "resnet50": tp.resnet50_small_images}[args.workload]
+    seeds = tp.RESNET18_B32_SEPARATED_SEEDS if (args.workload == "resnet18" and args.batch == 32) else range(1000, 1008)
+    model, _, lossf = make(batch_size=args.batch, seed=0, device=device, data_seed=seeds[0])
+    modelprep.prepare_model(model, channels_last=bool(args.channels_last))
+    batches = [make(batch_size=args.batch, seed=0, device=device, data_seed=sd)[1] for sd in seeds]
+    opt = hf.HessianFree(model.parameters(), graph_matvec=bool(args.graph))
+    times = []
+    for i in range(warmup + n_steps):
+        x, t = batches[i % len(batches)]
+
+        def forward():
+            out = model(x)
+            return lossf(out, t), out
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            opt.step(forward)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+    timed = times[warmup:]
+    st = opt.state
+    return {
+        "mean": sum(timed) / len(timed), "min": min(timed), "max": max(timed), "steps": n_steps,
+        "warmup_steps": warmup, "first_step_ms": times[0],
+        "cg_iters": st["num_cg_iters"][warmup:], "best_cg_iters": [int(b) for b in st["best_cg_iters"][warmup:]],
+        "learning_rates": st["learning_rates"][warmup:],
+        "loss_first_to_last": [st["init_losses"][0], st["init_losses"][-1]],
+        "mode": ("persistent engine session (engine + graphs kept across steps, graph-replayed forward / "
+                 "gradient / trial losses)" if getattr(opt, "_session", None) is not None
+                 else "generic path (operator rebuilt and re-captured per step, eager trial forwards)"),
+        "settings": "HessianFree defaults: damping 1.0 + LM, cg_max_iter 250, Martens' criterion, "
+                    "CG-backtracking, line search; a fresh batch per step",
     }
 
 
@@ -300,22 +367,31 @@ def main():
             torch.backends.cudnn.benchmark = find
 
     # guard: an operator is only timed after it reproduced a float64 stock-autograd product
-    # as well as stock fp32 autograd does (x5; deep random-init nets such as the ResNet-50
-    # workload are only good to ~1e-4 in fp32, ResNet-18 to 2e-7).  A wrong operator must
-    # never be what gets measured; NHWC falls back to NCHW, NCHW aborts.
+    # as well as stock fp32 autograd does (x5, floor 1e-5; deep random-init nets such as the
+    # ResNet-50 workload are only good to ~1e-4 in fp32, ResNet-18 to 2e-7).  A wrong operator
+    # must never be what gets measured; NHWC falls back to NCHW, NCHW aborts.
     check = {}
 
+    def reference_products():
+        """float64 and fp32 stock-autograd products of one random vector: the tolerance of every
+        operator check in this run is max(1e-5, 5 x what stock fp32 autograd itself achieves) -- the
+        engine's own first-use guard included."""
+        model, _, _, _ = problem(device)
+        n = sum(p.numel() for p in model.parameters() if p.requires_grad)
+        del model
+        v = torch.randn(n, device=device, generator=torch.Generator(device=device).manual_seed(7))
+        want = stock_product(v, torch.float64)
+        scale = float(want.abs().max())
+        stock_err = float((stock_product(v, torch.float32) - want).abs().max()) / scale
+        check.update(v=v, want=want, scale=scale, stock_err=stock_err, tol=max(1e-5, 5.0 * stock_err))
+        from pytorchhessianfree_amd.engine import FusedGGNEngine
+
+        FusedGGNEngine.verify_tol = check["tol"]
+
     def checked(channels_last):
-        op, grad, diag, n = build_operator(channels_last)
         if "want" not in check:
-            v = torch.randn(n, device=device, generator=torch.Generator(device=device).manual_seed(7))
-            want = stock_product(v, torch.float64)
-            scale = float(want.abs().max())
-            stock_err = float((stock_product(v, torch.float32) - want).abs().max()) / scale
-            # (floor: 1e-5; the 50-layer random-init net is badly conditioned -- any fp32 product of it,
-            # stock autograd included, lands between 1e-6 and 3e-4 from run to run)
-            floor = 5e-4 if args.workload == "resnet50" else 1e-5
-            check.update(v=v, want=want, scale=scale, stock_err=stock_err, tol=max(floor, 5.0 * stock_err))
+            reference_products()
+        op, grad, diag, n = build_operator(channels_last)
         got = op(check["v"]).double()
         err = float((got - check["want"]).abs().max()) / check["scale"]
         # the reference's own check (optimizer.py:414-448): the same product twice
@@ -343,8 +419,13 @@ def main():
         from pytorchhessianfree_amd import distributed as hfdist
 
         if world == 1:  # --force-dist on a single GPU, started without a launcher
+            import socket
+
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                free_port = sock.getsockname()[1]
             for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"),
-                             ("MASTER_PORT", "29517")):
+                             ("MASTER_PORT", str(free_port))):
                 os.environ.setdefault(key, val)
         # (gloo and RCCL print connection banners on fd 1: stdout carries the ONE JSON line only)
         sys.stdout.flush()
@@ -461,8 +542,11 @@ def main():
                             f"damping {args.damping}, eval-mode BN, CE-mean"
                             + (f" + L2 {l2:g}" if l2 > 0 else "") + ", x0=0, tol=0"
                             + (", diag empirical-Fisher preconditioner ^-0.75 (per-sample autograd)" if M is not None else ""),
-                "parallelism": f"dp{world} (batch sharded, one all-reduce per matvec: the 4N-byte vector, or only its "
-                               "entries that can be non-zero with the fused engine -- config.allreduce.bytes)"
+                "parallelism": f"dp{world} (batch sharded, {args.batch} samples per GPU, one all-reduce per matvec: the "
+                               "4N-byte vector, or only its entries that can be non-zero with the fused engine -- "
+                               "config.allreduce.bytes; `value` counts SHARD products: every rank's operator call "
+                               f"counts once, so one product over the global batch of {world * args.batch} counts {world}x "
+                               "-- weak scaling over the batch, SURVEY.md section 8e)"
                                + (f"; {world} ranks share {ndev} device(s) over gloo: functional run, not a "
                                   "scaling number" if oversubscribed else ""),
                 "matvec": getattr(op, "mode", "eager autograd")
@@ -513,10 +597,16 @@ def main():
                 if val is not None:
                     line["roofline"]["traffic"] = val
                     line["roofline"]["traffic_source"] = (
-                        "static: profiles/traffic.json, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                        "this command (not re-measured in this run)")
+                        "static: profiles/traffic.json -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes taken on "
+                        "scripts/pcg_kernel_bench.py (the same kernel at the same N; --pmc aborts this full "
+                        "command on this stack), not re-measured in this run")
             except Exception:
                 pass
+        if world == 1 and not dist_on and not hessian and not args.precond and not args.no_step_timing:
+            try:
+                line["step_ms"] = full_step_timing(args, device)
+            except Exception as exc:  # noqa: BLE001  (the headline number must not depend on this leg)
+                line["step_ms"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)

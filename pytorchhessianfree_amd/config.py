@@ -75,9 +75,9 @@ def configure(winograd=None, wrw_xdlops=None, suggest_nhwc=True, find=True, db=N
         return _state["settings"]
     env = os.environ
     if winograd is None:
-        winograd = bool(env.get("HF_ALLOW_WINOGRAD"))
+        winograd = env.get("HF_ALLOW_WINOGRAD", "0") not in ("", "0")
     if wrw_xdlops is None:
-        wrw_xdlops = bool(env.get("HF_ALLOW_WRW_XDLOPS"))
+        wrw_xdlops = env.get("HF_ALLOW_WRW_XDLOPS", "0") not in ("", "0")
     if db is None:
         db = env.get("HF_MIOPEN_DB", "user")
     applied = {}

@@ -938,8 +938,12 @@ def ce_loss_spec(loss, outputs, check_values=True):
         lsm = fn.next_functions[0][0]
         if lsm is None or lsm.name() != "LogSoftmaxBackward0" or lsm._saved_dim not in (1, -1):
             return None
-        if lsm.next_functions[0][0] is not outputs.grad_fn or outputs.grad_fn is None:
-            return None
+        src = lsm.next_functions[0][0]
+        if outputs.grad_fn is not None:
+            if src is not outputs.grad_fn:
+                return None
+        elif src is None or getattr(src, "variable", None) is not outputs:
+            return None  # (a leaf: the logits a persistent session handed out)
         if fn._saved_weight is not None:
             return None
         reduction = {1: "mean", 2: "sum"}.get(fn._saved_reduction)

@@ -47,6 +47,7 @@ class _Mode:
     prefilled = False
     producers = {}    # data_ptr -> (ctx, tensor) of this sweep's fused-layer tangent outputs
     consume_now = False  # adjoint sweep whose per-parameter results are gathered at once
+    session = None       # persistent engine session that may answer the model's forward pass
 
 
 class first_order_only:
@@ -579,11 +580,16 @@ def _own_conv_ok(x, w, cl, dilation, channels):
     """The package's implicit-GEMM kernels (``hf_conv2d_nhwc``: one launch, deterministic
     split-K, dead taps skipped) apply: NHWC fp32 on the GPU, unit dilation, both channel
     counts multiples of 4.  ``HF_OWN_CONV=0`` keeps MIOpen everywhere."""
-    return (
-        cl and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and list(dilation) == [1, 1]
-        and channels % 4 == 0 and w.shape[0] % 4 == 0 and w.shape[2] * w.shape[3] <= 64
-        and x.numel() < 2**31 and os.environ.get("HF_OWN_CONV", "1") != "0"
-    )
+    if not (cl and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and list(dilation) == [1, 1]
+            and channels % 4 == 0 and w.shape[0] % 4 == 0 and w.shape[2] * w.shape[3] <= 64
+            and os.environ.get("HF_OWN_CONV", "1") != "0"):
+        return False
+    # the kernels' 32-bit index limits (hf_conv.hip: check_common), with the output map bounded by
+    # the input map (stride >= 1, "same"-or-smaller padding is the common case; a layer that still
+    # exceeds them is refused by the library and falls back to MIOpen in the callers below)
+    n, _, h, w_ = x.shape
+    wide = max(channels, w.shape[0])
+    return n * h * w_ * wide < 2**31 and w.numel() * (channels // max(1, w.shape[1])) < 2**31
 
 
 def _use_own(mode, kind, rows):
@@ -771,6 +777,35 @@ class _ConvBwd(torch.autograd.Function):
         return v_gy, None, None, None, None, None, None, None, None, None
 
 
+def _own_backward(ctx, gy, xf, wf, stride, padding, own_dw, own_d):
+    """(gx, gw) of a conv layer on the package's deterministic one-launch kernels (hf_conv2d_nhwc);
+    raises ``RuntimeError`` when the library refuses the geometry."""
+    gy = _fmt(gy, True)
+    r, s_ = wf.shape[2], wf.shape[3]
+    # taps that only ever meet padding are never written: a zero-filled buffer,
+    # persistent while the results are consumed at once (the product's gather),
+    # fresh otherwise (a caller may retain several gradients of one graph)
+    if _Mode.consume_now:
+        if ctx.gw_buf is None:
+            ctx.gw_buf = torch.zeros_like(wf)
+        gw = ctx.gw_buf
+    else:
+        gw = torch.zeros_like(wf)
+    if (own_dw or own_d) and ctx.wT is None:  # weight stored (I, H, W, O), once per step
+        ctx.wT = wf.permute(1, 2, 3, 0).contiguous()
+    gx = None
+    if own_dw:
+        n_, c_, h_, w_ = xf.shape
+        gx = torch.empty_like(xf)  # channels_last like xf
+        _lib.conv2d_nhwc_backward(gx, gw, gy, xf, ctx.wT, n_, h_, w_, c_, wf.shape[0], r, s_,
+                                  stride, padding)  # data + weight gradient: ONE launch
+    else:
+        _own_conv_wgrad(gy, xf, wf, stride, padding, out=gw)
+        if own_d:
+            gx = _own_conv_dgrad(gy, xf.shape, ctx.wT, r, s_, stride, padding)
+    return gx, gw
+
+
 class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, padding, dilation, cl, mode=None):
@@ -788,16 +823,24 @@ class _Conv(torch.autograd.Function):
         # machines (a fresh box with a cold kernel cache), run to run.
         oh, ow = _out_hw(xf, wf, stride, padding)
         rows = xf.shape[0] * oh * ow
+        # (a geometry the library refuses -- HF_ERR_ARG / HF_ERR_CAPACITY: index or scratch limits of
+        # very large maps -- runs on MIOpen like any layer the own kernels do not cover)
         if _own_conv_ok(xf, wf, cl, dilation, xf.shape[1]) and _use_own(mode, "F", rows):
-            y = _own_conv_forward(xf, wf, stride, padding)
-            return y if b is None else y + b.view(1, -1, 1, 1)
-        if _tiny_cin(xf, w, cl) and _use_own(mode, "F", rows):
-            cols = _cols_of(ctx, xf, w, stride, padding)  # 1x1 product over the im2col, (c, r, s) order
-            n_, k_, j_ = xf.shape[0], w.shape[0], cols.shape[2]
-            y = torch.empty((n_, k_, oh, ow), dtype=xf.dtype, device=xf.device).contiguous(
-                memory_format=torch.channels_last)
-            _lib.conv2d_nhwc(0, y, cols, w, n_ * oh * ow, 1, 1, j_, k_, 1, 1, (1, 1), (0, 0))
-            return y if b is None else y + b.view(1, -1, 1, 1)
+            try:
+                y = _own_conv_forward(xf, wf, stride, padding)
+                return y if b is None else y + b.view(1, -1, 1, 1)
+            except RuntimeError:
+                pass
+        elif _tiny_cin(xf, w, cl) and _use_own(mode, "F", rows):
+            try:
+                cols = _cols_of(ctx, xf, w, stride, padding)  # 1x1 product over the im2col, (c, r, s) order
+                n_, k_, j_ = xf.shape[0], w.shape[0], cols.shape[2]
+                y = torch.empty((n_, k_, oh, ow), dtype=xf.dtype, device=xf.device).contiguous(
+                    memory_format=torch.channels_last)
+                _lib.conv2d_nhwc(0, y, cols, w, n_ * oh * ow, 1, 1, j_, k_, 1, 1, (1, 1), (0, 0))
+                return y if b is None else y + b.view(1, -1, 1, 1)
+            except RuntimeError:
+                ctx.cols = None
         c = _point(xf, wf, padding, dilation, cl)
         if c is not None:
             y = xf.flatten(1) @ wf[:, :, c, c].t()
@@ -835,29 +878,10 @@ class _Conv(torch.autograd.Function):
             own_d = own_w and need_gx and _use_own(mode, "D", rows)
             gx = gw = None
             if own_dw or own_w:
-                # the package's deterministic one-launch kernels (hf_conv2d_nhwc)
-                gy = _fmt(gy, True)
-                r, s_ = wf.shape[2], wf.shape[3]
-                # taps that only ever meet padding are never written: a zero-filled buffer,
-                # persistent while the results are consumed at once (the product's gather),
-                # fresh otherwise (a caller may retain several gradients of one graph)
-                if _Mode.consume_now:
-                    if ctx.gw_buf is None:
-                        ctx.gw_buf = torch.zeros_like(wf)
-                    gw = ctx.gw_buf
-                else:
-                    gw = torch.zeros_like(wf)
-                if (own_dw or own_d) and ctx.wT is None:  # weight stored (I, H, W, O), once per step
-                    ctx.wT = wf.permute(1, 2, 3, 0).contiguous()
-                if own_dw:
-                    n_, c_, h_, w_ = xf.shape
-                    gx = torch.empty_like(xf)  # channels_last like xf
-                    _lib.conv2d_nhwc_backward(gx, gw, gy, xf, ctx.wT, n_, h_, w_, c_, wf.shape[0], r, s_,
-                                              stride, padding)  # data + weight gradient: ONE launch
-                else:
-                    _own_conv_wgrad(gy, xf, wf, stride, padding, out=gw)
-                    if own_d:
-                        gx = _own_conv_dgrad(gy, xf.shape, ctx.wT, r, s_, stride, padding)
+                try:
+                    gx, gw = _own_backward(ctx, gy, xf, wf, stride, padding, own_dw, own_d)
+                except RuntimeError:  # refused by the library (size limits): MIOpen below
+                    gx = gw = None
             elif tiny:
                 # weight gradient of a tiny-Cin layer: gW[k, j] = sum_m gy[m, k] * cols[m, j]
                 cols = _cols_of(ctx, xf, wf, stride, padding)
@@ -955,6 +979,34 @@ def _tag_output(module, inputs, output):
         output._hf_input = inputs[0] if inputs else None
 
 
+class session_forward:
+    """Context ``HessianFree.step`` holds around the caller's ``forward()`` once a persistent engine
+    session exists for the model: the model's forward pass is then ONE graph replay on the
+    session's static buffers (``EngineSession.forward_override``) instead of ~60 Python-level layer
+    calls, and returns the logits as a fresh leaf -- the caller's loss function still runs under
+    autograd on it, which is all the step needs (the gradient is the engine's own sweep)."""
+
+    def __init__(self, session):
+        self.session = session
+
+    def __enter__(self):
+        self._old = _Mode.session
+        _Mode.session = self.session
+
+    def __exit__(self, *exc):
+        _Mode.session = self._old
+        return False
+
+
+def _model_forward(self, *args, **kwargs):
+    sess = _Mode.session
+    if sess is not None and len(args) == 1 and not kwargs:
+        out = sess.forward_override(self, args[0])
+        if out is not None:
+            return out
+    return self._hf_stock_model_forward(*args, **kwargs)
+
+
 def _install_engine_hooks(model):
     if getattr(model, "_hf_engine_hooks", False):
         return
@@ -962,6 +1014,8 @@ def _install_engine_hooks(model):
         if isinstance(m, (nn.MaxPool2d, nn.AdaptiveAvgPool2d, nn.Linear, nn.Flatten)):
             m.register_forward_hook(_record_io)
     model.register_forward_hook(_tag_output)
+    model._hf_stock_model_forward = model.forward
+    model.forward = types.MethodType(_model_forward, model)
     model._hf_engine_hooks = True
 
 

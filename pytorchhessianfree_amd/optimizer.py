@@ -332,9 +332,11 @@ class HessianFree(torch.optim.Optimizer):
         return sess, self._reduce_scalar(a)
 
     def _session_step_local(self, forward):
+        from .modelprep import session_forward
         from .session import EngineSession
 
-        loss, outputs = forward()
+        with session_forward(self._session):  # (an existing session answers the model's forward pass)
+            loss, outputs = forward()
         if not isinstance(outputs, torch.Tensor) or loss.grad_fn is None:
             self._session_off = True
             return None, None, None
@@ -477,13 +479,15 @@ class HessianFree(torch.optim.Optimizer):
         per ``acc_step`` (one all-reduce for all lists), not once per product: the
         counts are constants of the step, and reading them back inside ``mvp`` would
         put a second collective and a host sync into every PCG iteration."""
-        distinct = {id(dl): dl for dl in datalists}
-        local = [float(sum(targets.shape[0] for _, targets in dl)) for dl in distinct.values()]
+        # one entry per ARGUMENT (loss, gradient, curvature list), whether or not some of them are
+        # the same object: every rank then reduces a vector of the same length even if the ranks
+        # alias their lists differently
+        local = [float(sum(targets.shape[0] for _, targets in dl)) for dl in datalists]
         if self._acc_comm is not None:
             t = torch.tensor(local, dtype=torch.float64, device=self.device)
             torch.distributed.all_reduce(t, group=self._acc_comm)
             local = t.tolist()
-        self._acc_counts = dict(zip(distinct.keys(), local))
+        self._acc_counts = {id(dl): cnt for dl, cnt in zip(datalists, local)}
 
     def _total_count(self, datalist):
         count = self._acc_counts.get(id(datalist))

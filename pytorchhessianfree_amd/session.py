@@ -145,15 +145,42 @@ class EngineSession:
         return spec
 
     # ---- per step ------------------------------------------------------------------------
+    def forward_override(self, model, x):
+        """The model's forward pass answered by the session (``modelprep.session_forward``): new
+        batch + current parameters -> every static buffer of the engine, ONE graph replay; returns
+        the logits as a leaf that requires grad, or ``None`` when this call is not the session's
+        (another model / shape / mode) and the model must run itself."""
+        eng = self.engine
+        if (model is not eng.model_ref or model.training or not torch.is_grad_enabled()
+                or not isinstance(x, torch.Tensor) or tuple(x.shape) != tuple(eng.x_in.shape)
+                or x.dtype != torch.float32 or x.device != eng.x_in.device
+                or eng._flat_params is None or eng._flat_params.data_ptr() != eng.params[0].data_ptr()):
+            return None
+        with torch.no_grad():
+            eng.set_batch(x.detach())
+            self.g_wT.replay()
+            self.g_fwd.replay()
+            out = eng.logits.clone()
+        out.requires_grad_(True)
+        self._override_out = out
+        return out
+
     def begin_step(self, outputs, spec):
         """New batch + current parameters: refresh every static buffer of the engine (input, im2col,
         weights in kernel layout, activations, ReLU masks, pooling positions, probabilities) and
         return the session's own loss value as a 0-dim device tensor."""
         eng = self.engine
         with torch.no_grad():
-            eng.set_batch(getattr(outputs, "_hf_input").detach(), spec["targets"])
-            self.g_wT.replay()
-            self.g_fwd.replay()
+            if outputs is getattr(self, "_override_out", None):
+                # the forward pass of this very batch was the session's own replay: only the
+                # targets are new
+                eng.set_targets(spec["targets"])
+                eng._loss_head()
+            else:
+                eng.set_batch(getattr(outputs, "_hf_input").detach(), spec["targets"])
+                self.g_wT.replay()
+                self.g_fwd.replay()
+        self._override_out = None
         self._cache = {}
         self.steps += 1
         return eng.loss_buf

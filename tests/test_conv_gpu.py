@@ -115,3 +115,42 @@ def test_bad_geometry_is_refused():
     rc = lib.hf_conv2d_nhwc(0, p(x.data_ptr()), p(x.data_ptr()), p(x.data_ptr()), 1, 4, 4, 4, 4, 3, 3, 1, 1,
                             1, 1, 0, p(ws.data_ptr()), ws.numel() * 4, p(tk.data_ptr()), tk.numel(), 0, 1, None)
     assert rc == -1
+
+
+def test_weight_slice_of_a_wider_buffer():
+    """``mat_ld``: the weights are the first-C-channels slice of a wider [K][R][S][2C] buffer -- the W half
+    of the tangent sweep's [W | v_W] operand, which the engine's own forward pass reads in place."""
+    n, h, w_, c, k = 4, 6, 6, 16, 24
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = _cl(torch.randn(n, c, h, w_, device=DEV, generator=gen))
+    wcat = _cl(torch.randn(k, 2 * c, 3, 3, device=DEV, generator=gen))
+    sp = _lib.conv_plan(0, n, h, w_, c, k, 3, 3, (1, 1), (1, 1))
+    out = torch.empty((sp, n * h * w_ * k), device=DEV)
+    _lib.conv2d_nhwc_slabs(0, out, x, wcat, n, h, w_, c, k, 3, 3, (1, 1), (1, 1), sp, mat_ld=2 * c)
+    y = out.sum(0).view(n, h, w_, k).permute(0, 3, 1, 2)
+    want = torch.nn.functional.conv2d(x.double(), wcat[:, :c].double(), None, 1, 1)
+    assert float((y.double() - want).abs().max() / want.abs().max()) < 2e-5
+
+
+def test_more_output_tiles_than_tickets_runs_unsplit():
+    """A large batch of large maps: 9216 row tiles against 8192 ticket counters.  Such a launch needs no
+    K split (and draws no tickets): it must run, not be refused -- and the patched layer's forward
+    must work for it (own kernel or MIOpen, never an exception)."""
+    n, h, w_, c, k = 64, 96, 96, 8, 8
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    x = _cl(torch.randn(n, c, h, w_, device=DEV, generator=gen))
+    w = _cl(torch.randn(k, c, 3, 3, device=DEV, generator=gen))
+    y = _cl(torch.empty(n, k, h, w_, device=DEV))
+    _lib.conv2d_nhwc(0, y, x, w, n, h, w_, c, k, 3, 3, (1, 1), (1, 1))
+    want = torch.nn.functional.conv2d(x, w, None, 1, 1)
+    assert float((y - want).abs().max() / want.abs().max()) < 2e-5
+    from pytorchhessianfree_amd import modelprep
+
+    conv = torch.nn.Conv2d(c, k, 3, 1, 1, bias=False).to(DEV)
+    net = torch.nn.Sequential(conv)
+    modelprep.fuse_conv_tangent(net, channels_last=True)
+    got = net(x)
+    ref = torch.nn.functional.conv2d(x.double(), conv.weight.detach().double(), None, 1, 1)
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    (g,) = torch.autograd.grad(got.sum(), conv.weight)
+    assert torch.isfinite(g).all()

@@ -1,0 +1,190 @@
+"""GPU: the persistent engine session (``pytorchhessianfree_amd.session``) -- one fused curvature
+engine and its hipGraphs kept across ``HessianFree.step()`` calls, the forward pass / gradient /
+trial losses of LM damping, CG-backtracking and the line search as graph replays on static buffers
+(reference ``/root/reference/hessianfree/optimizer.py:216-234, :288-350``).
+
+Oracle: the CPU path -- stock model, torch autograd, and the host logic with ``oracle.pcg`` (the
+reference's PCG restated, pinned bit for bit by tests/golden/make_golden.py) plugged in.  Stated fp32
+tolerances are written at the assertions."""
+
+import warnings
+
+import pytest
+import torch
+
+import pytorchhessianfree_amd as hf
+from pytorchhessianfree_amd import curvature, modelprep
+from pytorchhessianfree_amd import testproblems as tp
+from pytorchhessianfree_amd.session import EngineSession
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SEEDS = tp.RESNET18_B32_SEPARATED_SEEDS
+
+
+def _prepared(batch=32, seed=SEEDS[0]):
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=batch, device=DEV, data_seed=seed)
+    modelprep.prepare_model(model, channels_last=True)
+    return model, x, t, lossf
+
+
+def _cpu_reference(batch=32, seed=SEEDS[0]):
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=batch, device="cpu", data_seed=seed)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    loss = lossf(out, t)
+    grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, params)])
+    return out.detach(), float(loss), grad
+
+
+def test_engine_forward_loss_and_gradient_match_cpu_reference():
+    """The engine's own forward pass (own kernels on static buffers), its loss value and its
+    one-sweep gradient against stock torch autograd on the CPU: logits 2e-6 (max-norm relative),
+    loss 1e-6, gradient 2e-6."""
+    model, x, t, lossf = _prepared()
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    sess = EngineSession.try_create(lossf(out, t), out, params)
+    assert sess is not None
+    want_out, want_loss, want_grad = _cpu_reference()
+    eng = sess.engine
+    assert float((eng.logits.cpu() - want_out).abs().max() / want_out.abs().max()) < 2e-6
+    assert abs(float(eng.loss_buf) - want_loss) <= 1e-6 * abs(want_loss)
+    got = sess.gradient().cpu()
+    assert float((got - want_grad).abs().max() / want_grad.abs().max()) < 2e-6
+    # a second replay of everything is bitwise the same
+    first = sess.gradient().clone()
+    sess.g_fwd.replay()
+    assert torch.equal(sess.gradient(), first)
+
+
+def test_session_refreshes_for_new_batch_and_new_parameters():
+    """``begin_step`` with another batch and perturbed parameters: loss, gradient and GGN product of
+    the SAME session equal those of a freshly built autograd operator (5e-6 / 2e-6 / 2e-6)."""
+    model, x, t, lossf = _prepared()
+    opt = hf.HessianFree(model.parameters(), graph_matvec=True)
+    opt._ensure_arena()  # parameters become views of one flat vector (what step() does first)
+    params = opt._params_list
+    out = model(x)
+    sess = EngineSession.try_create(lossf(out, t), out, params)
+    assert sess is not None
+    del out
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    with torch.no_grad():
+        for p in params:
+            if p.dim() > 1:  # (BatchNorm scales stay positive)
+                p.add_(0.02 * p.abs().mean() * torch.randn(p.shape, device=DEV, generator=gen))
+    _, (x2, t2), _ = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=SEEDS[1])
+    out2 = model(x2)
+    loss2 = lossf(out2, t2)
+    spec = sess.accepts(loss2, out2, params, 1.0, None)
+    assert spec is not None
+    own = sess.begin_step(out2, spec)
+    assert abs(float(own) - float(loss2)) <= 5e-6 * abs(float(loss2))
+    want_grad = curvature.flatten_into(torch.autograd.grad(loss2, params, retain_graph=True), params)
+    assert float((sess.gradient() - want_grad).abs().max() / want_grad.abs().max()) < 2e-6
+    v = torch.randn(sess.n, device=DEV, generator=gen)
+    want = curvature.GGNOperator(loss2, out2, params)(v)
+    assert float((sess(v) - want).abs().max() / want.abs().max()) < 2e-6
+
+
+def _run_steps(device, steps, session=True):
+    from oracle import pcg as oracle
+
+    model, _, lossf = tp.resnet18_mnist(batch_size=32, device=device, data_seed=SEEDS[0])
+    if device != "cpu":
+        modelprep.prepare_model(model, channels_last=True)
+    opt = hf.HessianFree(model.parameters(), graph_matvec=(device != "cpu"))
+    if device == "cpu":
+        opt._cg = oracle.pcg
+    if not session:
+        opt._session_off = True
+    finals = []
+    for i in range(steps):
+        _, (x, t), _ = tp.resnet18_mnist(batch_size=32, device=device, data_seed=SEEDS[i])
+
+        def forward():
+            out = model(x)
+            return lossf(out, t), out
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            finals.append(opt.step(forward))
+    return opt, finals
+
+
+def test_session_steps_match_reference_cpu_path():
+    """THREE consecutive default ``HessianFree.step()`` calls on fresh batches (config 2 of
+    BASELINE.json, N = 11 175 370) with the persistent session against the CPU path (stock model,
+    reference-order PCG): the session must serve steps 2 and 3 without being rebuilt.  Stated
+    tolerance: initial losses 1e-5 (steps 2+ start from fp32-different parameters), learning rates,
+    damping schedule and termination reasons identical, iteration counts +-2, final losses 1e-4."""
+    gpu, g_final = _run_steps(DEV, 3)
+    assert gpu._session is not None and gpu._session.steps == 3
+    cpu, c_final = _run_steps("cpu", 3)
+    sg, sc = gpu.state, cpu.state
+    for a, b in zip(sg["init_losses"], sc["init_losses"]):
+        assert abs(a - b) <= 1e-5 * abs(b)
+    assert sg["cg_reasons"] == sc["cg_reasons"]
+    assert sg["learning_rates"] == sc["learning_rates"]
+    assert sg["dampings"] == sc["dampings"]
+    for a, b in zip(sg["num_cg_iters"], sc["num_cg_iters"]):
+        assert abs(a - b) <= 2
+    for a, b in zip(g_final, c_final):
+        assert abs(a - b) <= 1e-4 * abs(b)
+
+
+def test_session_equals_generic_path_and_is_faster_to_restart():
+    """Session vs this package's generic path (engine rebuilt + re-captured every step, eager trial
+    forwards): same iteration counts, learning rates, damping schedule.  The first step's losses agree
+    to 1e-6; later steps start from parameters that differ like any two fp32 runs (back-tracking picks
+    between iterates whose losses tie to 1e-6): 1e-3."""
+    a, fa = _run_steps(DEV, 3, session=True)
+    b, fb = _run_steps(DEV, 3, session=False)
+    assert a._session is not None and b._session is None
+    assert a.state["num_cg_iters"] == b.state["num_cg_iters"]
+    assert a.state["learning_rates"] == b.state["learning_rates"]
+    assert a.state["dampings"] == b.state["dampings"]
+    assert abs(a.state["init_losses"][0] - b.state["init_losses"][0]) <= 1e-6 * abs(b.state["init_losses"][0])
+    assert abs(fa[0] - fb[0]) <= 1e-5 * abs(fb[0])
+    for x, y in zip(a.state["init_losses"] + fa, b.state["init_losses"] + fb):
+        assert abs(x - y) <= 1e-3 * abs(y)
+
+
+def test_session_is_refused_for_other_losses_and_models():
+    """A loss that is not a plain softmax cross-entropy (label smoothing), a batch whose shape
+    changed, and a model the engine does not cover all fall back to the generic path -- and
+    still step correctly."""
+    model, x, t, _ = _prepared(batch=8)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    smooth = torch.nn.CrossEntropyLoss(label_smoothing=0.1)
+    assert EngineSession.try_create(smooth(out, t), out, params) is None
+    # shape change between steps: the session is rebuilt, not reused
+    opt = hf.HessianFree(model.parameters(), graph_matvec=True, cg_max_iter=8)
+    lossf = torch.nn.CrossEntropyLoss()
+    for batch in (8, 4):
+        _, (xb, tb), _ = tp.resnet18_mnist(batch_size=batch, device=DEV, data_seed=SEEDS[2])
+
+        def forward():
+            o = model(xb)
+            return lossf(o, tb), o
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            final = opt.step(forward)
+        assert final < opt.state["init_losses"][-1]
+        assert opt._session is not None and tuple(opt._session.engine.x_in.shape)[0] == batch
+    # a plain MLP: no engine, generic path
+    mlp, (xm, tm), lm = tp.mwe_mlp(device=DEV)
+    opt = hf.HessianFree(mlp.parameters(), graph_matvec=True)
+
+    def fwd():
+        o = mlp(xm)
+        return lm(o, tm), o
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        opt.step(fwd)
+        opt.step(fwd)
+    assert opt._session is None
