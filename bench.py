@@ -45,6 +45,9 @@ def parse():
                     help="Tikhonov damping; 1e-3 keeps all 250 iterations numerically alive "
                          "(with 1.0 this random-init problem converges to fp32 round-off in ~15)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--watchdog", type=float, default=900.0,
+                    help="multi-rank runs: seconds after which a rank that is still waiting (a peer died, a "
+                         "collective hangs) dumps its stack and exits non-zero instead of blocking for good")
     ap.add_argument("--no-step-timing", action="store_true",
                     help="skip the `step_ms` leg (complete default HessianFree.step() calls)")
     ap.add_argument("--cpu-iters", type=int, default=120)
@@ -427,15 +430,24 @@ def main():
             for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"),
                              ("MASTER_PORT", str(free_port))):
                 os.environ.setdefault(key, val)
+        # every wait of this process is bounded: collectives issued through torch.distributed by the
+        # group's timeout, everything else (direct RCCL calls drained by a stream synchronisation) by a
+        # wall-clock watchdog that dumps the stacks and ends the process with a non-zero code -- the
+        # launcher above then ends the sibling ranks; nothing is ever re-exec'ed
+        import datetime
+        import faulthandler
+
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
+        limit = datetime.timedelta(seconds=args.watchdog)
         # (gloo and RCCL print connection banners on fd 1: stdout carries the ONE JSON line only)
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
             if args.backend == "nccl":
-                dist.init_process_group("nccl", device_id=device)
+                dist.init_process_group("nccl", device_id=device, timeout=limit)
             else:
-                dist.init_process_group(args.backend)
+                dist.init_process_group(args.backend, timeout=limit)
             dist.barrier()
         finally:
             sys.stdout.flush()
@@ -461,8 +473,14 @@ def main():
         del probe
         # policy: the two-graph overlap costs ~0.2 ms per product on its own,
         # so it is only worth switching on when the exposed all-reduce is slower than that
+        # ... and only for the AUTOGRAD operator: the fused engine keeps its own path (engine product
+        # graph -> compact all-reduce -> K1-K3 graph) whatever the collective costs, so that a
+        # functional multi-rank run on one device (slow gloo) exercises exactly what an 8-GPU RCCL run
+        # takes; `--overlap 1` forces the two-graph autograd split
+        engine_on = "engine" in getattr(op, "mode", "")
         if args.overlap < 0:
-            args.overlap = int(world > 1 and allreduce_ms > 0.6 and bool(args.graph) and not hessian)
+            args.overlap = int(world > 1 and allreduce_ms > 0.6 and bool(args.graph) and not hessian
+                               and not engine_on)
         if args.overlap and not isinstance(op, curvature.OverlappedGraphedOperator):
             del op
             op, grad, diag, n = build_operator(bool(args.channels_last), overlap=True)
@@ -613,6 +631,9 @@ def main():
     if group is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+        import faulthandler
+
+        faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":
