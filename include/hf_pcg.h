@@ -239,7 +239,8 @@ int hf_axpy_out(void* out, const void* a, const void* s, double alpha, int64_t n
  * ours, differentiates through on every GGN product, optimizer.py:461) issues ~16
  * small kernels per layer, plus 2 per add and 2 per ReLU; these two entry points are
  * the whole group in one launch each.
- *   hf_chan_affine    : t   = a*(w*rstd) + xhat*q + r + add      (a,q,r,add,w nullable)
+ *   hf_chan_affine    : t   = a*(w*rstd) + xhat*q + r + add      (a,q,r,add,w nullable; rstd == NULL
+ *                       means 1: a convolution + bias layer without BatchNorm, then q must be NULL)
  *                       out = relu_self ? max(t,0) : mask_src ? (mask_src>0 ? t : 0) : t
  *   hf_chan_affine_bwd: g = mask_src ? (gy+gy2)*(mask_src>0) : gy+gy2 ;
  *                       gx = g*w*rstd, gw = sum_{n,hw} g*xhat, gb = sum g, gres = g
@@ -482,6 +483,15 @@ int hf_linear_ce_head(void* g_feat, void* g_w, void* g_b, const void* t_feat, co
                       const void* v_w, const void* v_b, const void* p, double scale, int64_t rows,
                       int64_t features, int64_t classes, int dtype, void* stream);
 int hf_linear_ce_head_slabs(int64_t rows);
+/*
+ * hf_pool_ce_head: the head of a network that ends in global average pooling (All-CNN-C,
+ * examples/example_utils.py:59-83: logits = mean over the last map), inside J^T H_L J v, one launch:
+ *   Jv[n,k] = mean_hw t[n,hw,k];  HJv = scale * p * (Jv - <p, Jv>);  g[n,hw,k] = HJv[n,k] / hw
+ * t, g NHWC [n, hw, k]; p = softmax(logits) [n, k].  jv_out (nullable) receives Jv.  One workgroup per
+ * sample.  Replaced: a mean reduction, hf_softmax_ce_hvp, a division and a broadcast copy.
+ */
+int hf_pool_ce_head(void* g, void* jv_out, const void* t, const void* p, double scale, int64_t n, int64_t hw,
+                    int64_t k, int dtype, void* stream);
 
 /* ---- RCCL (resolved at run time from the already-loaded librccl) ----------- */
 typedef struct hf_comm hf_comm_t;

@@ -138,6 +138,7 @@ SIGNATURES = {
                                 + [c_int64] * 12 + [c_int, c_void_p]),
     "hf_linear_ce_head": (c_int, [c_void_p] * 9 + [c_double, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "hf_linear_ce_head_slabs": (c_int, [c_int64]),
+    "hf_pool_ce_head": (c_int, [c_void_p] * 4 + [c_double, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "hf_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "hf_comm_create": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_char_p, c_int, c_int]),
     "hf_comm_destroy": (c_int, [c_void_p]),

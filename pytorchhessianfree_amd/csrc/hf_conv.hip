@@ -40,14 +40,40 @@ constexpr int CT = 256;            // threads per block
 #ifndef HF_CONV_BK
 #define HF_CONV_BK 32
 #endif
-constexpr int BM = 64, BN = 64, BK = HF_CONV_BK;  // (BK = 64 measured the same: these kernels are latency-, not issue-bound)
-constexpr int KQ = BK / 4;          // float4 per row of a k-contiguous tile
-constexpr int RPT = CT / KQ;        // NT: rows covered per pass of the staging threads
-constexpr int NU = BM / RPT;        // NT: passes (float4 per thread and operand)
-constexpr int HK = BK / 2;          // k per lane half
-constexpr int LDK = BK + 4;        // NT: LDS row stride (floats): 16-B aligned, conflict-free b128 reads
-constexpr int LDT = BM + 4;        // TN: LDS row stride
 constexpr int MAX_TAPS = 64;
+
+// Tile configuration: 4 waves as WM x WN, each wave owns TM x TN MFMA tiles of 32x32 (block tile
+// 32*WM*TM x 32*WN*TN), BK reduction elements per step.  Three configurations are built:
+//   Small (2x2 waves, 1x1 tiles, BK 32): 64x64 -- the latency-bound small-map problems of the ResNet-18
+//     product (a few K-steps per workgroup; BK = 64 measured the same);
+//   Big   (2x2 waves, 2x2 tiles, BK 16): 128x128, four accumulators per wave -- problems with thousands
+//     of GEMM rows (All-CNN-C, ResNet-50-size maps), where the 64x64 kernel is issue-bound: per K-step
+//     it feeds 16 MFMAs per wave from 2+2 staged float4 per thread, this one 32 MFMAs from the same 2+2;
+//   Big96 (4x1 waves, 1x3 tiles, BK 16): 128x96 -- the same for column counts that are multiples of 96
+//     (All-CNN-C's 96 / 192 channels would waste a quarter of every 128-wide tile).  Staged like Big
+//     (128 LDS rows per operand, the last 32 of B unused).
+// All stage 2 + 2 float4 per thread and step, so the hand-counted prefetch ring below is shared.
+template <int WM_, int WN_, int TM_, int TN_, int BK_>
+struct Cfg {
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, BK = BK_;
+  static constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+  static constexpr int SM = (BM + 63) / 64 * 64, SN = (BN + 63) / 64 * 64;  // staged rows / columns per operand
+  static constexpr int KQ = BK / 4;          // float4 per row of a k-contiguous tile
+  static constexpr int RPT = CT / KQ;        // NT: rows covered per pass of the staging threads
+  static constexpr int HK = BK / 2;          // k per lane half
+  static constexpr int LDK = BK + 4;         // NT: LDS row stride (floats): 16-B aligned, conflict-free b128 reads
+  static constexpr int LDA = SM + 4, LDB = SN + 4;  // TN: LDS row strides
+  static constexpr int NT_FLOATS = 2 * (SM + SN) * LDK;
+  static constexpr int TN_FLOATS = 2 * BK * (LDA + LDB);
+  static constexpr int LDS_FLOATS = (NT_FLOATS > TN_FLOATS ? NT_FLOATS : TN_FLOATS) + 4;  // + the last-arriver flag
+  static_assert(WM * WN == 4, "four waves");
+  static_assert(SM / RPT == 2 && SN / RPT == 2, "the hand-counted prefetch ring assumes 2 + 2 loads per step (NT)");
+  static_assert(SM == SN, "both operands are staged at the same width");
+  static_assert(LDS_FLOATS * 4 <= 64 * 1024, "static LDS limit");
+};
+typedef Cfg<2, 2, 1, 1, HF_CONV_BK> Small;
+typedef Cfg<2, 2, 2, 2, 16> Big;
+typedef Cfg<4, 1, 1, 3, 16> Big96;
 
 struct ConvArgs {
   const float* src;    // gathered activations (F: X, D: dY, W: X)
@@ -74,6 +100,7 @@ struct ConvArgs {
   int out_c;           // W: channels of X that get an output column (<= cs: X may be zero-padded)
   int slabs;           // 1: split s writes its partial result, in the output's own layout, to
   long long slab_stride;  //    out + s*slab_stride; the CONSUMER kernel sums the slabs in its prologue
+  int big;             // tile configuration this problem was set up for (0: Small, 1: Big, 2: Big96)
 };
 
 // Pixel index into the gathered tensor for row coordinates (n, y, x) and tap (r, q); `valid` is
@@ -121,30 +148,43 @@ __device__ __forceinline__ float4 ldg4s(const float* p, int valid) {
   return v;
 }
 
-// Last-arriver reduction of the split-K partials of one 64x64 tile (fixed order).
-__device__ __forceinline__ void finish_tile(const ConvArgs& a, const f32x16& acc, int tile, int split,
+// Last-arriver reduction of the split-K partials of one block tile (fixed order).  The wave at
+// (wm, wn) holds TM x TN MFMA tiles: tile (im, in) covers rows wm*32*TM + im*32 .., cols likewise.
+template <typename C>
+__device__ __forceinline__ void finish_tile(const ConvArgs& a, const f32x16 (&acc)[C::TM][C::TN], int tile, int split,
                                             int wm, int wn, int lane, float* out_tile_base,
                                             int row0, int col0, int row_lim, int col_lim, int ldc,
                                             int* flag_lds) {
+  constexpr int BM = C::BM, BN = C::BN;
   const int i = lane & 31, h = lane >> 5;
   if (a.splits == 1 || a.slabs) {
     float* dst = out_tile_base + (a.slabs ? (size_t)split * (size_t)a.slab_stride : 0);
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h, col = wn * 32 + i;
-      if (row0 + row < row_lim && col0 + col < col_lim)
-        dst[(size_t)(row0 + row) * ldc + col0 + col] = acc[reg];
-    }
+    for (int im = 0; im < C::TM; ++im)
+#pragma unroll
+      for (int in = 0; in < C::TN; ++in)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = (wm * C::TM + im) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          const int col = (wn * C::TN + in) * 32 + i;
+          if (row0 + row < row_lim && col0 + col < col_lim)
+            dst[(size_t)(row0 + row) * ldc + col0 + col] = acc[im][in][reg];
+        }
     return;
   }
   const int tiles = a.tiles_m * a.tiles_n;
   float* mine = a.ws + ((size_t)split * tiles + tile) * (BM * BN);
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int row = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h, col = wn * 32 + i;
-    // write-through (sc1) store: visible device-wide once drained, no release fence needed
-    __hip_atomic_store(mine + row * BN + col, acc[reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  for (int im = 0; im < C::TM; ++im)
+#pragma unroll
+    for (int in = 0; in < C::TN; ++in)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = (wm * C::TM + im) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        const int col = (wn * C::TN + in) * 32 + i;
+        // write-through (sc1) store: visible device-wide once drained, no release fence needed
+        __hip_atomic_store(mine + row * BN + col, acc[im][in][reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
   // publish (cdna_hip_programming.md, in-launch split-K reduction, write-through form):
   // every wave drains its sc1 stores, ONE lane draws the ticket; the last arriver's lane 0
   // acquires once (drops stale lines), then all its waves read the slabs with plain loads
@@ -192,14 +232,15 @@ __device__ __forceinline__ void finish_tile(const ConvArgs& a, const f32x16& acc
 // ---------------------------------------------------------------------------------
 // NT kernel: F and D.   out[m][j] = sum_{tap, c} src[pix(m,tap)][c] * mat[j][tap][c]
 // ---------------------------------------------------------------------------------
-constexpr int LDS_FLOATS = 2 * 2 * BM * LDK + 4;  // NT: As + Bs (double-buffered) + the last-arriver flag
-
-template <bool SCALAR>
+template <bool SCALAR, typename C>
 __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int bid) {
-  float (*As)[BM][LDK] = reinterpret_cast<float (*)[BM][LDK]>(lds);
-  float (*Bs)[BN][LDK] = reinterpret_cast<float (*)[BN][LDK]>(lds + 2 * BM * LDK);
-  int& flag = *reinterpret_cast<int*>(lds + 4 * BM * LDK);
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  constexpr int BM = C::BM, BN = C::BN, BK = C::BK, KQ = C::KQ, RPT = C::RPT, HK = C::HK, LDK = C::LDK;
+  constexpr int NU = 2;
+  constexpr int SM = C::SM, SN = C::SN;
+  float (*As)[SM][LDK] = reinterpret_cast<float (*)[SM][LDK]>(lds);
+  float (*Bs)[SN][LDK] = reinterpret_cast<float (*)[SN][LDK]>(lds + 2 * SM * LDK);
+  int& flag = *reinterpret_cast<int*>(lds + C::LDS_FLOATS - 4);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / C::WN, wn = wave % C::WN;
   const int tile_n = bid % a.tiles_n; bid /= a.tiles_n;
   const int tile_m = bid % a.tiles_m;
   const int split = bid / a.tiles_m;
@@ -227,7 +268,7 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int j = tile_n * BN + lr + RPT * u;
-    bok[u] = j < a.nout;
+    bok[u] = (j < a.nout) & (lr + RPT * u < BN);  // (rows past BN belong to the next column tile)
     brow[u] = a.mat + (size_t)(bok[u] ? j : 0) * RS * a.mat_ld;
   }
 
@@ -251,13 +292,8 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
       const bool vb = cok & bok[u];
       const float* pa = a.src + (va ? (size_t)pix * a.cs_ld + c : 0);
       const float* pb = vb ? brow[u] + (size_t)(r * a.S + q) * a.mat_ld + c : a.mat;
-      if (SCALAR) {
-        ra[u] = ldg4s(pa, va ? a.cs - c : 0);
-        rb[u] = ldg4s(pb, vb ? a.cs - c : 0);
-      } else {
-        ra[u] = ldg4(pa);
-        rb[u] = ldg4(pb);
-      }
+      ra[u] = ldg4s(pa, va ? a.cs - c : 0);
+      rb[u] = ldg4s(pb, vb ? a.cs - c : 0);
       ok |= (va ? 1u : 0u) << (2 * u) | (vb ? 2u : 0u) << (2 * u);
     }
     return ok;
@@ -271,30 +307,52 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
     }
   };
 
-  f32x16 acc;
+  f32x16 acc[C::TM][C::TN];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int im = 0; im < C::TM; ++im)
+#pragma unroll
+    for (int in = 0; in < C::TN; ++in)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[im][in][r] = 0.f;
   const int i = lane & 31, h = lane >> 5;
   auto compute = [&](int cur) {
-    const float* ap = &As[cur][wm * 32 + i][HK * h];
-    const float* bp = &Bs[cur][wn * 32 + i][HK * h];
-    float av[HK], bv[HK];
+    float av[C::TM][HK], bv[C::TN][HK];
 #pragma unroll
-    for (int v = 0; v < HK / 4; ++v) {
-      *reinterpret_cast<float4*>(av + 4 * v) = *reinterpret_cast<const float4*>(ap + 4 * v);
-      *reinterpret_cast<float4*>(bv + 4 * v) = *reinterpret_cast<const float4*>(bp + 4 * v);
+    for (int im = 0; im < C::TM; ++im) {
+      const float* ap = &As[cur][(wm * C::TM + im) * 32 + i][HK * h];
+#pragma unroll
+      for (int v = 0; v < HK / 4; ++v)
+        *reinterpret_cast<float4*>(av[im] + 4 * v) = *reinterpret_cast<const float4*>(ap + 4 * v);
     }
 #pragma unroll
-    for (int s = 0; s < HK; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+    for (int in = 0; in < C::TN; ++in) {
+      const float* bp = &Bs[cur][(wn * C::TN + in) * 32 + i][HK * h];
+#pragma unroll
+      for (int v = 0; v < HK / 4; ++v)
+        *reinterpret_cast<float4*>(bv[in] + 4 * v) = *reinterpret_cast<const float4*>(bp + 4 * v);
+    }
+#pragma unroll
+    for (int s = 0; s < HK; ++s)
+#pragma unroll
+      for (int im = 0; im < C::TM; ++im)
+#pragma unroll
+        for (int in = 0; in < C::TN; ++in)
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[im][s], bv[in][s], acc[im][in], 0, 0, 0);
   };
-  static_assert(NU == 2, "the hand-counted prefetch ring assumes 2 + 2 loads per step");
   const int jl = j1 - 1;
   int cur = 0;
   if (!SCALAR) {
     // hand-counted ring: always three steps (12 loads) in flight; steps beyond the split's range
     // re-fetch step j1-1 and are never written to LDS, so the count at every wait is 8
+    // steps are fetched in increasing order (the clamped re-fetches at the end repeat the last
+    // one): the (tap, channel block) of the next fetch is kept incrementally -- no division per step
+    int f_step = j0, f_ti = j0 / csteps, f_cb = j0 - (j0 / csteps) * csteps;
     auto fetch_v = [&](int step, f32x4 (&ra)[NU], f32x4 (&rb)[NU]) -> unsigned {
-      const int ti = step / csteps, c = (step - ti * csteps) * BK + 4 * kq;
+      if (step > f_step) {  // (uniform; steps advance by one)
+        f_step = step;
+        if (++f_cb == csteps) { f_cb = 0; ++f_ti; }
+      }
+      const int ti = f_ti, c = f_cb * BK + 4 * kq;
       const int r = a.tap_r[ti], q = a.tap_s[ti];
       const bool cok = c < a.cs;
       unsigned ok = 0;
@@ -363,22 +421,21 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
     }
   }
   __syncthreads();  // the LDS array is reused below (last-arriver flag)
-  finish_tile(a, acc, tile, split, wm, wn, lane, a.out, tile_m * BM, tile_n * BN, a.rows, a.nout, a.ldc,
-              &flag);
+  finish_tile<C>(a, acc, tile, split, wm, wn, lane, a.out, tile_m * BM, tile_n * BN, a.rows, a.nout, a.ldc,
+                 &flag);
 }
 
 // ---------------------------------------------------------------------------------
 // TN kernel: W.   dW[k][tap][c] = sum_m dY[m][k] * X[pix(m,tap)][c]
-//   tile_m over k (dY channels), tile_n over (live tap, 64-channel block of X)
+//   tile_m over k (dY channels), tile_n over (live tap, BN-channel block of X)
 // ---------------------------------------------------------------------------------
-static_assert(2 * 2 * BK * LDT + 4 <= LDS_FLOATS, "TN tiles must fit the shared LDS array");
-
-template <bool SCALAR>
+template <bool SCALAR, typename C>
 __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int bid) {
-  float (*As)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(lds);
-  float (*Bs)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(lds + 2 * BK * LDT);
-  int& flag = *reinterpret_cast<int*>(lds + 4 * BK * LDT);
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+  constexpr int BM = C::BM, BN = C::BN, BK = C::BK, HK = C::HK, LDA = C::LDA, LDB = C::LDB;
+  float (*As)[BK][LDA] = reinterpret_cast<float (*)[BK][LDA]>(lds);
+  float (*Bs)[BK][LDB] = reinterpret_cast<float (*)[BK][LDB]>(lds + 2 * BK * LDA);
+  int& flag = *reinterpret_cast<int*>(lds + C::LDS_FLOATS - 4);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / C::WN, wn = wave % C::WN;
   const int tile_n = bid % a.tiles_n; bid /= a.tiles_n;
   const int tile_m = bid % a.tiles_m;
   const int split = bid / a.tiles_m;
@@ -390,18 +447,21 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
   const int ti = tile_n / cblocks, c0 = (tile_n - ti * cblocks) * BN;
   const int r = a.tap_r[ti], q = a.tap_s[ti];
 
-  // staging: thread -> rows kr, kr+16 of the step and the float4 at column 4*cq
-  const int kr = t >> 4, cq = t & 15;
+  // staging: thread -> rows kr, kr + RP of the step and the float4 at column 4*cq
+  constexpr int CQ = C::SM / 4;     // float4 per staged row (both operands are staged SM == SN wide)
+  constexpr int RP = CT / CQ;       // rows per pass
+  constexpr int TU = BK / RP;       // passes
+  static_assert(TU == 2, "the hand-counted prefetch ring assumes 2 + 2 loads per step (TN)");
+  const int kr = t / CQ, cq = t % CQ;
   const int ka = tile_m * BM + 4 * cq;  // dY channel
   const int cb = c0 + 4 * cq;           // X channel
-  const bool aok = ka < a.kout, bkok = cb < a.cs;
+  const bool aok = (ka < a.kout) & (4 * cq < BM), bkok = (cb < a.cs) & (4 * cq < BN);
 
-  constexpr int TU = BK / 16;
   auto fetch = [&](int step, float4 (&ra)[TU], float4 (&rb)[TU]) -> unsigned {
     unsigned ok = 0;
 #pragma unroll
     for (int u = 0; u < TU; ++u) {
-      const int m = step * BK + kr + 16 * u;
+      const int m = step * BK + kr + RP * u;
       const bool mok = m < a.rows;
       const int mm = mok ? m : 0;
       const int xx = mm % a.rw, tq = mm / a.rw;
@@ -411,13 +471,8 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
       const bool va = mok & aok;
       const float* pa = a.mat + (va ? (size_t)m * a.kout + ka : 0);
       const float* pb = a.src + (vb ? (size_t)pix * a.cs_ld + cb : 0);
-      if (SCALAR) {
-        ra[u] = ldg4s(pa, va ? a.kout - ka : 0);
-        rb[u] = ldg4s(pb, vb ? a.cs - cb : 0);
-      } else {
-        ra[u] = ldg4(pa);
-        rb[u] = ldg4(pb);
-      }
+      ra[u] = ldg4s(pa, va ? a.kout - ka : 0);
+      rb[u] = ldg4s(pb, vb ? a.cs - cb : 0);
       ok |= (va ? 1u : 0u) << (2 * u) | (vb ? 2u : 0u) << (2 * u);
     }
     return ok;
@@ -426,39 +481,64 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int u = 0; u < TU; ++u) {
-      *reinterpret_cast<float4*>(&As[buf][kr + 16 * u][4 * cq]) = (ok >> (2 * u)) & 1u ? ra[u] : zero;
-      *reinterpret_cast<float4*>(&Bs[buf][kr + 16 * u][4 * cq]) = (ok >> (2 * u)) & 2u ? rb[u] : zero;
+      *reinterpret_cast<float4*>(&As[buf][kr + RP * u][4 * cq]) = (ok >> (2 * u)) & 1u ? ra[u] : zero;
+      *reinterpret_cast<float4*>(&Bs[buf][kr + RP * u][4 * cq]) = (ok >> (2 * u)) & 2u ? rb[u] : zero;
     }
   };
 
-  f32x16 acc;
+  f32x16 acc[C::TM][C::TN];
 #pragma unroll
-  for (int x = 0; x < 16; ++x) acc[x] = 0.f;
+  for (int im = 0; im < C::TM; ++im)
+#pragma unroll
+    for (int in = 0; in < C::TN; ++in)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[im][in][x] = 0.f;
   const int i = lane & 31, h = lane >> 5;
   auto compute = [&](int cur) {
-    float av[HK], bv[HK];
+    float av[C::TM][HK], bv[C::TN][HK];
 #pragma unroll
     for (int s = 0; s < HK; ++s) {
-      av[s] = As[cur][HK * h + s][wm * 32 + i];
-      bv[s] = Bs[cur][HK * h + s][wn * 32 + i];
+#pragma unroll
+      for (int im = 0; im < C::TM; ++im) av[im][s] = As[cur][HK * h + s][(wm * C::TM + im) * 32 + i];
+#pragma unroll
+      for (int in = 0; in < C::TN; ++in) bv[in][s] = Bs[cur][HK * h + s][(wn * C::TN + in) * 32 + i];
     }
 #pragma unroll
-    for (int s = 0; s < HK; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+    for (int s = 0; s < HK; ++s)
+#pragma unroll
+      for (int im = 0; im < C::TM; ++im)
+#pragma unroll
+        for (int in = 0; in < C::TN; ++in)
+          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[im][s], bv[in][s], acc[im][in], 0, 0, 0);
   };
-  static_assert(TU == 2, "the hand-counted prefetch ring assumes 2 + 2 loads per step");
   const int jl = j1 - 1;
   int cur = 0;
   if (!SCALAR) {
+    // the rows of consecutive steps advance by BK: (n, y, x) of each staged row is kept
+    // incrementally (the per-step divisions were ~300 VALU instructions per thread and step)
+    int f_step = j0, fn_[TU], fy_[TU], fx_[TU];
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const int m = j0 * BK + kr + RP * u;
+      const int xx = m % a.rw, tq = m / a.rw;
+      fx_[u] = xx; fy_[u] = tq % a.rh; fn_[u] = tq / a.rh;
+    }
     auto fetch_v = [&](int step, f32x4 (&ra)[TU], f32x4 (&rb)[TU]) -> unsigned {
+      if (step > f_step) {  // (uniform; steps advance by one)
+        f_step = step;
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+          fx_[u] += BK;
+          while (fx_[u] >= a.rw) { fx_[u] -= a.rw; if (++fy_[u] == a.rh) { fy_[u] = 0; ++fn_[u]; } }
+        }
+      }
       unsigned ok = 0;
 #pragma unroll
       for (int u = 0; u < TU; ++u) {
-        const int m = step * BK + kr + 16 * u;
+        const int m = step * BK + kr + RP * u;
         const bool mok = m < a.rows;
-        const int mm = mok ? m : 0;
-        const int xx = mm % a.rw, tq = mm / a.rw;
         bool vb;
-        const int pix = gather_pixel(a, tq / a.rh, tq % a.rh, xx, r, q, vb);
+        const int pix = gather_pixel(a, fn_[u], fy_[u], fx_[u], r, q, vb);
         vb = vb & mok & bkok;
         const bool va = mok & aok;
         gload4(ra[u], a.mat + (va ? (size_t)m * a.kout + ka : 0));
@@ -471,8 +551,8 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int u = 0; u < TU; ++u) {
-        *reinterpret_cast<f32x4*>(&As[buf][kr + 16 * u][4 * cq]) = (ok >> (2 * u)) & 1u ? ra[u] : zero;
-        *reinterpret_cast<f32x4*>(&Bs[buf][kr + 16 * u][4 * cq]) = (ok >> (2 * u)) & 2u ? rb[u] : zero;
+        *reinterpret_cast<f32x4*>(&As[buf][kr + RP * u][4 * cq]) = (ok >> (2 * u)) & 1u ? ra[u] : zero;
+        *reinterpret_cast<f32x4*>(&Bs[buf][kr + RP * u][4 * cq]) = (ok >> (2 * u)) & 2u ? rb[u] : zero;
       }
     };
     f32x4 a0[TU], b0[TU], a1[TU], b1[TU], a2[TU], b2[TU];
@@ -522,28 +602,40 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
   __syncthreads();
   // output element (k, tap, c) at (k*RS + tap)*cs + c: rows = k, "columns" = c within this tap
   float* base = a.out + (size_t)(r * a.S + q) * a.out_c;
-  finish_tile(a, acc, tile, split, wm, wn, lane, base, tile_m * BM, c0, a.kout, a.out_c,
-              a.R * a.S * a.out_c, &flag);
+  finish_tile<C>(a, acc, tile, split, wm, wn, lane, base, tile_m * BM, c0, a.kout, a.out_c,
+                 a.R * a.S * a.out_c, &flag);
 }
 
-template <bool SCALAR>
+template <bool SCALAR, typename C>
 __global__ __launch_bounds__(CT) void k_conv_nt(const ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  conv_nt_body<SCALAR>(a, lds, blockIdx.x);
+  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  conv_nt_body<SCALAR, C>(a, lds, blockIdx.x);
 }
 
-template <bool SCALAR>
+template <bool SCALAR, typename C>
 __global__ __launch_bounds__(CT) void k_conv_tn(const ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  conv_tn_body<SCALAR>(a, lds, blockIdx.x);
+  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  conv_tn_body<SCALAR, C>(a, lds, blockIdx.x);
 }
 
 // Data gradient AND weight gradient of one layer in ONE launch: both read the same dY,
 // neither depends on the other; the first `nblocks_d` workgroups run the NT body.
+// ANYBIG: some problem of the launch runs in the Big configuration (decided per problem, `a.big`); the
+// all-Small instantiation keeps the register allocation of the small-map launches what it was.
+template <bool ANYBIG>
 __global__ __launch_bounds__(CT) void k_conv_dw(const ConvArgs d, const ConvArgs w, int nblocks_d) {
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-  if ((int)blockIdx.x < nblocks_d) conv_nt_body<false>(d, lds, blockIdx.x);
-  else conv_tn_body<false>(w, lds, blockIdx.x - nblocks_d);
+  constexpr int LDSB = Big::LDS_FLOATS > Big96::LDS_FLOATS ? Big::LDS_FLOATS : Big96::LDS_FLOATS;
+  constexpr int LDSF = ANYBIG ? (LDSB > Small::LDS_FLOATS ? LDSB : Small::LDS_FLOATS) : Small::LDS_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  if ((int)blockIdx.x < nblocks_d) {
+    if (ANYBIG && d.big == 1) conv_nt_body<false, Big>(d, lds, blockIdx.x);
+    else if (ANYBIG && d.big == 2) conv_nt_body<false, Big96>(d, lds, blockIdx.x);
+    else conv_nt_body<false, Small>(d, lds, blockIdx.x);
+  } else {
+    if (ANYBIG && w.big == 1) conv_tn_body<false, Big>(w, lds, blockIdx.x - nblocks_d);
+    else if (ANYBIG && w.big == 2) conv_tn_body<false, Big96>(w, lds, blockIdx.x - nblocks_d);
+    else conv_tn_body<false, Small>(w, lds, blockIdx.x - nblocks_d);
+  }
 }
 
 // Up to GROUP_MAX independent convolutions (any mix of directions) in ONE launch: workgroups
@@ -558,13 +650,24 @@ struct GroupArgs {
   int n;
 };
 
+template <bool ANYBIG>
 __global__ __launch_bounds__(CT) void k_conv_group(const GroupArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  constexpr int LDSB = Big::LDS_FLOATS > Big96::LDS_FLOATS ? Big::LDS_FLOATS : Big96::LDS_FLOATS;
+  constexpr int LDSF = ANYBIG ? (LDSB > Small::LDS_FLOATS ? LDSB : Small::LDS_FLOATS) : Small::LDS_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
   int p = 0;
   while (p + 1 < g.n && (int)blockIdx.x >= g.start[p + 1]) ++p;  // (uniform)
   const int local = (int)blockIdx.x - g.start[p];
-  if (g.tn[p]) conv_tn_body<false>(g.a[p], lds, local);
-  else conv_nt_body<false>(g.a[p], lds, local);
+  const ConvArgs& a = g.a[p];
+  if (g.tn[p]) {
+    if (ANYBIG && a.big == 1) conv_tn_body<false, Big>(a, lds, local);
+    else if (ANYBIG && a.big == 2) conv_tn_body<false, Big96>(a, lds, local);
+    else conv_tn_body<false, Small>(a, lds, local);
+  } else {
+    if (ANYBIG && a.big == 1) conv_nt_body<false, Big>(a, lds, local);
+    else if (ANYBIG && a.big == 2) conv_nt_body<false, Big96>(a, lds, local);
+    else conv_nt_body<false, Small>(a, lds, local);
+  }
 }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -595,18 +698,34 @@ inline int64_t hf_env_cap() {  // tuning knob, default measured on the ResNet-18
   return cap;
 }
 
-int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_bytes, bool slabs = false) {
+inline int64_t hf_env_big_blocks() {
+  static int64_t v = 0;
+  if (v == 0) {
+    const char* e = getenv("HF_CONV_BIG_BLOCKS");
+    v = e ? atoll(e) : 768;
+    if (v < 1) v = 768;
+  }
+  return v;
+}
+
+int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_bytes, bool slabs = false,
+                  int bk = Small::BK, int64_t tile_elems = Small::BM * Small::BN) {
   int64_t best = 1;
   if (slabs && target_blocks <= 0) {
     // no in-launch reduction: a split costs its consumer one more read per element; split
     // until one workgroup per CU exists (measured in the ResNet-18 product: 256 beats 384,
     // 512 and 768 -- the prefetch ring keeps a workgroup with several steps busy) or a split
     // is down to 2 steps
-    best = (256 + tiles - 1) / tiles;
+    // The 128-wide configurations (bk == 16) run one MFMA-heavy workgroup per CU at 256: a second and
+    // third resident workgroup fill the matrix pipe while the first stages its next tile (measured on
+    // the All-CNN-C shapes, scripts/conv_kernel_bench.py --big 1: 256 / 512 / 768 workgroups ->
+    // tangent 76 / 93 / 99, data gradient 68 / 83 / 87, weight gradient 39 / 52 / 65 TFLOP/s)
+    const bool big = bk != Small::BK;
+    best = ((big ? hf_env_big_blocks() : 256) + tiles - 1) / tiles;
     if (best > steps / 2) best = steps / 2;
     // (one or two output tiles -- the stem's weight gradient: 6272 rows into a 64 x 52 matrix --
     // would leave most of the chip idle at 32 splits)
-    const int64_t cap = tiles <= 2 ? hf_env_cap() : 32;
+    const int64_t cap = tiles <= 2 ? hf_env_cap() : (big ? 128 : 32);
     if (best > cap) best = cap;
     if (best < 1) best = 1;
     while (best > 1 && ((steps + best - 1) / best) * (best - 1) >= steps) --best;
@@ -623,12 +742,12 @@ int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_by
       const int64_t per = (steps + sp - 1) / sp;
       if (sp > 1 && per * (sp - 1) >= steps) continue;  // would leave a split empty
       const double rounds = (double)(tiles * sp) / 512.0;
-      double cost = (0.6 + 0.014 * BK) * (double)per * (rounds > 1.0 ? rounds : 1.0);
+      double cost = (0.6 + 0.014 * bk) * (double)per * (rounds > 1.0 ? rounds : 1.0);
       if (sp > 1) cost += 3.0 + 0.15 * (double)sp;
       if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
     }
   }
-  while (!slabs && best > 1 && best * tiles * BM * BN * (int64_t)sizeof(float) > ws_bytes) --best;
+  while (!slabs && best > 1 && best * tiles * tile_elems * (int64_t)sizeof(float) > ws_bytes) --best;
   while (best > 1 && ((steps + best - 1) / best) * (best - 1) >= steps) --best;
   return (int)best;
 }
@@ -637,12 +756,39 @@ int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_by
 void launch_one(int direction, const ConvArgs& a, int64_t blocks, hipStream_t stream) {
   const dim3 grid((unsigned)blocks), block(CT);
   if (direction <= 1) {
-    if (a.scalar) hipLaunchKernelGGL(k_conv_nt<true>, grid, block, 0, stream, a);
-    else hipLaunchKernelGGL(k_conv_nt<false>, grid, block, 0, stream, a);
+    if (a.scalar) hipLaunchKernelGGL((k_conv_nt<true, Small>), grid, block, 0, stream, a);
+    else if (a.big == 1) hipLaunchKernelGGL((k_conv_nt<false, Big>), grid, block, 0, stream, a);
+    else if (a.big == 2) hipLaunchKernelGGL((k_conv_nt<false, Big96>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_conv_nt<false, Small>), grid, block, 0, stream, a);
   } else {
-    if (a.scalar) hipLaunchKernelGGL(k_conv_tn<true>, grid, block, 0, stream, a);
-    else hipLaunchKernelGGL(k_conv_tn<false>, grid, block, 0, stream, a);
+    if (a.scalar) hipLaunchKernelGGL((k_conv_tn<true, Small>), grid, block, 0, stream, a);
+    else if (a.big == 1) hipLaunchKernelGGL((k_conv_tn<false, Big>), grid, block, 0, stream, a);
+    else if (a.big == 2) hipLaunchKernelGGL((k_conv_tn<false, Big96>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_conv_tn<false, Small>), grid, block, 0, stream, a);
   }
+}
+
+// Which tile configuration a problem runs in: a pure function of its geometry (hf_conv2d_nhwc_plan and
+// every launch path must agree).  Big (128x128) needs both output dimensions to fill most of a tile
+// and enough GEMM rows that the 64x64 kernel would be issue-bound; HF_CONV_BIG=0/1 forces it (tuning).
+inline int hf_env_big() {
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("HF_CONV_BIG"); v = e ? atoi(e) : -1; }
+  return v;
+}
+
+int want_big(int direction, int64_t rows, int64_t dim_m, int64_t dim_n, bool scalar) {
+  // dim_m x dim_n: the output matrix (NT: rows x nout; TN: kout x cs per tap); rows: GEMM rows of the layer.
+  // Returns 0 (Small), 1 (Big: 128x128) or 2 (Big96: 128x96), whichever wastes less of its tiles.
+  if (scalar) return 0;
+  const int force = hf_env_big();
+  if (force == 0) return 0;
+  auto fill = [](int64_t d, int64_t t) { return (double)d / (double)(((d + t - 1) / t) * t); };
+  const double f128 = fill(dim_m, 128) * fill(dim_n, 128), f96 = fill(dim_m, 128) * fill(dim_n, 96);
+  const int kind = f96 > f128 + 1e-9 ? 2 : 1;
+  const bool fits = (kind == 2 ? f96 : f128) >= 0.7;
+  if (force > 0) return fits ? kind : 0;
+  return (fits && rows >= 2048) ? kind : 0;
 }
 
 int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void* mat, int64_t n, int64_t h,
@@ -694,6 +840,10 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
   a.mat_ld = (int)(mat_ld > 0 ? mat_ld : a.cs);
   a.scalar = ((c % 4) || (k % 4) || (a.cs_ld % 4) || (a.mat_ld % 4)) ? 1 : 0;
   if (a.cs_ld < a.cs || a.mat_ld < a.cs || (mat_ld > 0 && direction == 2)) return HF_ERR_ARG;
+  a.big = direction <= 1 ? want_big(direction, rows, rows, a.nout, a.scalar)
+                         : want_big(direction, rows, a.kout, a.cs, a.scalar);
+  const int BM = a.big ? Big::BM : Small::BM, BN = a.big == 2 ? Big96::BN : a.big ? Big::BN : Small::BN;
+  const int BK = a.big ? Big::BK : Small::BK;
   if (direction <= 1) {
     a.tiles_m = (int)((rows + BM - 1) / BM);
     a.tiles_n = (a.nout + BN - 1) / BN;
@@ -708,7 +858,7 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
   if (slab_splits >= 0) {  // consumer-side reduction: no workspace, no tickets
     a.slabs = 1;
     a.slab_stride = slab_stride;
-    int sp = slab_splits > 0 ? slab_splits : choose_splits(tiles, red_steps, target_blocks, 0, true);
+    int sp = slab_splits > 0 ? slab_splits : choose_splits(tiles, red_steps, target_blocks, 0, true, BK);
     if (sp > red_steps) sp = (int)red_steps;
     while (sp > 1 && ((red_steps + sp - 1) / sp) * (sp - 1) >= red_steps) --sp;
     a.splits = sp < 1 ? 1 : sp;
@@ -716,7 +866,8 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
   }
   // more output tiles than ticket counters (large batches / maps): such a launch fills the chip
   // without a K split, and an unsplit launch draws no tickets
-  a.splits = tiles > n_tickets ? 1 : choose_splits(tiles, red_steps, target_blocks, ws_bytes);
+  a.splits = tiles > n_tickets ? 1 : choose_splits(tiles, red_steps, target_blocks, ws_bytes, false, BK,
+                                                    (int64_t)BM * BN);
   return tiles * a.splits;
 }
 
@@ -783,7 +934,8 @@ int hf_conv2d_nhwc_backward(void* dx, void* dw, const void* dy, const void* x, c
                            target_blocks);
   if (bw <= 0) return (int)bw;
   if (d.scalar || g.scalar) return HF_ERR_ARG;  // the merged launch has the 16-byte gather variant only
-  hipLaunchKernelGGL(k_conv_dw, dim3((unsigned)(bd + bw)), dim3(CT), 0, (hipStream_t)stream, d, g, (int)bd);
+  if (d.big || g.big) hipLaunchKernelGGL(k_conv_dw<true>, dim3((unsigned)(bd + bw)), dim3(CT), 0, (hipStream_t)stream, d, g, (int)bd);
+  else hipLaunchKernelGGL(k_conv_dw<false>, dim3((unsigned)(bd + bw)), dim3(CT), 0, (hipStream_t)stream, d, g, (int)bd);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }
@@ -849,7 +1001,8 @@ int hf_conv2d_nhwc_backward_slabs(void* dx, void* dw, const void* dy, const void
   if (bw <= 0) return (int)bw;
   if (d.splits != splits_d || g.splits != splits_w) return HF_ERR_ARG;
   if (d.scalar || g.scalar) return HF_ERR_ARG;  // the merged launch has the 16-byte gather variant only
-  hipLaunchKernelGGL(k_conv_dw, dim3((unsigned)(bd + bw)), dim3(CT), 0, (hipStream_t)stream, d, g, (int)bd);
+  if (d.big || g.big) hipLaunchKernelGGL(k_conv_dw<true>, dim3((unsigned)(bd + bw)), dim3(CT), 0, (hipStream_t)stream, d, g, (int)bd);
+  else hipLaunchKernelGGL(k_conv_dw<false>, dim3((unsigned)(bd + bw)), dim3(CT), 0, (hipStream_t)stream, d, g, (int)bd);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }
@@ -881,7 +1034,10 @@ int hf_conv2d_nhwc_group_slabs(const hf_conv_problem* problems, int n_problems, 
   }
   q.start[n_problems] = (int)total;
   q.n = n_problems;
-  hipLaunchKernelGGL(k_conv_group, dim3((unsigned)total), dim3(CT), 0, (hipStream_t)stream, q);
+  bool anybig = false;
+  for (int i = 0; i < n_problems; ++i) anybig = anybig || q.a[i].big;
+  if (anybig) hipLaunchKernelGGL(k_conv_group<true>, dim3((unsigned)total), dim3(CT), 0, (hipStream_t)stream, q);
+  else hipLaunchKernelGGL(k_conv_group<false>, dim3((unsigned)total), dim3(CT), 0, (hipStream_t)stream, q);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }

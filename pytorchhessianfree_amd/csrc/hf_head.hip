@@ -240,6 +240,48 @@ __global__ __launch_bounds__(HEAD_T) void k_linear_ce_head(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Head of a network ending in global average pooling, inside J^T H_L J v (one workgroup per sample):
+//   Jv[k] = mean_hw t[hw][k];  h = scale * p * (Jv - <p, Jv>);  g[hw][k] = h[k] / hw
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(HB) void k_pool_ce_head(float* __restrict__ g, float* __restrict__ jv_out,
+                                                     const float* __restrict__ t, const float* __restrict__ p,
+                                                     float scale, int HW, int K) {
+  __shared__ double red[HB / 64];
+  __shared__ float s_h[1024];
+  const int n = blockIdx.x;
+  const float* tn = t + (size_t)n * HW * K;
+  double part = 0.0;
+  float jv_mine[4];  // K <= 1024: up to 4 classes per thread
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int k = threadIdx.x + u * HB;
+    float s = 0.f;
+    if (k < K) {
+      for (int q = 0; q < HW; ++q) s += tn[(size_t)q * K + k];
+      s = s / (float)HW;
+      if (jv_out) jv_out[(size_t)n * K + k] = s;
+      part += (double)p[(size_t)n * K + k] * (double)s;
+    }
+    jv_mine[u] = s;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  double d = red[0];
+#pragma unroll
+  for (int w = 1; w < HB / 64; ++w) d += red[w];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int k = threadIdx.x + u * HB;
+    if (k < K) s_h[k] = (scale * (p[(size_t)n * K + k] * (jv_mine[u] - (float)d))) / (float)HW;
+  }
+  __syncthreads();
+  float* gn = g + (size_t)n * HW * K;
+  for (int e = threadIdx.x; e < HW * K; e += HB) gn[e] = s_h[e % K];
+}
+
 inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
@@ -315,6 +357,15 @@ int hf_linear_ce_head(void* g_feat, void* g_w, void* g_b, const void* t_feat, co
   if (ch <= 1) HF_HEAD(1);
   else HF_HEAD(2);
 #undef HF_HEAD
+  return (int)hipGetLastError();
+}
+
+int hf_pool_ce_head(void* g, void* jv_out, const void* t, const void* p, double scale, int64_t n, int64_t hw,
+                    int64_t k, int dtype, void* stream) {
+  if (dtype != HF_F32 || !g || !t || !p || n < 1 || hw < 1 || k < 1 || k > 1024) return -1;
+  if (n * hw * k >= (1LL << 31)) return -1;
+  hipLaunchKernelGGL(k_pool_ce_head, dim3((unsigned)n), dim3(HB), 0, (hipStream_t)stream, (float*)g,
+                     (float*)jv_out, (const float*)t, (const float*)p, (float)scale, (int)hw, (int)k);
   return (int)hipGetLastError();
 }
 

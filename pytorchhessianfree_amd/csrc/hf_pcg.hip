@@ -895,7 +895,7 @@ __device__ __forceinline__ void chan_affine_body(
   const I CHW = C * HW;
   for (I i = bid * BLOCK + threadIdx.x; i < total; i += nblocks * BLOCK) {
     const I c = (nhwc || HW == 1 ? i : i / HW) % C;  // NHWC: the channel is the fastest index
-    const T rs = rstd[c];
+    const T rs = rstd ? rstd[c] : (T)1;  // (no BatchNorm: conv + bias layers of plain stacks)
     T acc = (T)0;
     if (a) {
       T av = a[i];
@@ -2290,8 +2290,8 @@ int hf_chan_affine_ex(void* out, const void* a, const void* x, const void* mean,
                       int channels_last, int64_t out_ld, int64_t add_ld, int a_splits, int64_t a_slab,
                       int dtype, void* stream) {
   if (a_splits < 1 || (a_splits > 1 && (!a || a_slab <= 0))) return HF_ERR_ARG;
-  if (!out || !rstd || n <= 0 || c <= 0 || hw <= 0) return HF_ERR_ARG;
-  if (q && (!x || !mean)) return HF_ERR_ARG;
+  if (!out || n <= 0 || c <= 0 || hw <= 0) return HF_ERR_ARG;
+  if (q && (!x || !mean || !rstd)) return HF_ERR_ARG;
   // a leading dimension is that of a buffer with MORE channels: >= 2x would be the
   // tangent buffers' case, anything above the dense one is accepted
   const int64_t dense = channels_last ? c : c * hw;
@@ -2319,7 +2319,7 @@ int hf_chan_affine_pair(const hf_affine_problem* problems, int dtype, void* stre
   for (int i = 0; i < 2; ++i) {
     const hf_affine_problem& p = problems[i];
     if (p.a_splits < 1 || (p.a_splits > 1 && (!p.a || p.a_slab <= 0))) return HF_ERR_ARG;
-    if (!p.out || !p.rstd || p.n <= 0 || p.c <= 0 || p.hw <= 0 || (p.q && (!p.x || !p.mean))) return HF_ERR_ARG;
+    if (!p.out || p.n <= 0 || p.c <= 0 || p.hw <= 0 || (p.q && (!p.x || !p.mean || !p.rstd))) return HF_ERR_ARG;
     const int64_t dense = p.c;  // NHWC
     if ((p.out_ld && p.out_ld < dense) || (p.add_ld && (p.add_ld < dense || !p.add)) ||
         p.out_ld > 0x3fffffffLL || p.add_ld > 0x3fffffffLL)
@@ -2438,7 +2438,7 @@ int hf_chan_affine_bwd_ex(void* gx, void* gw, void* gb, void* gres, const void* 
   }
   if ((gy_splits > 1 && gy_slab <= 0) || (gy2 && gy2_splits > 1 && gy2_slab <= 0)) return HF_ERR_ARG;
   if ((gy_splits > 1 || gy2_splits > 1) && !(channels_last || hw == 1)) return HF_ERR_ARG;
-  if ((gw && (!x || !mean || !rstd)) || (gx && !rstd)) return HF_ERR_ARG;
+  if (gw && (!x || !mean || !rstd)) return HF_ERR_ARG;  // (rstd == NULL: no BatchNorm, gx = g * w or g)
   if (!gw) x = nullptr;  // plain per-channel sums (a conv layer's bias gradient)
   hipStream_t s = (hipStream_t)stream;
   if (dtype == HF_F32)

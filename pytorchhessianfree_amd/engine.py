@@ -59,14 +59,31 @@ def _cl(t):
 
 
 class _Unit:
-    """conv -> eval-BatchNorm (-> + residual) (-> ReLU)."""
+    """conv -> eval-BatchNorm (-> + residual) (-> ReLU), or conv + bias (-> ReLU) when ``bn`` is None."""
 
     def __init__(self, name, conv, bn):
         self.name, self.conv, self.bn = name, conv, bn
+        self.rstd = None
+        self.first = False        # first layer of a plain stack: no input tangent, no data gradient
+        self.needs_g = True       # the masked cotangent itself is read by a residual branch
+        self.im2col = False       # tiny-Cin layer: runs as a 1x1 product over the im2col of the input
         self.res_unit = None      # downsample unit whose output is added before the activation
         self.res_identity = False  # ... or the block input itself
         self.consumers = 0
         self.src = None           # what the convolution reads: "input", "pool" or the producing unit
+
+    # per-channel affine map behind the convolution: BatchNorm statistics / scale / shift, or a bias
+    @property
+    def mean(self):
+        return self.bn.running_mean if self.bn is not None else None
+
+    @property
+    def scale(self):
+        return self.bn.weight if self.bn is not None else None
+
+    @property
+    def shift(self):
+        return self.bn.bias if self.bn is not None else self.conv.bias
 
 
 class FusedGGNEngine(_Operator):
@@ -85,18 +102,21 @@ class FusedGGNEngine(_Operator):
         model = ref() if ref is not None else None
         if model is None or not outputs.is_cuda or outputs.dtype != torch.float32 or outputs.dim() != 2:
             return None
-        try:
-            eng = cls(model, loss, outputs, params, weight, group)
-        except _Unsupported as exc:
-            # (a model the engine does not cover is the normal case: quiet unless asked;
-            # a product that FAILED its check is always reported)
-            if os.environ.get("HF_ENGINE_DEBUG") or getattr(exc, "loud", False):
-                warnings.warn(f"fused curvature engine not used: {exc}")
-            return None
-        except RuntimeError as exc:  # a kernel refused its arguments (alignment, size limits ...)
-            warnings.warn(f"fused curvature engine not used: {exc}")
-            return None
-        return eng
+        kinds = [cls] if cls is not FusedGGNEngine else [FusedGGNEngine, PlainStackEngine]
+        for kind in kinds:
+            try:
+                return kind(model, loss, outputs, params, weight, group)
+            except _Unsupported as exc:
+                # (a model the engine does not cover is the normal case: quiet unless asked;
+                # a product that FAILED its check is always reported)
+                if os.environ.get("HF_ENGINE_DEBUG") or getattr(exc, "loud", False):
+                    warnings.warn(f"fused curvature engine ({kind.__name__}) not used: {exc}")
+                if getattr(exc, "loud", False):
+                    return None
+            except RuntimeError as exc:  # a kernel refused its arguments (alignment, size limits ...)
+                warnings.warn(f"fused curvature engine ({kind.__name__}) not used: {exc}")
+                return None
+        return None
 
     def __init__(self, model, loss, outputs, params, weight, group):
         super().__init__(params, weight, group)
@@ -180,7 +200,7 @@ class FusedGGNEngine(_Operator):
         stem = make_unit("stem", model.conv1, model.bn1, True)
         if not _same(stem.rx, x_in.detach()) or stem.res is not None:
             raise _Unsupported("stem does not start at the network input")
-        stem.src = "input"
+        stem.src, stem.im2col, stem.first = "input", True, True
         self.model_ref, self._in_shape = model, tuple(x_in.shape)
         mp_x, mp_y = io(model.maxpool, 2)
         if not _same(mp_x, stem.ry):
@@ -237,6 +257,7 @@ class FusedGGNEngine(_Operator):
         self.fc, self.feat = fc, fc_x
         self.pfw, self.pfb = self._param(fc.weight), self._param(fc.bias)
         self.units = units
+        self.tail = self.blocks[-1][0][-1]
         used = {i for u in units for i in (u.pw, u.pg, u.pb)} | {self.pfw} | ({self.pfb} if self.pfb is not None else set())
         if used != set(range(len(self.params))):
             raise _Unsupported("the parameter list has entries the engine's layers do not cover")
@@ -264,13 +285,14 @@ class FusedGGNEngine(_Operator):
         if tuple(x.shape) != tuple(self.x_in.shape):
             raise RuntimeError("engine: input shape changed")
         self.x_in.copy_(x)
-        s = self.stem
-        cols = torch.nn.functional.unfold(self.x_in.contiguous(), tuple(s.conv.kernel_size),
-                                          padding=tuple(s.conv.padding), stride=tuple(s.conv.stride))
-        s.cols.copy_(cols.transpose(1, 2))
-        s.cols_pad[:, :, :s.jcols].copy_(s.cols)
+        s = self.units[0]
+        if s.im2col:
+            cols = torch.nn.functional.unfold(self.x_in.contiguous(), tuple(s.conv.kernel_size),
+                                              padding=tuple(s.conv.padding), stride=tuple(s.conv.stride))
+            s.cols.copy_(cols.transpose(1, 2))
+            s.cols_pad[:, :, :s.jcols].copy_(s.cols)
         for u in self.units:  # eval-mode statistics are constants -- unless somebody retrained them
-            if u.bn.running_var._version != u.rstd_version:
+            if u.bn is not None and u.bn.running_var._version != u.rstd_version:
                 torch.rsqrt(u.bn.running_var + u.bn.eps, out=u.rstd)
                 u.rstd_version = u.bn.running_var._version
         if targets is not None:
@@ -297,12 +319,12 @@ class FusedGGNEngine(_Operator):
             _lib.unpack_tangent(flat, self._slot_list, half=0)
         else:
             for u in self.units:
-                if u is not self.stem:
+                if not u.im2col:
                     c = u.x.shape[1]
                     u.wcat[:, :c].copy_(self.params[u.pw].detach())
         if transposed:
             for u in self.units:
-                if u is not self.stem:
+                if not u.im2col and not u.first:
                     u.wT.copy_(self.params[u.pw].detach().permute(1, 2, 3, 0))
 
     def _bn_forward(self, u, splits):
@@ -310,11 +332,14 @@ class FusedGGNEngine(_Operator):
         res = u.res
         _lib.check(_lib.load().hf_bn_forward(
             _ptr(u.y), _ptr(u.yout2), 2 * k if u.yout2 is not None else 0, _ptr(u.a), _ptr(u.tbuf), splits,
-            u.tbuf.shape[1], _ptr(u.bn.running_mean), _ptr(u.rstd), _ptr(u.bn.weight), _ptr(u.bn.bias),
+            u.tbuf.shape[1], _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.shift),
             _ptr(res), 0, 1 if u.relu else 0, n * oh * ow, k, _lib.HF_F32, _lib.current_stream_ptr(self.dev)),
             "hf_bn_forward")
 
     def _conv_forward(self, u):
+        if u.im2col:  # 1x1 product over the im2col; the weight is read from the parameter itself
+            self._conv_slabs(0, u.tbuf, u.cols, u.conv.weight.detach(), u.geo, u.sF)
+            return
         n, h, w, c, k, r, s, st, pd = u.geo
         self._conv_slabs(0, u.tbuf, u.x, u.wcat, u.geo, u.sF, mat_ld=2 * c)
 
@@ -324,7 +349,7 @@ class FusedGGNEngine(_Operator):
         / residual, and the x half of the consumer's [t_x | x] operand), max-pool positions, logits
         and -- for a softmax cross-entropy -- probabilities and the loss value."""
         s = self.stem
-        self._conv_slabs(0, s.tbuf, s.cols, s.conv.weight.detach(), s.geo, s.sF)
+        self._conv_forward(s)
         self._bn_forward(s, s.sF)
         ks, st_, pd, _dl, _cm = self.pool_args
         pn, ph, pw, poh, pow_, c0 = self._pool_geometry()
@@ -340,7 +365,7 @@ class FusedGGNEngine(_Operator):
             for u in chain:
                 self._conv_forward(u)
                 self._bn_forward(u, u.sF)
-        tail = self.blocks[-1][0][-1]
+        tail = self.tail
         if self._head_hw > 1:
             torch.mean(tail.y, dim=(2, 3), out=self.feat)
         fw = self.fc.weight.detach()
@@ -377,7 +402,7 @@ class FusedGGNEngine(_Operator):
         return self._gather(out, g_fw, g_fb)
 
     def _feature_cotangent(self, g_feat):
-        tail = self.blocks[-1][0][-1]
+        tail = self.tail
         if self._head_hw == 1:
             return g_feat.view(tail.y.shape)
         return _cl((g_feat / self._head_hw).view(g_feat.shape[0], -1, 1, 1).expand(tail.y.shape))
@@ -406,18 +431,22 @@ class FusedGGNEngine(_Operator):
         def nhwc(shape):
             return torch.empty(shape, dtype=f32, device=dev).contiguous(memory_format=cl)
 
+        self._nhwc = nhwc
         self.x_in = nhwc(self._in_shape)
-        self.pool_out = nhwc(self.pool_out.shape)
+        if self.pool_args is not None:
+            self.pool_out = nhwc(self.pool_out.shape)
         for u in self.units:
             u.a, u.y = nhwc(u.a.shape), nhwc(u.y.shape)
-            u.rstd = torch.rsqrt(u.bn.running_var + u.bn.eps)
-            u.rstd_version = u.bn.running_var._version
+            if u.bn is not None:
+                u.rstd = torch.rsqrt(u.bn.running_var + u.bn.eps)
+                u.rstd_version = u.bn.running_var._version
+        tails = {id(c[-1]): c[0] for c, _, _ in self.blocks}
         for u in self.units:  # the convolution's input IS its producer's output buffer
             u.x = self.x_in if u.src == "input" else self.pool_out if u.src == "pool" else u.src.y
             if u.res_unit is not None:
                 u.res = u.res_unit.y
             elif u.res_identity:
-                u.res = self.blocks[[c[-1] for c, _, _ in self.blocks].index(u)][0][0].x
+                u.res = tails[id(u)].x  # the block input
             else:
                 u.res = None
         xcats = {}
@@ -425,9 +454,9 @@ class FusedGGNEngine(_Operator):
         for u in self.units:
             n, c, h, w = u.x.shape
             k, _, r, s = u.conv.weight.shape
-            if u is self.stem:
+            if u.im2col:
                 if c * r * s > 256:
-                    raise _Unsupported("stem: too many taps for the im2col formulation")
+                    raise _Unsupported(f"{u.name}: too many taps for the im2col formulation")
                 oh, ow = u.a.shape[2], u.a.shape[3]
                 j = c * r * s
                 u.cols = torch.empty((n, oh * ow, j), dtype=f32, device=dev)  # [N, OH*OW, c*r*s]
@@ -439,7 +468,7 @@ class FusedGGNEngine(_Operator):
                 u.geo_w = (n * oh * ow, 1, 1, jp, k, 1, 1, (1, 1), (0, 0))
                 u.jcols = j
                 if not u.conv.weight.is_contiguous():
-                    raise _Unsupported("stem weight layout")
+                    raise _Unsupported(f"{u.name}: weight layout")
             else:
                 if c % 4 or k % 4:
                     raise _Unsupported(f"{u.name}: channel counts must be multiples of 4")
@@ -456,18 +485,19 @@ class FusedGGNEngine(_Operator):
             oh, ow = u.a.shape[2], u.a.shape[3]
             u.rows, u.cout = n * oh * ow, k
             # split-K slab buffers
-            if u is self.stem:
+            if u.im2col:
                 u.sT = u.sF = self._plan_stem(0, u.geo)
                 u.sW = self._plan_stem(2, u.geo_w)
                 u.sD = 0
             else:
-                u.sT, u.sD, u.sW = self._plan(0, u), self._plan(1, u), self._plan(2, u)
+                u.sT, u.sW = self._plan(0, u), self._plan(2, u)
+                u.sD = 0 if u.first else self._plan(1, u)
                 u.sF = self._plan(0, u, forward=True)
             u.tbuf = torch.empty((max(u.sT, u.sF), u.rows * k), dtype=f32, device=dev)
             u.wbuf = torch.zeros((u.sW, u.conv.weight.numel()), dtype=f32, device=dev)  # dead taps stay 0
             if u.sD:
                 u.dbuf = torch.empty((u.sD, u.x.numel()), dtype=f32, device=dev)
-            u.g = torch.empty_like(u.a)    # masked cotangent of the unit's output
+            u.g = torch.empty_like(u.a) if u.needs_g else None  # masked cotangent of the unit's output
             u.ga = torch.empty_like(u.a)   # cotangent of the convolution output
             # the BatchNorm adjoint shares the rows among `rb` workgroups per channel column; the
             # per-channel sums arrive as rb partial rows that hf_pack_ex adds up
@@ -493,16 +523,28 @@ class FusedGGNEngine(_Operator):
                 u.tout, u.tout_ld, u.yout2 = xc[:, :c], 2 * c, xc[:, c:]
             else:
                 u.tout, u.tout_ld, u.yout2 = torch.empty_like(u.y), 0, None
-        self.pool_t = xcats.get(id(self.pool_out))
+        self._xcats = xcats
+        self._slot_list = list(self._tangent_slots.values())
+        self._allocate_pool()
+        self._allocate_head()
+        # the parameters as ONE flat vector, when they are consecutive views of one (the optimizer's
+        # arena): every W half is then refreshed by a single scatter launch
+        self._flat_params = _flat_view(self.params, self.n)
+
+    def _allocate_pool(self):
+        self.pool_t = self._xcats.get(id(self.pool_out))
         if self.pool_t is None:
             raise _Unsupported("nothing consumes the pooled stem output")
         if _pair(self.pool_args[3]) != [1, 1] or self.pool_args[4]:
             raise _Unsupported("max-pool with dilation / ceil_mode")
-        self.pool_idx32 = torch.empty(tuple(self.pool_out.permute(0, 2, 3, 1).shape), dtype=torch.int32, device=dev)
+        self.pool_idx32 = torch.empty(tuple(self.pool_out.permute(0, 2, 3, 1).shape), dtype=torch.int32,
+                                      device=self.dev)
         self._g_stem = torch.empty_like(self.stem.y)
-        self._slot_list = list(self._tangent_slots.values())
-        # classifier head
-        tail = self.blocks[-1][0][-1]
+
+    def _allocate_head(self):
+        """Classifier head: (global average pool ->) linear layer."""
+        f32, dev = torch.float32, self.dev
+        tail = self.tail
         n, k = tail.y.shape[0], tail.y.shape[1]
         self._head_hw = tail.y.shape[2] * tail.y.shape[3]
         if self._head_hw == 1:
@@ -514,9 +556,6 @@ class FusedGGNEngine(_Operator):
         self.logits = torch.empty((n, self.fc.weight.shape[0]), dtype=f32, device=dev)
         self._p = torch.empty_like(self.logits)
         self.loss_buf = torch.zeros((), dtype=f32, device=dev)
-        # the parameters as ONE flat vector, when they are consecutive views of one (the optimizer's
-        # arena): every W half is then refreshed by a single scatter launch
-        self._flat_params = _flat_view(self.params, self.n)
 
     def _plan_stem(self, direction, geo):
         n, h, w, c, k, r, s, st, pd = geo
@@ -537,10 +576,10 @@ class FusedGGNEngine(_Operator):
     def _bn_tangent(self, u, v, add, add_ld):
         """t_y = mask * (sum(T slabs) * w*rstd + xhat * v_w + v_b + add), into the consumer's operand."""
         n, k, oh, ow = u.a.shape
-        vg = v[self._offs[u.pg]: self._offs[u.pg] + k]
-        vb = v[self._offs[u.pb]: self._offs[u.pb] + k]
+        vg = v[self._offs[u.pg]: self._offs[u.pg] + k] if u.pg is not None else None
+        vb = v[self._offs[u.pb]: self._offs[u.pb] + k] if u.pb is not None else None
         _lib.check(_lib.load().hf_chan_affine_ex(
-            _ptr(u.tout), _ptr(u.tbuf), _ptr(u.a), _ptr(u.bn.running_mean), _ptr(u.rstd), _ptr(u.bn.weight),
+            _ptr(u.tout), _ptr(u.tbuf), _ptr(u.a), _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale),
             _ptr(vg), _ptr(vb), _ptr(add), _ptr(u.y) if u.relu else None, 0, n, k, oh * ow, 1, u.tout_ld, add_ld,
             u.sT, u.tbuf.shape[1], _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_chan_affine_ex")
 
@@ -590,16 +629,21 @@ class FusedGGNEngine(_Operator):
         lib, st = _lib.load(), _lib.current_stream_ptr(self.dev)
         n, k, oh, ow = u.a.shape
         # g = mask * (sum of both cotangents' slabs) -> u.g; g * w*rstd -> u.ga; per-channel sums
+        bn = u.bn is not None
         _lib.check(lib.hf_chan_affine_bwd_ex(
-            _ptr(u.ga), _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a),
-            _ptr(u.bn.running_mean), _ptr(u.rstd), _ptr(u.bn.weight), _ptr(u.y) if u.relu else None, n, k,
+            _ptr(u.ga), _ptr(u.gw) if bn else None, _ptr(u.gb) if u.pb is not None else None,
+            _ptr(u.g) if u.needs_g else None, _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a) if bn else None,
+            _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.y) if u.relu else None, n, k,
             oh * ow, 1, u.rb, _lib.HF_F32, st), "hf_chan_affine_bwd_ex")
 
     def _conv_adjoint(self, u):
         """Data + weight gradient of the unit's convolution from ``u.ga``, one launch."""
         lib, st = _lib.load(), _lib.current_stream_ptr(self.dev)
-        if u is self.stem:
+        if u.im2col:
             self._conv_slabs(2, u.wbuf, u.cols_pad, u.ga, u.geo_w, u.sW, out_c=u.jcols)
+            return
+        if u.first:  # the network input needs no gradient
+            self._conv_slabs(2, u.wbuf, u.x, u.ga, u.geo, u.sW)
             return
         n_, h, w, c, k_, r, s, sd, pd = u.geo
         _lib.check(lib.hf_conv2d_nhwc_backward_slabs(
@@ -673,7 +717,7 @@ class FusedGGNEngine(_Operator):
     # ---- classifier head: logits' tangent, loss Hessian, the head's gradients ----------------------
     def _head(self, v):
         """Returns the cotangent of the last unit's output and the head's weight / bias gradients."""
-        tail = self.blocks[-1][0][-1]
+        tail = self.tail
         t_last = tail.tout
         hw = t_last.shape[2] * t_last.shape[3]
         fw = self.fc.weight
@@ -707,7 +751,7 @@ class FusedGGNEngine(_Operator):
     def _adjoint_blocks(self, g_last):
         """Walks the blocks backwards; returns the two cotangents of the pooled stem output."""
         group = self._grouping()
-        tail = self.blocks[-1][0][-1]
+        tail = self.tail
         incoming = {id(tail): [(g_last, 1, 0)]}
         pool_srcs = None
         for bi in range(len(self.blocks) - 1, -1, -1):
@@ -811,7 +855,7 @@ class FusedGGNEngine(_Operator):
             self._pack_live = {}
             for u in self.units:
                 tensors[u.pw] = u.wbuf[0]
-                if u is not self.stem:
+                if not u.im2col:
                     k, c, r, s_ = u.conv.weight.shape
                     if r * s_ > 1:
                         perms[u.pw] = (c, r * s_)  # stored (O, H, W, I); 1x1 kernels: already in order
@@ -819,9 +863,11 @@ class FusedGGNEngine(_Operator):
                             self._pack_live[u.pw] = u.live
                 if u.sW > 1:
                     splits[u.pw] = (u.sW, u.wbuf.shape[1])
-                tensors[u.pg], tensors[u.pb] = u.gw[0], u.gb[0]
-                if u.rb > 1:
-                    splits[u.pg] = splits[u.pb] = (u.rb, u.cout)
+                for pi, buf in ((u.pg, u.gw), (u.pb, u.gb)):
+                    if pi is not None:
+                        tensors[pi] = buf[0]
+                        if u.rb > 1:
+                            splits[pi] = (u.rb, u.cout)
             self._pack = (tensors, perms, splits)
         return self._pack
 
@@ -841,7 +887,7 @@ class FusedGGNEngine(_Operator):
         inputs: 4.3 M of 11.2 M entries."""
         if not hasattr(self, "_live_segs"):
             self._live_segs = None
-            masked = {u.pw: u for u in self.units if u is not self.stem and getattr(u, "live", 0)}
+            masked = {u.pw: u for u in self.units if not u.im2col and getattr(u, "live", 0)}
             segs, dead, run_start = [], 0, None  # (full offset, count in the full vector, period, mask)
             for i, p in enumerate(self.params):
                 off = self._offs[i]
@@ -902,7 +948,7 @@ class FusedGGNEngine(_Operator):
         """First product of every (model, shape) signature against the autograd operator."""
         policy = os.environ.get("HF_ENGINE_VERIFY", "first")
         key = (id(self.model_ref), tuple(type(m).__name__ for m in self.model_ref.modules()), self.n,
-               tuple(tuple(p.shape) for p in self.params), tuple(self.logits.shape), tuple(self.stem.x.shape),
+               tuple(tuple(p.shape) for p in self.params), tuple(self.logits.shape), tuple(self.x_in.shape),
                str(self.dev))
         if policy == "never" or (policy != "always" and key in FusedGGNEngine._verified):
             return
@@ -921,6 +967,161 @@ class FusedGGNEngine(_Operator):
             exc.loud = True
             raise exc
         FusedGGNEngine._verified.add(key)
+
+
+class PlainStackEngine(FusedGGNEngine):
+    """The same sweeps for a plain stack ``[Dropout] conv(+bias) [ReLU] ... -> AdaptiveAvgPool2d(1) ->
+    flatten`` with a softmax cross-entropy on the pooled map -- the All-CNN-C of the reference's
+    examples (examples/example_utils.py:59-83, BASELINE.json configs[3]).  Per layer: tangent
+    convolution -> bias tangent + ReLU mask (into the next layer's operand) / masked slab sum + bias
+    gradient -> data + weight gradient; the head (average pool, loss Hessian, broadcast) is ONE launch
+    (``hf_pool_ce_head``).  3 launches per layer and product, bitwise repeatable."""
+
+    mode = ("fused curvature engine (plain conv-ReLU stack): own deterministic convolutions (split-K slabs summed "
+            "by the consumer kernel), bias / ReLU fused, 4 launches per layer")
+
+    def _layout(self, model):
+        x_in = getattr(self.outputs, "_hf_input", None)
+        if x_in is None or x_in.dim() != 4:
+            raise _Unsupported("no recorded input")
+        if model.training:
+            raise _Unsupported("the model must be in eval mode")
+        leaves = [m for m in model.modules() if not list(m.children())]
+
+        def io(m):
+            rec = getattr(m, "_hf_io", None)
+            if rec is None or len(rec) != 2 or rec[0] is None:
+                raise _Unsupported(f"{type(m).__name__} has no record of this forward pass")
+            return rec
+
+        units, cur, prev, pooled, i = [], x_in.detach(), "input", None, 0
+        while i < len(leaves):
+            m = leaves[i]
+            if isinstance(m, (nn.Dropout, nn.Dropout2d, nn.Identity)):
+                i += 1
+                continue
+            if pooled is not None:
+                raise _Unsupported(f"{type(m).__name__} after the pooling layer")
+            if type(m) is nn.Conv2d:
+                if m.groups != 1 or tuple(m.dilation) != (1, 1) or not getattr(m, "_hf_channels_last", False):
+                    raise _Unsupported(f"conv {len(units)}: needs prepare_model(channels_last=True), groups = dilation = 1")
+                cx, cy = io(m)
+                if not _same(cx, cur):
+                    raise _Unsupported(f"conv {len(units)}: input is not the previous activation")
+                u = _Unit(f"conv{len(units)}", m, None)
+                y, u.relu = cy, False
+                nxt = leaves[i + 1] if i + 1 < len(leaves) else None
+                if type(nxt) is nn.ReLU and not nxt.inplace:
+                    rx, ry = io(nxt)
+                    if _same(rx, cy):
+                        y, u.relu = ry, True
+                        i += 1
+                u.kx, u.ky, u.rx, u.ry = cx.data_ptr(), y.data_ptr(), cx, y
+                u.a, u.y, u.needs_g = _cl(cy), _cl(y), False
+                u.pw = self._param(m.weight)
+                u.pb = self._param(m.bias) if m.bias is not None else None
+                u.pg = None
+                u.src, prev, cur = prev, u, y
+                units.append(u)
+            elif isinstance(m, nn.AdaptiveAvgPool2d) and m.output_size in (1, (1, 1)):
+                px, py = io(m)
+                if not units or not _same(px, cur):
+                    raise _Unsupported("the pooling layer does not follow the last convolution")
+                pooled = py
+            else:
+                raise _Unsupported(f"unsupported layer {type(m).__name__}")
+            i += 1
+        if pooled is None or not units:
+            raise _Unsupported("not a conv stack that ends in global average pooling")
+        out = self.outputs.detach()
+        if out.data_ptr() != pooled.data_ptr() or tuple(out.shape) != (pooled.shape[0], pooled.shape[1]):
+            raise _Unsupported("the network output is not the flattened pooled map")
+        first = units[0]
+        first.first = True
+        first.im2col = first.a.shape[1] > 0 and first.rx.shape[1] < 4
+        self.units, self.tail, self.blocks = units, units[-1], []
+        self.stem, self.pool_args, self.fc, self.pfw, self.pfb = None, None, None, None, None
+        self.model_ref, self._in_shape = model, tuple(x_in.shape)
+        used = {i for u in units for i in (u.pw, u.pb) if i is not None}
+        if used != set(range(len(self.params))):
+            raise _Unsupported("the parameter list has entries the engine's layers do not cover")
+
+    def _allocate_pool(self):
+        pass
+
+    def _allocate_head(self):
+        f32, dev = torch.float32, self.dev
+        n, k, h, w = self.tail.y.shape
+        self._head_hw = h * w
+        self.logits = torch.empty((n, k), dtype=f32, device=dev)
+        self._p = torch.empty_like(self.logits)
+        self.loss_buf = torch.zeros((), dtype=f32, device=dev)
+        self._g_last = torch.empty_like(self.tail.y)
+        if k > 1024:
+            raise _Unsupported("more than 1024 classes")
+
+    def _loss_setup(self, loss, outputs):
+        super()._loss_setup(loss, outputs)
+        if self.loss_spec is None:
+            raise _Unsupported("the plain-stack engine needs a plain softmax cross-entropy loss")
+
+    # ---- forward -----------------------------------------------------------------------------
+    def forward_own(self):
+        for u in self.units:
+            self._conv_forward(u)
+            self._bn_forward(u, u.sF)
+        torch.mean(self.tail.y, dim=(2, 3), out=self.logits)
+        if getattr(self, "loss_spec", None) is not None:
+            self._loss_head()
+        return self.logits
+
+    # ---- product ------------------------------------------------------------------------------
+    def _tangent_sweep(self, v):
+        if self._slot_list:
+            _lib.unpack_tangent(v, self._slot_list)  # v_W halves of all [W | v_W] operands: one launch
+        for u in self.units:
+            if u.im2col:  # no input tangent: conv(x, v_W) as a 1x1 product over the im2col
+                vw = v[self._offs[u.pw]: self._offs[u.pw] + u.conv.weight.numel()]
+                self._conv_slabs(0, u.tbuf, u.cols, vw, u.geo, u.sT)
+            else:
+                self._conv_slabs(0, u.tbuf, u.xcat, u.wcat, self._tgeo(u), u.sT)
+            self._bn_tangent(u, v, None, 0)
+
+    def _adjoint_sweep(self, g_last):
+        srcs = [(g_last, 1, 0)]
+        for u in reversed(self.units):
+            self._bn_adjoint(u, srcs)
+            self._conv_adjoint(u)
+            if u.sD:
+                srcs = [(u.dbuf, u.sD, u.dbuf.shape[1])]
+
+    def local(self, v, out=None):
+        if out is None:
+            out = torch.empty(self.n, dtype=torch.float32, device=self.dev)
+        v = v.detach()
+        if not v.is_contiguous():
+            v = v.contiguous()
+        self._tangent_sweep(v)
+        n, k = self.logits.shape
+        _lib.check(_lib.load().hf_pool_ce_head(
+            _ptr(self._g_last), None, _ptr(self.tail.tout), _ptr(self._ce[0]), float(self._ce[1]), n, self._head_hw, k,
+            _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_pool_ce_head")
+        self._adjoint_sweep(self._g_last)
+        return self._gather(out, None, None)
+
+    def gradient(self, out=None):
+        if out is None:
+            out = torch.empty(self.n, dtype=torch.float32, device=self.dev)
+        n, k, h, w = self.tail.y.shape
+        g = (self._p - self._onehot) * (self._ce[1] / self._head_hw)  # d loss / d (last map), per pixel
+        self._g_last.permute(0, 2, 3, 1).copy_(g.view(n, 1, 1, k).expand(n, h, w, k))
+        self._adjoint_sweep(self._g_last)
+        return self._gather(out, None, None)
+
+    def _gather(self, out, g_fw, g_fb):
+        tensors, perms, splits = self._pack_args()
+        _lib.pack_ex(out, list(tensors), perms, splits, scale=self.weight, live=self._pack_live)
+        return out
 
 
 class _Unsupported(Exception):

@@ -1011,7 +1011,7 @@ def _install_engine_hooks(model):
     if getattr(model, "_hf_engine_hooks", False):
         return
     for m in model.modules():
-        if isinstance(m, (nn.MaxPool2d, nn.AdaptiveAvgPool2d, nn.Linear, nn.Flatten)):
+        if isinstance(m, (nn.MaxPool2d, nn.AdaptiveAvgPool2d, nn.Linear, nn.Flatten, nn.ReLU)):
             m.register_forward_hook(_record_io)
     model.register_forward_hook(_tag_output)
     model._hf_stock_model_forward = model.forward

@@ -24,6 +24,13 @@ SHAPES = [("layer1", 32, 7, 7, 64, 64, 3, 1, 1), ("layer2.0", 32, 7, 7, 64, 128,
           ("layer2.ds", 32, 7, 7, 64, 128, 1, 2, 0), ("layer2", 32, 4, 4, 128, 128, 3, 1, 1),
           ("layer3.0", 32, 4, 4, 128, 256, 3, 2, 1), ("layer3", 32, 2, 2, 256, 256, 3, 1, 1),
           ("layer4.0", 32, 2, 2, 256, 512, 3, 2, 1), ("layer4", 32, 1, 1, 512, 512, 3, 1, 1)]
+# large-M problems (All-CNN-C at batch 32; ResNet-50 on 64x64 images): the 128x128-tile configuration
+BIG_SHAPES = [("allcnnc.2", 32, 32, 32, 96, 96, 3, 1, 1), ("allcnnc.3", 32, 32, 32, 96, 96, 3, 2, 1),
+              ("allcnnc.4", 32, 16, 16, 96, 192, 3, 1, 1), ("allcnnc.5", 32, 16, 16, 192, 192, 3, 1, 1),
+              ("allcnnc.6", 32, 16, 16, 192, 192, 3, 2, 1), ("allcnnc.7", 32, 8, 8, 192, 192, 3, 1, 0),
+              ("allcnnc.8", 32, 6, 6, 192, 192, 1, 1, 0), ("r50.l1.conv2", 32, 16, 16, 64, 64, 3, 1, 1),
+              ("r50.l1.conv3", 32, 16, 16, 64, 256, 1, 1, 0), ("r50.l2.conv2", 32, 8, 8, 128, 128, 3, 1, 1),
+              ("r50.l2.conv3", 32, 8, 8, 128, 512, 1, 1, 0), ("r50.l3.conv2", 32, 4, 4, 256, 256, 3, 1, 1)]
 
 
 def timed(fn):
@@ -53,11 +60,13 @@ def main():
     ap.add_argument("--no-reduce", type=int, default=0,
                     help="1: also time the slab-mode launches (hf_conv2d_nhwc_slabs: split-K partial results left "
                          "for the consumer kernel's prologue, as the fused curvature engine runs them)")
+    ap.add_argument("--big", type=int, default=0, help="1: the large-M shapes (All-CNN-C, ResNet-50) instead")
     args = ap.parse_args()
+    shapes = BIG_SHAPES if args.big else SHAPES
     if args.blocks:
         os.environ["HF_CONV_BLOCKS"] = str(args.blocks)
     torch.backends.cudnn.benchmark = False  # immediate mode on the shipped find-db, as the product runs
-    for name, n, h, w, c, k, r, st, pd in SHAPES:
+    for name, n, h, w, c, k, r, st, pd in shapes:
         stride, pad = (st, st), (pd, pd)
         oh = (h + 2 * pd - r) // st + 1
         x2, w2 = cl(torch.randn(n, 2 * c, h, w, device=DEV)), cl(torch.randn(k, 2 * c, r, r, device=DEV))
@@ -88,6 +97,13 @@ def main():
             gy, x, wt, None, stride, pad, [1, 1], False, [0, 0], 1, [True, False, False]))
         line["W_miopen"] = timed(lambda: torch.ops.aten.convolution_backward(
             gy, x, wt, None, stride, pad, [1, 1], False, [0, 0], 1, [False, True, False]))
+        taps = r * r
+        gf = 2.0 * n * oh * oh * k * c * taps * 1e-9  # GFLOP of D and of W; T is twice that (2*Cin channels)
+        line["GFLOP_DW_each"] = gf
+        for key, mul in (("T", 2.0), ("D", 1.0), ("W", 1.0)):
+            for impl in ("own", "slab", "miopen"):
+                if f"{key}_{impl}" in line:
+                    line[f"{key}_{impl}_TF"] = mul * gf / line[f"{key}_{impl}"] * 1e-3 * 1e3
         print(json.dumps({k_: (round(v, 2) if isinstance(v, float) else v) for k_, v in line.items()}), flush=True)
 
 

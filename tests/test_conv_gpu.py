@@ -33,6 +33,12 @@ GEOMS = [
     (1, 3, 3, 4, 4, 3, 3, (1, 1), (0, 0)),         # one output pixel
     (3, 8, 8, 3, 6, 3, 3, (1, 1), (1, 1)),         # channel counts not multiples of 4: scalar gathers
     (32 * 196, 1, 1, 49, 64, 1, 1, (1, 1), (0, 0)),  # the stem as a 1x1 product over its im2col
+    # large-M problems: the 128x128-tile configuration (four accumulators per wave)
+    (32, 32, 32, 96, 96, 3, 3, (1, 1), (1, 1)),    # All-CNN-C conv2: 32768 rows
+    (32, 16, 16, 96, 192, 3, 3, (2, 2), (1, 1)),   # strided, 96 -> 192
+    (8, 16, 16, 192, 192, 3, 3, (1, 1), (0, 0)),   # no padding, ragged row tile (8*14*14 = 1568 rows: small config)
+    (32, 12, 12, 192, 100, 1, 1, (1, 1), (0, 0)),  # 1x1, 100 output channels (ragged column tile)
+    (16, 16, 16, 256, 128, 1, 1, (1, 1), (0, 0)),  # ResNet-50-like 1x1 reduction
 ]
 
 
@@ -80,6 +86,17 @@ def test_three_directions_match_float64(geom):
             gx3, gw3 = torch.empty_like(gx), torch.zeros_like(w)
             _lib.conv2d_nhwc_backward(gx3, gw3, gy, x, wT, n, h, w_, c, k, r, s, stride, padding)
             assert rel(gx3, gx64) < 2e-5 and rel(gw3, gw64) < 2e-5
+
+        # slab mode (what the curvature engine launches): the consumer sums the split-K slabs
+        if c % 4 == 0 and k % 4 == 0:
+            for d, act, mat, ref, shape in ((0, x, w, y64, (n, oh, ow, k)), (1, gy, wT, gx64, (n, h, w_, c)),
+                                            (2, x, gy, gw64, (k, r, s, c))):
+                sp = _lib.conv_plan(d, n, h, w_, c, k, r, s, stride, padding)
+                numel = shape[0] * shape[1] * shape[2] * shape[3]
+                slabs = torch.zeros((sp, numel), device=DEV)  # (zeros: direction 2 skips dead taps)
+                _lib.conv2d_nhwc_slabs(d, slabs, act, mat, n, h, w_, c, k, r, s, stride, padding, sp)
+                got = slabs.sum(0).view(shape).permute(0, 3, 1, 2)
+                assert rel(got, ref) < 2e-5, (d, sp)
 
         # bitwise repeatable
         y2, gx2, gw2 = torch.empty_like(y), torch.empty_like(gx), torch.zeros_like(w)

@@ -56,8 +56,7 @@ def test_bottleneck_net_engine_product_matches_float64():
     params = [p for p in model.parameters() if p.requires_grad]
     out = model(x)
     op = curvature.ggn_operator(lossf(out, t), out, params)
-    if not isinstance(op, FusedGGNEngine):  # e.g. a stem the im2col formulation does not cover
-        pytest.skip("engine does not take this model; the autograd operator is used")
+    assert isinstance(op, FusedGGNEngine)  # (a regression that makes the engine decline must fail here)
     v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
     got = op(v)
     want = _float64_product(tp.resnet50_small_images, v, batch_size=4, image=32)
@@ -84,10 +83,85 @@ def test_engine_declines_what_it_does_not_know():
     out = model(x)
     params = list(model.parameters())
     assert type(curvature.ggn_operator(lossf(out, t), out, params)) is curvature.GGNOperator
-    net, (x, t), lossf = tp.allcnnc_cifar100(batch_size=4, device=DEV)
+    # a conv stack the plain-stack engine does not cover (a grouped convolution; no global pooling)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(),
+                              torch.nn.Conv2d(8, 8, 3, padding=1, groups=2), torch.nn.ReLU(),
+                              torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten()).to(DEV).eval()
+    modelprep.prepare_model(net, channels_last=True)
+    x, t = torch.rand(4, 3, 8, 8, device=DEV), torch.randint(0, 8, (4,), device=DEV)
+    out = net(x)
+    lossf = torch.nn.CrossEntropyLoss()
+    assert type(curvature.ggn_operator(lossf(out, t), out, list(net.parameters()))) is curvature.GGNOperator
+    # All-CNN-C with a loss that is not a plain cross-entropy: the plain-stack engine needs the closed form
+    net, (x, t), _ = tp.allcnnc_cifar100(batch_size=4, device=DEV)
     modelprep.prepare_model(net, channels_last=True)
     out = net(x)
-    assert type(curvature.ggn_operator(lossf(out, t), out, list(net.parameters()))) is curvature.GGNOperator
+    mse = torch.nn.MSELoss()
+    onehot = torch.nn.functional.one_hot(t, 100).float()
+    assert type(curvature.ggn_operator(mse(out, onehot), out, list(net.parameters()))) is curvature.GGNOperator
+
+
+@pytest.mark.parametrize("batch", [32, 3])
+def test_allcnnc_plain_stack_engine_product_matches_float64_and_cpu_oracle(batch):
+    """BASELINE.json configs[3]'s topology (All-CNN-C, examples/example_utils.py:59-83) on the
+    plain-stack engine: GGN product against float64 autograd of the STOCK model (5e-7 max-norm
+    relative) and, at batch 32, against the CPU oracle (BackPACK's published algorithm restated,
+    oracle/backpack_restated.py: 1e-5), bitwise repeatable, symmetric."""
+    from pytorchhessianfree_amd.engine import PlainStackEngine
+
+    model, (x, t), lossf = tp.allcnnc_cifar100(batch_size=batch, device=DEV)
+    modelprep.prepare_model(model, channels_last=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    op = curvature.ggn_operator(lossf(out, t), out, params)
+    assert isinstance(op, PlainStackEngine)
+    v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    got = op(v).clone()
+    for _ in range(3):
+        assert torch.equal(op(v), got)
+    want = _float64_product(tp.allcnnc_cifar100, v, batch_size=batch)
+    assert float((got.double() - want).abs().max() / want.abs().max()) < 5e-7
+    u = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    a, b = float(u.double() @ got.double()), float(v.double() @ op(u).double())
+    assert abs(a - b) <= 1e-5 * abs(a)
+    if batch == 32:
+        from oracle import backpack_restated as bp
+        from pytorchhessianfree_amd.utils import vector_to_parameter_list
+
+        cm, (cx, ct), cl = tp.allcnnc_cifar100(batch_size=batch, device="cpu")
+        cp = [p for p in cm.parameters() if p.requires_grad]
+        co = cm(cx)
+        ref = torch.cat([g.reshape(-1) for g in bp.ggn_vector_product_from_plist(
+            cl(co, ct), co, cp, vector_to_parameter_list(v.cpu(), cp))])
+        assert float((got.cpu() - ref).abs().max() / ref.abs().max()) < 1e-5
+        # the engine's own forward pass and one-sweep gradient against CPU autograd
+        grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(cl(co, ct), cp)])
+        assert float((op.gradient().cpu() - grad).abs().max() / grad.abs().max()) < 2e-6
+        assert float((op.logits.cpu() - co.detach()).abs().max() / co.detach().abs().max()) < 2e-6
+
+
+def test_resnet18_engine_product_matches_cpu_oracle_at_batch_32():
+    """The engine's product DIRECTLY against the CPU oracle (oracle/backpack_restated.py: BackPACK's
+    ``ggn_vector_product_from_plist`` restated; reference call site optimizer.py:457-462) at
+    BASELINE.json config 2's batch 32: 1e-5 max-norm relative."""
+    from oracle import backpack_restated as bp
+    from pytorchhessianfree_amd.utils import vector_to_parameter_list
+
+    seed = tp.RESNET18_B32_SEPARATED_SEEDS[0]
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=seed)
+    modelprep.prepare_model(model, channels_last=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    op = curvature.ggn_operator(lossf(out, t), out, params)
+    assert isinstance(op, FusedGGNEngine)
+    v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(21))
+    got = op(v).cpu()
+    cm, (cx, ct), cl = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=seed)
+    cp = [p for p in cm.parameters() if p.requires_grad]
+    co = cm(cx)
+    ref = torch.cat([g.reshape(-1) for g in bp.ggn_vector_product_from_plist(
+        cl(co, ct), co, cp, vector_to_parameter_list(v.cpu(), cp))])
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5
 
 
 def test_step_with_engine_graph_and_data_parallel_weight():
