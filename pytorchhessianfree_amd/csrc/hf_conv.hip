@@ -688,16 +688,6 @@ namespace {
 // hides (~1.0 us at BK = 32, ~1.5 us at BK = 64; the fp32 MFMA work itself is 0.43 / 0.86 us),
 // a split run pays ~3 us to publish and collect tickets plus ~0.15 us per slab the last
 // arriver sums; workgroups beyond two per CU queue.
-inline int64_t hf_env_cap() {  // tuning knob, default measured on the ResNet-18 bench
-  static int64_t cap = 0;
-  if (cap == 0) {
-    const char* e = getenv("HF_CONV_FEW_TILES_CAP");
-    cap = e ? atoll(e) : 96;
-    if (cap < 1) cap = 32;
-  }
-  return cap;
-}
-
 inline int64_t hf_env_big_blocks() {
   static int64_t v = 0;
   if (v == 0) {
@@ -706,6 +696,16 @@ inline int64_t hf_env_big_blocks() {
     if (v < 1) v = 768;
   }
   return v;
+}
+
+inline int64_t hf_env_cap() {  // tuning knob, default measured on the ResNet-18 bench
+  static int64_t cap = 0;
+  if (cap == 0) {
+    const char* e = getenv("HF_CONV_FEW_TILES_CAP");
+    cap = e ? atoll(e) : 96;
+    if (cap < 1) cap = 32;
+  }
+  return cap;
 }
 
 int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_bytes, bool slabs = false,
@@ -777,8 +777,9 @@ inline int hf_env_big() {
   return v;
 }
 
-int want_big(int direction, int64_t rows, int64_t dim_m, int64_t dim_n, bool scalar) {
-  // dim_m x dim_n: the output matrix (NT: rows x nout; TN: kout x cs per tap); rows: GEMM rows of the layer.
+int want_big(int direction, int64_t rows, int64_t dim_m, int64_t dim_n, int64_t red, int64_t mult, bool scalar) {
+  // dim_m x dim_n: the output matrix (NT: rows x nout; TN: kout x cs per tap, `mult` = live taps of them);
+  // red: length of the reduction; rows: GEMM rows of the layer.
   // Returns 0 (Small), 1 (Big: 128x128) or 2 (Big96: 128x96), whichever wastes less of its tiles.
   if (scalar) return 0;
   const int force = hf_env_big();
@@ -788,7 +789,14 @@ int want_big(int direction, int64_t rows, int64_t dim_m, int64_t dim_n, bool sca
   const int kind = f96 > f128 + 1e-9 ? 2 : 1;
   const bool fits = (kind == 2 ? f96 : f128) >= 0.7;
   if (force > 0) return fits ? kind : 0;
-  return (fits && rows >= 2048) ? kind : 0;
+  // ... and only where the launch has enough work to give ~3 workgroups per CU a K loop of >= 8 steps of 16
+  // each: with a handful of steps per workgroup the 128-wide tiles lose to the 64x64 ones, whose prologue /
+  // epilogue are a quarter the size (ResNet-50 on 64x64 images, batch 32: 260 matvecs/s with the 64x64
+  // tiles everywhere, 228 -> 198 with the 128-wide ones wherever they fit; All-CNN-C's 8192-row layers,
+  // 9 steps per workgroup: 128x96 tiles 37 us, 64x64 tiles 64 us)
+  const int64_t tiles = ((dim_m + 127) / 128) * ((dim_n + (kind == 2 ? 95 : 127)) / (kind == 2 ? 96 : 128)) * mult;
+  const int64_t steps = (red + Big::BK - 1) / Big::BK;
+  return (fits && rows >= 2048 && tiles * steps >= hf_env_big_blocks() * 8) ? kind : 0;
 }
 
 int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void* mat, int64_t n, int64_t h,
@@ -840,8 +848,8 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
   a.mat_ld = (int)(mat_ld > 0 ? mat_ld : a.cs);
   a.scalar = ((c % 4) || (k % 4) || (a.cs_ld % 4) || (a.mat_ld % 4)) ? 1 : 0;
   if (a.cs_ld < a.cs || a.mat_ld < a.cs || (mat_ld > 0 && direction == 2)) return HF_ERR_ARG;
-  a.big = direction <= 1 ? want_big(direction, rows, rows, a.nout, a.scalar)
-                         : want_big(direction, rows, a.kout, a.cs, a.scalar);
+  a.big = direction <= 1 ? want_big(direction, rows, rows, a.nout, (int64_t)a.ntaps * a.cs, 1, a.scalar)
+                         : want_big(direction, rows, a.kout, a.cs, rows, a.ntaps, a.scalar);
   const int BM = a.big ? Big::BM : Small::BM, BN = a.big == 2 ? Big96::BN : a.big ? Big::BN : Small::BN;
   const int BK = a.big ? Big::BK : Small::BK;
   if (direction <= 1) {

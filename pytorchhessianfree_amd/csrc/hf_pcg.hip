@@ -620,6 +620,19 @@ __global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackA
         acc[k] = rd[k] ? src[e[k]] : (T)0;
       }
       int sp = 1;
+      // (weight gradients of large-map layers arrive as up to 128 slabs: eight slabs x E elements in
+      // flight per lane, added in split order -- two at a time cost one round trip per pair)
+      for (; sp + 8 <= nsp; sp += 8) {
+        T tt[8][E];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int k = 0; k < E; ++k) tt[u][k] = rd[k] ? src[e[k] + (long long)(sp + u) * sps] : (T)0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int k = 0; k < E; ++k) acc[k] += tt[u][k];
+      }
       for (; sp + 2 <= nsp; sp += 2) {
         T t0[E], t1[E];
 #pragma unroll
@@ -1206,21 +1219,22 @@ __device__ __forceinline__ void bn_adjoint_rows_body(
       if (gx) { *reinterpret_cast<Col*>(gx + idx0) = o0; if (two) *reinterpret_cast<Col*>(gx + idx1) = o1; }
     }
   }
+  // cross-row sums: red[k][ty][tx] (consecutive lanes -> consecutive words: no bank conflicts), then
+  // 8*quads threads each add one (k, tx) column over ty in a fixed order.  (The first version let the
+  // `quads` threads of ty == 0 walk all 8 sums serially: 8*RP dependent LDS reads per thread behind
+  // 8-way bank conflicts -- 72 % of this kernel's LDS cycles were conflict cycles,
+  // profiles/r03_engine_kernel_counters.json.)  Same summation order, bitwise the same sums.
+  if (live) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = live ? acc[k] : 0.0;
+    for (int k = 0; k < 8; ++k) red[(k * RP + ty) * quads + tx] = acc[k];
+  }
   __syncthreads();
-  if (ty == 0) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      double sum = 0.0;
-      for (unsigned t = 0; t < RP; ++t) sum += red[(t * quads + tx) * 8 + k];  // fixed order over ty
-      acc[k] = sum;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (gw) gw[bid * C + c0 + k] = (float)acc[2 * k];
-      if (gb) gb[bid * C + c0 + k] = (float)acc[2 * k + 1];
-    }
+  for (unsigned idx = threadIdx.x; idx < 8 * quads; idx += BLOCK) {
+    const unsigned k = idx / quads, col = idx - k * quads;
+    double sum = 0.0;
+    for (unsigned t = 0; t < RP; ++t) sum += red[(k * RP + t) * quads + col];  // fixed order over ty
+    float* dst = (k & 1) ? gb : gw;
+    if (dst) dst[bid * C + col * 4 + (k >> 1)] = (float)sum;
   }
 }
 

@@ -507,7 +507,9 @@ class FusedGGNEngine(_Operator):
                 # pass of the row loop where the map is small enough (measured on the ResNet-18
                 # bench: 32 workgroups x 2 passes 1124, 64 x 1 1150, 128 x 1 the same, 256 x 1 1138)
                 rp = 256 // (k // 4)
-                tgt = int(os.environ.get("HF_BN_ROW_BLOCKS", "64"))
+                # (64 workgroups suit the <= 1.6 MB maps of ResNet-18; a 12.6 MB map of All-CNN-C needs the
+                # whole chip: one workgroup per 32 KB of the map, 64 ... 1024)
+                tgt = int(os.environ.get("HF_BN_ROW_BLOCKS", "0")) or min(1024, max(64, u.a.numel() * 4 // 32768))
                 per = max(int(os.environ.get("HF_BN_ROW_PASSES", "1")) * rp, -(-u.rows // tgt))
                 u.rb = -(-u.rows // per)
                 if u.rb < 2:

@@ -149,6 +149,11 @@ class Recorder:
         return [("k_maxpool_adjoint", po * (1 + sa + (sb if b else 0)), 4 * n * h * w * c, 0.0)]
 
     @staticmethod
+    def _cost_hf_pool_ce_head(g, jv, t, p, scale, n, hw, k, dtype, stream):
+        tot = 4 * n * hw * k
+        return [("k_pool_ce_head", tot + 4 * n * k, tot, 0.0)]
+
+    @staticmethod
     def _cost_hf_linear_ce_head(gf, gw, gb, tf, f, w, vw, vb, p, scale, rows, feat, classes, dtype, stream):
         groups = (rows + 3) // 4
         rd = 4 * (2 * rows * feat + 2 * classes * feat * groups + rows * classes)
@@ -160,10 +165,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--products", type=int, default=20)
     ap.add_argument("--out", default="")
+    ap.add_argument("--workload", default="resnet18", choices=["resnet18", "allcnnc", "resnet50"])
     args = ap.parse_args()
     hf.configure()
     dev = "cuda"
-    model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device=dev, data_seed=tp.RESNET18_B32_SEPARATED_SEEDS[0])
+    if args.workload == "resnet18":
+        model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device=dev, data_seed=tp.RESNET18_B32_SEPARATED_SEEDS[0])
+    elif args.workload == "allcnnc":
+        model, (x, t), lossf = tp.allcnnc_cifar100(batch_size=32, device=dev)
+    else:
+        model, (x, t), lossf = tp.resnet50_small_images(batch_size=32, device=dev)
     modelprep.prepare_model(model, channels_last=True)
     params = [p for p in model.parameters() if p.requires_grad]
     out = model(x)
