@@ -319,7 +319,7 @@ def main():
 
     def make_operator(loss, out, params):
         if hessian:
-            return curvature.HessianOperator(loss, params, weight=weight, group=None)
+            return curvature.hessian_operator(loss, out, params, weight=weight, group=None)
         return curvature.ggn_operator(loss, out, params, weight=weight, group=None)
 
     def build_operator(channels_last, overlap=False):
@@ -353,10 +353,34 @@ def main():
             op = curvature.maybe_graphed(builder, enable=bool(args.graph), params=params)
         return op, grad, diag, sum(p.numel() for p in params)
 
-    def stock_product(v, dtype):
+    def stock_product(v, dtype, masks=None, record=None):
         """The same product by stock PyTorch-ROCm autograd on an unpatched NCHW model
-        (float64: the reference; float32: what the stock fp32 path itself achieves)."""
+        (float64: the reference; float32: what the stock fp32 path itself achieves).
+
+        ``masks`` / ``record``: the sign decisions of the model's ReLU calls, in call order -- replayed
+        from a list / appended to one.  Two correct fp32 forward passes may decide a ReLU whose input lies
+        within rounding of zero differently, and ONE such decision moves a curvature product of a deep net
+        by ~1e-4 of its max-norm (it is why products of the 50-layer net scatter between 1e-6 and 3e-4 of
+        the float64 product from run to run, for every implementation): an operator is therefore compared
+        with the float64 product that takes ITS OWN ReLU decisions -- the same piecewise-linear network."""
+        import types
+
         model, x, t, lossf = problem(device, dtype)
+        if masks is not None or record is not None:
+            cursor = [0]
+
+            def relu_forward(self, inp):
+                if masks is not None:
+                    m = masks[cursor[0]]
+                    cursor[0] += 1
+                else:
+                    m = inp > 0
+                    record.append(m)
+                return inp * m.to(inp.dtype)
+
+            for mod in model.modules():
+                if isinstance(mod, torch.nn.ReLU):
+                    mod.forward = types.MethodType(relu_forward, mod)
         params = [p for p in model.parameters() if p.requires_grad]
         find = torch.backends.cudnn.benchmark
         # one product only: MIOpen's immediate mode, no find step (and no find-db records)
@@ -368,6 +392,15 @@ def main():
             return op(v.to(dtype)).double().clone()
         finally:
             torch.backends.cudnn.benchmark = find
+
+    def relu_decisions(op):
+        """The ReLU sign decisions of a fused-engine operator, in the model's call order (``None`` for
+        operators that do not expose them: the plain float64 product is the reference then)."""
+        eng = getattr(op, "engine", None) or getattr(op, "op", op)
+        units = getattr(eng, "units", None)
+        if not units or "engine" not in getattr(eng, "mode", ""):
+            return None
+        return [(u.y > 0) for u in units if u.relu]
 
     # guard: an operator is only timed after it reproduced a float64 stock-autograd product
     # as well as stock fp32 autograd does (x5, floor 1e-5; deep random-init nets such as the
@@ -385,8 +418,14 @@ def main():
         v = torch.randn(n, device=device, generator=torch.Generator(device=device).manual_seed(7))
         want = stock_product(v, torch.float64)
         scale = float(want.abs().max())
-        stock_err = float((stock_product(v, torch.float32) - want).abs().max()) / scale
-        check.update(v=v, want=want, scale=scale, stock_err=stock_err, tol=max(1e-5, 5.0 * stock_err))
+        rec = []
+        stock32 = stock_product(v, torch.float32, record=rec)
+        # stock fp32 autograd against the float64 product on ITS ReLU decisions: the fp32 noise floor of
+        # the workload; `stock_err_plain` (against the float64 network's own decisions) for the record
+        stock_err = float((stock32 - stock_product(v, torch.float64, masks=rec)).abs().max()) / scale
+        check.update(v=v, want=want, scale=scale, stock_err=stock_err, tol=max(1e-5, 5.0 * stock_err),
+                     stock_err_plain=float((stock32 - want).abs().max()) / scale)
+        del rec, stock32
         from pytorchhessianfree_amd.engine import FusedGGNEngine
 
         FusedGGNEngine.verify_tol = check["tol"]
@@ -396,22 +435,43 @@ def main():
             reference_products()
         op, grad, diag, n = build_operator(channels_last)
         got = op(check["v"]).double()
-        err = float((got - check["want"]).abs().max()) / check["scale"]
+        masks = relu_decisions(op)
+        ref = check["want"] if masks is None else stock_product(check["v"], torch.float64, masks=masks)
+        err = float((got - ref).abs().max()) / check["scale"]
+        check["err_plain"] = float((got - check["want"]).abs().max()) / check["scale"]
+        check["masked"] = masks is not None
+        # (an operator that does not expose its ReLU decisions is held to what stock fp32 autograd achieves
+        # against the same plain float64 product)
+        check["tol_eff"] = check["tol"] if masks is not None else max(1e-5, 5.0 * check["stock_err_plain"])
+        del masks, ref
         # the reference's own check (optimizer.py:414-448): the same product twice
         check["deterministic"] = bool(torch.equal(op(check["v"]).double(), got))
         return op, grad, diag, n, err
 
     op, grad, diag, n, err = checked(bool(args.channels_last))
-    note = "max-norm error against float64 stock autograd {:.1e}, stock fp32 autograd {:.1e}"
+    def note_text(err):
+        if check.get("masked"):
+            return ("max-norm error against float64 stock autograd on this operator's own ReLU decisions {:.1e} "
+                    "(on the float64 network's decisions {:.1e}); stock fp32 autograd likewise {:.1e} ({:.1e})"
+                    ).format(err, check["err_plain"], check["stock_err"], check["stock_err_plain"])
+        return "max-norm error against float64 stock autograd {:.1e}, stock fp32 autograd {:.1e}".format(
+            err, check["stock_err_plain"])
+
+    class _Note:  # (keeps the two call sites below unchanged)
+        @staticmethod
+        def format(err, _unused):
+            return note_text(err)
+
+    note = _Note
     layout = ("NHWC" if args.channels_last else "NCHW") + " (" + note.format(err, check["stock_err"]) + ")"
-    if not err < check["tol"] and args.channels_last:
+    if not err < check["tol_eff"] and args.channels_last:
         print(f"[bench] NHWC product off by {err:.2e} (float64 reference); using NCHW",
               file=sys.stderr, flush=True)
         del op
         args.channels_last = 0
         op, grad, diag, n, err = checked(False)
         layout = "NCHW (NHWC failed its check; " + note.format(err, check["stock_err"]) + ")"
-    if not err < check["tol"]:
+    if not err < check["tol_eff"]:
         raise SystemExit(f"bench: the curvature product is off by {err:.2e} against float64 stock autograd")
     del check["want"], check["v"]
 

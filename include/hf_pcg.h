@@ -199,7 +199,10 @@ int hf_unpack_tangent_ex(const void* src, void* const* dsts, const int64_t* src_
                          const int64_t* numels, const int64_t* slabs, const int64_t* inners,
                          const int64_t* live, int n_tensors, int dtype, void* stream);
 /* The same scatter with a per-tensor choice of the half it fills (`halves`, HOST, or NULL = all 1):
- * 1 = the v_W half (above), 0 = the W half -- dst[(o*HW + hw)*2I + i] resp. dst[o*2*slab + r].  The
+ * 1 = the v_W half (above), 0 = the W half -- dst[(o*HW + hw)*2I + i] resp. dst[o*2*slab + r]; 2 = a
+ * DENSE transposed copy dst[(i*HW + hw)*O + o] (inners[t] = I required): the (I, H, W, O) operand of the
+ * data-gradient convolutions -- the weights once per step, and the vector's weight slices V once per
+ * Hessian product (the term V^T g of the R-op of the backward pass, optimizer.py:450-455).  The
  * persistent curvature engine refreshes the W halves of all [W | v_W] operands from the flat
  * parameter vector with ONE launch per trial point theta0 + alpha*step (optimizer.py:288-294), where
  * the reference re-binds every parameter (utils.py:8-38) and PyTorch re-converts every NCHW weight. */
@@ -410,6 +413,13 @@ typedef struct hf_conv_problem {
   int64_t mat_ld;           /* see hf_conv2d_nhwc_slabs; 0 = dense */
 } hf_conv_problem;
 int hf_conv2d_nhwc_group_slabs(const hf_conv_problem* problems, int n_problems, int dtype, void* stream);
+/* ONE forward / data-gradient problem (`d`, direction 0 or 1) and ONE weight-gradient problem (`w`, direction 2)
+ * in one launch, each described like a grouped problem (so either may read an operand that is a channel slice
+ * of a wider buffer: act_ld / mat_ld).  hf_conv2d_nhwc_backward_slabs is the special case "same layer, dense
+ * operands".  The Hessian sweep of the curvature engine issues, per layer, this launch twice: the GGN's pair
+ * conv_D(g', W), conv_W(x, g') and the pair that carries the network's own curvature, conv_D(g, V),
+ * conv_W(t_x, g) with t_x read in place from the [t_x | x] operand (optimizer.py:450-455). */
+int hf_conv2d_nhwc_dw_slabs(const hf_conv_problem* d, const hf_conv_problem* w, int dtype, void* stream);
 
 /* Data gradient AND weight gradient of one layer (directions 1 and 2 above) in ONE launch:
  * both read dY [n,oh,ow,k], neither depends on the other.  dx [n,h,w,c]; dw [k][r][q][c]

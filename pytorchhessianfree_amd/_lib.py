@@ -117,6 +117,7 @@ SIGNATURES = {
     "hf_conv2d_nhwc_slabs": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int64] * 14
                              + [c_int, c_int64, c_int, c_void_p]),
     "hf_conv2d_nhwc_group_slabs": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "hf_conv2d_nhwc_dw_slabs": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "hf_chan_affine_pair": (c_int, [c_void_p, c_int, c_void_p]),
     "hf_chan_affine_bwd_pair": (c_int, [c_void_p, c_int, c_void_p]),
     "hf_conv2d_nhwc_backward_slabs": (c_int, [c_void_p] * 5 + [c_int64] * 11
@@ -258,9 +259,23 @@ def unpack_tangent(v, slots, half=1):
     dsts = (c_void_p * n)()
     offs, numels, slabs, inners, live, halves = ((c_int64 * n)() for _ in range(6))
     for k, slot in enumerate(slots):
-        halves[k] = 1 if half else 0
+        halves[k] = int(half)  # 0: W half, 1: v_W half, 2: dense (I, H, W, O) transposed copy
         off, buf, cin = slot[:3]
         live[k] = slot[3] if len(slot) > 3 else 0  # bit mask of the kernel taps that meet data (0 = all)
+        if half == 2:  # buf: (I, H, W, O) dense
+            if buf.dtype != v.dtype or buf.device != v.device or buf.dim() != 4 or buf.shape[0] != cin or \
+                    not buf.is_contiguous():
+                raise RuntimeError("unpack_tangent: transposed buffer does not match")
+            hw = buf.shape[1] * buf.shape[2]
+            inners[k] = cin
+            dsts[k] = buf.data_ptr()
+            offs[k] = off
+            slabs[k] = cin * hw
+            numels[k] = buf.shape[3] * cin * hw
+            if off < 0 or off + numels[k] > v.numel():
+                raise RuntimeError("unpack_tangent: slice outside the vector")
+            live[k] = 0
+            continue
         if buf.dtype != v.dtype or buf.device != v.device or buf.dim() != 4 or buf.shape[1] != 2 * cin:
             raise RuntimeError("unpack_tangent: buffer does not match")
         hw = buf.shape[2] * buf.shape[3]
@@ -453,6 +468,27 @@ def conv_group_slabs(problems, device):
         q.slab_stride = out.shape[1] if out.dim() == 2 else 0
     check(load().hf_conv2d_nhwc_group_slabs(ctypes.cast(arr, c_void_p), len(problems), HF_F32,
                                             current_stream_ptr(device)), "hf_conv2d_nhwc_group_slabs")
+
+
+def _fill_problem(q, prob):
+    direction, out, act, mat, geo, splits, act_ld, out_c = prob[:8]
+    q.mat_ld = prob[8] if len(prob) > 8 else 0
+    n, h, w, c, k, r, s, st, pd = geo
+    q.direction, q.out, q.act, q.mat = int(direction), out.data_ptr(), act.data_ptr(), mat.data_ptr()
+    q.n, q.h, q.w, q.c, q.k, q.r, q.s = n, h, w, c, k, r, s
+    q.stride_h, q.stride_w, q.pad_h, q.pad_w = st[0], st[1], pd[0], pd[1]
+    q.act_ld, q.out_c, q.splits = act_ld, out_c, splits
+    q.slab_stride = out.shape[1] if out.dim() == 2 else 0
+
+
+def conv_dw_slabs(d_problem, w_problem, device):
+    """One data-gradient (or forward) problem and one weight-gradient problem in ONE launch; tuples as for
+    ``conv_group_slabs``."""
+    arr = (ConvProblem * 2)()
+    _fill_problem(arr[0], d_problem)
+    _fill_problem(arr[1], w_problem)
+    check(load().hf_conv2d_nhwc_dw_slabs(ctypes.byref(arr[0]), ctypes.byref(arr[1]), HF_F32,
+                                         current_stream_ptr(device)), "hf_conv2d_nhwc_dw_slabs")
 
 
 def conv_plan(direction, n, h, w, c, k, r, s, stride, padding):

@@ -101,6 +101,14 @@ struct ConvArgs {
   int slabs;           // 1: split s writes its partial result, in the output's own layout, to
   long long slab_stride;  //    out + s*slab_stride; the CONSUMER kernel sums the slabs in its prologue
   int big;             // tile configuration this problem was set up for (0: Small, 1: Big, 2: Big96)
+  // Data gradient of a STRIDED convolution, decomposed by residue class of the input pixel: pixel (y, x) only
+  // receives the taps with (y + pad - r) % stride == 0, so rows are enumerated class by class ((y % sh, x % sw)
+  // fixed within a row tile) and every tile loops over ITS taps only -- a stride-2 3x3 layer does 9/4 taps per
+  // pixel instead of 9, of which 3/4 would gather nothing.  ncls == 0: plain enumeration.
+  int ncls;
+  int cls_tile0[5];    // first row tile of class i ([ncls] = tiles_m)
+  int cls_tap0[5];     // taps of class i: tap_r/tap_s[cls_tap0[i] .. cls_tap0[i+1])
+  int cls_h[4], cls_w[4], cls_py[4], cls_px[4];  // pixels of the class: y = y'*stride_h + py, y' < cls_h
 };
 
 // Pixel index into the gathered tensor for row coordinates (n, y, x) and tap (r, q); `valid` is
@@ -154,7 +162,7 @@ template <typename C>
 __device__ __forceinline__ void finish_tile(const ConvArgs& a, const f32x16 (&acc)[C::TM][C::TN], int tile, int split,
                                             int wm, int wn, int lane, float* out_tile_base,
                                             int row0, int col0, int row_lim, int col_lim, int ldc,
-                                            int* flag_lds) {
+                                            int* flag_lds, int cls = -1) {
   constexpr int BM = C::BM, BN = C::BN;
   const int i = lane & 31, h = lane >> 5;
   if (a.splits == 1 || a.slabs) {
@@ -162,14 +170,22 @@ __device__ __forceinline__ void finish_tile(const ConvArgs& a, const f32x16 (&ac
 #pragma unroll
     for (int im = 0; im < C::TM; ++im)
 #pragma unroll
-      for (int in = 0; in < C::TN; ++in)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int row = (wm * C::TM + im) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-          const int col = (wn * C::TN + in) * 32 + i;
-          if (row0 + row < row_lim && col0 + col < col_lim)
-            dst[(size_t)(row0 + row) * ldc + col0 + col] = acc[im][in][reg];
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = (wm * C::TM + im) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        int orow = row0 + row;  // output row (= pixel index) of this accumulator row
+        bool rok = orow < row_lim;
+        if (cls >= 0) {  // (uniform) class-major enumeration: row -> (n, y', x') -> pixel (n, y'*sh + py, x'*sw + px)
+          const int wc = a.cls_w[cls], hc = a.cls_h[cls];
+          const int xq = orow % wc, tq = orow / wc;
+          const int yq = tq % hc, nq = tq / hc;
+          orow = (nq * a.rh + yq * a.stride_h + a.cls_py[cls]) * a.rw + xq * a.stride_w + a.cls_px[cls];
         }
+#pragma unroll
+        for (int in = 0; in < C::TN; ++in) {
+          const int col = (wn * C::TN + in) * 32 + i;
+          if (rok && col0 + col < col_lim) dst[(size_t)orow * ldc + col0 + col] = acc[im][in][reg];
+        }
+      }
     return;
   }
   const int tiles = a.tiles_m * a.tiles_n;
@@ -245,23 +261,39 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
   const int tile_m = bid % a.tiles_m;
   const int split = bid / a.tiles_m;
   const int tile = tile_m * a.tiles_n + tile_n;
-  const int per = (a.steps + a.splits - 1) / a.splits;
-  const int j0 = split * per, j1 = (j0 + per < a.steps) ? j0 + per : a.steps;
+  const int csteps = (a.cs + BK - 1) / BK;
+  // residue class of this row tile (strided data gradients, see ConvArgs): its rows, taps and step count
+  int cls = -1, row_base = tile_m * BM, rows_c = a.rows, tap0 = 0, steps = a.steps;
+  if (a.ncls > 0) {  // (uniform)
+    cls = 0;
+    while (cls + 1 < a.ncls && tile_m >= a.cls_tile0[cls + 1]) ++cls;
+    row_base = (tile_m - a.cls_tile0[cls]) * BM;
+    rows_c = (a.rows / (a.rh * a.rw)) * a.cls_h[cls] * a.cls_w[cls];  // images x pixels of the class
+    tap0 = a.cls_tap0[cls];
+    steps = (a.cls_tap0[cls + 1] - tap0) * csteps;
+  }
+  const int per = (steps + a.splits - 1) / a.splits;
+  const int j0 = split * per < steps ? split * per : steps, j1 = (j0 + per < steps) ? j0 + per : steps;
 
   // staging assignment: thread -> rows lr + RPT*u and the float4 at k offset 4*kq
   const int lr = t / KQ, kq = t % KQ;
   int rn[NU], ry[NU], rx[NU];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const int m = tile_m * BM + lr + RPT * u;
-    if (m < a.rows) {
-      const int xx = m % a.rw, tq = m / a.rw;
-      rx[u] = xx; ry[u] = tq % a.rh; rn[u] = tq / a.rh;
+    const int m = row_base + lr + RPT * u;
+    if (m < rows_c) {
+      if (cls >= 0) {
+        const int wc = a.cls_w[cls], hc = a.cls_h[cls];
+        const int xx = m % wc, tq = m / wc;
+        rx[u] = xx * a.stride_w + a.cls_px[cls]; ry[u] = (tq % hc) * a.stride_h + a.cls_py[cls]; rn[u] = tq / hc;
+      } else {
+        const int xx = m % a.rw, tq = m / a.rw;
+        rx[u] = xx; ry[u] = tq % a.rh; rn[u] = tq / a.rh;
+      }
     } else {
       rn[u] = -1; ry[u] = rx[u] = 0;
     }
   }
-  const int csteps = (a.cs + BK - 1) / BK;
   const int RS = a.R * a.S;
   const float* brow[NU];
   bool bok[NU];
@@ -280,7 +312,7 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
   // and is zeroed when the registers are written to LDS: a branch around a load makes hipcc
   // drain the whole queue, vmcnt(0), before the next use; cdna_hip_programming.md trap 4c)
   auto fetch = [&](int step, float4 (&ra)[NU], float4 (&rb)[NU]) -> unsigned {
-    const int ti = step / csteps, c = (step - ti * csteps) * BK + 4 * kq;
+    const int tl = step / csteps, c = (step - tl * csteps) * BK + 4 * kq, ti = tap0 + tl;
     const int r = a.tap_r[ti], q = a.tap_s[ti];
     const bool cok = c < a.cs;
     unsigned ok = 0;
@@ -352,7 +384,7 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
         f_step = step;
         if (++f_cb == csteps) { f_cb = 0; ++f_ti; }
       }
-      const int ti = f_ti, c = f_cb * BK + 4 * kq;
+      const int ti = tap0 + f_ti, c = f_cb * BK + 4 * kq;
       const int r = a.tap_r[ti], q = a.tap_s[ti];
       const bool cok = c < a.cs;
       unsigned ok = 0;
@@ -421,8 +453,8 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
     }
   }
   __syncthreads();  // the LDS array is reused below (last-arriver flag)
-  finish_tile<C>(a, acc, tile, split, wm, wn, lane, a.out, tile_m * BM, tile_n * BN, a.rows, a.nout, a.ldc,
-                 &flag);
+  finish_tile<C>(a, acc, tile, split, wm, wn, lane, a.out, row_base, tile_n * BN, rows_c, a.nout, a.ldc,
+                 &flag, cls);
 }
 
 // ---------------------------------------------------------------------------------
@@ -650,16 +682,18 @@ struct GroupArgs {
   int n;
 };
 
+// (the problems arrive as SEPARATE by-value arguments: indexing an array of them inside one by-value
+// struct made hipcc copy all 1.2 KB to scratch memory, and every field read in the K loops a scratch
+// load -- measured 3x on the 128-wide configurations)
+struct GroupMeta {
+  int tn[GROUP_MAX];       // 1: weight gradient (TN body), 0: forward / data gradient (NT body)
+  int start[GROUP_MAX + 1];
+  int n;
+};
+
 template <bool ANYBIG>
-__global__ __launch_bounds__(CT) void k_conv_group(const GroupArgs g) {
-  constexpr int LDSB = Big::LDS_FLOATS > Big96::LDS_FLOATS ? Big::LDS_FLOATS : Big96::LDS_FLOATS;
-  constexpr int LDSF = ANYBIG ? (LDSB > Small::LDS_FLOATS ? LDSB : Small::LDS_FLOATS) : Small::LDS_FLOATS;
-  __shared__ __attribute__((aligned(16))) float lds[LDSF];
-  int p = 0;
-  while (p + 1 < g.n && (int)blockIdx.x >= g.start[p + 1]) ++p;  // (uniform)
-  const int local = (int)blockIdx.x - g.start[p];
-  const ConvArgs& a = g.a[p];
-  if (g.tn[p]) {
+__device__ __forceinline__ void group_run(const ConvArgs& a, int tn, float* lds, int local) {
+  if (tn) {
     if (ANYBIG && a.big == 1) conv_tn_body<false, Big>(a, lds, local);
     else if (ANYBIG && a.big == 2) conv_tn_body<false, Big96>(a, lds, local);
     else conv_tn_body<false, Small>(a, lds, local);
@@ -668,6 +702,19 @@ __global__ __launch_bounds__(CT) void k_conv_group(const GroupArgs g) {
     else if (ANYBIG && a.big == 2) conv_nt_body<false, Big96>(a, lds, local);
     else conv_nt_body<false, Small>(a, lds, local);
   }
+}
+
+template <bool ANYBIG>
+__global__ __launch_bounds__(CT) void k_conv_group(const ConvArgs a0, const ConvArgs a1, const ConvArgs a2,
+                                                   const ConvArgs a3, const GroupMeta m) {
+  constexpr int LDSB = Big::LDS_FLOATS > Big96::LDS_FLOATS ? Big::LDS_FLOATS : Big96::LDS_FLOATS;
+  constexpr int LDSF = ANYBIG ? (LDSB > Small::LDS_FLOATS ? LDSB : Small::LDS_FLOATS) : Small::LDS_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  const int b = (int)blockIdx.x;
+  if (b < m.start[1]) group_run<ANYBIG>(a0, m.tn[0], lds, b);
+  else if (b < m.start[2]) group_run<ANYBIG>(a1, m.tn[1], lds, b - m.start[1]);
+  else if (b < m.start[3]) group_run<ANYBIG>(a2, m.tn[2], lds, b - m.start[2]);
+  else group_run<ANYBIG>(a3, m.tn[3], lds, b - m.start[3]);
 }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -771,6 +818,12 @@ void launch_one(int direction, const ConvArgs& a, int64_t blocks, hipStream_t st
 // Which tile configuration a problem runs in: a pure function of its geometry (hf_conv2d_nhwc_plan and
 // every launch path must agree).  Big (128x128) needs both output dimensions to fill most of a tile
 // and enough GEMM rows that the 64x64 kernel would be issue-bound; HF_CONV_BIG=0/1 forces it (tuning).
+inline int hf_env_dclass() {  // HF_CONV_DCLASS=0: plain enumeration for strided data gradients (tuning / bisecting)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("HF_CONV_DCLASS"); v = e ? (atoi(e) != 0) : 1; }
+  return v;
+}
+
 inline int hf_env_big() {
   static int v = -2;
   if (v == -2) { const char* e = getenv("HF_CONV_BIG"); v = e ? atoi(e) : -1; }
@@ -848,14 +901,53 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
   a.mat_ld = (int)(mat_ld > 0 ? mat_ld : a.cs);
   a.scalar = ((c % 4) || (k % 4) || (a.cs_ld % 4) || (a.mat_ld % 4)) ? 1 : 0;
   if (a.cs_ld < a.cs || a.mat_ld < a.cs || (mat_ld > 0 && direction == 2)) return HF_ERR_ARG;
-  a.big = direction <= 1 ? want_big(direction, rows, rows, a.nout, (int64_t)a.ntaps * a.cs, 1, a.scalar)
+  // strided data gradient in slab mode: residue classes of the input pixel (see ConvArgs)
+  int cls_taps_max = a.ntaps;
+  const bool classes = direction == 1 && slab_splits >= 0 && (stride_h > 1 || stride_w > 1) &&
+                       stride_h * stride_w <= 4 && !a.scalar && hf_env_dclass();
+  struct { int py, px, hc, wc, ntaps; unsigned char r[MAX_TAPS], q[MAX_TAPS]; } cl[4];
+  int ncls = 0;
+  if (classes) {
+    cls_taps_max = 0;
+    for (int py = 0; py < stride_h; ++py)
+      for (int px = 0; px < stride_w; ++px) {
+        const int hc = (int)((h - py + stride_h - 1) / stride_h), wc = (int)((w - px + stride_w - 1) / stride_w);
+        if (hc <= 0 || wc <= 0) continue;
+        auto& c_ = cl[ncls];
+        c_.py = py; c_.px = px; c_.hc = hc; c_.wc = wc; c_.ntaps = 0;
+        for (int t_ = 0; t_ < a.ntaps; ++t_) {
+          const int rr = a.tap_r[t_], qq = a.tap_s[t_];
+          const int64_t dy = py + pad_h - rr, dx = px + pad_w - qq;
+          if (((dy % stride_h) + stride_h) % stride_h == 0 && ((dx % stride_w) + stride_w) % stride_w == 0) {
+            c_.r[c_.ntaps] = (unsigned char)rr; c_.q[c_.ntaps] = (unsigned char)qq; c_.ntaps++;
+          }
+        }
+        if (c_.ntaps > cls_taps_max) cls_taps_max = c_.ntaps;
+        ++ncls;
+      }
+  }
+  a.big = direction <= 1 ? want_big(direction, rows, rows, a.nout, (int64_t)cls_taps_max * a.cs, 1, a.scalar)
                          : want_big(direction, rows, a.kout, a.cs, rows, a.ntaps, a.scalar);
   const int BM = a.big ? Big::BM : Small::BM, BN = a.big == 2 ? Big96::BN : a.big ? Big::BN : Small::BN;
   const int BK = a.big ? Big::BK : Small::BK;
   if (direction <= 1) {
     a.tiles_m = (int)((rows + BM - 1) / BM);
     a.tiles_n = (a.nout + BN - 1) / BN;
-    red_steps = (int64_t)a.ntaps * ((a.cs + BK - 1) / BK);
+    red_steps = (int64_t)cls_taps_max * ((a.cs + BK - 1) / BK);
+    if (ncls > 0) {  // rows class by class, taps reordered class-major
+      a.ncls = ncls;
+      int tile0 = 0, tap0 = 0;
+      for (int i = 0; i < ncls; ++i) {
+        a.cls_tile0[i] = tile0; a.cls_tap0[i] = tap0;
+        a.cls_h[i] = cl[i].hc; a.cls_w[i] = cl[i].wc; a.cls_py[i] = cl[i].py; a.cls_px[i] = cl[i].px;
+        for (int t_ = 0; t_ < cl[i].ntaps; ++t_) { a.tap_r[tap0 + t_] = cl[i].r[t_]; a.tap_s[tap0 + t_] = cl[i].q[t_]; }
+        tap0 += cl[i].ntaps;
+        tile0 += (int)((n * cl[i].hc * cl[i].wc + BM - 1) / BM);
+      }
+      a.cls_tile0[ncls] = tile0; a.cls_tap0[ncls] = tap0;
+      a.tiles_m = tile0;
+      if (red_steps < 1) red_steps = 1;
+    }
   } else {
     a.tiles_m = (a.kout + BM - 1) / BM;
     a.tiles_n = a.ntaps * ((a.cs + BN - 1) / BN);
@@ -1015,6 +1107,35 @@ int hf_conv2d_nhwc_backward_slabs(void* dx, void* dw, const void* dy, const void
   return HF_OK;
 }
 
+int hf_conv2d_nhwc_dw_slabs(const hf_conv_problem* d, const hf_conv_problem* w, int dtype, void* stream) {
+  if (!d || !w || d->direction > 1 || d->direction < 0 || w->direction != 2) return HF_ERR_ARG;
+  ConvArgs a[2];
+  int64_t blocks[2];
+  alignas(16) float dummy_ws[4];
+  const hf_conv_problem* pr[2] = {d, w};
+  for (int i = 0; i < 2; ++i) {
+    const hf_conv_problem& q = *pr[i];
+    if (q.splits < 1 || q.slab_stride < 0 || q.mat_ld < 0 || q.out_c < 0 || q.out_c > q.c || (q.out_c && i == 0))
+      return HF_ERR_ARG;
+    const int rc = check_common(q.out, q.act, q.mat, dummy_ws, dummy_ws, dtype, q.n, q.h, q.w, q.c, q.k, q.r, q.s,
+                                q.stride_h, q.stride_w, q.pad_h, q.pad_w);
+    if (rc) return rc;
+    blocks[i] = setup(a[i], q.direction, q.out, q.act, q.mat, q.n, q.h, q.w, q.c, q.k, q.r, q.s, q.stride_h,
+                      q.stride_w, q.pad_h, q.pad_w, q.act_ld, nullptr, 0, nullptr, 0, 0, q.splits, q.slab_stride,
+                      q.mat_ld);
+    if (blocks[i] <= 0) return (int)blocks[i];
+    if (a[i].splits != q.splits || a[i].scalar) return HF_ERR_ARG;
+    if (q.out_c) a[i].out_c = (int)q.out_c;
+  }
+  const dim3 grid((unsigned)(blocks[0] + blocks[1]));
+  if (a[0].big || a[1].big)
+    hipLaunchKernelGGL(k_conv_dw<true>, grid, dim3(CT), 0, (hipStream_t)stream, a[0], a[1], (int)blocks[0]);
+  else
+    hipLaunchKernelGGL(k_conv_dw<false>, grid, dim3(CT), 0, (hipStream_t)stream, a[0], a[1], (int)blocks[0]);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
 int hf_conv2d_nhwc_group_slabs(const hf_conv_problem* problems, int n_problems, int dtype, void* stream) {
   if (!problems || n_problems < 1 || n_problems > GROUP_MAX) return HF_ERR_ARG;
   GroupArgs q;  // (~1.2 KB, passed to the kernel by value)
@@ -1044,8 +1165,20 @@ int hf_conv2d_nhwc_group_slabs(const hf_conv_problem* problems, int n_problems, 
   q.n = n_problems;
   bool anybig = false;
   for (int i = 0; i < n_problems; ++i) anybig = anybig || q.a[i].big;
-  if (anybig) hipLaunchKernelGGL(k_conv_group<true>, dim3((unsigned)total), dim3(CT), 0, (hipStream_t)stream, q);
-  else hipLaunchKernelGGL(k_conv_group<false>, dim3((unsigned)total), dim3(CT), 0, (hipStream_t)stream, q);
+  GroupMeta m;
+  memset(&m, 0, sizeof(m));
+  for (int i = 0; i < GROUP_MAX; ++i) {
+    m.tn[i] = q.tn[i];
+    m.start[i] = i <= n_problems ? q.start[i] : (int)total;  // (unused slots: empty ranges at the end)
+  }
+  m.start[GROUP_MAX] = (int)total;
+  m.n = n_problems;
+  if (anybig)
+    hipLaunchKernelGGL(k_conv_group<true>, dim3((unsigned)total), dim3(CT), 0, (hipStream_t)stream, q.a[0], q.a[1],
+                       q.a[2], q.a[3], m);
+  else
+    hipLaunchKernelGGL(k_conv_group<false>, dim3((unsigned)total), dim3(CT), 0, (hipStream_t)stream, q.a[0], q.a[1],
+                       q.a[2], q.a[3], m);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }

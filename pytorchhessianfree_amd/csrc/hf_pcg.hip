@@ -773,6 +773,17 @@ __global__ __launch_bounds__(BLOCK) void k_unpack_tangent(const T* __restrict__ 
   constexpr int W = VecOf<T>::W;
   typedef typename VecOf<T>::type V;
   const bool al = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+  if (half == 2) {
+    // transposed copy: dst stored (I, H, W, O) dense -- the operand of a data-gradient convolution:
+    // dst[(i*HW + hw)*O + o] = src[(o*I + i)*HW + hw]; walked in source order (coalesced reads)
+    const unsigned HW = slab / I, O = (unsigned)(numel / slab);
+    for (long long j = j0 + threadIdx.x; j < j1; j += BLOCK) {
+      const unsigned o = (unsigned)(j / slab), rem = (unsigned)(j - (long long)o * slab);
+      const unsigned i = rem / HW, hw = rem - i * HW;
+      dst[((long long)i * HW + hw) * O + o] = src[j];
+    }
+    return;
+  }
   if (I == 0) {  // dst[o*2*slab + half*slab + r] = src[o*slab + r]
     if (al && slab % W == 0) {
       for (long long j = j0 + (long long)threadIdx.x * W; j < j1; j += (long long)BLOCK * W) {
@@ -2086,7 +2097,8 @@ static int unpack_impl(const void* src, void* const* dsts, const int64_t* src_of
         a.inner[k] = (int)I;
         if (live && live[t] > 0 && I > 0 && slab / I <= 16)
           a.live[k] = (unsigned short)(live[t] & ((1 << (slab / I)) - 1));
-        a.half[k] = (unsigned char)((halves && halves[t] == 0) ? 0 : 1);
+        a.half[k] = (unsigned char)(!halves ? 1 : halves[t] == 0 ? 0 : halves[t] == 2 ? 2 : 1);
+        if (a.half[k] == 2 && I <= 0) return HF_ERR_ARG;
         a.chunk[k] = PACK_CHUNK;  // (an LDS-tiled NHWC variant measured slower: 30.9 vs 24.5 us)
         a.blk_start[k] = blocks;
         blocks += (int)((numels[t] + a.chunk[k] - 1) / a.chunk[k]);

@@ -209,6 +209,20 @@ def ggn_operator(loss, outputs, params, weight=1.0, group=None):
     return GGNOperator(loss, outputs, params, weight=weight, group=group)
 
 
+def hessian_operator(loss, outputs, params, grad_with_graph=None, weight=1.0, group=None):
+    """The Hessian operator for ``loss``: the fused curvature engine in Hessian mode (engine.py:
+    forward-over-reverse on the package's own kernels) when ``outputs`` comes from a prepared model of
+    a family it covers (plain conv-ReLU stacks with a softmax cross-entropy, optionally plus a tagged
+    L2 term), else the autograd operator below."""
+    if isinstance(outputs, torch.Tensor) and getattr(outputs, "_hf_model", None) is not None:
+        from .engine import FusedGGNEngine
+
+        eng = FusedGGNEngine.try_build(loss, outputs, list(params), weight=weight, group=group, hessian=True)
+        if eng is not None:
+            return eng
+    return HessianOperator(loss, params, grad_with_graph=grad_with_graph, weight=weight, group=group)
+
+
 class HessianOperator(_Operator):
     """``v -> (d^2 loss / d params^2) v`` (BackPACK's ``hessian_vector_product``,
     optimizer.py:450-455).  ``grad_with_graph`` are the per-parameter gradients

@@ -95,7 +95,7 @@ class FusedGGNEngine(_Operator):
 
     # ------------------------------------------------------------------------------------
     @classmethod
-    def try_build(cls, loss, outputs, params, weight=1.0, group=None):
+    def try_build(cls, loss, outputs, params, weight=1.0, group=None, hessian=False):
         if os.environ.get("HF_ENGINE", "1") == "0":
             return None
         ref = getattr(outputs, "_hf_model", None)
@@ -103,9 +103,11 @@ class FusedGGNEngine(_Operator):
         if model is None or not outputs.is_cuda or outputs.dtype != torch.float32 or outputs.dim() != 2:
             return None
         kinds = [cls] if cls is not FusedGGNEngine else [FusedGGNEngine, PlainStackEngine]
+        if hessian:
+            kinds = [k for k in kinds if k.supports_hessian]
         for kind in kinds:
             try:
-                return kind(model, loss, outputs, params, weight, group)
+                return kind(model, loss, outputs, params, weight, group, hessian=hessian)
             except _Unsupported as exc:
                 # (a model the engine does not cover is the normal case: quiet unless asked;
                 # a product that FAILED its check is always reported)
@@ -118,8 +120,12 @@ class FusedGGNEngine(_Operator):
                 return None
         return None
 
-    def __init__(self, model, loss, outputs, params, weight, group):
+    supports_hessian = False
+
+    def __init__(self, model, loss, outputs, params, weight, group, hessian=False):
         super().__init__(params, weight, group)
+        self.hessian = bool(hessian)
+        self._l2 = None
         self.outputs = outputs
         self.dev = outputs.device
         self._index = {id(p): i for i, p in enumerate(self.params)}
@@ -140,6 +146,9 @@ class FusedGGNEngine(_Operator):
             raise _Unsupported(f"the engine's forward pass differs from the model's output by {err:.2e}")
         self._loss_setup(loss, outputs)
         self._verify(loss)
+        for u in self.units:  # the model's own activations were only needed up to here
+            u.rx = u.ry = u.ra = None
+        self._rec_pool = None
         if self.loss_spec is not None:
             self.outputs = None  # nothing of the step's autograd graph stays alive in the engine
 
@@ -190,7 +199,7 @@ class FusedGGNEngine(_Operator):
                 raise _Unsupported(f"{name}: unexpected activation")
             # identity of activations: the RAW records (a 1-channel stem runs NCHW, its records are
             # converted below); the kernels get NHWC copies / views
-            u.kx, u.ky, u.rx, u.ry = cx.data_ptr(), by.data_ptr(), cx, by
+            u.kx, u.ky, u.rx, u.ry, u.ra = cx.data_ptr(), by.data_ptr(), cx, by, cy
             u.x, u.a, u.y, u.relu, u.rstd, u.res = _cl(cx), _cl(cy), _cl(by), brelu, rstd, bres
             u.pw, u.pg, u.pb = self._param(conv.weight), self._param(bn.weight), self._param(bn.bias)
             units.append(u)
@@ -209,7 +218,7 @@ class FusedGGNEngine(_Operator):
         mp = model.maxpool
         self.stem, self.pool_args = stem, (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode)
         cur = mp_y
-        self.pool_out, self.pool_key = _cl(mp_y), mp_y.data_ptr()
+        self.pool_out, self.pool_key, self._rec_pool = _cl(mp_y), mp_y.data_ptr(), mp_y
         self.blocks = []
         prev = "pool"  # producer of the current block input
         for bi, b in enumerate(blocks):
@@ -265,7 +274,7 @@ class FusedGGNEngine(_Operator):
     # ---- loss Hessian (same contract as GGNOperator) -------------------------------------
     def _loss_setup(self, loss, outputs):
         (self._dl,) = torch.autograd.grad(loss, outputs, create_graph=True, retain_graph=True)
-        self._ce = GGNOperator._closed_form_loss_hessian(self, loss, outputs)
+        self._ce = GGNOperator._closed_form_loss_hessian(self, _Node(_ce_node(loss)), outputs)
         # a plain softmax cross-entropy (checked numerically above): the engine can then evaluate
         # loss, probabilities and d loss / d logits itself, on its own forward pass -- which is what
         # lets ONE engine serve many steps and trial points (``session.EngineSession``)
@@ -274,10 +283,34 @@ class FusedGGNEngine(_Operator):
             spec = ce_loss_spec(loss, outputs)
             if spec is not None:
                 self.loss_spec = spec
+                self._set_quadratic(spec.get("quadratic"))
                 self.set_targets(spec["targets"])
                 self._loss_head()
                 self._ce = (self._p, self._ce[1])  # the static buffer the own forward pass refreshes
                 self._dl = None                     # (nothing of this step's autograd graph is kept)
+
+    def _set_quadratic(self, terms):
+        """``loss = cross-entropy + sum_j 0.5 * coef_j * ||w_j||^2`` (the L2 term of the reference's
+        All-CNN-C example, examples/example_utils.py:77-81): per-entry coefficients of the flat vector.
+        Loss value, gradient and Hessian product of that term are ``0.5 <d*theta, theta>``,
+        ``d*theta`` and ``d*v``."""
+        self._l2 = None
+        if not terms:
+            return
+        d = torch.zeros(self.n, dtype=torch.float32, device=self.dev)
+        for coef, tensors in terms:
+            for w in tensors:
+                i = self._index.get(id(w))
+                if i is None:
+                    raise _Unsupported("a regularised tensor is not among the optimizer's parameters")
+                d[self._offs[i]: self._offs[i] + w.numel()] += float(coef)
+        self._l2 = d
+
+    def _theta(self):
+        flat = self._flat_params
+        if flat is not None and flat.data_ptr() == self.params[0].data_ptr():
+            return flat
+        return torch.cat([p.detach().reshape(-1) for p in self.params])
 
     # ---- own forward pass ------------------------------------------------------------------
     def set_batch(self, x, targets=None):
@@ -323,9 +356,12 @@ class FusedGGNEngine(_Operator):
                     c = u.x.shape[1]
                     u.wcat[:, :c].copy_(self.params[u.pw].detach())
         if transposed:
-            for u in self.units:
-                if not u.im2col and not u.first:
-                    u.wT.copy_(self.params[u.pw].detach().permute(1, 2, 3, 0))
+            if flat is not None and flat.data_ptr() == self.params[0].data_ptr() and self._wt_slots:
+                _lib.unpack_tangent(flat, self._wt_slots, half=2)
+            else:
+                for u in self.units:
+                    if not u.im2col and not u.first:
+                        u.wT.copy_(self.params[u.pw].detach().permute(1, 2, 3, 0))
 
     def _bn_forward(self, u, splits):
         n, k, oh, ow = u.a.shape
@@ -382,7 +418,11 @@ class FusedGGNEngine(_Operator):
         ``forward()[0]``, optimizer.py:216-229; same ATen ops as ``F.cross_entropy``)."""
         torch.softmax(self.logits, 1, out=self._p)
         lsm = torch.log_softmax(self.logits, 1)
-        self.loss_buf.copy_(torch.nn.functional.nll_loss(lsm, self._targets, reduction=self.loss_spec["reduction"]))
+        val = torch.nn.functional.nll_loss(lsm, self._targets, reduction=self.loss_spec["reduction"])
+        if getattr(self, "_l2", None) is not None:
+            theta = self._theta()
+            val = val + 0.5 * torch.dot(self._l2 * theta, theta)
+        self.loss_buf.copy_(val)
 
     def gradient(self, out=None):
         """``weight * d loss / d params`` of the softmax cross-entropy by ONE adjoint sweep of the
@@ -399,7 +439,10 @@ class FusedGGNEngine(_Operator):
         g_feat = g @ fw
         pool_srcs = self._adjoint_blocks(self._feature_cotangent(g_feat))
         self._adjoint_stem(pool_srcs)
-        return self._gather(out, g_fw, g_fb)
+        self._gather(out, g_fw, g_fb)
+        if self._l2 is not None:
+            out.addcmul_(self._l2, self._theta(), value=self.weight)
+        return out
 
     def _feature_cotangent(self, g_feat):
         tail = self.tail
@@ -494,9 +537,18 @@ class FusedGGNEngine(_Operator):
                 u.sD = 0 if u.first else self._plan(1, u)
                 u.sF = self._plan(0, u, forward=True)
             u.tbuf = torch.empty((max(u.sT, u.sF), u.rows * k), dtype=f32, device=dev)
-            u.wbuf = torch.zeros((u.sW, u.conv.weight.numel()), dtype=f32, device=dev)  # dead taps stay 0
+            # Hessian products add, per layer, conv_W(t_x, g) to the weight gradient and conv_D(g, V) to the
+            # data gradient (g: the step's first-order cotangent): as MORE SLABS of the same buffers, which
+            # the consumers sum anyway
+            u.nW = u.sW * (2 if (self.hessian and not u.first) else 1)
+            u.nD = u.sD * (2 if self.hessian else 1)
+            u.wbuf = torch.zeros((u.nW, u.conv.weight.numel()), dtype=f32, device=dev)  # dead taps stay 0
             if u.sD:
-                u.dbuf = torch.empty((u.sD, u.x.numel()), dtype=f32, device=dev)
+                u.dbuf = torch.empty((u.nD, u.x.numel()), dtype=f32, device=dev)
+            if self.hessian:
+                u.ga1 = torch.empty_like(u.a)  # first-order cotangent of the convolution output (per step)
+                if u.sD:
+                    u.vT = torch.empty((c, r, s, k), dtype=f32, device=dev)  # V as (I, H, W, O), per product
             u.g = torch.empty_like(u.a) if u.needs_g else None  # masked cotangent of the unit's output
             u.ga = torch.empty_like(u.a)   # cotangent of the convolution output
             # the BatchNorm adjoint shares the rows among `rb` workgroups per channel column; the
@@ -527,6 +579,10 @@ class FusedGGNEngine(_Operator):
                 u.tout, u.tout_ld, u.yout2 = torch.empty_like(u.y), 0, None
         self._xcats = xcats
         self._slot_list = list(self._tangent_slots.values())
+        # (I, H, W, O) copies: the weights (once per step) and, for Hessian products, V (per product)
+        self._wt_slots = [(self._offs[u.pw], u.wT, u.x.shape[1]) for u in self.units if not u.im2col and not u.first]
+        self._vt_slots = [(self._offs[u.pw], u.vT, u.x.shape[1]) for u in self.units
+                          if self.hessian and not u.im2col and u.sD]
         self._allocate_pool()
         self._allocate_head()
         # the parameters as ONE flat vector, when they are consecutive views of one (the optimizer's
@@ -623,7 +679,8 @@ class FusedGGNEngine(_Operator):
         self._bn_adjoint(u, srcs)
         self._conv_adjoint(u)
 
-    def _bn_adjoint(self, u, srcs):
+    def _bn_adjoint(self, u, srcs, ga=None):
+        ga = u.ga if ga is None else ga
         if not 1 <= len(srcs) <= 2:
             raise RuntimeError(f"{u.name}: {len(srcs)} consumers")
         (a, sa, la) = srcs[0]
@@ -633,23 +690,24 @@ class FusedGGNEngine(_Operator):
         # g = mask * (sum of both cotangents' slabs) -> u.g; g * w*rstd -> u.ga; per-channel sums
         bn = u.bn is not None
         _lib.check(lib.hf_chan_affine_bwd_ex(
-            _ptr(u.ga), _ptr(u.gw) if bn else None, _ptr(u.gb) if u.pb is not None else None,
+            _ptr(ga), _ptr(u.gw) if bn else None, _ptr(u.gb) if u.pb is not None else None,
             _ptr(u.g) if u.needs_g else None, _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a) if bn else None,
             _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.y) if u.relu else None, n, k,
             oh * ow, 1, u.rb, _lib.HF_F32, st), "hf_chan_affine_bwd_ex")
 
-    def _conv_adjoint(self, u):
-        """Data + weight gradient of the unit's convolution from ``u.ga``, one launch."""
+    def _conv_adjoint(self, u, ga=None):
+        """Data + weight gradient of the unit's convolution from ``ga`` (default ``u.ga``), one launch."""
+        ga = u.ga if ga is None else ga
         lib, st = _lib.load(), _lib.current_stream_ptr(self.dev)
         if u.im2col:
-            self._conv_slabs(2, u.wbuf, u.cols_pad, u.ga, u.geo_w, u.sW, out_c=u.jcols)
+            self._conv_slabs(2, u.wbuf, u.cols_pad, ga, u.geo_w, u.sW, out_c=u.jcols)
             return
         if u.first:  # the network input needs no gradient
-            self._conv_slabs(2, u.wbuf, u.x, u.ga, u.geo, u.sW)
+            self._conv_slabs(2, u.wbuf, u.x, ga, u.geo, u.sW)
             return
         n_, h, w, c, k_, r, s, sd, pd = u.geo
         _lib.check(lib.hf_conv2d_nhwc_backward_slabs(
-            _ptr(u.dbuf), _ptr(u.wbuf), _ptr(u.ga), _ptr(u.x), _ptr(u.wT), n_, h, w, c, k_, r, s, sd[0], sd[1],
+            _ptr(u.dbuf), _ptr(u.wbuf), _ptr(ga), _ptr(u.x), _ptr(u.wT), n_, h, w, c, k_, r, s, sd[0], sd[1],
             pd[0], pd[1], u.sD, u.dbuf.shape[1], u.sW, u.wbuf.shape[1], _lib.HF_F32, st),
             "hf_conv2d_nhwc_backward_slabs")
 
@@ -851,7 +909,19 @@ class FusedGGNEngine(_Operator):
             self._head_ok = ok
         return ok and v_fw.data_ptr() % 16 == 0
 
-    def _pack_args(self):
+    def _pack_args(self, first_order=False):
+        """(tensors, perms, splits) of ``hf_pack_ex``.  ``first_order``: a gradient sweep of a Hessian
+        engine fills only the first ``sW`` weight-gradient slabs of each layer."""
+        if first_order and self.hessian:
+            tensors, perms, splits = self._pack_args()
+            splits = dict(splits)
+            for u in self.units:
+                if u.nW != u.sW:
+                    if u.sW > 1:
+                        splits[u.pw] = (u.sW, u.wbuf.shape[1])
+                    else:
+                        splits.pop(u.pw, None)
+            return tensors, perms, splits
         if getattr(self, "_pack", None) is None:
             tensors, perms, splits = [None] * len(self.params), {}, {}
             self._pack_live = {}
@@ -863,8 +933,8 @@ class FusedGGNEngine(_Operator):
                         perms[u.pw] = (c, r * s_)  # stored (O, H, W, I); 1x1 kernels: already in order
                         if u.live:
                             self._pack_live[u.pw] = u.live
-                if u.sW > 1:
-                    splits[u.pw] = (u.sW, u.wbuf.shape[1])
+                if u.nW > 1:
+                    splits[u.pw] = (u.nW, u.wbuf.shape[1])
                 for pi, buf in ((u.pg, u.gw), (u.pb, u.gb)):
                     if pi is not None:
                         tensors[pi] = buf[0]
@@ -946,8 +1016,33 @@ class FusedGGNEngine(_Operator):
     # fp32 autograd achieves against float64 (bench.py) raise it to max(1e-5, 5 x that error)
     verify_tol = float(os.environ.get("HF_ENGINE_VERIFY_TOL", "1e-5"))
 
+    def _load_recorded(self, outputs):
+        """Overwrite the engine's activations with the ones the MODEL's forward pass recorded, so that a
+        product of the engine and one of the autograd operator linearise at bitwise the same point -- same
+        ReLU masks, same pooling positions.  Two correct fp32 forward passes may decide a ReLU whose input
+        is within rounding of zero differently, and one such sign moves a product of a deep net by ~1e-4 of
+        its max-norm: not an error of either, but it would drown the comparison below."""
+        for u in self.units:
+            u.a.copy_(u.ra)
+            u.y.copy_(u.ry)
+            if u.yout2 is not None:
+                u.yout2.copy_(u.ry)
+        if self.pool_args is not None:
+            ks, st_, pd, dl, cm = self.pool_args
+            _, idx = torch.nn.functional.max_pool2d(self.stem.ry, ks, st_, pd, dl, cm, return_indices=True)
+            self.pool_idx32.copy_(idx.permute(0, 2, 3, 1))
+            self.pool_out.copy_(self._rec_pool)
+            c0 = self.pool_out.shape[1]
+            self.pool_t[:, c0:].copy_(self._rec_pool)
+        if self.fc is not None and self._head_hw > 1:
+            torch.mean(self.tail.y, dim=(2, 3), out=self.feat)
+        self.logits.copy_(outputs.detach())
+        if getattr(self, "loss_spec", None) is not None:
+            self._loss_head()
+
     def _verify(self, loss):
-        """First product of every (model, shape) signature against the autograd operator."""
+        """First product of every (model, shape) signature against the autograd operator, both on the
+        activations the model's own forward pass recorded (``_load_recorded``)."""
         policy = os.environ.get("HF_ENGINE_VERIFY", "first")
         key = (id(self.model_ref), tuple(type(m).__name__ for m in self.model_ref.modules()), self.n,
                tuple(tuple(p.shape) for p in self.params), tuple(self.logits.shape), tuple(self.x_in.shape),
@@ -957,10 +1052,12 @@ class FusedGGNEngine(_Operator):
         gen = torch.Generator(device=self.dev).manual_seed(4321)
         v = torch.randn(self.n, device=self.dev, generator=gen)
         weight, self.weight = self.weight, 1.0
+        self._load_recorded(self.outputs)
         try:
             got = self.local(v).clone()
         finally:
             self.weight = weight
+            self.forward_own()  # back to the engine's own activations
         want = GGNOperator(loss, self.outputs, self.params).local(v)
         err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
         if not err < FusedGGNEngine.verify_tol:
@@ -981,6 +1078,12 @@ class PlainStackEngine(FusedGGNEngine):
 
     mode = ("fused curvature engine (plain conv-ReLU stack): own deterministic convolutions (split-K slabs summed "
             "by the consumer kernel), bias / ReLU fused, 4 launches per layer")
+    # Hessian products (optimizer.py:450-455) by forward-over-reverse on the same kernels: the tangent
+    # sweep, then the TANGENT OF THE BACKWARD SWEEP -- per layer, besides the GGN's conv_D(g', W) and
+    # conv_W(x, g'), the two terms that carry the network's own curvature, conv_D(g, V) and conv_W(t_x, g)
+    # (g: first-order cotangent of the step, g': its tangent; ReLU masks are piecewise constant), all four
+    # in ONE grouped launch whose extra results are simply more split-K slabs for the consumers to sum.
+    supports_hessian = True
 
     def _layout(self, model):
         x_in = getattr(self.outputs, "_hf_input", None)
@@ -1018,7 +1121,7 @@ class PlainStackEngine(FusedGGNEngine):
                     if _same(rx, cy):
                         y, u.relu = ry, True
                         i += 1
-                u.kx, u.ky, u.rx, u.ry = cx.data_ptr(), y.data_ptr(), cx, y
+                u.kx, u.ky, u.rx, u.ry, u.ra = cx.data_ptr(), y.data_ptr(), cx, y, cy
                 u.a, u.y, u.needs_g = _cl(cy), _cl(y), False
                 u.pw = self._param(m.weight)
                 u.pb = self._param(m.bias) if m.bias is not None else None
@@ -1062,11 +1165,6 @@ class PlainStackEngine(FusedGGNEngine):
         if k > 1024:
             raise _Unsupported("more than 1024 classes")
 
-    def _loss_setup(self, loss, outputs):
-        super()._loss_setup(loss, outputs)
-        if self.loss_spec is None:
-            raise _Unsupported("the plain-stack engine needs a plain softmax cross-entropy loss")
-
     # ---- forward -----------------------------------------------------------------------------
     def forward_own(self):
         for u in self.units:
@@ -1089,13 +1187,26 @@ class PlainStackEngine(FusedGGNEngine):
                 self._conv_slabs(0, u.tbuf, u.xcat, u.wcat, self._tgeo(u), u.sT)
             self._bn_tangent(u, v, None, 0)
 
-    def _adjoint_sweep(self, g_last):
+    def _adjoint_sweep(self, g_last, first_order=False):
+        """``first_order``: the gradient's sweep (cotangents kept in ``ga1`` for later Hessian products);
+        otherwise the product's sweep -- for a Hessian engine with the two extra convolutions per layer."""
+        second = self.hessian and not first_order
         srcs = [(g_last, 1, 0)]
         for u in reversed(self.units):
-            self._bn_adjoint(u, srcs)
-            self._conv_adjoint(u)
+            ga = u.ga1 if (self.hessian and first_order) else u.ga
+            self._bn_adjoint(u, srcs, ga)
+            if second and not u.im2col and not u.first:
+                n_, h, w, c, k_, r, s, sd, pd = u.geo
+                # (two launches of two problems each; four in one grouped launch ran 3x slower -- with four
+                # by-value problem descriptions hipcc spills them to scratch memory)
+                _lib.conv_dw_slabs((1, u.dbuf, ga, u.wT, u.geo, u.sD, 0, 0), (2, u.wbuf, u.x, ga, u.geo, u.sW, 0, 0),
+                                   self.dev)
+                _lib.conv_dw_slabs((1, u.dbuf[u.sD:], u.ga1, u.vT, u.geo, u.sD, 0, 0),
+                                   (2, u.wbuf[u.sW:], u.xcat, u.ga1, u.geo, u.sW, 2 * c, 0), self.dev)
+            else:
+                self._conv_adjoint(u, ga)
             if u.sD:
-                srcs = [(u.dbuf, u.sD, u.dbuf.shape[1])]
+                srcs = [(u.dbuf, u.nD if second else u.sD, u.dbuf.shape[1])]
 
     def local(self, v, out=None):
         if out is None:
@@ -1104,12 +1215,17 @@ class PlainStackEngine(FusedGGNEngine):
         if not v.is_contiguous():
             v = v.contiguous()
         self._tangent_sweep(v)
+        if self.hessian and self._vt_slots:
+            _lib.unpack_tangent(v, self._vt_slots, half=2)  # V as (I, H, W, O): the operand of conv_D(g, V)
         n, k = self.logits.shape
         _lib.check(_lib.load().hf_pool_ce_head(
             _ptr(self._g_last), None, _ptr(self.tail.tout), _ptr(self._ce[0]), float(self._ce[1]), n, self._head_hw, k,
             _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_pool_ce_head")
         self._adjoint_sweep(self._g_last)
-        return self._gather(out, None, None)
+        self._gather(out, None, None)
+        if self.hessian and self._l2 is not None:  # the regulariser's Hessian: coef on its tensors' entries
+            out.addcmul_(self._l2, v, value=self.weight)
+        return out
 
     def gradient(self, out=None):
         if out is None:
@@ -1117,13 +1233,53 @@ class PlainStackEngine(FusedGGNEngine):
         n, k, h, w = self.tail.y.shape
         g = (self._p - self._onehot) * (self._ce[1] / self._head_hw)  # d loss / d (last map), per pixel
         self._g_last.permute(0, 2, 3, 1).copy_(g.view(n, 1, 1, k).expand(n, h, w, k))
-        self._adjoint_sweep(self._g_last)
-        return self._gather(out, None, None)
+        self._adjoint_sweep(self._g_last, first_order=True)
+        self._gather(out, None, None, first_order=True)
+        if self._l2 is not None:
+            out.addcmul_(self._l2, self._theta(), value=self.weight)
+        return out
 
-    def _gather(self, out, g_fw, g_fb):
-        tensors, perms, splits = self._pack_args()
+    def _gather(self, out, g_fw, g_fb, first_order=False):
+        tensors, perms, splits = self._pack_args(first_order)
         _lib.pack_ex(out, list(tensors), perms, splits, scale=self.weight, live=self._pack_live)
         return out
+
+    def _loss_setup(self, loss, outputs):
+        FusedGGNEngine._loss_setup(self, loss, outputs)
+        if self.loss_spec is None:
+            raise _Unsupported("the plain-stack engine needs a plain softmax cross-entropy loss")
+        if self.hessian:
+            self.gradient()  # fills the first-order cotangents the Hessian products read
+
+    def _verify(self, loss):
+        if not self.hessian:
+            return FusedGGNEngine._verify(self, loss)
+        from .curvature import HessianOperator
+
+        policy = os.environ.get("HF_ENGINE_VERIFY", "first")
+        key = ("hessian", id(self.model_ref), self.n, tuple(tuple(p.shape) for p in self.params),
+               tuple(self.x_in.shape), str(self.dev))
+        if policy == "never" or (policy != "always" and key in FusedGGNEngine._verified):
+            return
+        gen = torch.Generator(device=self.dev).manual_seed(4321)
+        v = torch.randn(self.n, device=self.dev, generator=gen)
+        weight, self.weight = self.weight, 1.0
+        self._load_recorded(self.outputs)
+        try:
+            self.gradient()  # first-order cotangents at the recorded activations
+            got = self.local(v).clone()
+        finally:
+            self.weight = weight
+            self.forward_own()
+            self.gradient()
+        want = HessianOperator(loss, self.params).local(v)
+        err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
+        if not err < FusedGGNEngine.verify_tol:
+            exc = _Unsupported(f"engine Hessian product differs from the autograd product by {err:.2e} "
+                               f"(tolerance {FusedGGNEngine.verify_tol:.1e}); using the autograd operator")
+            exc.loud = True
+            raise exc
+        FusedGGNEngine._verified.add(key)
 
 
 class _Unsupported(Exception):
@@ -1134,7 +1290,7 @@ def ce_loss_spec(loss, outputs, check_values=True):
     """``{"reduction", "targets"}`` if ``loss`` is ``F.cross_entropy(outputs, targets)`` with class-index
     targets, no class weights, no label smoothing and no ignored target -- read off the autograd
     graph (``NllLossBackward0 <- LogSoftmaxBackward0 <- outputs``) --, else ``None``."""
-    fn = loss.grad_fn
+    fn = _ce_node(loss)
     try:
         if fn is None or fn.name() != "NllLossBackward0" or outputs.dim() != 2:
             return None
@@ -1159,7 +1315,30 @@ def ce_loss_spec(loss, outputs, check_values=True):
             return None
     except AttributeError:
         return None
-    return {"reduction": reduction, "targets": targets.detach()}
+    spec = {"reduction": reduction, "targets": targets.detach()}
+    if fn is not loss.grad_fn:
+        spec["quadratic"] = loss._hf_quadratic
+    return spec
+
+
+class _Node:
+    """Stands in for a loss tensor where only its ``grad_fn`` is looked at."""
+
+    def __init__(self, fn):
+        self.grad_fn = fn
+
+
+def _ce_node(loss):
+    """The autograd node of the cross-entropy inside ``loss``: ``loss.grad_fn`` itself, or -- for a loss
+    tagged ``_hf_quadratic = ((coef, [tensors]), ...)`` by its constructor (``testproblems.l2_regularized``:
+    ``loss = cross_entropy + sum 0.5 * coef * ||w||^2``) -- the addend that is an ``NllLossBackward0``."""
+    fn = loss.grad_fn
+    if fn is not None and fn.name() == "AddBackward0" and getattr(loss, "_hf_quadratic", None):
+        for nxt, _ in fn.next_functions:
+            if nxt is not None and nxt.name() == "NllLossBackward0":
+                return nxt
+        return None
+    return fn
 
 
 def _pair(v):

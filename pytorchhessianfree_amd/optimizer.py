@@ -193,15 +193,15 @@ class HessianFree(torch.optim.Optimizer):
             if user_mvp:
                 return None
             if curvature_opt == "hessian":
-                return curvature.HessianOperator(
-                    loss, self._params_list,
+                return curvature.hessian_operator(
+                    loss, outputs, self._params_list,
                     grad_with_graph=None if (grads is None or any(g is None for g in grads)) else grads,
                     weight=self.shard_weight, group=self.process_group)
             return curvature.ggn_operator(loss, outputs, self._params_list,
                                           weight=self.shard_weight, group=self.process_group)
 
         sess = None
-        if (self.graph_matvec and not user_mvp and not user_grad and curvature_opt == "ggn"
+        if (self.graph_matvec and not user_mvp and not user_grad
                 and self.device.type == "cuda" and not self._session_off and self._cg is cg):
             sess, init_loss = self._session_step(forward)
         if sess is not None:
@@ -342,11 +342,14 @@ class HessianFree(torch.optim.Optimizer):
             return None, None, None
         sess = self._session
         args = (loss, outputs, self._params_list, self.shard_weight, self.process_group)
+        hessian = self._group["curvature_opt"] == "hessian"
+        if sess is not None and sess.engine.hessian != hessian:
+            sess = None
         spec = sess.accepts(*args) if sess is not None else None
         if spec is None:
             self._session = sess = None
             if getattr(outputs, "_hf_model", None) is not None:
-                sess = EngineSession.try_create(*args)
+                sess = EngineSession.try_create(*args, hessian=hessian)
             spec = sess.accepts(*args) if sess is not None else None
             if spec is None:
                 self._session_failures += 1

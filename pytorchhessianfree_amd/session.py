@@ -46,7 +46,7 @@ class EngineSession:
 
     # ------------------------------------------------------------------------------------
     @classmethod
-    def try_create(cls, loss, outputs, params, weight=1.0, group=None):
+    def try_create(cls, loss, outputs, params, weight=1.0, group=None, hessian=False):
         """A session for the model that produced ``outputs`` (``None`` if the engine does not cover
         it or the loss is not a plain softmax cross-entropy)."""
         if os.environ.get("HF_SESSION", "1") == "0" or not torch.cuda.is_available():
@@ -56,7 +56,8 @@ class EngineSession:
         holder = {}
 
         def builder():
-            holder["eng"] = FusedGGNEngine.try_build(loss, outputs, list(params), weight=weight, group=group)
+            holder["eng"] = FusedGGNEngine.try_build(loss, outputs, list(params), weight=weight, group=group,
+                                                     hessian=hessian)
             return holder["eng"]
 
         sess = cls.__new__(cls)
@@ -140,6 +141,8 @@ class EngineSession:
         spec = ce_loss_spec(loss, outputs, check_values=False)
         if spec is None or spec["reduction"] != eng.loss_spec["reduction"]:
             return None
+        if _quadratic_signature(spec) != _quadratic_signature(eng.loss_spec):
+            return None  # (another regulariser: coefficients or tensors differ)
         if tuple(spec["targets"].shape) != tuple(eng._targets.shape):
             return None
         return spec
@@ -218,6 +221,10 @@ class EngineSession:
     def __call__(self, v, out=None):
         self.calls += 1
         return self.reduce(self.local(v, out))
+
+
+def _quadratic_signature(spec):
+    return tuple((float(c), tuple(id(w) for w in ws)) for c, ws in (spec.get("quadratic") or ()))
 
 
 class _NoEngine(Exception):

@@ -143,7 +143,11 @@ def l2_regularized(loss_function, model, l2=5e-4):
 
     def regularized(outputs, targets):
         reg = sum((w * w).sum() for w in weights)
-        return loss_function(outputs, targets) + (0.5 * l2) * reg
+        total = loss_function(outputs, targets) + (0.5 * l2) * reg
+        # what the curvature engine may assume about this loss (checked numerically on first use):
+        # base loss + sum 0.5 * coef * ||w||^2 over the listed tensors
+        total._hf_quadratic = ((float(l2), tuple(weights)),)
+        return total
 
     return regularized
 

@@ -166,6 +166,7 @@ def main():
     ap.add_argument("--products", type=int, default=20)
     ap.add_argument("--out", default="")
     ap.add_argument("--workload", default="resnet18", choices=["resnet18", "allcnnc", "resnet50"])
+    ap.add_argument("--curvature", default="ggn", choices=["ggn", "hessian"])
     args = ap.parse_args()
     hf.configure()
     dev = "cuda"
@@ -178,7 +179,10 @@ def main():
     modelprep.prepare_model(model, channels_last=True)
     params = [p for p in model.parameters() if p.requires_grad]
     out = model(x)
-    eng = curvature.ggn_operator(lossf(out, t), out, params)
+    if args.curvature == "hessian":
+        eng = curvature.hessian_operator(lossf(out, t), out, params)
+    else:
+        eng = curvature.ggn_operator(lossf(out, t), out, params)
     assert "engine" in eng.mode, "the engine did not take this model"
     v = torch.randn(eng.n, device=dev)
     res = torch.empty(eng.n, device=dev)

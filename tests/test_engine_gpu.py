@@ -22,9 +22,26 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _float64_product(make, v, **kw):
+def _float64_product(make, v, masks=None, **kw):
+    """float64 autograd product of the STOCK model; ``masks``: the ReLU sign decisions to take instead of the
+    float64 network's own, in call order (the product of the same piecewise-linear network an fp32 operator
+    linearised: one ReLU input within fp32 rounding of zero, decided the other way, moves a product of a
+    deep net by ~1e-4 of its max-norm -- no error of either side)."""
+    import types
+
     model, (x, t), lossf = make(device=DEV, **kw)
     model, x = model.double(), x.double()
+    if masks is not None:
+        cursor = [0]
+
+        def relu_forward(self, inp):
+            m = masks[cursor[0]]
+            cursor[0] += 1
+            return inp * m.to(inp.dtype)
+
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.ReLU):
+                mod.forward = types.MethodType(relu_forward, mod)
     params = [p for p in model.parameters() if p.requires_grad]
     out = model(x)
     return curvature.GGNOperator(lossf(out, t), out, params)(v.double())
@@ -51,6 +68,10 @@ def test_resnet18_engine_product_matches_float64(batch):
 
 
 def test_bottleneck_net_engine_product_matches_float64():
+    """Bottleneck (ResNet-50) blocks: the engine's product against float64 autograd of the stock model ON THE
+    ENGINE'S OWN ReLU DECISIONS, fixed bound 5e-6 (max-norm relative).  Against the float64 network's own
+    decisions this deep random-init net gives 1e-6 ... 3e-4 from run to run for every fp32 implementation,
+    stock autograd included: a handful of its ~10^6 pre-activations lie within fp32 rounding of zero."""
     model, (x, t), lossf = tp.resnet50_small_images(batch_size=4, device=DEV, image=32)
     modelprep.prepare_model(model, channels_last=True)
     params = [p for p in model.parameters() if p.requires_grad]
@@ -59,21 +80,16 @@ def test_bottleneck_net_engine_product_matches_float64():
     assert isinstance(op, FusedGGNEngine)  # (a regression that makes the engine decline must fail here)
     v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
     got = op(v)
-    want = _float64_product(tp.resnet50_small_images, v, batch_size=4, image=32)
+    masks = [(u.y > 0) for u in op.units if u.relu]
+    want = _float64_product(tp.resnet50_small_images, v, masks=masks, batch_size=4, image=32)
     err = float((got.double() - want).abs().max() / want.abs().max())
-    # this deep random-init net is badly conditioned: stock fp32 autograd itself is only good to
-    # 1e-4..1e-3 of the float64 product; the engine must be as good as that
-    stock, (xs, ts), lossf2 = tp.resnet50_small_images(batch_size=4, device=DEV, image=32)
-    ps = [p for p in stock.parameters() if p.requires_grad]
-    os_ = stock(xs)
-    stock_err = float((curvature.GGNOperator(lossf2(os_, ts), os_, ps)(v).double() - want).abs().max()
-                      / want.abs().max())
     worst, off = [], 0
     for name, p in model.named_parameters():
         a, b = got[off:off + p.numel()].double(), want[off:off + p.numel()]
         worst.append((float((a - b).abs().max() / want.abs().max()), name))
         off += p.numel()
-    assert err < max(2e-5, 3.0 * stock_err), (err, stock_err, sorted(worst, reverse=True)[:5])
+    assert err < 5e-6, (err, sorted(worst, reverse=True)[:5])
+    assert torch.equal(op(v), got)
 
 
 def test_engine_declines_what_it_does_not_know():
@@ -138,6 +154,51 @@ def test_allcnnc_plain_stack_engine_product_matches_float64_and_cpu_oracle(batch
         grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(cl(co, ct), cp)])
         assert float((op.gradient().cpu() - grad).abs().max() / grad.abs().max()) < 2e-6
         assert float((op.logits.cpu() - co.detach()).abs().max() / co.detach().abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("l2", [0.0, 5e-4])
+def test_allcnnc_engine_hessian_product_matches_float64_and_cpu_oracle(l2):
+    """BASELINE.json configs[3]: the HESSIAN product of All-CNN-C (cross-entropy, optionally + the L2 term
+    of examples/example_utils.py:77-81) on the plain-stack engine -- forward-over-reverse on the own
+    kernels -- against float64 autograd double-backward of the STOCK model (2e-6 max-norm relative), against
+    the CPU oracle (BackPACK's ``hessian_vector_product`` restated, reference call site
+    optimizer.py:450-455: 1e-5), bitwise repeatable, symmetric."""
+    from oracle import backpack_restated as bp
+    from pytorchhessianfree_amd.engine import PlainStackEngine
+    from pytorchhessianfree_amd.utils import vector_to_parameter_list
+
+    def problem(device, dtype=torch.float32):
+        model, (x, t), lossf = tp.allcnnc_cifar100(batch_size=32, device=device)
+        model, x = model.to(dtype), x.to(dtype)
+        if l2 > 0:
+            lossf = tp.l2_regularized(lossf, model, l2)
+        return model, x, t, lossf
+
+    model, x, t, lossf = problem(DEV)
+    modelprep.prepare_model(model, channels_last=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    op = curvature.hessian_operator(lossf(out, t), out, params)
+    assert isinstance(op, PlainStackEngine) and op.hessian
+    v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(8))
+    got = op(v).clone()
+    for _ in range(2):
+        assert torch.equal(op(v), got)
+    m64, x64, t64, l64 = problem(DEV, torch.float64)
+    p64 = [p for p in m64.parameters() if p.requires_grad]
+    want = curvature.HessianOperator(l64(m64(x64), t64), p64)(v.double())
+    assert float((got.double() - want).abs().max() / want.abs().max()) < 2e-6
+    u = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
+    a, b = float(u.double() @ got.double()), float(v.double() @ op(u).double())
+    assert abs(a - b) <= 1e-5 * abs(a)
+    cm, cx, ct, cl = problem("cpu")
+    cp = [p for p in cm.parameters() if p.requires_grad]
+    closs = cl(cm(cx), ct)
+    ref = torch.cat([g.reshape(-1) for g in bp.hessian_vector_product(closs, cp, vector_to_parameter_list(v.cpu(), cp))])
+    assert float((got.cpu() - ref).abs().max() / ref.abs().max()) < 1e-5
+    grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(closs, cp)])
+    assert float((op.gradient().cpu() - grad).abs().max() / grad.abs().max()) < 2e-6
+    assert abs(float(op.loss_buf) - float(closs)) <= 1e-6 * abs(float(closs))
 
 
 def test_resnet18_engine_product_matches_cpu_oracle_at_batch_32():
