@@ -69,6 +69,10 @@ def parse():
                          "the split costs +0.19 ms and the two async collectives +0.4 ms per product, "
                          "so it only pays when the all-reduce itself takes > ~0.6 ms; -1 = decided from a one-off "
                          "timing of the all-reduce at start-up)")
+    ap.add_argument("--chunk", type=int, default=-1,
+                    help="data parallel + fused engine: two hipGraphs per product, the all-reduce chunked by stage "
+                         "and the late layers' share (ResNet-18: 14 of 17 MB) overlapped with the rest of the adjoint "
+                         "sweep on a second communicator (session.ChunkedEngineOperator); -1 = on for > 1 rank")
     ap.add_argument("--force-dist", type=int, default=0,
                     help="create the process group even for WORLD_SIZE=1 (exercises the RCCL path on one GPU)")
     ap.add_argument("--conv", default="", choices=["", "auto", "own", "miopen"],
@@ -309,6 +313,7 @@ def main():
     l2 = args.l2 if args.l2 >= 0 else (5e-4 if (args.workload == "allcnnc" and args.curvature == "hessian") else 0.0)
     hessian = args.curvature == "hessian"
     dist_on = world > 1 or bool(args.force_dist)
+    chunk_on = bool(args.chunk) if args.chunk >= 0 else world > 1
 
     def problem(dev, dtype=torch.float32):
         model, (x, t), lossf = build_problem(args, dev, rank)
@@ -346,10 +351,18 @@ def main():
             out = model(x)
             return make_operator(lossf(out, t), out, params)
 
+        op = None
         if args.graph and overlap and not hessian:
             os.environ["HF_ENGINE"] = "0"  # the two-graph split is a split of the autograd sweeps
             op = curvature.OverlappedGraphedOperator(builder, params=params)
-        else:
+        elif args.graph and chunk_on and not hessian and args.engine:
+            from pytorchhessianfree_amd.session import ChunkedEngineOperator
+
+            try:
+                op = ChunkedEngineOperator(builder, params=params)
+            except TypeError as exc:  # (no engine / no suffix split for this model: the single-graph operator)
+                print(f"[bench] chunked all-reduce not available: {exc}", file=sys.stderr, flush=True)
+        if op is None:
             op = curvature.maybe_graphed(builder, enable=bool(args.graph), params=params)
         return op, grad, diag, sum(p.numel() for p in params)
 
@@ -634,6 +647,9 @@ def main():
                           + ("; deterministic (two products bitwise equal)" if check.get("deterministic")
                              else "; NOT bitwise repeatable (library kernels with atomics)"),
                 "iteration": ("one hipGraph launch per PCG iteration (product -> K1 -> K2 -> K3)" if fused and group is None
+                              else "product graph A -> [all-reduce of the late layers' share on a second communicator] "
+                                   "|| product graph B -> all-reduce of the rest -> scatter -> K1-K3 graph"
+                              if fused and hasattr(op, "replay_and_reduce")
                               else "product graph -> all-reduce -> K1-K3 graph" if fused
                               else "product, then K1, K2, K3 as separate launches"),
                 "termination": reason,

@@ -369,8 +369,12 @@ def cg(
             if group is None:
                 matvec.calls += 1
             else:
-                matvec.replay_local()
-                matvec.reduce(matvec.output_buffer)
+                fused_reduce = getattr(matvec, "replay_and_reduce", None)
+                if fused_reduce is not None:  # (the operator overlaps its collective with its own sweep)
+                    fused_reduce()
+                else:
+                    matvec.replay_local()
+                    matvec.reduce(matvec.output_buffer)
                 matvec.calls += 1
             fused.launch(stream, timed)
             timed_pending = timed_pending or timed

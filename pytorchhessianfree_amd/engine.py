@@ -726,6 +726,81 @@ class FusedGGNEngine(_Operator):
         self._adjoint_stem(pool_srcs)
         return self._gather(out, g_fw, g_fb)
 
+    # ---- the product in two phases, for overlapping the all-reduce with the rest of the sweep ----
+    def phase_split(self, tail_fraction=0.7):
+        """Block index ``cut`` such that the parameters of blocks ``cut ...`` and of the classifier are a
+        contiguous SUFFIX of the flat vector holding at least ``tail_fraction`` of the entries that travel
+        (the adjoint sweep finishes them first: ResNet-18 on 28x28 inputs, layer3 + layer4 + fc = 14 of
+        17 MB after ~60 % of the product), with the flat offset of that suffix; ``None`` if the layout does
+        not allow it."""
+        if not self.blocks or self.fc is None:
+            return None
+        live = self._live_counts()
+        total = sum(live)
+        acc = live[self.pfw] + (live[self.pfb] if self.pfb is not None else 0)
+        cut = None
+        for bi in range(len(self.blocks) - 1, 0, -1):
+            chain, ds, _ = self.blocks[bi]
+            acc += sum(live[i] for u in chain + ([ds] if ds is not None else []) for i in (u.pw, u.pg, u.pb))
+            if acc >= tail_fraction * total:
+                cut = bi
+                break
+        if cut is None:
+            return None
+        late = {i for bi in range(cut, len(self.blocks)) for u in self.blocks[bi][0] + ([self.blocks[bi][1]] if self.blocks[bi][1] is not None else [])
+                for i in (u.pw, u.pg, u.pb)} | {self.pfw} | ({self.pfb} if self.pfb is not None else set())
+        first = min(late)
+        if late != set(range(first, len(self.params))):
+            return None  # the late layers' parameters are not a suffix of the vector
+        return cut, first, self._offs[first]
+
+    def _live_counts(self):
+        counts = [p.numel() for p in self.params]
+        for u in self.units:
+            if not u.im2col and getattr(u, "live", 0):
+                rs = u.conv.weight.shape[2] * u.conv.weight.shape[3]
+                counts[u.pw] = u.conv.weight.numel() // rs * bin(u.live).count("1")
+        return counts
+
+    def local_phase_a(self, v, out, split):
+        """Tangent sweep, head, adjoint sweep of blocks ``cut ...``, and the suffix of the product they
+        determine (``out[offset:]``)."""
+        cut, first, offset = split
+        v = v.detach()
+        _lib.unpack_tangent(v, self._slot_list)
+        self._tangent_stem(v)
+        self._tangent_blocks(v)
+        g_last, g_fw, g_fb = self._head(v)
+        self._phase_state = self._adjoint_blocks(g_last, last_block=cut)
+        self._gather_range(out, g_fw, g_fb, first, len(self.params))
+
+    def local_phase_b(self, out, split):
+        """The rest of the adjoint sweep and ``out[:offset]``."""
+        cut, first, offset = split
+        pool_srcs = self._adjoint_blocks(None, first=cut - 1, last_block=0, incoming=self._phase_state)
+        self._adjoint_stem(pool_srcs)
+        self._gather_range(out, None, None, 0, first)
+
+    def _gather_range(self, out, g_fw, g_fb, lo, hi):
+        """``_gather`` for the parameters ``lo ... hi-1`` only (a contiguous range of the flat vector)."""
+        tensors, perms, splits = self._pack_args()
+        tensors, splits = list(tensors), dict(splits)
+        if g_fw is not None:
+            if g_fw.dim() == 3:
+                tensors[self.pfw] = g_fw[0]
+                splits[self.pfw] = (g_fw.shape[0], g_fw[0].numel())
+                if self.pfb is not None:
+                    tensors[self.pfb] = g_fb[0]
+                    splits[self.pfb] = (g_fb.shape[0], g_fb.shape[1])
+            else:
+                tensors[self.pfw] = g_fw
+                if self.pfb is not None:
+                    tensors[self.pfb] = g_fb
+        sub = lambda d: {i - lo: val for i, val in d.items() if lo <= i < hi}  # noqa: E731
+        end = self._offs[hi] if hi < len(self.params) else self.n
+        _lib.pack_ex(out[self._offs[lo]:end], tensors[lo:hi], sub(perms), sub(splits), scale=self.weight,
+                     live=sub(self._pack_live))
+
     # ---- tangent sweep -------------------------------------------------------------------------
     def _pool_geometry(self):
         """(n, h, w, oh, ow, c) of the stem's max-pool (window maxima's positions: ``forward_own``)."""
@@ -808,13 +883,17 @@ class FusedGGNEngine(_Operator):
         return self._feature_cotangent(g_feat), g_fw, g_fb
 
     # ---- adjoint sweep -------------------------------------------------------------------------
-    def _adjoint_blocks(self, g_last):
-        """Walks the blocks backwards; returns the two cotangents of the pooled stem output."""
+    def _adjoint_blocks(self, g_last, first=None, last_block=0, incoming=None):
+        """Walks the blocks ``first`` (default: the last one) ... ``last_block`` backwards; returns the
+        two cotangents of the pooled stem output -- or, when the walk stops before block 0, the state
+        (``incoming``) a later call continues from (the product in two phases, ``local_phases``)."""
         group = self._grouping()
         tail = self.tail
-        incoming = {id(tail): [(g_last, 1, 0)]}
+        if incoming is None:
+            incoming = {id(tail): [(g_last, 1, 0)]}
         pool_srcs = None
-        for bi in range(len(self.blocks) - 1, -1, -1):
+        first = len(self.blocks) - 1 if first is None else first
+        for bi in range(first, last_block - 1, -1):
             chain, ds, _x = self.blocks[bi]
             head, last = chain[0], chain[-1]
             for k in range(len(chain) - 1, -1, -1):
@@ -847,7 +926,7 @@ class FusedGGNEngine(_Operator):
                 incoming[id(self.blocks[bi - 1][0][-1])] = srcs
             else:
                 pool_srcs = srcs
-        return pool_srcs
+        return pool_srcs if last_block == 0 else incoming
 
     def _adjoint_stem(self, pool_srcs):
         """Block 0's input is the pooled stem output: sum its two cotangents, undo the max-pool,
@@ -961,8 +1040,15 @@ class FusedGGNEngine(_Operator):
             self._live_segs = None
             masked = {u.pw: u for u in self.units if not u.im2col and getattr(u, "live", 0)}
             segs, dead, run_start = [], 0, None  # (full offset, count in the full vector, period, mask)
+            brk = getattr(self, "_seg_break", None)  # parameter index at which a dense run must end
+            self._seg_cut = None                     # (chunked all-reduce: the suffix starts a segment)
             for i, p in enumerate(self.params):
                 off = self._offs[i]
+                if i == brk:
+                    if run_start is not None:
+                        segs.append((run_start, off - run_start, 0, 0))
+                        run_start = None
+                    self._seg_cut = (len(segs), off - dead)  # (segment index, compact offset) of the suffix
                 if i in masked:
                     if run_start is not None:
                         segs.append((run_start, off - run_start, 0, 0))
@@ -982,10 +1068,17 @@ class FusedGGNEngine(_Operator):
                 self._compact = torch.empty(self.n - dead, dtype=torch.float32, device=self.dev)
         return self._live_segs
 
-    def _live_copy(self, full, scatter):
+    def _live_copy(self, full, scatter, part=None):
+        """Gather (``scatter=False``) the live entries of ``full`` into the compact vector, or scatter them
+        back; ``part``: "head" / "tail" of the chunked layout (segments before / from ``_seg_cut``)."""
         offs, counts, periods, masks, ns = self._live_segs
-        _lib.check(_lib.load().hf_live_copy(_ptr(full), _ptr(self._compact), int(scatter), offs, counts, periods,
-                                            masks, ns, _lib.HF_F32, _lib.current_stream_ptr(self.dev)),
+        lo, hi, comp = 0, ns, self._compact
+        if part is not None:
+            k, coff = self._seg_cut
+            lo, hi, comp = (0, k, self._compact[:coff]) if part == "head" else (k, ns, self._compact[coff:])
+        sub = lambda a: (_lib.c_int64 * (hi - lo))(*a[lo:hi])  # noqa: E731
+        _lib.check(_lib.load().hf_live_copy(_ptr(full), _ptr(comp), int(scatter), sub(offs), sub(counts), sub(periods),
+                                            sub(masks), hi - lo, _lib.HF_F32, _lib.current_stream_ptr(self.dev)),
                    "hf_live_copy")
 
     @property

@@ -140,6 +140,26 @@ def main(outdir):
         out["engine/equal_plain_allreduce"] = np.array([bool(torch.equal(got, plain))])
         out["engine/reduce_bytes"] = np.array([eng.reduce_bytes, 4 * eng.n])
         out["engine/checksum"] = np.array([float(got.double().sum()), float(got.double().abs().max())])
+        # ---- the same product with the all-reduce chunked by stage and overlapped (two hipGraphs,
+        # session.ChunkedEngineOperator): bitwise the single compact all-reduce, and a solve through it
+        from pytorchhessianfree_amd.session import ChunkedEngineOperator
+
+        def builder():
+            oo = net(xb)
+            return curvature.ggn_operator(ce(oo, tb), oo, ps, weight=0.5, group=group)
+
+        chunked = ChunkedEngineOperator(builder, params=ps)
+        got2 = chunked(v).clone()
+        out["chunked/equal_plain_allreduce"] = np.array([bool(torch.equal(got2, plain))])
+        k, coff = chunked.engine._seg_cut
+        out["chunked/tail_share"] = np.array([1.0 - coff / chunked.engine._compact.numel()])
+        grad = torch.randn(eng.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            xa, _, ra = hf.cg(hf.DampedCurvature(chunked, 0.1), grad, max_iter=12, tol=0.0, store_x_at_iters=[0])
+            xb_, _, rb = hf.cg(hf.DampedCurvature(eng, 0.1), grad, max_iter=12, tol=0.0, store_x_at_iters=[0])
+        out["chunked/solve_equal"] = np.array([bool(torch.equal(xa[-1], xb_[-1])) and ra == rb])
+        out["chunked/solve_x"] = xa[-1].cpu().numpy()
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
         dist.barrier()
     finally:

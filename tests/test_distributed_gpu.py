@@ -98,6 +98,18 @@ def test_engine_product_two_ranks_compact_allreduce(two_rank_run):
     assert moved < 0.5 * full and full == 4 * 11175370
 
 
+def test_engine_product_two_ranks_chunked_overlapped_allreduce(two_rank_run):
+    """The all-reduce chunked by stage (late layers' share first, on its own communicator / asynchronously,
+    while the rest of the adjoint sweep runs as a second hipGraph): bitwise the plain all-reduce of the local
+    products on 2 ranks, both ranks identical, the overlapped share is most of the bytes, and a 12-iteration
+    PCG solve through it (lockstep rule, K1-K3 graph) equals the solve through the single-graph operator."""
+    r0, r1 = two_rank_run
+    assert bool(r0["chunked/equal_plain_allreduce"][0]) and bool(r1["chunked/equal_plain_allreduce"][0])
+    assert float(r0["chunked/tail_share"][0]) > 0.6
+    assert bool(r0["chunked/solve_equal"][0]) and bool(r1["chunked/solve_equal"][0])
+    assert np.array_equal(r0["chunked/solve_x"], r1["chunked/solve_x"])
+
+
 def test_bench_gpus_2_starts_two_ranks_itself():
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
@@ -112,3 +124,9 @@ def test_bench_gpus_2_starts_two_ranks_itself():
     assert rec["n_gpus"] == 2
     assert rec["config"]["parallelism"].startswith("dp2")
     assert rec["value"] > 0
+    # the functional 2-rank run takes the path an 8-GPU run takes: fused engine, chunked compact all-reduce
+    # (not the two-graph autograd split a slow gloo collective used to switch on), K1-K3 as one graph
+    assert "engine" in rec["config"]["matvec"]
+    assert rec["config"]["allreduce"]["overlap_two_graphs"] is False
+    assert "product graph A" in rec["config"]["iteration"]
+    assert rec["config"]["allreduce"]["bytes"] < 0.5 * 4 * 11175370
