@@ -83,6 +83,9 @@ def parse():
                     help="1: the fused curvature engine (own deterministic convolutions, BatchNorm fused, "
                          "split-K slabs summed by the consumer kernel) where the model family is supported; "
                          "0: the autograd product")
+    ap.add_argument("--bn", default="eval", choices=["eval", "train"],
+                    help="BatchNorm mode: eval (running statistics; what batch sharding needs) or train (batch "
+                         "statistics, what examples/run_resnet18_mnist.py runs; single GPU)")
     ap.add_argument("--curvature", default="ggn", choices=["ggn", "hessian"],
                     help="curvature_opt of the reference (optimizer.py:25); hessian = BASELINE.json configs[3]")
     ap.add_argument("--precond", type=int, default=0,
@@ -162,6 +165,8 @@ def cpu_baseline(args):
     from pytorchhessianfree_amd import testproblems as tp
 
     model, (x, t), lossf = build_problem(args, "cpu", 0)
+    if args.bn == "train":
+        model.train()
     l2 = args.l2 if args.l2 >= 0 else (5e-4 if (args.workload == "allcnnc" and args.curvature == "hessian") else 0.0)
     if l2 > 0:
         lossf = tp.l2_regularized(lossf, model, l2)
@@ -241,6 +246,8 @@ def full_step_timing(args, device, n_steps=8, warmup=2):
             "resnet50": tp.resnet50_small_images}[args.workload]
     seeds = tp.RESNET18_B32_SEPARATED_SEEDS if (args.workload == "resnet18" and args.batch == 32) else range(1000, 1008)
     model, _, lossf = make(batch_size=args.batch, seed=0, device=device, data_seed=seeds[0])
+    if args.bn == "train":
+        model.train()
     modelprep.prepare_model(model, channels_last=bool(args.channels_last))
     batches = [make(batch_size=args.batch, seed=0, device=device, data_seed=sd)[1] for sd in seeds]
     opt = hf.HessianFree(model.parameters(), graph_matvec=bool(args.graph))
@@ -318,6 +325,8 @@ def main():
     def problem(dev, dtype=torch.float32):
         model, (x, t), lossf = build_problem(args, dev, rank)
         model, x = model.to(dtype), x.to(dtype)
+        if args.bn == "train":
+            model.train()
         if l2 > 0:  # examples/example_utils.py:77-81 (DeepOBS' L2 term on the weights)
             lossf = tp.l2_regularized(lossf, model, l2)
         return model, x, t, lossf
@@ -630,7 +639,7 @@ def main():
                 "workload": f"{args.workload} {args.curvature.upper()} PCG solve: N={n} fp32 parameters, "
                             f"batch {args.batch}/GPU, {iters_done} PCG iterations in the last step "
                             f"({matvecs} operator calls in {args.steps} steps, max_iter {args.iters}), "
-                            f"damping {args.damping}, eval-mode BN, CE-mean"
+                            f"damping {args.damping}, {args.bn}-mode BN, CE-mean"
                             + (f" + L2 {l2:g}" if l2 > 0 else "") + ", x0=0, tol=0"
                             + (", diag empirical-Fisher preconditioner ^-0.75 (per-sample autograd)" if M is not None else ""),
                 "parallelism": f"dp{world} (batch sharded, {args.batch} samples per GPU, one all-reduce per matvec: the "

@@ -323,6 +323,21 @@ int hf_bn_forward(void* y, void* y2, int64_t y2_ld, void* a_out, const void* a, 
                   const void* mean, const void* rstd, const void* w, const void* b, const void* res,
                   int64_t res_ld, int relu, int64_t rows, int64_t c, int dtype, void* stream);
 
+/*
+ * TRAIN-mode BatchNorm inside the curvature product (what examples/run_resnet18_mnist.py runs: no
+ * model.eval(), so BackPACK's R-op / L-op differentiate through the batch statistics, optimizer.py:461).
+ * Tangent and adjoint of xhat = (a - mean_B(a)) * rstd_B are the same operator
+ *     xhat' = rstd * [a' - mean(a') - xhat * mean(xhat * a')],
+ * whose two per-channel corrections fold into the per-channel vectors of hf_chan_affine_ex
+ * (t = a*(w*rstd) + xhat*q + r):   q = vq - w*rstd*S_x/count,   r = vr - w*rstd*S_1/count,
+ * S_x = sum(xhat*a'), S_1 = sum(a') over the batch -- given as `nparts` partial sums c elements apart (what
+ * hf_chan_affine_bwd_ex writes to gw / gb with gx = NULL), added here in order.  vq / vr nullable (the adjoint
+ * has none), w nullable (1).
+ */
+int hf_bn_train_coeffs(void* q_out, void* r_out, const void* part_x, const void* part_1, int nparts, const void* w,
+                       const void* rstd, const void* vq, const void* vr, double count, int64_t c, int dtype,
+                       void* stream);
+
 /* Elementwise adjoint pre-pass of a fused BatchNorm(+add+ReLU) layer, NHWC [rows, c]:
  *   g = (sum of gy_a's slabs + sum of gy_b's slabs) * [mask_src > 0];  g_out = g (nullable);
  *   ga_out = g * w[c]*rstd[c] (nullable): the cotangent of the convolution output that

@@ -99,6 +99,8 @@ SIGNATURES = {
         c_int,
         [c_void_p, ctypes.POINTER(c_void_p)] + [ctypes.POINTER(c_int64)] * 6 + [c_int, c_int, c_void_p],
     ),
+    "hf_bn_train_coeffs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 4
+                           + [c_double, c_int64, c_int, c_void_p]),
     "hf_bn_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64] + [c_void_p] * 5
                       + [c_int64, c_int, c_int64, c_int64, c_int, c_void_p]),
     "hf_maxpool_forward_nhwc": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p] + [c_int64] * 12

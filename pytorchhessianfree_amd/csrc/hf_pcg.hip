@@ -1339,6 +1339,31 @@ __global__ __launch_bounds__(BLOCK) void k_bn_forward(
   }
 }
 
+// Train-mode BatchNorm inside the curvature product: the batch statistics depend on the layer input, so
+// tangent and adjoint carry two per-channel corrections,
+//     xhat' = rstd * [a' - mean(a') - xhat * mean(xhat * a')]          (the same operator for the adjoint),
+// which fold into the per-channel vectors of the elementwise kernel k_chan_affine (t = a*(w*rstd) + xhat*q + r):
+//     q[c] = vq[c] - w[c]*rstd[c] * S_x[c]/m ,   r[c] = vr[c] - w[c]*rstd[c] * S_1[c]/m
+// with S_x = sum(xhat * a'), S_1 = sum(a') given as `nparts` partial sums (the row shares of k_bn_adjoint_rows),
+// added up here in order.  One tiny launch per layer and sweep.
+__global__ __launch_bounds__(BLOCK) void k_bn_train_coeffs(float* __restrict__ q_out, float* __restrict__ r_out,
+                                                           const float* __restrict__ part_x,
+                                                           const float* __restrict__ part_1, int nparts,
+                                                           const float* __restrict__ w, const float* __restrict__ rstd,
+                                                           const float* __restrict__ vq, const float* __restrict__ vr,
+                                                           float inv_m, int C) {
+  const int c = blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= C) return;
+  double sx = 0.0, s1 = 0.0;
+  for (int p = 0; p < nparts; ++p) {
+    sx += (double)part_x[(size_t)p * C + c];
+    s1 += (double)part_1[(size_t)p * C + c];
+  }
+  const float k = (w ? w[c] : 1.f) * rstd[c] * inv_m;
+  q_out[c] = (vq ? vq[c] : 0.f) - k * (float)sx;
+  r_out[c] = (vr ? vr[c] : 0.f) - k * (float)s1;
+}
+
 // Hessian of a softmax cross-entropy w.r.t. the logits, applied to v, row by row:
 //   out[r, :] = scale * p[r, :] * (v[r, :] - <p[r, :], v[r, :]>)      (p = softmax(logits))
 // One block per row; the dot product is accumulated in fp64.
@@ -2243,6 +2268,18 @@ int hf_bn_adjoint_pre(void* g_out, void* ga_out, const void* gy_a, int a_splits,
                        (const double*)rstd, (unsigned)total, (unsigned)c);
   else
     return HF_ERR_ARG;
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_bn_train_coeffs(void* q_out, void* r_out, const void* part_x, const void* part_1, int nparts, const void* w,
+                       const void* rstd, const void* vq, const void* vr, double count, int64_t c, int dtype,
+                       void* stream) {
+  if (dtype != HF_F32 || !q_out || !r_out || !part_x || !part_1 || !rstd || nparts < 1 || c < 1 || !(count > 0))
+    return HF_ERR_ARG;
+  hipLaunchKernelGGL(k_bn_train_coeffs, dim3((unsigned)((c + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     (float*)q_out, (float*)r_out, (const float*)part_x, (const float*)part_1, nparts, (const float*)w,
+                     (const float*)rstd, (const float*)vq, (const float*)vr, (float)(1.0 / count), (int)c);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }

@@ -67,6 +67,8 @@ class _Unit:
         self.first = False        # first layer of a plain stack: no input tangent, no data gradient
         self.needs_g = True       # the masked cotangent itself is read by a residual branch
         self.im2col = False       # tiny-Cin layer: runs as a 1x1 product over the im2col of the input
+        self.train = False        # train-mode BatchNorm: batch statistics (recorded), tangent / adjoint carry
+        self.mean_t = None        # the statistics' dependence on the layer input
         self.res_unit = None      # downsample unit whose output is added before the activation
         self.res_identity = False  # ... or the block input itself
         self.consumers = 0
@@ -75,6 +77,8 @@ class _Unit:
     # per-channel affine map behind the convolution: BatchNorm statistics / scale / shift, or a bias
     @property
     def mean(self):
+        if self.train:
+            return self.mean_t
         return self.bn.running_mean if self.bn is not None else None
 
     @property
@@ -134,16 +138,23 @@ class FusedGGNEngine(_Operator):
             offs.append(o)
             o += p.numel()
         self._offs = offs
+        self.train_bn = False
         self._layout(model)
         self._allocate()
-        # own forward pass on the engine's static buffers; it must reproduce the model's output
         self.set_batch(getattr(outputs, "_hf_input").detach(), None)
         self.refresh_weights(transposed=True)
-        self.forward_own()
-        want = outputs.detach()
-        err = float((self.logits - want).abs().max() / want.abs().max().clamp_min(1e-30))
-        if not err < 1e-4:
-            raise _Unsupported(f"the engine's forward pass differs from the model's output by {err:.2e}")
+        if self.train_bn:
+            # train-mode BatchNorm: the engine linearises at the activations and batch statistics the MODEL's
+            # forward pass recorded (no own forward pass, no persistent session: every forward of such a model
+            # also moves its running statistics)
+            self._load_recorded(outputs)
+        else:
+            # own forward pass on the engine's static buffers; it must reproduce the model's output
+            self.forward_own()
+            want = outputs.detach()
+            err = float((self.logits - want).abs().max() / want.abs().max().clamp_min(1e-30))
+            if not err < 1e-4:
+                raise _Unsupported(f"the engine's forward pass differs from the model's output by {err:.2e}")
         self._loss_setup(loss, outputs)
         self._verify(loss)
         for u in self.units:  # the model's own activations were only needed up to here
@@ -182,17 +193,27 @@ class FusedGGNEngine(_Operator):
             return rec
 
         units = []
+        group_is_set = self.group is not None
 
         def make_unit(name, conv, bn, relu_expected):
             if type(conv) is not nn.Conv2d or conv.bias is not None or conv.groups != 1:
                 raise _Unsupported(f"{name}: unsupported convolution")
             if not getattr(conv, "_hf_channels_last", False) or tuple(conv.dilation) != (1, 1):
                 raise _Unsupported(f"{name}: needs prepare_model(channels_last=True)")
-            if bn.training or not isinstance(bn, nn.BatchNorm2d):
-                raise _Unsupported(f"{name}: BatchNorm must be in eval mode")
+            if not isinstance(bn, nn.BatchNorm2d):
+                raise _Unsupported(f"{name}: not a BatchNorm2d")
             u = _Unit(name, conv, bn)
             cx, cy = io(conv, 2)
-            bx, bres, by, brelu, rstd = io(bn, 5)
+            rec = getattr(bn, "_hf_io", None)
+            if bn.training:
+                # train mode: the layer ran on stock ops and recorded its batch statistics (modelprep)
+                if rec is None or len(rec) != 6 or group_is_set:
+                    raise _Unsupported(f"{name}: train-mode BatchNorm without a record (or under data "
+                                       "parallelism: batch statistics couple the samples of a shard)")
+                bx, bres, by, brelu, rstd, u.mean_t = rec
+                u.train = True
+            else:
+                bx, bres, by, brelu, rstd = io(bn, 5)
             if not _same(cy, bx):
                 raise _Unsupported(f"{name}: the BatchNorm does not consume the convolution's output")
             if brelu != relu_expected:
@@ -223,7 +244,7 @@ class FusedGGNEngine(_Operator):
         prev = "pool"  # producer of the current block input
         for bi, b in enumerate(blocks):
             convs = [n for n in ("conv1", "conv2", "conv3") if isinstance(getattr(b, n, None), nn.Conv2d)]
-            if not getattr(b, "_hf_block_patched", False) or len(convs) < 2 or b.training:
+            if not getattr(b, "_hf_block_patched", False) or len(convs) < 2:
                 raise _Unsupported(f"block {bi}: not a fused residual block")
             chain, inp = [], cur
             for k, cn in enumerate(convs):
@@ -267,6 +288,7 @@ class FusedGGNEngine(_Operator):
         self.pfw, self.pfb = self._param(fc.weight), self._param(fc.bias)
         self.units = units
         self.tail = self.blocks[-1][0][-1]
+        self.train_bn = any(u.train for u in units)
         used = {i for u in units for i in (u.pw, u.pg, u.pb)} | {self.pfw} | ({self.pfb} if self.pfb is not None else set())
         if used != set(range(len(self.params))):
             raise _Unsupported("the parameter list has entries the engine's layers do not cover")
@@ -279,7 +301,7 @@ class FusedGGNEngine(_Operator):
         # loss, probabilities and d loss / d logits itself, on its own forward pass -- which is what
         # lets ONE engine serve many steps and trial points (``session.EngineSession``)
         self.loss_spec = None
-        if self._ce is not None:
+        if self._ce is not None and not self.train_bn:
             spec = ce_loss_spec(loss, outputs)
             if spec is not None:
                 self.loss_spec = spec
@@ -325,7 +347,7 @@ class FusedGGNEngine(_Operator):
             s.cols.copy_(cols.transpose(1, 2))
             s.cols_pad[:, :, :s.jcols].copy_(s.cols)
         for u in self.units:  # eval-mode statistics are constants -- unless somebody retrained them
-            if u.bn is not None and u.bn.running_var._version != u.rstd_version:
+            if u.bn is not None and not u.train and u.bn.running_var._version != u.rstd_version:
                 torch.rsqrt(u.bn.running_var + u.bn.eps, out=u.rstd)
                 u.rstd_version = u.bn.running_var._version
         if targets is not None:
@@ -480,7 +502,11 @@ class FusedGGNEngine(_Operator):
             self.pool_out = nhwc(self.pool_out.shape)
         for u in self.units:
             u.a, u.y = nhwc(u.a.shape), nhwc(u.y.shape)
-            if u.bn is not None:
+            if u.train:
+                u.rstd_version = None  # (u.rstd: the batch statistics recorded by the model's forward pass)
+                u.cq = torch.empty(u.a.shape[1], dtype=f32, device=dev)  # per-channel vectors of the corrected
+                u.cr = torch.empty(u.a.shape[1], dtype=f32, device=dev)  # elementwise pass (hf_bn_train_coeffs)
+            elif u.bn is not None:
                 u.rstd = torch.rsqrt(u.bn.running_var + u.bn.eps)
                 u.rstd_version = u.bn.running_var._version
         tails = {id(c[-1]): c[0] for c, _, _ in self.blocks}
@@ -631,11 +657,29 @@ class FusedGGNEngine(_Operator):
             mat_ld, out_c, splits, out.shape[1] if out.dim() == 2 else 0, _lib.HF_F32,
             _lib.current_stream_ptr(self.dev)), "hf_conv2d_nhwc_slabs")
 
+    def _train_coeffs(self, u, vq, vr):
+        """Per-channel vectors of the elementwise pass of a train-mode BatchNorm from the partial sums in
+        ``u.gw`` / ``u.gb`` (sum xhat*a', sum a' over the batch): see ``hf_bn_train_coeffs``."""
+        n, k, oh, ow = u.a.shape
+        _lib.check(_lib.load().hf_bn_train_coeffs(
+            _ptr(u.cq), _ptr(u.cr), _ptr(u.gw), _ptr(u.gb), u.rb, _ptr(u.scale), _ptr(u.rstd), _ptr(vq), _ptr(vr),
+            float(n * oh * ow), k, _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_bn_train_coeffs")
+
     def _bn_tangent(self, u, v, add, add_ld):
         """t_y = mask * (sum(T slabs) * w*rstd + xhat * v_w + v_b + add), into the consumer's operand."""
         n, k, oh, ow = u.a.shape
         vg = v[self._offs[u.pg]: self._offs[u.pg] + k] if u.pg is not None else None
         vb = v[self._offs[u.pb]: self._offs[u.pb] + k] if u.pb is not None else None
+        if u.train:
+            # batch statistics move with the input: sums of a' and xhat*a' over the batch (the adjoint's
+            # reduction kernel on the tangent slabs), folded into the per-channel vectors of the same pass
+            lib, st = _lib.load(), _lib.current_stream_ptr(self.dev)
+            _lib.check(lib.hf_chan_affine_bwd_ex(
+                None, _ptr(u.gw), _ptr(u.gb), None, _ptr(u.tbuf), u.sT, u.tbuf.shape[1], None, 1, 0, _ptr(u.a),
+                _ptr(u.mean), _ptr(u.rstd), None, None, n, k, oh * ow, 1, u.rb, _lib.HF_F32, st),
+                "hf_chan_affine_bwd_ex")
+            self._train_coeffs(u, vg, vb)
+            vg, vb = u.cq, u.cr
         _lib.check(_lib.load().hf_chan_affine_ex(
             _ptr(u.tout), _ptr(u.tbuf), _ptr(u.a), _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale),
             _ptr(vg), _ptr(vb), _ptr(add), _ptr(u.y) if u.relu else None, 0, n, k, oh * ow, 1, u.tout_ld, add_ld,
@@ -687,6 +731,19 @@ class FusedGGNEngine(_Operator):
         (b, sb, lb) = srcs[1] if len(srcs) == 2 else (None, 1, 0)
         lib, st = _lib.load(), _lib.current_stream_ptr(self.dev)
         n, k, oh, ow = u.a.shape
+        if u.train:
+            # pass 1: g = mask * (sum of the cotangents' slabs) and its per-channel sums (the parameter
+            # gradients); pass 2: g_a = rstd*w * [g - mean(g) - xhat * mean(xhat*g)] (the batch statistics'
+            # share), by the elementwise kernel with the corrections folded into its per-channel vectors
+            _lib.check(lib.hf_chan_affine_bwd_ex(
+                None, _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a), _ptr(u.mean),
+                _ptr(u.rstd), _ptr(u.scale), _ptr(u.y) if u.relu else None, n, k, oh * ow, 1, u.rb, _lib.HF_F32, st),
+                "hf_chan_affine_bwd_ex")
+            self._train_coeffs(u, None, None)
+            _lib.check(lib.hf_chan_affine_ex(
+                _ptr(ga), _ptr(u.g), _ptr(u.a), _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.cq), _ptr(u.cr),
+                None, None, 0, n, k, oh * ow, 1, 0, 0, 1, 0, _lib.HF_F32, st), "hf_chan_affine_ex")
+            return
         # g = mask * (sum of both cotangents' slabs) -> u.g; g * w*rstd -> u.ga; per-channel sums
         bn = u.bn is not None
         _lib.check(lib.hf_chan_affine_bwd_ex(
@@ -828,7 +885,8 @@ class FusedGGNEngine(_Operator):
                 _lib.conv_group_slabs([(0, ds.tbuf, ds.xcat, ds.wcat, self._tgeo(ds), ds.sT, 0, 0),
                                        (0, head.tbuf, head.xcat, head.wcat, self._tgeo(head), head.sT, 0, 0)],
                                       self.dev)
-                paired = head.res_unit is None and not head.res_identity and len(chain) > 1
+                paired = (head.res_unit is None and not head.res_identity and len(chain) > 1
+                          and not head.train and not ds.train)
                 if paired:  # ... and both BatchNorm tangents in one
                     self._bn_tangent_pair(ds, head, v)
                 else:
@@ -901,7 +959,7 @@ class FusedGGNEngine(_Operator):
                 if k == 0 and ds is not None and group:
                     # both BatchNorm adjoints, then the data + weight gradients of the block's first
                     # convolution AND of its downsample branch in ONE launch (four problems)
-                    if u.rb > 1 and ds.rb > 1:
+                    if u.rb > 1 and ds.rb > 1 and not u.train and not ds.train:
                         self._bn_adjoint_pair(u, incoming.pop(id(u)), ds, [(last.g, 1, 0)])
                     else:
                         self._bn_adjoint(u, incoming.pop(id(u)))
@@ -1150,7 +1208,8 @@ class FusedGGNEngine(_Operator):
             got = self.local(v).clone()
         finally:
             self.weight = weight
-            self.forward_own()  # back to the engine's own activations
+            if not self.train_bn:
+                self.forward_own()  # back to the engine's own activations
         want = GGNOperator(loss, self.outputs, self.params).local(v)
         err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
         if not err < FusedGGNEngine.verify_tol:

@@ -280,7 +280,16 @@ def fused_bn_act(bn, x, res=None, relu=False, twin=False):
         y = fwd(x)
         if res is not None:
             y = y + res
-        return torch.relu(y) if relu else y
+        y = torch.relu(y) if relu else y
+        if (bn.training and isinstance(bn, nn.BatchNorm2d) and x.is_cuda and x.dim() == 4 and bn.weight is not None
+                and bn.bias is not None and x.dtype == torch.float32):
+            # train mode (stock ops above): what the curvature engine needs of this pass -- the batch
+            # statistics the layer normalised with, as a 6-entry record
+            with torch.no_grad():
+                var, mean = torch.var_mean(x.detach(), dim=(0, 2, 3), unbiased=False)
+                rstd = torch.rsqrt(var + bn.eps)
+            bn._hf_io = (x.detach(), None if res is None else res.detach(), y.detach(), relu, rstd, mean)
+        return y
     rstd = torch.rsqrt(bn.running_var + bn.eps)
     if not twin:
         y = _ChanAffine.apply(x, bn.weight, bn.bias, bn.running_mean, rstd, res, relu)
@@ -296,13 +305,20 @@ def _fused_forward(self, x):
     y = fused_bn_act(self, x)
     if _bn_usable(self, x):
         y._hf_bn_src = (self, x)  # lets a directly following ReLU module fuse with this layer
+    elif self.training and getattr(self, "_hf_io", None) is not None:
+        y._hf_bn_train_src = self  # train mode: a following ReLU module completes this layer's record
     return y
 
 
 def _relu_forward(self, x):
     src = getattr(x, "_hf_bn_src", None)
     if src is None:
-        return self._hf_stock_forward(x)
+        y = self._hf_stock_forward(x)
+        bn = getattr(x, "_hf_bn_train_src", None)
+        if bn is not None and getattr(bn, "_hf_io", None) is not None and len(bn._hf_io) == 6:
+            rec = bn._hf_io  # (train-mode BatchNorm, stock ops): the layer's output is the ReLU's
+            bn._hf_io = (rec[0], rec[1], y.detach(), True, rec[4], rec[5])
+        return y
     bn, xin = src
     return fused_bn_act(bn, xin, relu=True)  # the unfused BatchNorm output drops out of the graph
 

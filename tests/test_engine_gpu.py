@@ -27,24 +27,29 @@ def _float64_product(make, v, masks=None, **kw):
     float64 network's own, in call order (the product of the same piecewise-linear network an fp32 operator
     linearised: one ReLU input within fp32 rounding of zero, decided the other way, moves a product of a
     deep net by ~1e-4 of its max-norm -- no error of either side)."""
-    import types
-
     model, (x, t), lossf = make(device=DEV, **kw)
     model, x = model.double(), x.double()
     if masks is not None:
-        cursor = [0]
-
-        def relu_forward(self, inp):
-            m = masks[cursor[0]]
-            cursor[0] += 1
-            return inp * m.to(inp.dtype)
-
-        for mod in model.modules():
-            if isinstance(mod, torch.nn.ReLU):
-                mod.forward = types.MethodType(relu_forward, mod)
+        _replay_relu_decisions(model, masks)
     params = [p for p in model.parameters() if p.requires_grad]
     out = model(x)
     return curvature.GGNOperator(lossf(out, t), out, params)(v.double())
+
+
+def _replay_relu_decisions(model, masks):
+    """Make every ``nn.ReLU`` call of ``model`` take the sign decisions ``masks`` (in call order)."""
+    import types
+
+    cursor = [0]
+
+    def relu_forward(self, inp):
+        m = masks[cursor[0]]
+        cursor[0] += 1
+        return inp * m.to(device=inp.device, dtype=inp.dtype)
+
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.ReLU):
+            mod.forward = types.MethodType(relu_forward, mod)
 
 
 @pytest.mark.parametrize("batch", [32, 5])
@@ -199,6 +204,59 @@ def test_allcnnc_engine_hessian_product_matches_float64_and_cpu_oracle(l2):
     grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(closs, cp)])
     assert float((op.gradient().cpu() - grad).abs().max() / grad.abs().max()) < 2e-6
     assert abs(float(op.loss_buf) - float(closs)) <= 1e-6 * abs(float(closs))
+
+
+def test_train_mode_batchnorm_engine_product_matches_cpu_oracle_and_float64():
+    """What ``examples/run_resnet18_mnist.py:19-35`` actually runs -- no ``model.eval()``: BatchNorm normalises
+    with BATCH statistics and the GGN couples the samples.  The engine takes such a model (single GPU): tangent
+    and adjoint of every BatchNorm carry the statistics' dependence on the layer input (two per-channel sums per
+    sweep, folded into the elementwise kernels).  Product against the CPU oracle (BackPACK's algorithm restated
+    on the stock train-mode model: 5e-5, the tolerance of test_optimizer_gpu's stock-layer test) and against
+    float64 autograd on the GPU (1e-5), both on the engine's ReLU decisions (batch normalisation centres the
+    pre-activations at zero: with ~10^6 of them some always lie within fp32 rounding of it, and the plain
+    float64 product is 2e-3 away from EVERY fp32 product, stock autograd included); bitwise repeatable."""
+    from oracle import backpack_restated as bp
+    from pytorchhessianfree_amd.utils import vector_to_parameter_list
+
+    seed = tp.RESNET18_B32_SEPARATED_SEEDS[1]
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=16, device=DEV, data_seed=seed)
+    model.train()
+    modelprep.prepare_model(model, channels_last=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    op = curvature.ggn_operator(lossf(out, t), out, params)
+    assert isinstance(op, FusedGGNEngine) and op.train_bn
+    v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(31))
+    got = op(v).clone()
+    assert torch.equal(op(v), got)
+    masks = [(u.y > 0) for u in op.units if u.relu]
+    # float64 stock model in train mode, same data
+    m64, (x64, t64), l64 = tp.resnet18_mnist(batch_size=16, device=DEV, data_seed=seed)
+    m64 = m64.double().train()
+    _replay_relu_decisions(m64, masks)
+    p64 = [p for p in m64.parameters() if p.requires_grad]
+    o64 = m64(x64.double())
+    want = curvature.GGNOperator(l64(o64, t64), o64, p64)(v.double())
+    assert float((got.double() - want).abs().max() / want.abs().max()) < 1e-5
+    cm, (cx, ct), cl = tp.resnet18_mnist(batch_size=16, device="cpu", data_seed=seed)
+    cm.train()
+    _replay_relu_decisions(cm, [m.cpu() for m in masks])
+    cp = [p for p in cm.parameters() if p.requires_grad]
+    co = cm(cx)
+    ref = torch.cat([g.reshape(-1) for g in bp.ggn_vector_product_from_plist(
+        cl(co, ct), co, cp, vector_to_parameter_list(v.cpu(), cp))])
+    assert float((got.cpu() - ref).abs().max() / ref.abs().max()) < 5e-5
+    # a full step through the hipGraph-replayed engine decreases the loss
+    opt = hf.HessianFree(model.parameters(), graph_matvec=True, cg_max_iter=30)
+
+    def forward():
+        o = model(x)
+        return lossf(o, t), o
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        final = opt.step(forward)
+    assert final < opt.state["init_losses"][0]
 
 
 def test_resnet18_engine_product_matches_cpu_oracle_at_batch_32():
