@@ -1,0 +1,163 @@
+"""CPU: host logic added around the persistent engine session -- batched / cached trial-loss
+evaluation (``optimizer._SessionTrials``), the prefetch hooks of CG-backtracking and the line search
+(reference ``hessianfree/cg_backtracking.py:53-112``, ``hessianfree/linesearch.py:8-103``: same results, same
+early exits, fewer device->host reads), and the structural loss detection (``engine.ce_loss_spec``)."""
+
+import torch
+
+from pytorchhessianfree_amd.cg_backtracking import cg_efficient_backtracking
+from pytorchhessianfree_amd.engine import ce_loss_spec
+from pytorchhessianfree_amd.linesearch import simple_linesearch
+from pytorchhessianfree_amd.optimizer import _SessionTrials
+from pytorchhessianfree_amd.utils import ParameterArena
+
+
+class _FakeSession:
+    """Stands in for ``session.EngineSession``: ``forward_loss(slot)`` evaluates a fixed quadratic of the
+    arena's current parameters into ``losses[slot]`` (no host synchronisation in the real one)."""
+
+    def __init__(self, arena, target):
+        self.arena, self.target = arena, target
+        self.losses = torch.zeros(8)
+        self.forwards = 0
+        self.base_loss = float(((arena.theta - target) ** 2).sum())
+
+    def forward_loss(self, slot):
+        self.forwards += 1
+        self.losses[slot] = ((self.arena.theta - self.target) ** 2).sum()
+        return self.losses[slot]
+
+
+class _FakeOpt:
+    process_group, shard_weight = None, 1.0
+
+
+def _setup(n=12, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    params = [torch.nn.Parameter(torch.randn(n, generator=g))]
+    arena = ParameterArena(params)
+    base = arena.snapshot()
+    target = torch.randn(n, generator=g)
+    sess = _FakeSession(arena, target)
+    trials = _SessionTrials(_FakeOpt(), sess, arena, base)
+    flushes = [0]
+    real_flush = trials.flush
+
+    def counting_flush():
+        if trials.pending:
+            flushes[0] += 1
+        real_flush()
+
+    trials.flush = counting_flush
+    return arena, base, target, sess, trials, flushes
+
+
+def _direct(base, target, step, alpha):
+    return float(((base + alpha * step - target) ** 2).sum())
+
+
+def test_trial_values_are_exact_cached_and_batched():
+    arena, base, target, sess, trials, flushes = _setup()
+    steps = [torch.randn(12, generator=torch.Generator().manual_seed(i)) for i in range(4)]
+    trials.prefetch([(steps[0], 1.0), (steps[1], 1.0)])  # LM damping's pair: one read-back
+    assert flushes[0] == 0 and sess.forwards == 2
+    a, b = trials.value(steps[0], 1.0), trials.value(steps[1], 1.0)
+    assert flushes[0] == 1
+    assert abs(a - _direct(base, target, steps[0], 1.0)) < 1e-5 * abs(a)
+    assert abs(b - _direct(base, target, steps[1], 1.0)) < 1e-5 * abs(b)
+    # asked again (the last CG iterate in back-tracking, the chosen step at alpha = 1): no forward, no read
+    assert trials.value(steps[1], 1.0) == b and sess.forwards == 2 and flushes[0] == 1
+    # alpha = 0 is the base point of the step: the loss the step's own forward pass produced
+    assert trials.value(steps[2], 0.0) == sess.base_loss and sess.forwards == 2
+    # a scaled step is another point
+    c = trials.value(steps[1], 0.5)
+    assert sess.forwards == 3 and abs(c - _direct(base, target, steps[1], 0.5)) < 1e-5 * abs(c)
+    # more pending points than loss slots: flushed in between, all values right
+    many = [(steps[3], 0.1 * k) for k in range(1, 12)]
+    trials.prefetch(many)
+    for s, al in many:
+        v = trials.value(s, al)
+        assert abs(v - _direct(base, target, s, al)) < 1e-5 * max(1.0, abs(v))
+
+
+def test_backtracking_with_prefetch_equals_reference_walk():
+    """The reference's toy sequence (tests/test_cg_backtracking.py:8-44): walk from the last stored step
+    backwards, stop at the first non-improvement.  With the prefetch hook the same index / value come out, at
+    most one candidate beyond the stopping point is evaluated, and a pair of values costs one read-back."""
+    values = [2.0, 1.0, None, 2.7, 2.4, None, None, 7.3]
+    steps = [None if v is None else torch.full((3,), float(i)) for i, v in enumerate(values)]
+    evaluated, reads, pending = [], [0], []
+
+    def f(step):
+        idx = int(step[0])
+        if idx in pending:
+            reads[0] += 1
+            pending.clear()
+        elif idx not in evaluated:
+            evaluated.append(idx)
+            reads[0] += 1
+        return values[idx]
+
+    def prefetch(points):
+        for step, alpha in points:
+            idx = int(step[0])
+            if idx not in evaluated:
+                evaluated.append(idx)
+                pending.append(idx)
+
+    plain = cg_efficient_backtracking(f, steps)
+    n_plain = len(evaluated)
+    evaluated.clear(); pending.clear(); reads[0] = 0
+    f.prefetch = prefetch
+    hooked = cg_efficient_backtracking(f, steps)
+    assert hooked == plain == (4, 2.4)
+    assert len(evaluated) <= n_plain + 1  # the early exit is the reference's, one speculative evaluation at most
+    assert reads[0] <= (len(evaluated) + 1) // 2 + 1
+
+
+def test_linesearch_with_prefetch_equals_plain():
+    arena, base, target, sess, trials, flushes = _setup(seed=3)
+    step = 6.0 * (target - base)  # overshoots: the Armijo rule has to shrink alpha a few times
+    grad0 = 2.0 * (base - target)
+
+    def f_plain(s):
+        return _direct(base, target, s, 1.0)
+
+    want = simple_linesearch(f_plain, grad0, step, init_alpha=1.0)
+
+    def tfunc(s):
+        return trials.value(s, 1.0)
+
+    tfunc.scaled = trials.value
+    tfunc.prefetch = trials.prefetch
+    got = simple_linesearch(tfunc, grad0, step, init_alpha=1.0)
+    assert got[0] == want[0] and abs(got[1] - want[1]) <= 1e-5 * abs(want[1])
+    assert got[0] < 1.0  # (the search really iterated)
+    assert flushes[0] < sess.forwards  # fewer read-backs than evaluations
+
+
+def test_ce_loss_spec_reads_the_loss_structure():
+    torch.manual_seed(0)
+    w = torch.randn(5, 4, requires_grad=True)
+    x, t = torch.randn(6, 4), torch.randint(0, 5, (6,))
+    out = x @ w.t()
+    ce = torch.nn.functional.cross_entropy
+    spec = ce_loss_spec(ce(out, t), out)
+    assert spec is not None and spec["reduction"] == "mean" and torch.equal(spec["targets"], t)
+    assert ce_loss_spec(ce(out, t, reduction="sum"), out)["reduction"] == "sum"
+    assert ce_loss_spec(ce(out, t, label_smoothing=0.1), out) is None
+    assert ce_loss_spec(ce(out, t, weight=torch.rand(5)), out) is None
+    assert ce_loss_spec(ce(2.0 * out, t), out) is None  # not the cross-entropy OF `outputs`
+    assert ce_loss_spec(torch.nn.functional.mse_loss(out, torch.randn(6, 5)), out) is None
+    t_ignored = t.clone()
+    t_ignored[0] = -100
+    assert ce_loss_spec(ce(out, t_ignored), out) is None
+    # cross-entropy + a tagged quadratic regulariser (testproblems.l2_regularized)
+    total = ce(out, t) + 0.5 * 1e-3 * (w * w).sum()
+    assert ce_loss_spec(total, out) is None  # untagged: unknown structure
+    total._hf_quadratic = ((1e-3, (w,)),)
+    spec = ce_loss_spec(total, out)
+    assert spec is not None and spec["quadratic"][0][0] == 1e-3 and spec["quadratic"][0][1][0] is w
+    # logits handed out as a leaf (what a persistent session's forward pass returns)
+    leaf = out.detach().clone().requires_grad_(True)
+    assert ce_loss_spec(ce(leaf, t), leaf) is not None
