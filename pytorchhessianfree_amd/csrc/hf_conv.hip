@@ -93,7 +93,10 @@ struct ConvArgs {
   int kout;            // W: number of dY channels (output rows of dW)
   int R, S, stride_h, stride_w, pad_h, pad_w;
   int ntaps;           // live taps
-  unsigned char tap_r[MAX_TAPS], tap_s[MAX_TAPS];
+  // live taps as (r | s << 8).  DWORDS on purpose: a dynamically indexed BYTE array in the kernel arguments
+  // compiles to global_load_ubyte + s_waitcnt vmcnt(0) (gfx950 has no scalar byte load), which drained the
+  // three-deep prefetch ring at every step; a dword is one s_load on the scalar (lgkm) counter
+  int tap_rs[MAX_TAPS];
   int tiles_m, tiles_n, splits, steps;  // steps = reduction steps in total
   int scalar;          // 1: channel counts not multiples of 4 -> element-wise gathers
   int shift_h, shift_w;  // log2 of the strides when both are powers of two, else -1
@@ -158,7 +161,7 @@ __device__ __forceinline__ float4 ldg4s(const float* p, int valid) {
 
 // Last-arriver reduction of the split-K partials of one block tile (fixed order).  The wave at
 // (wm, wn) holds TM x TN MFMA tiles: tile (im, in) covers rows wm*32*TM + im*32 .., cols likewise.
-template <typename C>
+template <typename C, bool CLS = false>
 __device__ __forceinline__ void finish_tile(const ConvArgs& a, const f32x16 (&acc)[C::TM][C::TN], int tile, int split,
                                             int wm, int wn, int lane, float* out_tile_base,
                                             int row0, int col0, int row_lim, int col_lim, int ldc,
@@ -174,7 +177,7 @@ __device__ __forceinline__ void finish_tile(const ConvArgs& a, const f32x16 (&ac
         const int row = (wm * C::TM + im) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
         int orow = row0 + row;  // output row (= pixel index) of this accumulator row
         bool rok = orow < row_lim;
-        if (cls >= 0) {  // (uniform) class-major enumeration: row -> (n, y', x') -> pixel (n, y'*sh + py, x'*sw + px)
+        if (CLS && cls >= 0) {  // (uniform) class-major enumeration: row -> (n, y', x') -> pixel (n, y'*sh + py, x'*sw + px)
           const int wc = a.cls_w[cls], hc = a.cls_h[cls];
           const int xq = orow % wc, tq = orow / wc;
           const int yq = tq % hc, nq = tq / hc;
@@ -248,7 +251,9 @@ __device__ __forceinline__ void finish_tile(const ConvArgs& a, const f32x16 (&ac
 // ---------------------------------------------------------------------------------
 // NT kernel: F and D.   out[m][j] = sum_{tap, c} src[pix(m,tap)][c] * mat[j][tap][c]
 // ---------------------------------------------------------------------------------
-template <bool SCALAR, typename C>
+// CLS: the instantiation that understands the residue-class enumeration of strided data gradients (ConvArgs::ncls);
+// the plain one keeps the prologue of the latency-bound small-map launches short (+1 us per launch otherwise).
+template <bool SCALAR, typename C, bool CLS = false>
 __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int bid) {
   constexpr int BM = C::BM, BN = C::BN, BK = C::BK, KQ = C::KQ, RPT = C::RPT, HK = C::HK, LDK = C::LDK;
   constexpr int NU = 2;
@@ -264,7 +269,7 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
   const int csteps = (a.cs + BK - 1) / BK;
   // residue class of this row tile (strided data gradients, see ConvArgs): its rows, taps and step count
   int cls = -1, row_base = tile_m * BM, rows_c = a.rows, tap0 = 0, steps = a.steps;
-  if (a.ncls > 0) {  // (uniform)
+  if (CLS && a.ncls > 0) {  // (uniform)
     cls = 0;
     while (cls + 1 < a.ncls && tile_m >= a.cls_tile0[cls + 1]) ++cls;
     row_base = (tile_m - a.cls_tile0[cls]) * BM;
@@ -282,7 +287,7 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
   for (int u = 0; u < NU; ++u) {
     const int m = row_base + lr + RPT * u;
     if (m < rows_c) {
-      if (cls >= 0) {
+      if (CLS && cls >= 0) {
         const int wc = a.cls_w[cls], hc = a.cls_h[cls];
         const int xx = m % wc, tq = m / wc;
         rx[u] = xx * a.stride_w + a.cls_px[cls]; ry[u] = (tq % hc) * a.stride_h + a.cls_py[cls]; rn[u] = tq / hc;
@@ -313,7 +318,7 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
   // drain the whole queue, vmcnt(0), before the next use; cdna_hip_programming.md trap 4c)
   auto fetch = [&](int step, float4 (&ra)[NU], float4 (&rb)[NU]) -> unsigned {
     const int tl = step / csteps, c = (step - tl * csteps) * BK + 4 * kq, ti = tap0 + tl;
-    const int r = a.tap_r[ti], q = a.tap_s[ti];
+    const int rs_ = a.tap_rs[ti], r = rs_ & 255, q = rs_ >> 8;
     const bool cok = c < a.cs;
     unsigned ok = 0;
 #pragma unroll
@@ -385,7 +390,7 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
         if (++f_cb == csteps) { f_cb = 0; ++f_ti; }
       }
       const int ti = tap0 + f_ti, c = f_cb * BK + 4 * kq;
-      const int r = a.tap_r[ti], q = a.tap_s[ti];
+      const int rs_ = a.tap_rs[ti], r = rs_ & 255, q = rs_ >> 8;
       const bool cok = c < a.cs;
       unsigned ok = 0;
 #pragma unroll
@@ -453,8 +458,8 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
     }
   }
   __syncthreads();  // the LDS array is reused below (last-arriver flag)
-  finish_tile<C>(a, acc, tile, split, wm, wn, lane, a.out, row_base, tile_n * BN, rows_c, a.nout, a.ldc,
-                 &flag, cls);
+  finish_tile<C, CLS>(a, acc, tile, split, wm, wn, lane, a.out, row_base, tile_n * BN, rows_c, a.nout, a.ldc,
+                      &flag, cls);
 }
 
 // ---------------------------------------------------------------------------------
@@ -477,7 +482,7 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
 
   const int cblocks = (a.cs + BN - 1) / BN;
   const int ti = tile_n / cblocks, c0 = (tile_n - ti * cblocks) * BN;
-  const int r = a.tap_r[ti], q = a.tap_s[ti];
+  const int rs_ = a.tap_rs[ti], r = rs_ & 255, q = rs_ >> 8;
 
   // staging: thread -> rows kr, kr + RP of the step and the float4 at column 4*cq
   constexpr int CQ = C::SM / 4;     // float4 per staged row (both operands are staged SM == SN wide)
@@ -638,10 +643,10 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
                  a.R * a.S * a.out_c, &flag);
 }
 
-template <bool SCALAR, typename C>
+template <bool SCALAR, typename C, bool CLS = false>
 __global__ __launch_bounds__(CT) void k_conv_nt(const ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
-  conv_nt_body<SCALAR, C>(a, lds, blockIdx.x);
+  conv_nt_body<SCALAR, C, CLS>(a, lds, blockIdx.x);
 }
 
 template <bool SCALAR, typename C>
@@ -654,15 +659,15 @@ __global__ __launch_bounds__(CT) void k_conv_tn(const ConvArgs a) {
 // neither depends on the other; the first `nblocks_d` workgroups run the NT body.
 // ANYBIG: some problem of the launch runs in the Big configuration (decided per problem, `a.big`); the
 // all-Small instantiation keeps the register allocation of the small-map launches what it was.
-template <bool ANYBIG>
+template <bool ANYBIG, bool CLS = false>
 __global__ __launch_bounds__(CT) void k_conv_dw(const ConvArgs d, const ConvArgs w, int nblocks_d) {
   constexpr int LDSB = Big::LDS_FLOATS > Big96::LDS_FLOATS ? Big::LDS_FLOATS : Big96::LDS_FLOATS;
   constexpr int LDSF = ANYBIG ? (LDSB > Small::LDS_FLOATS ? LDSB : Small::LDS_FLOATS) : Small::LDS_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[LDSF];
   if ((int)blockIdx.x < nblocks_d) {
-    if (ANYBIG && d.big == 1) conv_nt_body<false, Big>(d, lds, blockIdx.x);
-    else if (ANYBIG && d.big == 2) conv_nt_body<false, Big96>(d, lds, blockIdx.x);
-    else conv_nt_body<false, Small>(d, lds, blockIdx.x);
+    if (ANYBIG && d.big == 1) conv_nt_body<false, Big, CLS>(d, lds, blockIdx.x);
+    else if (ANYBIG && d.big == 2) conv_nt_body<false, Big96, CLS>(d, lds, blockIdx.x);
+    else conv_nt_body<false, Small, CLS>(d, lds, blockIdx.x);
   } else {
     if (ANYBIG && w.big == 1) conv_tn_body<false, Big>(w, lds, blockIdx.x - nblocks_d);
     else if (ANYBIG && w.big == 2) conv_tn_body<false, Big96>(w, lds, blockIdx.x - nblocks_d);
@@ -691,30 +696,30 @@ struct GroupMeta {
   int n;
 };
 
-template <bool ANYBIG>
+template <bool ANYBIG, bool CLS>
 __device__ __forceinline__ void group_run(const ConvArgs& a, int tn, float* lds, int local) {
   if (tn) {
     if (ANYBIG && a.big == 1) conv_tn_body<false, Big>(a, lds, local);
     else if (ANYBIG && a.big == 2) conv_tn_body<false, Big96>(a, lds, local);
     else conv_tn_body<false, Small>(a, lds, local);
   } else {
-    if (ANYBIG && a.big == 1) conv_nt_body<false, Big>(a, lds, local);
-    else if (ANYBIG && a.big == 2) conv_nt_body<false, Big96>(a, lds, local);
-    else conv_nt_body<false, Small>(a, lds, local);
+    if (ANYBIG && a.big == 1) conv_nt_body<false, Big, CLS>(a, lds, local);
+    else if (ANYBIG && a.big == 2) conv_nt_body<false, Big96, CLS>(a, lds, local);
+    else conv_nt_body<false, Small, CLS>(a, lds, local);
   }
 }
 
-template <bool ANYBIG>
+template <bool ANYBIG, bool CLS = false>
 __global__ __launch_bounds__(CT) void k_conv_group(const ConvArgs a0, const ConvArgs a1, const ConvArgs a2,
                                                    const ConvArgs a3, const GroupMeta m) {
   constexpr int LDSB = Big::LDS_FLOATS > Big96::LDS_FLOATS ? Big::LDS_FLOATS : Big96::LDS_FLOATS;
   constexpr int LDSF = ANYBIG ? (LDSB > Small::LDS_FLOATS ? LDSB : Small::LDS_FLOATS) : Small::LDS_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[LDSF];
   const int b = (int)blockIdx.x;
-  if (b < m.start[1]) group_run<ANYBIG>(a0, m.tn[0], lds, b);
-  else if (b < m.start[2]) group_run<ANYBIG>(a1, m.tn[1], lds, b - m.start[1]);
-  else if (b < m.start[3]) group_run<ANYBIG>(a2, m.tn[2], lds, b - m.start[2]);
-  else group_run<ANYBIG>(a3, m.tn[3], lds, b - m.start[3]);
+  if (b < m.start[1]) group_run<ANYBIG, CLS>(a0, m.tn[0], lds, b);
+  else if (b < m.start[2]) group_run<ANYBIG, CLS>(a1, m.tn[1], lds, b - m.start[1]);
+  else if (b < m.start[3]) group_run<ANYBIG, CLS>(a2, m.tn[2], lds, b - m.start[2]);
+  else group_run<ANYBIG, CLS>(a3, m.tn[3], lds, b - m.start[3]);
 }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -804,6 +809,9 @@ void launch_one(int direction, const ConvArgs& a, int64_t blocks, hipStream_t st
   const dim3 grid((unsigned)blocks), block(CT);
   if (direction <= 1) {
     if (a.scalar) hipLaunchKernelGGL((k_conv_nt<true, Small>), grid, block, 0, stream, a);
+    else if (a.ncls > 0 && a.big == 1) hipLaunchKernelGGL((k_conv_nt<false, Big, true>), grid, block, 0, stream, a);
+    else if (a.ncls > 0 && a.big == 2) hipLaunchKernelGGL((k_conv_nt<false, Big96, true>), grid, block, 0, stream, a);
+    else if (a.ncls > 0) hipLaunchKernelGGL((k_conv_nt<false, Small, true>), grid, block, 0, stream, a);
     else if (a.big == 1) hipLaunchKernelGGL((k_conv_nt<false, Big>), grid, block, 0, stream, a);
     else if (a.big == 2) hipLaunchKernelGGL((k_conv_nt<false, Big96>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((k_conv_nt<false, Small>), grid, block, 0, stream, a);
@@ -813,6 +821,15 @@ void launch_one(int direction, const ConvArgs& a, int64_t blocks, hipStream_t st
     else if (a.big == 2) hipLaunchKernelGGL((k_conv_tn<false, Big96>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((k_conv_tn<false, Small>), grid, block, 0, stream, a);
   }
+}
+
+void launch_dw(const ConvArgs& d, const ConvArgs& w, int64_t bd, int64_t bw, hipStream_t stream) {
+  const dim3 grid((unsigned)(bd + bw)), block(CT);
+  const bool big = d.big || w.big, cls = d.ncls > 0;
+  if (big && cls) hipLaunchKernelGGL((k_conv_dw<true, true>), grid, block, 0, stream, d, w, (int)bd);
+  else if (big) hipLaunchKernelGGL((k_conv_dw<true, false>), grid, block, 0, stream, d, w, (int)bd);
+  else if (cls) hipLaunchKernelGGL((k_conv_dw<false, true>), grid, block, 0, stream, d, w, (int)bd);
+  else hipLaunchKernelGGL((k_conv_dw<false, false>), grid, block, 0, stream, d, w, (int)bd);
 }
 
 // Which tile configuration a problem runs in: a pure function of its geometry (hf_conv2d_nhwc_plan and
@@ -880,7 +897,7 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
     for (int qq = 0; qq < s; ++qq) {
       bool live_q = false;
       for (int64_t x = 0; x < ow && !live_q; ++x) { const int64_t ix = x * stride_w - pad_w + qq; live_q = ix >= 0 && ix < w; }
-      if (live_q) { a.tap_r[a.ntaps] = (unsigned char)rr; a.tap_s[a.ntaps] = (unsigned char)qq; a.ntaps++; }
+      if (live_q) { a.tap_rs[a.ntaps] = rr | (qq << 8); a.ntaps++; }
     }
   }
   if (a.ntaps == 0) return HF_ERR_ARG;
@@ -903,8 +920,10 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
   if (a.cs_ld < a.cs || a.mat_ld < a.cs || (mat_ld > 0 && direction == 2)) return HF_ERR_ARG;
   // strided data gradient in slab mode: residue classes of the input pixel (see ConvArgs)
   int cls_taps_max = a.ntaps;
+  // (large maps only: on ResNet-18's <= 1568-row layers the launch is latency-bound either way and the extra
+  // partially-filled row tiles cost ~1 % of the bench)
   const bool classes = direction == 1 && slab_splits >= 0 && (stride_h > 1 || stride_w > 1) &&
-                       stride_h * stride_w <= 4 && !a.scalar && hf_env_dclass();
+                       stride_h * stride_w <= 4 && !a.scalar && n * h * w >= 2048 && hf_env_dclass();
   struct { int py, px, hc, wc, ntaps; unsigned char r[MAX_TAPS], q[MAX_TAPS]; } cl[4];
   int ncls = 0;
   if (classes) {
@@ -916,7 +935,7 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
         auto& c_ = cl[ncls];
         c_.py = py; c_.px = px; c_.hc = hc; c_.wc = wc; c_.ntaps = 0;
         for (int t_ = 0; t_ < a.ntaps; ++t_) {
-          const int rr = a.tap_r[t_], qq = a.tap_s[t_];
+          const int rr = a.tap_rs[t_] & 255, qq = a.tap_rs[t_] >> 8;
           const int64_t dy = py + pad_h - rr, dx = px + pad_w - qq;
           if (((dy % stride_h) + stride_h) % stride_h == 0 && ((dx % stride_w) + stride_w) % stride_w == 0) {
             c_.r[c_.ntaps] = (unsigned char)rr; c_.q[c_.ntaps] = (unsigned char)qq; c_.ntaps++;
@@ -940,7 +959,7 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
       for (int i = 0; i < ncls; ++i) {
         a.cls_tile0[i] = tile0; a.cls_tap0[i] = tap0;
         a.cls_h[i] = cl[i].hc; a.cls_w[i] = cl[i].wc; a.cls_py[i] = cl[i].py; a.cls_px[i] = cl[i].px;
-        for (int t_ = 0; t_ < cl[i].ntaps; ++t_) { a.tap_r[tap0 + t_] = cl[i].r[t_]; a.tap_s[tap0 + t_] = cl[i].q[t_]; }
+        for (int t_ = 0; t_ < cl[i].ntaps; ++t_) a.tap_rs[tap0 + t_] = cl[i].r[t_] | (cl[i].q[t_] << 8);
         tap0 += cl[i].ntaps;
         tile0 += (int)((n * cl[i].hc * cl[i].wc + BM - 1) / BM);
       }
@@ -1034,8 +1053,7 @@ int hf_conv2d_nhwc_backward(void* dx, void* dw, const void* dy, const void* x, c
                            target_blocks);
   if (bw <= 0) return (int)bw;
   if (d.scalar || g.scalar) return HF_ERR_ARG;  // the merged launch has the 16-byte gather variant only
-  if (d.big || g.big) hipLaunchKernelGGL(k_conv_dw<true>, dim3((unsigned)(bd + bw)), dim3(CT), 0, (hipStream_t)stream, d, g, (int)bd);
-  else hipLaunchKernelGGL(k_conv_dw<false>, dim3((unsigned)(bd + bw)), dim3(CT), 0, (hipStream_t)stream, d, g, (int)bd);
+  launch_dw(d, g, bd, bw, (hipStream_t)stream);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }
@@ -1101,8 +1119,7 @@ int hf_conv2d_nhwc_backward_slabs(void* dx, void* dw, const void* dy, const void
   if (bw <= 0) return (int)bw;
   if (d.splits != splits_d || g.splits != splits_w) return HF_ERR_ARG;
   if (d.scalar || g.scalar) return HF_ERR_ARG;  // the merged launch has the 16-byte gather variant only
-  if (d.big || g.big) hipLaunchKernelGGL(k_conv_dw<true>, dim3((unsigned)(bd + bw)), dim3(CT), 0, (hipStream_t)stream, d, g, (int)bd);
-  else hipLaunchKernelGGL(k_conv_dw<false>, dim3((unsigned)(bd + bw)), dim3(CT), 0, (hipStream_t)stream, d, g, (int)bd);
+  launch_dw(d, g, bd, bw, (hipStream_t)stream);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }
@@ -1128,10 +1145,8 @@ int hf_conv2d_nhwc_dw_slabs(const hf_conv_problem* d, const hf_conv_problem* w, 
     if (q.out_c) a[i].out_c = (int)q.out_c;
   }
   const dim3 grid((unsigned)(blocks[0] + blocks[1]));
-  if (a[0].big || a[1].big)
-    hipLaunchKernelGGL(k_conv_dw<true>, grid, dim3(CT), 0, (hipStream_t)stream, a[0], a[1], (int)blocks[0]);
-  else
-    hipLaunchKernelGGL(k_conv_dw<false>, grid, dim3(CT), 0, (hipStream_t)stream, a[0], a[1], (int)blocks[0]);
+  (void)grid;
+  launch_dw(a[0], a[1], blocks[0], blocks[1], (hipStream_t)stream);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }
@@ -1173,12 +1188,14 @@ int hf_conv2d_nhwc_group_slabs(const hf_conv_problem* problems, int n_problems, 
   }
   m.start[GROUP_MAX] = (int)total;
   m.n = n_problems;
-  if (anybig)
-    hipLaunchKernelGGL(k_conv_group<true>, dim3((unsigned)total), dim3(CT), 0, (hipStream_t)stream, q.a[0], q.a[1],
-                       q.a[2], q.a[3], m);
-  else
-    hipLaunchKernelGGL(k_conv_group<false>, dim3((unsigned)total), dim3(CT), 0, (hipStream_t)stream, q.a[0], q.a[1],
-                       q.a[2], q.a[3], m);
+  bool anycls = false;
+  for (int i = 0; i < n_problems; ++i) anycls = anycls || q.a[i].ncls > 0;
+  const dim3 grid((unsigned)total), block(CT);
+  hipStream_t st = (hipStream_t)stream;
+  if (anybig && anycls) hipLaunchKernelGGL((k_conv_group<true, true>), grid, block, 0, st, q.a[0], q.a[1], q.a[2], q.a[3], m);
+  else if (anybig) hipLaunchKernelGGL((k_conv_group<true, false>), grid, block, 0, st, q.a[0], q.a[1], q.a[2], q.a[3], m);
+  else if (anycls) hipLaunchKernelGGL((k_conv_group<false, true>), grid, block, 0, st, q.a[0], q.a[1], q.a[2], q.a[3], m);
+  else hipLaunchKernelGGL((k_conv_group<false, false>), grid, block, 0, st, q.a[0], q.a[1], q.a[2], q.a[3], m);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }
