@@ -774,6 +774,7 @@ int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_by
     // tangent 76 / 93 / 99, data gradient 68 / 83 / 87, weight gradient 39 / 52 / 65 TFLOP/s)
     const bool big = bk != Small::BK;
     best = ((big ? hf_env_big_blocks() : 256) + tiles - 1) / tiles;
+    if (big && best > steps / 8) best = steps / 8;  // (>= 8 steps per workgroup)
     if (best > steps / 2) best = steps / 2;
     // (one or two output tiles -- the stem's weight gradient: 6272 rows into a 64 x 52 matrix --
     // would leave most of the chip idle at 32 splits)
@@ -859,11 +860,12 @@ int want_big(int direction, int64_t rows, int64_t dim_m, int64_t dim_n, int64_t 
   const int kind = f96 > f128 + 1e-9 ? 2 : 1;
   const bool fits = (kind == 2 ? f96 : f128) >= 0.7;
   if (force > 0) return fits ? kind : 0;
-  // ... and only where the launch has enough work to give ~3 workgroups per CU a K loop of >= 8 steps of 16
-  // each: with a handful of steps per workgroup the 128-wide tiles lose to the 64x64 ones, whose prologue /
-  // epilogue are a quarter the size (ResNet-50 on 64x64 images, batch 32: 260 matvecs/s with the 64x64
-  // tiles everywhere, 228 -> 198 with the 128-wide ones wherever they fit; All-CNN-C's 8192-row layers,
-  // 9 steps per workgroup: 128x96 tiles 37 us, 64x64 tiles 64 us)
+  // ... and only where the launch has enough work to give ~3 workgroups per CU a K loop of >= 8 steps of 16 each
+  // (a looser rule -- any reduction of >= 64 steps, splits capped at 8 steps per workgroup -- was measured to put
+  // ResNet-50 layers on the 128-wide tiles and lose: 289 -> 268 matvecs/s): with a handful of steps per workgroup the 128-wide
+  // tiles lose to the 64x64 ones, whose prologue / epilogue are a quarter the size (ResNet-50 on 64x64
+  // images, batch 32: 260 matvecs/s with the 64x64 tiles everywhere, 228 -> 198 with the 128-wide ones wherever
+  // they fit; All-CNN-C's 8192-row layers, 9 steps per workgroup: 128x96 tiles 37 us, 64x64 tiles 64 us)
   const int64_t tiles = ((dim_m + 127) / 128) * ((dim_n + (kind == 2 ? 95 : 127)) / (kind == 2 ? 96 : 128)) * mult;
   const int64_t steps = (red + Big::BK - 1) / Big::BK;
   return (fits && rows >= 2048 && tiles * steps >= hf_env_big_blocks() * 8) ? kind : 0;
