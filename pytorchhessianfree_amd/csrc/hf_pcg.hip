@@ -608,15 +608,18 @@ __global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackA
     const unsigned I = (unsigned)a.perm_I[lo], HW = (unsigned)a.perm_HW[lo], slab = I * HW;
     const unsigned live = a.live[lo];
     constexpr int E = 4;
-    for (long long base = j0 + threadIdx.x; base < j1; base += (long long)BLOCK * E) {
+    // (element indices of one tensor fit 32 bits -- checked on the host: the per-element divisions below are
+    // 32-bit, a 64-bit division is ~5x the instructions and these blocks were VALU-bound on them)
+    const unsigned j1u = (unsigned)j1;
+    for (unsigned base = (unsigned)j0 + threadIdx.x; base < j1u; base += BLOCK * E) {
       T acc[E];
-      long long e[E];
+      unsigned e[E];
       bool rd[E];  // inside the tensor and not a structurally-zero tap
 #pragma unroll
       for (int k = 0; k < E; ++k) {
-        e[k] = base + (long long)k * BLOCK;
-        rd[k] = e[k] < j1;
-        if (live && rd[k]) rd[k] = (live >> (unsigned)((e[k] % slab) / I)) & 1u;
+        e[k] = base + (unsigned)k * BLOCK;
+        rd[k] = e[k] < j1u;
+        if (live && rd[k]) rd[k] = (live >> ((e[k] % slab) / I)) & 1u;
         acc[k] = rd[k] ? src[e[k]] : (T)0;
       }
       int sp = 1;
@@ -649,13 +652,13 @@ __global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackA
       }
 #pragma unroll
       for (int k = 0; k < E; ++k) {
-        if (e[k] >= j1) continue;
-        long long j = e[k];
+        if (e[k] >= j1u) continue;
+        unsigned j = e[k];
         if (I > 0) {  // source (o, hw, i) -> destination (o, i, hw)
-          const long long o = j / slab;
-          const unsigned rem = (unsigned)(j - o * slab);
+          const unsigned o = j / slab;
+          const unsigned rem = j - o * slab;
           const unsigned hw = rem / I, i = rem - hw * I;
-          j = o * slab + (long long)i * HW + hw;
+          j = o * slab + i * HW + hw;
         }
         out[j] = pack_op<T, OP>(out[j], acc[k], scale);
       }
@@ -669,24 +672,25 @@ __global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackA
     const unsigned I = (unsigned)a.perm_I[lo], HW = (unsigned)a.perm_HW[lo], slab = I * HW;
     const unsigned live = a.live[lo];
     const bool al = (((uintptr_t)(out + j0)) & 15) == 0;
-    for (long long j = j0 + (long long)threadIdx.x * W; j < j1; j += (long long)BLOCK * W) {
+    const unsigned j1u = (unsigned)j1;
+    for (unsigned j = (unsigned)j0 + threadIdx.x * W; j < j1u; j += BLOCK * W) {
       VU<T> v;
 #pragma unroll
       for (int c = 0; c < W; ++c) {
-        const long long jj = j + c;
-        const long long o = jj / slab;
-        const unsigned rem = (unsigned)(jj - o * slab);
+        const unsigned jj = j + c;
+        const unsigned o = jj / slab;
+        const unsigned rem = jj - o * slab;
         const unsigned i = rem / HW, hw = rem - i * HW;
-        v.e[c] = (jj < j1 && ((live >> hw) & 1u)) ? src[o * slab + (long long)hw * I + i] : (T)0;
+        v.e[c] = (jj < j1u && ((live >> hw) & 1u)) ? src[o * slab + hw * I + i] : (T)0;
       }
-      if (OP == 0 && al && j + W <= j1) {
+      if (OP == 0 && al && j + W <= j1u) {
 #pragma unroll
         for (int c = 0; c < W; ++c) v.e[c] = pack_op<T, OP>((T)0, v.e[c], scale);
         *reinterpret_cast<V*>(out + j) = v.v;
       } else {
 #pragma unroll
         for (int c = 0; c < W; ++c)
-          if (j + c < j1) out[j + c] = pack_op<T, OP>(out[j + c], v.e[c], scale);
+          if (j + c < j1u) out[j + c] = pack_op<T, OP>(out[j + c], v.e[c], scale);
       }
     }
     return;
@@ -799,18 +803,19 @@ __global__ __launch_bounds__(BLOCK) void k_unpack_tangent(const T* __restrict__ 
   // destination order d = (o*HW + hw)*I + i  ->  dst[(o*HW + hw)*2I + half*I + i] = src[(o*I + i)*HW + hw]
   const unsigned HW = slab / I;
   const unsigned live = a.live[lo] ? a.live[lo] : 0xffffffffu;
-  if (al && I % W == 0) {
-    for (long long d = j0 + (long long)threadIdx.x * W; d < j1; d += (long long)BLOCK * W) {
-      const long long row = d / I;  // o*HW + hw
-      const unsigned i = (unsigned)(d - row * I);
-      const long long o = row / HW;
-      const unsigned hw = (unsigned)(row - o * HW);
+  if (al && I % W == 0 && numel < 0x7fffffffLL) {
+    const unsigned j1u = (unsigned)j1;  // (32-bit index arithmetic: see k_pack)
+    for (unsigned d = (unsigned)j0 + threadIdx.x * W; d < j1u; d += BLOCK * W) {
+      const unsigned row = d / I;  // o*HW + hw
+      const unsigned i = d - row * I;
+      const unsigned o = row / HW;
+      const unsigned hw = row - o * HW;
       if (!((live >> hw) & 1u)) continue;  // a tap that never meets data: its slice is never read
-      const T* s = src + o * slab + (long long)i * HW + hw;
+      const T* s = src + (size_t)o * slab + i * HW + hw;
       VU<T> v;
 #pragma unroll
-      for (int c = 0; c < W; ++c) v.e[c] = s[(long long)c * HW];
-      *reinterpret_cast<V*>(dst + row * 2 * I + i) = v.v;
+      for (int c = 0; c < W; ++c) v.e[c] = s[c * HW];
+      *reinterpret_cast<V*>(dst + (size_t)row * 2 * I + i) = v.v;
     }
   } else {
     for (long long d = j0 + threadIdx.x; d < j1; d += BLOCK) {
@@ -2036,6 +2041,7 @@ static int pack_impl(void* dst, const void* const* srcs, const int64_t* numels,
           a.split_stride[k] = splits[2 * t + 1];
           if (a.nsplit[k] > 1) a.chunk[k] = BLOCK * 4;  // latency-bound blocks: more of them
         }
+        if (((perm && perm[2 * t] > 0) || a.nsplit[k] > 1) && numels[t] >= 0xffffffffLL) return HF_ERR_ARG;
         if (perm && perm[2 * t] > 0) {
           const int64_t I = perm[2 * t], HW = perm[2 * t + 1];
           if (HW <= 0 || numels[t] % (I * HW) != 0 || I * HW > 0x7fffffffLL) return HF_ERR_ARG;
