@@ -834,34 +834,65 @@ __global__ __launch_bounds__(BLOCK) void k_unpack_tangent(const T* __restrict__ 
 // of segments: dense ones, and conv weights [O, I, H*W] of which only the kernel taps in `mask`
 // are live (period HW, nl = popcount(mask) live entries per period, pos[] their tap indices).
 constexpr int LIVE_MAXS = 24;
+constexpr int LIVE_CHUNK = BLOCK * 8;  // compact entries per block
 struct LiveSegs {
   long long full_off[LIVE_MAXS];
   long long comp_off[LIVE_MAXS + 1];  // compact offsets; [ns] = total
+  int blk_start[LIVE_MAXS + 1];       // blocks never straddle segments: the segment look-up is per block
   int hw[LIVE_MAXS];                  // 0: dense
   int nl[LIVE_MAXS];
-  unsigned char pos[LIVE_MAXS][16];
+  int pos[LIVE_MAXS][16];             // (ints: a byte table in the kernel arguments is read with vector loads)
   int ns;
 };
 
 // SCATTER = false: comp[k] = full[index(k)];  true: full[index(k)] = comp[k]
 template <typename T, bool SCATTER>
 __global__ __launch_bounds__(BLOCK) void k_live_copy(T* __restrict__ full, T* __restrict__ comp,
-                                                     const LiveSegs a, long long total) {
-  for (long long k = (long long)blockIdx.x * BLOCK + threadIdx.x; k < total; k += (long long)gridDim.x * BLOCK) {
-    int lo = 0, hi = a.ns;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (a.comp_off[mid] <= k) lo = mid; else hi = mid;
-    }
-    const long long r = k - a.comp_off[lo];
-    long long f = a.full_off[lo];
-    if (a.hw[lo] == 0) {
-      f += r;
+                                                     const LiveSegs a) {
+  int lo = 0, hi = a.ns;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.blk_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const long long len = a.comp_off[lo + 1] - a.comp_off[lo];
+  const long long r0 = (long long)((int)blockIdx.x - a.blk_start[lo]) * LIVE_CHUNK;
+  const unsigned cnt = (unsigned)(len - r0 < LIVE_CHUNK ? len - r0 : LIVE_CHUNK);
+  T* __restrict__ c = comp + a.comp_off[lo] + r0;
+  const unsigned hw = (unsigned)a.hw[lo], nl = (unsigned)a.nl[lo];
+  if (hw == 0) {
+    T* __restrict__ f = full + a.full_off[lo] + r0;
+    constexpr int W = VecOf<T>::W;
+    typedef typename VecOf<T>::type V;
+    if ((((uintptr_t)f | (uintptr_t)c) & 15) == 0) {
+      const unsigned nv = cnt / W;
+      for (unsigned i = threadIdx.x; i < nv; i += BLOCK) {
+        if (SCATTER) reinterpret_cast<V*>(f)[i] = reinterpret_cast<const V*>(c)[i];
+        else reinterpret_cast<V*>(c)[i] = reinterpret_cast<const V*>(f)[i];
+      }
+      for (unsigned i = nv * W + threadIdx.x; i < cnt; i += BLOCK) {
+        if (SCATTER) f[i] = c[i]; else c[i] = f[i];
+      }
     } else {
-      const long long g = r / a.nl[lo];
-      f += g * a.hw[lo] + a.pos[lo][(int)(r - g * a.nl[lo])];
+      for (unsigned i = threadIdx.x; i < cnt; i += BLOCK) {
+        if (SCATTER) f[i] = c[i]; else c[i] = f[i];
+      }
     }
-    if (SCATTER) full[f] = comp[k]; else comp[k] = full[f];
+    return;
+  }
+  // periodic: compact entry r = g*nl + l  <->  full entry g*hw + pos[l]
+  T* __restrict__ f = full + a.full_off[lo];
+  const unsigned r0u = (unsigned)r0;  // (one segment's compact length fits 32 bits: host check)
+  if (nl == 1) {
+    f += (size_t)r0u * hw + a.pos[lo][0];
+    for (unsigned i = threadIdx.x; i < cnt; i += BLOCK) {
+      if (SCATTER) f[(size_t)i * hw] = c[i]; else c[i] = f[(size_t)i * hw];
+    }
+    return;
+  }
+  for (unsigned i = threadIdx.x; i < cnt; i += BLOCK) {
+    const unsigned r = r0u + i, g = r / nl, l = r - g * nl;
+    T* q = f + (size_t)g * hw + a.pos[lo][l];
+    if (SCATTER) *q = c[i]; else c[i] = *q;
   }
 }
 
@@ -2192,7 +2223,7 @@ int hf_live_copy(void* full, void* compact, int scatter, const int64_t* full_off
       if (counts[i] % periods[i] != 0) return HF_ERR_ARG;
       int nl = 0;
       for (int t = 0; t < (int)periods[i]; ++t)
-        if ((masks[i] >> t) & 1) a.pos[i][nl++] = (unsigned char)t;
+        if ((masks[i] >> t) & 1) a.pos[i][nl++] = t;
       if (nl < 1) return HF_ERR_ARG;
       a.nl[i] = nl;
       total += counts[i] / periods[i] * nl;
@@ -2200,16 +2231,22 @@ int hf_live_copy(void* full, void* compact, int scatter, const int64_t* full_off
   }
   a.comp_off[n_segments] = total;
   a.ns = n_segments;
-  long long blocks = (total + (long long)BLOCK * 4 - 1) / ((long long)BLOCK * 4);
-  if (blocks < 1) blocks = 1;
-  if (blocks > 8192) blocks = 8192;
+  // blocks never straddle segments
+  long long blocks = 0;
+  for (int i = 0; i < n_segments; ++i) {
+    if (a.comp_off[i + 1] - a.comp_off[i] >= 0xffffffffLL) return HF_ERR_ARG;
+    a.blk_start[i] = (int)blocks;
+    blocks += (a.comp_off[i + 1] - a.comp_off[i] + LIVE_CHUNK - 1) / LIVE_CHUNK;
+  }
+  a.blk_start[n_segments] = (int)blocks;
+  if (blocks < 1 || blocks > 0x7fffffffLL) return HF_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == HF_F32) {
-    if (scatter) hipLaunchKernelGGL((k_live_copy<float, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (float*)full, (float*)compact, a, total);
-    else hipLaunchKernelGGL((k_live_copy<float, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (float*)full, (float*)compact, a, total);
+    if (scatter) hipLaunchKernelGGL((k_live_copy<float, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (float*)full, (float*)compact, a);
+    else hipLaunchKernelGGL((k_live_copy<float, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (float*)full, (float*)compact, a);
   } else if (dtype == HF_F64) {
-    if (scatter) hipLaunchKernelGGL((k_live_copy<double, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (double*)full, (double*)compact, a, total);
-    else hipLaunchKernelGGL((k_live_copy<double, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (double*)full, (double*)compact, a, total);
+    if (scatter) hipLaunchKernelGGL((k_live_copy<double, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (double*)full, (double*)compact, a);
+    else hipLaunchKernelGGL((k_live_copy<double, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, (double*)full, (double*)compact, a);
   } else {
     return HF_ERR_ARG;
   }

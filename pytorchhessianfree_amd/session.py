@@ -232,11 +232,12 @@ class ChunkedEngineOperator:
     (the ``result += N * mb_result`` of optimizer.py:677-684 across GPUs, once per PCG iteration):
 
         G_a  tangent sweep, head, adjoint sweep of the late blocks, gather of their gradients
-             -> live entries of the vector's suffix                           (compact tail, ~80 % of the bytes)
-        side stream / second communicator:   all-reduce(compact tail)          <- overlaps G_b
-        G_b  the rest of the adjoint sweep, gather -> compact head
-        compute stream:                      all-reduce(compact head)
-        wait for the side stream; scatter the sums back into the full vector; K1-K3 graph
+             -> the vector's suffix is final; its staged part (live taps of tensors with dead ones) is gathered
+        side stream / second communicator:   all-reduce(tail pieces: the dense run in place + the staging
+                                             vector, ~80 % of the bytes)       <- overlaps G_b
+        G_b  the rest of the adjoint sweep
+        compute stream:                      all-reduce(head pieces: in place in the full vector)
+        wait for the side stream; scatter the staged sums back into the full vector; K1-K3 graph
 
     Two plain hipGraphs and events BETWEEN graph launches (fork / join nodes inside one graph cost ~45 us
     each on this stack).  On 2 ranks the result is bitwise the single all-reduce's (a + b in either
@@ -299,7 +300,7 @@ class ChunkedEngineOperator:
 
     @property
     def reduce_bytes(self):
-        return 4 * self.engine._compact.numel()
+        return self.engine.reduce_bytes
 
     def raw_graph(self):  # (two graphs: cg() fuses K1-K3 only, which needs no product graph)
         return None
@@ -318,25 +319,27 @@ class ChunkedEngineOperator:
         eng, group = self.engine, self.group
         if group is None:
             return self.replay_local()
-        k, coff = eng._seg_cut
-        head, tail = eng._compact[:coff], eng._compact[coff:]
+        head = eng._reduce_pieces(self.output_buffer, "head")
+        tail = eng._reduce_pieces(self.output_buffer, "tail")
         cur = torch.cuda.current_stream()
-        side_comm = hfdist.side_comm(tail, group)
+        side_comm = hfdist.side_comm(tail[0], group)
         self.g_a.replay()
-        work = None
+        works = []
         if side_comm is not None:
             if self._side is None:
                 self._side = torch.cuda.Stream()
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
-                side_comm.all_reduce_sum(tail)
+                for piece in tail:
+                    side_comm.all_reduce_sum(piece)
         else:
-            work = torch.distributed.all_reduce(tail, group=group, async_op=True)
+            works = [torch.distributed.all_reduce(piece, group=group, async_op=True) for piece in tail]
         self.g_b.replay()
-        hfdist.all_reduce_sum(head, group)
+        for piece in head:
+            hfdist.all_reduce_sum(piece, group)
         if side_comm is not None:
             cur.wait_stream(self._side)
-        else:
+        for work in works:
             work.wait()
         eng._live_copy(self.output_buffer, True)
 

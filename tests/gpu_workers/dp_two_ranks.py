@@ -151,8 +151,11 @@ def main(outdir):
         chunked = ChunkedEngineOperator(builder, params=ps)
         got2 = chunked(v).clone()
         out["chunked/equal_plain_allreduce"] = np.array([bool(torch.equal(got2, plain))])
-        k, coff = chunked.engine._seg_cut
-        out["chunked/tail_share"] = np.array([1.0 - coff / chunked.engine._compact.numel()])
+        eng = chunked.engine
+        tail = sum(t.numel() for t in eng._reduce_pieces(chunked.output_buffer, "tail"))
+        out["chunked/tail_share"] = np.array([4.0 * tail / eng.reduce_bytes])
+        out["chunked/pieces"] = np.array([len(eng._reduce_pieces(chunked.output_buffer, "head")),
+                                          len(eng._reduce_pieces(chunked.output_buffer, "tail"))])
         grad = torch.randn(eng.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")

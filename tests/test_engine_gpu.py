@@ -451,12 +451,26 @@ def test_live_copy_gathers_and_scatters_the_live_entries():
     indexing with an explicit boolean mask; scatter restores exactly the gathered entries."""
     from pytorchhessianfree_amd import _lib
 
+    _check_live_copy([(0, 37, 0, 0), (37, 270, 9, 1 << 4), (307, 11, 0, 0), (318, 108, 9, 0b110110000), (426, 5, 0, 0)],
+                     431)
+    # several blocks per segment (2048 compact entries each), a tap count that does not divide the block's
+    # share (6 of 9), unaligned dense runs
+    big, off = [], 3
+    for cnt, per, mask in [(70001, 0, 0), (300 * 40 * 9, 9, 1 << 4), (4099, 0, 0), (128 * 64 * 9, 9, 0b110110110),
+                           (96 * 48 * 9, 9, 0b110110000), (8192, 0, 0)]:
+        big.append((off, cnt, per, mask))
+        off += cnt + (5 if per == 0 else 0)  # (gaps: entries that belong to no segment stay untouched)
+    _check_live_copy(big, off + 2)
+
+
+def _check_live_copy(segs, n):
+    from pytorchhessianfree_amd import _lib
+
     gen = torch.Generator(device=DEV).manual_seed(21)
     # [dense 37 | weight 6x5x(3x3), centre tap | dense 11 | weight 4x3x(3x3), 4 taps | dense 5]
-    segs = [(0, 37, 0, 0), (37, 270, 9, 1 << 4), (307, 11, 0, 0), (318, 108, 9, 0b110110000), (426, 5, 0, 0)]
-    n = 431
-    keep = torch.ones(n, dtype=torch.bool, device=DEV)
+    keep = torch.zeros(n, dtype=torch.bool, device=DEV)
     for off, cnt, per, mask in segs:
+        keep[off:off + cnt] = True
         if per:
             taps = torch.tensor([(mask >> t) & 1 for t in range(per)], dtype=torch.bool, device=DEV)
             keep[off:off + cnt] = taps.repeat(cnt // per)
