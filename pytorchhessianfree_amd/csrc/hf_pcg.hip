@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include <vector>
@@ -979,6 +980,71 @@ __device__ __forceinline__ void chan_affine_body(
   }
 }
 
+// fp32 NHWC, C % 4 == 0, every operand 16-byte aligned: one 16-byte channel quad per thread, and EVERY load
+// of the quad -- per-channel vectors, x / add / mask, up to 17 split-K slabs -- issued before the first use.
+// These launches move a few MB and take ~5 us: what they cost is dependent round trips (~0.6 us each from the
+// memory-side cache the producer's slabs sit in), not bytes; the scalar walk above paid one per slab batch of
+// eight, one for w[c], one for x / q / r, one for add, one for the mask.  Same expressions, same order of
+// additions: bitwise the scalar walk's results.
+struct alignas(16) F4 { float e[4]; };
+__device__ __forceinline__ F4 ld4(const float* p) { return *reinterpret_cast<const F4*>(p); }
+
+__device__ __forceinline__ void chan_affine_v4_body(
+    float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ w,
+    const float* __restrict__ q, const float* __restrict__ r, const float* __restrict__ add,
+    const float* __restrict__ mask_src, int relu_self, unsigned total, unsigned C, unsigned out_ld,
+    unsigned add_ld, int a_splits, long long a_slab, unsigned bid, unsigned nblocks) {
+  const unsigned quads = total >> 2;
+  for (unsigned v = bid * BLOCK + threadIdx.x; v < quads; v += nblocks * BLOCK) {
+    const unsigned i = v << 2;
+    const unsigned row = i / C, c = i - row * C;
+    F4 rs4, w4, q4, r4, mu4, xv, addv, mv, av;
+    if (rstd) rs4 = ld4(rstd + c);
+    if (w) w4 = ld4(w + c);
+    if (q) { q4 = ld4(q + c); mu4 = ld4(mean + c); xv = ld4(x + i); }
+    if (r) r4 = ld4(r + c);
+    if (add) addv = ld4(add + (add_ld ? row * add_ld + c : i));
+    if (mask_src && !relu_self) mv = ld4(mask_src + i);
+    if (a) {
+      av = ld4(a + i);
+      for (int sp = 1; sp < a_splits; sp += 16) {  // split-K slabs: sixteen loads in flight, summed in split order
+        F4 t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = ld4(a + (long long)(sp + u < a_splits ? sp + u : 0) * a_slab + i);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) av.e[k] += sp + u < a_splits ? t[u].e[k] : 0.f;
+      }
+    }
+    F4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float rs = rstd ? rs4.e[k] : 1.f;
+      float acc = 0.f;
+      if (a) acc = av.e[k] * ((w ? w4.e[k] : 1.f) * rs);
+      if (q) acc += ((xv.e[k] - mu4.e[k]) * rs) * q4.e[k];
+      if (r) acc += r4.e[k];
+      if (add) acc += addv.e[k];
+      if (relu_self) acc = acc > 0.f ? acc : 0.f;
+      else if (mask_src) acc = mv.e[k] > 0.f ? acc : 0.f;
+      o.e[k] = acc;
+    }
+    *reinterpret_cast<F4*>(out + (out_ld ? row * out_ld + c : i)) = o;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_chan_affine_v4(
+    float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ w,
+    const float* __restrict__ q, const float* __restrict__ r, const float* __restrict__ add,
+    const float* __restrict__ mask_src, int relu_self, unsigned total, unsigned C, unsigned out_ld,
+    unsigned add_ld, int a_splits, long long a_slab) {
+  chan_affine_v4_body(out, a, x, mean, rstd, w, q, r, add, mask_src, relu_self, total, C, out_ld, add_ld, a_splits,
+                      a_slab, blockIdx.x, gridDim.x);
+}
+
 template <typename T, typename I>
 __global__ __launch_bounds__(BLOCK) void k_chan_affine(
     T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ x,
@@ -1001,11 +1067,18 @@ struct AffArgs {
   unsigned out_ld, add_ld;
   int a_splits;
   long long a_slab;
+  int vec4;  // eligible for the quad-per-thread walk (alignment checked on the host)
 };
 
 __global__ __launch_bounds__(BLOCK) void k_chan_affine_pair(const AffArgs A, const AffArgs B, unsigned blocks_a) {
   const bool first = blockIdx.x < blocks_a;
   const AffArgs& p = first ? A : B;
+  if (p.vec4) {
+    chan_affine_v4_body(p.out, p.a, p.x, p.mean, p.rstd, p.w, p.q, p.r, p.add, p.mask_src, p.relu_self, p.total,
+                        p.C, p.out_ld, p.add_ld, p.a_splits, p.a_slab, first ? blockIdx.x : blockIdx.x - blocks_a,
+                        first ? blocks_a : gridDim.x - blocks_a);
+    return;
+  }
   chan_affine_body<float, unsigned>(p.out, p.a, p.x, p.mean, p.rstd, p.w, p.q, p.r, p.add, p.mask_src, p.relu_self,
                                     p.total, p.C, p.HW, p.nhwc, p.out_ld, p.add_ld, p.a_splits, p.a_slab,
                                     first ? blockIdx.x : blockIdx.x - blocks_a,
@@ -1243,10 +1316,42 @@ __device__ __forceinline__ void bn_adjoint_rows_body(
         m0 = *reinterpret_cast<const Col*>(mask_src + idx0);
         m1 = *reinterpret_cast<const Col*>(mask_src + idx1);
       }
-      if (s1 > 1) { g0 = slab_sum<float, Col, 4>(g0, gy + idx0, s1, l1); g1 = slab_sum<float, Col, 4>(g1, gy + idx1, s1, l1); }
-      if (gy2 && s2 > 1) {
-        h0 = slab_sum<float, Col, 4>(h0, gy2 + idx0, s2, l2);
-        h1 = slab_sum<float, Col, 4>(h1, gy2 + idx1, s2, l2);
+      // split-K slabs of both rows and both cotangents: one loop, 8 slabs x up to 4 columns in flight per
+      // pass (each column still adds its slabs in split order: bitwise the one-column-at-a-time sums, which
+      // cost a round trip per column and batch)
+      const int smax = (gy2 && s2 > s1) ? s2 : s1;
+      for (int sp = 1; sp < smax; sp += 8) {
+        Col vg0[8], vg1[8], vh0[8], vh1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const long long o1 = (long long)(sp + u < s1 ? sp + u : 0) * l1;
+          vg0[u] = *reinterpret_cast<const Col*>(gy + o1 + idx0);
+          vg1[u] = *reinterpret_cast<const Col*>(gy + o1 + idx1);
+        }
+        if (gy2 && s2 > 1) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const long long o2 = (long long)(sp + u < s2 ? sp + u : 0) * l2;
+            vh0[u] = *reinterpret_cast<const Col*>(gy2 + o2 + idx0);
+            vh1[u] = *reinterpret_cast<const Col*>(gy2 + o2 + idx1);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (sp + u < s1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { g0.e[k] += vg0[u].e[k]; g1.e[k] += vg1[u].e[k]; }
+          }
+        }
+        if (gy2 && s2 > 1) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (sp + u < s2) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) { h0.e[k] += vh0[u].e[k]; h1.e[k] += vh1[u].e[k]; }
+            }
+          }
+        }
       }
       Col o0, o1;
 #pragma unroll
@@ -2362,6 +2467,18 @@ int hf_softmax_ce_hvp(void* out, const void* p, const void* v, double scale, int
   return HF_OK;
 }
 
+static bool affine_vec4_ok(const void* out, const void* a, const void* x, const void* mean, const void* rstd,
+                          const void* w, const void* q, const void* r, const void* add, const void* mask_src,
+                          long long total, long long c, int nhwc, long long out_ld, long long add_ld,
+                          long long a_slab) {
+  const void* ptrs[] = {out, a, x, mean, rstd, w, q, r, add, mask_src};
+  for (const void* p : ptrs)
+    if (p && !aligned16(p)) return false;
+  static const bool scalar_only = getenv("HF_AFFINE_SCALAR") != nullptr;  // (A/B switch for measurements)
+  return nhwc && c % 4 == 0 && out_ld % 4 == 0 && add_ld % 4 == 0 && a_slab % 4 == 0 && 2 * total < 0x7fffffffLL &&
+         !scalar_only;
+}
+
 template <typename T>
 static void launch_chan_affine(hipStream_t s, void* out, const void* a, const void* x,
                                const void* mean, const void* rstd, const void* w, const void* q,
@@ -2369,7 +2486,13 @@ static void launch_chan_affine(hipStream_t s, void* out, const void* a, const vo
                                int relu_self, long long total, long long c, long long hw,
                                int nhwc, long long out_ld, long long add_ld, int a_splits = 1,
                                long long a_slab = 0) {
-  if (2 * total < 0x7fffffffLL)  // strided operands reach at most 2*total
+  if (sizeof(T) == 4 && affine_vec4_ok(out, a, x, mean, rstd, w, q, r, add, mask_src, total, c, nhwc || hw == 1,
+                                       out_ld, add_ld, a_slab))
+    hipLaunchKernelGGL(k_chan_affine_v4, dim3(wide_grid(total / 4)), dim3(BLOCK), 0, s, (float*)out,
+                       (const float*)a, (const float*)x, (const float*)mean, (const float*)rstd, (const float*)w,
+                       (const float*)q, (const float*)r, (const float*)add, (const float*)mask_src, relu_self,
+                       (unsigned)total, (unsigned)c, (unsigned)out_ld, (unsigned)add_ld, a_splits, a_slab);
+  else if (2 * total < 0x7fffffffLL)  // strided operands reach at most 2*total
     hipLaunchKernelGGL((k_chan_affine<T, unsigned>), dim3(wide_grid(total)), dim3(BLOCK), 0, s,
                        (T*)out, (const T*)a, (const T*)x, (const T*)mean, (const T*)rstd,
                        (const T*)w, (const T*)q, (const T*)r, (const T*)add, (const T*)mask_src,
@@ -2435,8 +2558,10 @@ int hf_chan_affine_pair(const hf_affine_problem* problems, int dtype, void* stre
     q[i] = AffArgs{(float*)p.out, (const float*)p.a, (const float*)p.x, (const float*)p.mean,
                    (const float*)p.rstd, (const float*)p.w, (const float*)p.q, (const float*)p.r,
                    (const float*)p.add, (const float*)p.mask_src, p.relu_self, (unsigned)total, (unsigned)p.c,
-                   (unsigned)p.hw, 1, (unsigned)p.out_ld, (unsigned)p.add_ld, p.a_splits, (long long)p.a_slab};
-    blocks[i] = (unsigned)wide_grid(total);
+                   (unsigned)p.hw, 1, (unsigned)p.out_ld, (unsigned)p.add_ld, p.a_splits, (long long)p.a_slab, 0};
+    q[i].vec4 = affine_vec4_ok(p.out, p.a, p.x, p.mean, p.rstd, p.w, p.q, p.r, p.add, p.mask_src, total, p.c, 1,
+                               p.out_ld, p.add_ld, p.a_slab) ? 1 : 0;
+    blocks[i] = (unsigned)wide_grid(q[i].vec4 ? total / 4 : total);
   }
   hipLaunchKernelGGL(k_chan_affine_pair, dim3(blocks[0] + blocks[1]), dim3(BLOCK), 0, (hipStream_t)stream, q[0],
                      q[1], blocks[0]);
