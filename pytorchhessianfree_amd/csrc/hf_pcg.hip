@@ -637,19 +637,17 @@ __global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackA
 #pragma unroll
           for (int k = 0; k < E; ++k) acc[k] += tt[u][k];
       }
-      for (; sp + 2 <= nsp; sp += 2) {
-        T t0[E], t1[E];
-#pragma unroll
-        for (int k = 0; k < E; ++k) {
-          t0[k] = rd[k] ? src[e[k] + (long long)sp * sps] : (T)0;
-          t1[k] = rd[k] ? src[e[k] + (long long)(sp + 1) * sps] : (T)0;
-        }
-#pragma unroll
-        for (int k = 0; k < E; ++k) acc[k] = (acc[k] + t0[k]) + t1[k];
-      }
       if (sp < nsp) {
+        // the last (partial) batch, predicated: all its loads in flight at once (pairs cost a round trip each)
+        T tt[8][E];
 #pragma unroll
-        for (int k = 0; k < E; ++k) acc[k] += rd[k] ? src[e[k] + (long long)sp * sps] : (T)0;
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int k = 0; k < E; ++k) tt[u][k] = (rd[k] && sp + u < nsp) ? src[e[k] + (long long)(sp + u) * sps] : (T)0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int k = 0; k < E; ++k) acc[k] += tt[u][k];
       }
 #pragma unroll
       for (int k = 0; k < E; ++k) {
@@ -1113,17 +1111,24 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
 #pragma unroll
       for (int t = 0; t < ITER; ++t) {
         const I e = e0 + (I)t * TPC;
+        idx[t] = 0;
         if (e < per) {
           const I n = HW == 1 ? e : e / HW;
           idx[t] = (n * C + c) * HW + (e - n * HW);
           g[t] = gy[idx[t]];
-          for (int sp = 1; sp < s1; ++sp) g[t] += gy[(long long)sp * l1 + idx[t]];  // split-K slabs
-          if (gy2) {
-            h[t] = gy2[idx[t]];
-            for (int sp = 1; sp < s2; ++sp) h[t] += gy2[(long long)sp * l2 + idx[t]];
-          }
+          if (gy2) h[t] = gy2[idx[t]];
           if (mask_src) m[t] = mask_src[idx[t]];
           if (x) xv[t] = x[idx[t]];
+        }
+      }
+      // split-K slabs, added in split order (batching eight slabs of every element per pass was measured: no
+      // gain on these 32-row maps, 252 instead of 58 VGPRs)
+#pragma unroll
+      for (int t = 0; t < ITER; ++t) {
+        if (e0 + (I)t * TPC < per) {
+          for (int sp = 1; sp < s1; ++sp) g[t] += gy[(long long)sp * l1 + idx[t]];
+          if (gy2)
+            for (int sp = 1; sp < s2; ++sp) h[t] += gy2[(long long)sp * l2 + idx[t]];
         }
       }
 #pragma unroll
@@ -1319,6 +1324,7 @@ __device__ __forceinline__ void bn_adjoint_rows_body(
       // split-K slabs of both rows and both cotangents: one loop, 8 slabs x up to 4 columns in flight per
       // pass (each column still adds its slabs in split order: bitwise the one-column-at-a-time sums, which
       // cost a round trip per column and batch)
+      // (sixteen slabs x two columns per pass was measured slower: 272 VGPRs)
       const int smax = (gy2 && s2 > s1) ? s2 : s1;
       for (int sp = 1; sp < smax; sp += 8) {
         Col vg0[8], vg1[8], vh0[8], vh1[8];
