@@ -588,6 +588,8 @@ template <typename T, int OP>
 __global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackArgs a, T scale) {
   constexpr int W = VecOf<T>::W;
   typedef typename VecOf<T>::type V;
+  constexpr unsigned TILE = TILE_BYTES / sizeof(T);
+  __shared__ __attribute__((aligned(16))) T tile[TILE];  // staging of the layout-permuting paths
   // binary search: tensor t with blk_start[t] <= blockIdx.x < blk_start[t+1]
   int lo = 0, hi = a.nt;
   while (hi - lo > 1) {
@@ -608,6 +610,69 @@ __global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackA
     const long long sps = a.split_stride[lo];
     const unsigned I = (unsigned)a.perm_I[lo], HW = (unsigned)a.perm_HW[lo], slab = I * HW;
     const unsigned live = a.live[lo];
+    if (sizeof(T) == 4 && (((uintptr_t)src) & 15) == 0 && (sps & 3) == 0 && (j0 & 3) == 0 && (numel & 3) == 0 &&
+        (I & 3) == 0) {
+      // 16-byte loads: one quad of consecutive source elements per lane and pass (a quad never leaves its
+      // (o, hw) row: I % 4 == 0), eight slabs in flight; dword loads moved these 50 MB at 3 TB/s
+      const unsigned j1u = (unsigned)j1;
+      // whole slabs per block (host: chunk = a few slabs): the permuted order is assembled in LDS and leaves as
+      // 16-byte stores -- four 4-byte stores per lane, 144 bytes apart across the lanes, cost more L2
+      // transactions than the loads they follow
+      const bool staged = I > 0 && (unsigned)a.chunk[lo] % slab == 0 && (unsigned)a.chunk[lo] <= TILE &&
+                          (((uintptr_t)(out + j0)) & 15) == 0;
+      for (unsigned e = (unsigned)j0 + threadIdx.x * 4; e < j1u; e += BLOCK * 4) {
+        unsigned jd = e, step = 1;  // destination of the quad's first element, distance between its elements
+        bool rd = true;
+        if (I > 0) {
+          const unsigned o = e / slab, rem = e - o * slab;
+          const unsigned hw = rem / I, i = rem - hw * I;
+          jd = o * slab + i * HW + hw;
+          step = HW;
+          if (live) rd = (live >> hw) & 1u;
+        }
+        VU<T> acc;
+#pragma unroll
+        for (int c = 0; c < W; ++c) acc.e[c] = (T)0;
+        if (rd) acc.v = *reinterpret_cast<const V*>(src + e);
+        for (int sp = 1; sp < nsp; sp += 8) {
+          VU<T> tt[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int c = 0; c < W; ++c) tt[u].e[c] = (T)0;
+            if (rd && sp + u < nsp) tt[u].v = *reinterpret_cast<const V*>(src + e + (long long)(sp + u) * sps);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < W; ++c) acc.e[c] += tt[u].e[c];
+        }
+        if (staged) {
+#pragma unroll
+          for (int c = 0; c < W; ++c) tile[jd - (unsigned)j0 + c * step] = acc.e[c];
+        } else if (I == 0 && OP == 0 && (((uintptr_t)(out + jd)) & 15) == 0) {
+#pragma unroll
+          for (int c = 0; c < W; ++c) acc.e[c] = pack_op<T, OP>((T)0, acc.e[c], scale);
+          *reinterpret_cast<V*>(out + jd) = acc.v;
+        } else {
+#pragma unroll
+          for (int c = 0; c < W; ++c) out[jd + c * step] = pack_op<T, OP>(out[jd + c * step], acc.e[c], scale);
+        }
+      }
+      if (staged) {
+        __syncthreads();
+        const unsigned len = j1u - (unsigned)j0;  // (a multiple of 4: whole slabs, I % 4 == 0)
+        for (unsigned t = threadIdx.x * 4; t < len; t += BLOCK * 4) {
+          VU<T> v, d;
+          v.v = *reinterpret_cast<const V*>(tile + t);
+          if (OP == 1) d.v = *reinterpret_cast<const V*>(out + j0 + t);
+#pragma unroll
+          for (int c = 0; c < W; ++c) v.e[c] = pack_op<T, OP>(OP == 1 ? d.e[c] : (T)0, v.e[c], scale);
+          *reinterpret_cast<V*>(out + j0 + t) = v.v;
+        }
+      }
+      return;
+    }
     constexpr int E = 4;
     // (element indices of one tensor fit 32 bits -- checked on the host: the per-element divisions below are
     // 32-bit, a 64-bit division is ~5x the instructions and these blocks were VALU-bound on them)
@@ -672,6 +737,34 @@ __global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackA
     const unsigned live = a.live[lo];
     const bool al = (((uintptr_t)(out + j0)) & 15) == 0;
     const unsigned j1u = (unsigned)j1;
+    if (OP == 0 && al && ((unsigned)a.chunk[lo] % slab) == 0 && ((j1u - (unsigned)j0) & (W - 1)) == 0) {
+      // whole (o) slabs per block: a pure stream of zero vectors over the chunk (no index arithmetic: the
+      // per-element divisions of the walk below held this 33 MB store stream at 2.3 TB/s), then, behind a
+      // barrier, the live taps' values on top -- source order, coalesced reads, 4-byte stores into lines this
+      // workgroup has just written
+      VU<T> z;
+#pragma unroll
+      for (int c = 0; c < W; ++c) z.e[c] = (T)0;
+      for (unsigned j = (unsigned)j0 + threadIdx.x * W; j < j1u; j += BLOCK * W) *reinterpret_cast<V*>(out + j) = z.v;
+      __syncthreads();  // (s_waitcnt vmcnt(0) + barrier: the zeros are acknowledged before any value store is issued)
+      const unsigned o0 = (unsigned)j0 / slab, no = (j1u - (unsigned)j0) / slab;
+      const unsigned nl = (unsigned)__popc(live);
+      const unsigned per_o = nl * I, total = no * per_o;
+      for (unsigned q = threadIdx.x; q < total; q += BLOCK) {
+        const unsigned ol = q / per_o, rem = q - ol * per_o;
+        const unsigned l = rem / I, i = rem - l * I;
+        unsigned hw = 0, seen = 0;  // the l-th live tap (registers only: an indexed local array would go to scratch)
+#pragma unroll
+        for (unsigned t = 0; t < 16; ++t) {
+          const unsigned bit = (live >> t) & 1u;
+          hw = (bit && seen == l) ? t : hw;
+          seen += bit;
+        }
+        const unsigned ob = (o0 + ol) * slab;
+        out[ob + i * HW + hw] = pack_op<T, OP>((T)0, src[ob + hw * I + i], scale);
+      }
+      return;
+    }
     for (unsigned j = (unsigned)j0 + threadIdx.x * W; j < j1u; j += BLOCK * W) {
       VU<T> v;
 #pragma unroll
@@ -697,11 +790,9 @@ __global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackA
   if (a.perm_I[lo] > 0) {
     // dst index j = (o*I + i)*HW + hw   <-   src index (o*HW + hw)*I + i
     const unsigned I = (unsigned)a.perm_I[lo], HW = (unsigned)a.perm_HW[lo], slab = I * HW;
-    constexpr unsigned TILE = TILE_BYTES / sizeof(T);
     if ((unsigned)a.chunk[lo] % slab == 0 && (unsigned)a.chunk[lo] / slab * (slab + HW) <= TILE) {
       // whole slabs per block: read them contiguously into LDS (rows of I padded to I+1
       // against bank conflicts), write the permuted order contiguously
-      __shared__ T tile[TILE];
       const unsigned len = (unsigned)(j1 - j0);
       for (unsigned t = threadIdx.x; t < len; t += BLOCK) {
         const unsigned row = t / I;  // (o_local*HW + hw)
@@ -2193,6 +2284,10 @@ static int pack_impl(void* dst, const void* const* srcs, const int64_t* numels,
           const int64_t slabs = (int64_t)(TILE_BYTES / sizeof(T)) / (I * HW + HW);
           if (slabs >= 1 && !(splits && splits[2 * t] > 1) && a.live[k] == 0)
             a.chunk[k] = (int)(slabs * I * HW);  // LDS-tiled path
+          else if (a.nsplit[k] > 1 && sizeof(T) == 4 && I % 4 == 0 && I * HW <= (int64_t)(TILE_BYTES / sizeof(T)))
+            a.chunk[k] = (int)(((2048 + I * HW - 1) / (I * HW)) * I * HW);  // LDS-staged stores, >= 2048 elements
+          else if (a.live[k] != 0 && a.nsplit[k] == 1 && I * HW <= 2 * PACK_CHUNK)
+            a.chunk[k] = (int)(((PACK_CHUNK + I * HW - 1) / (I * HW)) * I * HW);  // zero stream + live stores
         }
         a.blk_start[k] = blocks;
         blocks += (int)((numels[t] + a.chunk[k] - 1) / a.chunk[k]);
