@@ -2367,7 +2367,9 @@ static int unpack_impl(const void* src, void* const* dsts, const int64_t* src_of
           a.live[k] = (unsigned short)(live[t] & ((1 << (slab / I)) - 1));
         a.half[k] = (unsigned char)(!halves ? 1 : halves[t] == 0 ? 0 : halves[t] == 2 ? 2 : 1);
         if (a.half[k] == 2 && I <= 0) return HF_ERR_ARG;
-        a.chunk[k] = PACK_CHUNK;  // (an LDS-tiled NHWC variant measured slower: 30.9 vs 24.5 us)
+        // (LDS-staged NHWC variants measured slower twice: round 1 30.9 vs 24.5 us; round 3 -- contiguous 16-byte
+        // reads into LDS, lane = channel on the way out -- 21.2 vs 14.3 us, scripts/experiments/unpack_time.py)
+        a.chunk[k] = PACK_CHUNK;
         a.blk_start[k] = blocks;
         blocks += (int)((numels[t] + a.chunk[k] - 1) / a.chunk[k]);
         ++k;
