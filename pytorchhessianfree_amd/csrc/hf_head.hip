@@ -65,11 +65,25 @@ __global__ __launch_bounds__(HB) void k_maxpool_adjoint(float* __restrict__ g, c
     for (int ox = ox0; ox <= ox1; ++ox) {
       const size_t o = ((size_t)(n * q.OH + oy) * q.OW + ox) * C + c;
       if (idx[o] != self) continue;
+      // slabs in batches of eight, all in flight before the first addition (one at a time is a dependent round
+      // trip per slab: the first block's data gradient arrives as ~15 of them); same order of additions
       float v = A[o];
-      for (int s = 1; s < a_splits; ++s) v += A[(size_t)s * a_slab + o];
+      float w = B ? B[o] : 0.f;
+      for (int s = 1; s < a_splits; s += 8) {
+        float t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t8[u] = A[(size_t)(s + u < a_splits ? s + u : 0) * a_slab + o];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += s + u < a_splits ? t8[u] : 0.f;
+      }
       if (B) {
-        float w = B[o];
-        for (int s = 1; s < b_splits; ++s) w += B[(size_t)s * b_slab + o];
+        for (int s = 1; s < b_splits; s += 8) {
+          float t8[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t8[u] = B[(size_t)(s + u < b_splits ? s + u : 0) * b_slab + o];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) w += s + u < b_splits ? t8[u] : 0.f;
+        }
         v = v + w;
       }
       acc += v;
