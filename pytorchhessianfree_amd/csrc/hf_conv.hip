@@ -384,13 +384,22 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
     // steps are fetched in increasing order (the clamped re-fetches at the end repeat the last
     // one): the (tap, channel block) of the next fetch is kept incrementally -- no division per step
     int f_step = j0, f_ti = j0 / csteps, f_cb = j0 - (j0 / csteps) * csteps;
+    // the tap table entry of the NEXT tap is loaded when a tap begins: the scalar load (a dynamic index into
+    // the kernel arguments) has a whole tap's steps to land instead of stalling the step that needs it
+    auto tap_at = [&](int ti) { return a.tap_rs[ti < MAX_TAPS ? ti : MAX_TAPS - 1]; };
+    int f_rs = tap_at(tap0 + f_ti), f_rs_next = tap_at(tap0 + f_ti + 1);
     auto fetch_v = [&](int step, f32x4 (&ra)[NU], f32x4 (&rb)[NU]) -> unsigned {
       if (step > f_step) {  // (uniform; steps advance by one)
         f_step = step;
-        if (++f_cb == csteps) { f_cb = 0; ++f_ti; }
+        if (++f_cb == csteps) {
+          f_cb = 0;
+          ++f_ti;
+          f_rs = f_rs_next;
+          f_rs_next = tap_at(tap0 + f_ti + 1);
+        }
       }
-      const int ti = tap0 + f_ti, c = f_cb * BK + 4 * kq;
-      const int rs_ = a.tap_rs[ti], r = rs_ & 255, q = rs_ >> 8;
+      const int c = f_cb * BK + 4 * kq;
+      const int rs_ = f_rs, r = rs_ & 255, q = rs_ >> 8;
       const bool cok = c < a.cs;
       unsigned ok = 0;
 #pragma unroll
