@@ -75,6 +75,22 @@ typedef Cfg<2, 2, 1, 1, HF_CONV_BK> Small;
 typedef Cfg<2, 2, 2, 2, 16> Big;
 typedef Cfg<4, 1, 1, 3, 16> Big96;
 
+// Division by a launch constant as multiply-high + shift (Granlund-Montgomery, n < 2^31): the host fills
+// (mul, shift) per divisor.  The prologue of a convolution workgroup decodes its tile, its K range and the
+// (n, y, x) of its staged rows with ~12 divisions by runtime values; as emulated 32-bit divisions (~35 VALU
+// instructions each, the uniform ones included: there is no scalar divide) they were ~40 % of the ~800
+// instructions in front of the first load of launches that take 7-10 us in all.
+struct FastDiv {
+  unsigned mul, shift;
+};
+__host__ __device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (__umulhi(n, f.mul) + n) >> f.shift;
+#else
+  return (unsigned)((((unsigned long long)n * f.mul) >> 32) + n) >> f.shift;
+#endif
+}
+
 struct ConvArgs {
   const float* src;    // gathered activations (F: X, D: dY, W: X)
   const float* mat;    // F: Wt [Nout][RS][Cs]; D: WT [Nout][RS][Cs]; W: dY [M][Kout]
@@ -112,6 +128,8 @@ struct ConvArgs {
   int cls_tile0[5];    // first row tile of class i ([ncls] = tiles_m)
   int cls_tap0[5];     // taps of class i: tap_r/tap_s[cls_tap0[i] .. cls_tap0[i+1])
   int cls_h[4], cls_w[4], cls_py[4], cls_px[4];  // pixels of the class: y = y'*stride_h + py, y' < cls_h
+  // launch constants as divisors (filled by seal() right before the launch)
+  FastDiv fd_tiles_n, fd_tiles_m, fd_splits, fd_rw, fd_rh, fd_csteps, fd_cblocks;
 };
 
 // Pixel index into the gathered tensor for row coordinates (n, y, x) and tap (r, q); `valid` is
@@ -262,9 +280,8 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
   float (*Bs)[SN][LDK] = reinterpret_cast<float (*)[SN][LDK]>(lds + 2 * SM * LDK);
   int& flag = *reinterpret_cast<int*>(lds + C::LDS_FLOATS - 4);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / C::WN, wn = wave % C::WN;
-  const int tile_n = bid % a.tiles_n; bid /= a.tiles_n;
-  const int tile_m = bid % a.tiles_m;
-  const int split = bid / a.tiles_m;
+  const int bq = (int)fdiv((unsigned)bid, a.fd_tiles_n), tile_n = bid - bq * a.tiles_n;
+  const int split = (int)fdiv((unsigned)bq, a.fd_tiles_m), tile_m = bq - split * a.tiles_m;
   const int tile = tile_m * a.tiles_n + tile_n;
   const int csteps = (a.cs + BK - 1) / BK;
   // residue class of this row tile (strided data gradients, see ConvArgs): its rows, taps and step count
@@ -277,7 +294,7 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
     tap0 = a.cls_tap0[cls];
     steps = (a.cls_tap0[cls + 1] - tap0) * csteps;
   }
-  const int per = (steps + a.splits - 1) / a.splits;
+  const int per = (int)fdiv((unsigned)(steps + a.splits - 1), a.fd_splits);
   const int j0 = split * per < steps ? split * per : steps, j1 = (j0 + per < steps) ? j0 + per : steps;
 
   // staging assignment: thread -> rows lr + RPT*u and the float4 at k offset 4*kq
@@ -292,8 +309,9 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
         const int xx = m % wc, tq = m / wc;
         rx[u] = xx * a.stride_w + a.cls_px[cls]; ry[u] = (tq % hc) * a.stride_h + a.cls_py[cls]; rn[u] = tq / hc;
       } else {
-        const int xx = m % a.rw, tq = m / a.rw;
-        rx[u] = xx; ry[u] = tq % a.rh; rn[u] = tq / a.rh;
+        const int tq = (int)fdiv((unsigned)m, a.fd_rw), xx = m - tq * a.rw;
+        rn[u] = (int)fdiv((unsigned)tq, a.fd_rh);
+        rx[u] = xx; ry[u] = tq - rn[u] * a.rh;
       }
     } else {
       rn[u] = -1; ry[u] = rx[u] = 0;
@@ -383,7 +401,7 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
     // re-fetch step j1-1 and are never written to LDS, so the count at every wait is 8
     // steps are fetched in increasing order (the clamped re-fetches at the end repeat the last
     // one): the (tap, channel block) of the next fetch is kept incrementally -- no division per step
-    int f_step = j0, f_ti = j0 / csteps, f_cb = j0 - (j0 / csteps) * csteps;
+    int f_step = j0, f_ti = (int)fdiv((unsigned)j0, a.fd_csteps), f_cb = j0 - f_ti * csteps;
     // the tap table entry of the NEXT tap is loaded when a tap begins: the scalar load (a dynamic index into
     // the kernel arguments) has a whole tap's steps to land instead of stalling the step that needs it
     auto tap_at = [&](int ti) { return a.tap_rs[ti < MAX_TAPS ? ti : MAX_TAPS - 1]; };
@@ -482,15 +500,14 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
   float (*Bs)[BK][LDB] = reinterpret_cast<float (*)[BK][LDB]>(lds + 2 * BK * LDA);
   int& flag = *reinterpret_cast<int*>(lds + C::LDS_FLOATS - 4);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / C::WN, wn = wave % C::WN;
-  const int tile_n = bid % a.tiles_n; bid /= a.tiles_n;
-  const int tile_m = bid % a.tiles_m;
-  const int split = bid / a.tiles_m;
+  const int bq = (int)fdiv((unsigned)bid, a.fd_tiles_n), tile_n = bid - bq * a.tiles_n;
+  const int split = (int)fdiv((unsigned)bq, a.fd_tiles_m), tile_m = bq - split * a.tiles_m;
   const int tile = tile_m * a.tiles_n + tile_n;
-  const int per = (a.steps + a.splits - 1) / a.splits;
+  const int per = (int)fdiv((unsigned)(a.steps + a.splits - 1), a.fd_splits);
   const int j0 = split * per, j1 = (j0 + per < a.steps) ? j0 + per : a.steps;
 
   const int cblocks = (a.cs + BN - 1) / BN;
-  const int ti = tile_n / cblocks, c0 = (tile_n - ti * cblocks) * BN;
+  const int ti = (int)fdiv((unsigned)tile_n, a.fd_cblocks), c0 = (tile_n - ti * cblocks) * BN;
   const int rs_ = a.tap_rs[ti], r = rs_ & 255, q = rs_ >> 8;
 
   // staging: thread -> rows kr, kr + RP of the step and the float4 at column 4*cq
@@ -566,8 +583,9 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
 #pragma unroll
     for (int u = 0; u < TU; ++u) {
       const int m = j0 * BK + kr + RP * u;
-      const int xx = m % a.rw, tq = m / a.rw;
-      fx_[u] = xx; fy_[u] = tq % a.rh; fn_[u] = tq / a.rh;
+      const int tq = (int)fdiv((unsigned)m, a.fd_rw), xx = m - tq * a.rw;
+      fn_[u] = (int)fdiv((unsigned)tq, a.fd_rh);
+      fx_[u] = xx; fy_[u] = tq - fn_[u] * a.rh;
     }
     auto fetch_v = [&](int step, f32x4 (&ra)[TU], f32x4 (&rb)[TU]) -> unsigned {
       if (step > f_step) {  // (uniform; steps advance by one)
@@ -814,8 +832,34 @@ int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_by
   return (int)best;
 }
 
+FastDiv make_fastdiv(int64_t d) {
+  if (d < 1) d = 1;
+  unsigned l = 0;
+  while ((1LL << l) < d) ++l;  // ceil(log2 d)
+  FastDiv f;
+  f.mul = (unsigned)((((unsigned long long)((1ULL << l) - (unsigned long long)d)) << 32) / (unsigned long long)d + 1);
+  f.shift = l;
+  return f;
+}
+
+// the divisors of the kernels' prologues (see FastDiv); called on the copy that is handed to the launch
+void seal(ConvArgs& a, int direction) {
+  const int bk = a.big ? Big::BK : Small::BK;
+  const int bn = a.big == 1 ? Big::BN : a.big == 2 ? Big96::BN : Small::BN;
+  a.fd_tiles_n = make_fastdiv(a.tiles_n);
+  a.fd_tiles_m = make_fastdiv(a.tiles_m);
+  a.fd_splits = make_fastdiv(a.splits);
+  a.fd_rw = make_fastdiv(a.rw);
+  a.fd_rh = make_fastdiv(a.rh);
+  a.fd_csteps = make_fastdiv((a.cs + bk - 1) / bk);
+  a.fd_cblocks = make_fastdiv((a.cs + bn - 1) / bn);
+  (void)direction;
+}
+
 // Fill `a` for one direction; returns the number of workgroups (<= 0: error code).
-void launch_one(int direction, const ConvArgs& a, int64_t blocks, hipStream_t stream) {
+void launch_one(int direction, const ConvArgs& a_in, int64_t blocks, hipStream_t stream) {
+  ConvArgs a = a_in;
+  seal(a, direction);
   const dim3 grid((unsigned)blocks), block(CT);
   if (direction <= 1) {
     if (a.scalar) hipLaunchKernelGGL((k_conv_nt<true, Small>), grid, block, 0, stream, a);
@@ -833,7 +877,10 @@ void launch_one(int direction, const ConvArgs& a, int64_t blocks, hipStream_t st
   }
 }
 
-void launch_dw(const ConvArgs& d, const ConvArgs& w, int64_t bd, int64_t bw, hipStream_t stream) {
+void launch_dw(const ConvArgs& d_in, const ConvArgs& w_in, int64_t bd, int64_t bw, hipStream_t stream) {
+  ConvArgs d = d_in, w = w_in;
+  seal(d, 1);
+  seal(w, 2);
   const dim3 grid((unsigned)(bd + bw)), block(CT);
   const bool big = d.big || w.big, cls = d.ncls > 0;
   if (big && cls) hipLaunchKernelGGL((k_conv_dw<true, true>), grid, block, 0, stream, d, w, (int)bd);
@@ -1201,6 +1248,7 @@ int hf_conv2d_nhwc_group_slabs(const hf_conv_problem* problems, int n_problems, 
   m.n = n_problems;
   bool anycls = false;
   for (int i = 0; i < n_problems; ++i) anycls = anycls || q.a[i].ncls > 0;
+  for (int i = 0; i < n_problems; ++i) seal(q.a[i], 0);
   const dim3 grid((unsigned)total), block(CT);
   hipStream_t st = (hipStream_t)stream;
   if (anybig && anycls) hipLaunchKernelGGL((k_conv_group<true, true>), grid, block, 0, st, q.a[0], q.a[1], q.a[2], q.a[3], m);
