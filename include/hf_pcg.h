@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 4
+#define HF_ABI_VERSION 5
 
 enum hf_dtype { HF_F32 = 0, HF_F64 = 1 };
 
@@ -381,6 +381,20 @@ int hf_conv2d_nhwc(int direction, void* out, const void* act, const void* mat, i
                    int64_t stride_h, int64_t stride_w, int64_t pad_h, int64_t pad_w,
                    int64_t act_ld, void* workspace, int64_t workspace_bytes, void* tickets,
                    int64_t n_tickets, int target_blocks, int dtype, void* stream);
+
+/* hf_conv2d_nhwc_slabs (direction 0) and hf_unpack_weights in ONE launch: the scatter's workgroups follow the
+ * convolution's.  For a convolution that reads none of the scattered operands -- the stem's tangent convolution of
+ * the GGN product (BackPACK's R-op through the first layer, /root/reference/hessianfree/optimizer.py:457-462) -- while
+ * every later layer's [W | v_W] operand must be complete before ITS launch: 14 us of scatter hide behind a 12 us
+ * latency-bound launch.  u* arguments as hf_unpack_weights (at most 64 non-empty tensors); fp32, small-map tile
+ * configuration only (else HF_ERR_ARG: call the two entry points separately). */
+int hf_conv2d_nhwc_slabs_unpack(void* out, const void* act, const void* mat, int64_t n, int64_t h, int64_t w,
+                                int64_t c, int64_t k, int64_t r, int64_t s, int64_t stride_h, int64_t stride_w,
+                                int64_t pad_h, int64_t pad_w, int64_t act_ld, int64_t mat_ld, int splits,
+                                int64_t slab_stride, const void* usrc, void* const* udsts, const int64_t* usrc_offs,
+                                const int64_t* unumels, const int64_t* uslabs, const int64_t* uinners,
+                                const int64_t* ulive, const int64_t* uhalves, int n_tensors, int dtype,
+                                void* stream);
 
 /*
  * Consumer-side reduction ("slab") variants: split s of the reduction writes its partial result,

@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HF_PCG_LIB") or os.path.join(_HERE, "csrc", "libhfpcg.so")
 
 HF_F32, HF_F64 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
+HF_ERR_ARG = -1  # hf_status of include/hf_pcg.h: null / negative / inconsistent argument
 HF_M_NONE, HF_M_DIAG, HF_M_EXTERNAL = 0, 1, 2
 REASONS = {
     1: "Convergence (Martens)",
@@ -118,6 +119,9 @@ SIGNATURES = {
     "hf_conv2d_nhwc_plan": (c_int, [c_int] + [c_int64] * 11 + [c_int]),
     "hf_conv2d_nhwc_slabs": (c_int, [c_int, c_void_p, c_void_p, c_void_p] + [c_int64] * 14
                              + [c_int, c_int64, c_int, c_void_p]),
+    "hf_conv2d_nhwc_slabs_unpack": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int64] * 13 + [c_int, c_int64, c_void_p,
+                                            ctypes.POINTER(c_void_p)] + [ctypes.POINTER(c_int64)] * 6
+                                    + [c_int, c_int, c_void_p]),
     "hf_conv2d_nhwc_group_slabs": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "hf_conv2d_nhwc_dw_slabs": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "hf_chan_affine_pair": (c_int, [c_void_p, c_int, c_void_p]),
@@ -257,6 +261,16 @@ def unpack_tangent(v, slots, half=1):
     or channels_last."""
     lib = load()
     require_device_tensor(v, "v")
+    table = unpack_table(v, slots, half)
+    check(
+        lib.hf_unpack_weights(c_void_p(v.data_ptr()), *table, dtype_code(v.dtype), current_stream_ptr(v.device)),
+        "hf_unpack_weights",
+    )
+
+
+def unpack_table(v, slots, half=1):
+    """The argument arrays of ``hf_unpack_weights`` for ``slots`` (see :func:`unpack_tangent`):
+    ``(dsts, offs, numels, slabs, inners, live, halves, n)``."""
     n = len(slots)
     dsts = (c_void_p * n)()
     offs, numels, slabs, inners, live, halves = ((c_int64 * n)() for _ in range(6))
@@ -293,13 +307,7 @@ def unpack_tangent(v, slots, half=1):
         numels[k] = buf.shape[0] * cin * hw
         if off < 0 or off + numels[k] > v.numel():
             raise RuntimeError("unpack_tangent: slice outside the vector")
-    check(
-        lib.hf_unpack_weights(
-            c_void_p(v.data_ptr()), dsts, offs, numels, slabs, inners, live, halves, n, dtype_code(v.dtype),
-            current_stream_ptr(v.device),
-        ),
-        "hf_unpack_weights",
-    )
+    return dsts, offs, numels, slabs, inners, live, halves, n
 
 
 def softmax_ce_hvp(p, v, scale):

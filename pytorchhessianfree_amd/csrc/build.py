@@ -15,6 +15,7 @@ SRC_CONV = os.path.join(HERE, "hf_conv.hip")
 SRC_HEAD = os.path.join(HERE, "hf_head.hip")
 SOURCES = [SRC, SRC_CONV, SRC_HEAD]
 HDR = os.path.join(ROOT, "include", "hf_pcg.h")
+HDR_SHARED = os.path.join(HERE, "hf_unpack.h")  # shared by hf_pcg.hip and hf_conv.hip
 OUT = os.path.join(HERE, "libhfpcg.so")
 
 FLAGS = [
@@ -35,7 +36,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in (*SOURCES, HDR, __file__))
+    return any(os.path.getmtime(f) > t for f in (*SOURCES, HDR, HDR_SHARED, __file__))
 
 
 def build(force=False, verbose=True, out=None, extra_flags=()):

@@ -31,6 +31,7 @@
 #include <string.h>
 
 #include "hf_pcg.h"
+#include "hf_unpack.h"
 
 namespace {
 
@@ -693,6 +694,18 @@ __global__ __launch_bounds__(CT) void k_conv_nt(const ConvArgs a) {
   conv_nt_body<SCALAR, C, CLS>(a, lds, blockIdx.x);
 }
 
+// A forward / tangent convolution whose launch CARRIES the tangent sweep's weight scatter (hf_unpack_weights) as
+// extra workgroups behind its own: the stem's convolution does not read any scattered operand (its v_W is a slice
+// of the vector itself), the scatter only has to land before the NEXT launch -- as one launch the 14 us scatter
+// hides behind the 12 us latency-bound convolution (they were 26 us in sequence).
+template <bool SCALAR, typename C>
+__global__ __launch_bounds__(CT) void k_conv_nt_unpack(const ConvArgs a, const hf_shared::UnpackArgs u,
+                                                       const float* __restrict__ usrc, int conv_blocks) {
+  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  if ((int)blockIdx.x < conv_blocks) conv_nt_body<SCALAR, C, false>(a, lds, blockIdx.x);
+  else hf_shared::unpack_block<float>(usrc, u, blockIdx.x - (unsigned)conv_blocks);
+}
+
 template <bool SCALAR, typename C>
 __global__ __launch_bounds__(CT) void k_conv_tn(const ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
@@ -1170,6 +1183,42 @@ int hf_conv2d_nhwc_slabs(int direction, void* out, const void* act, const void* 
   if (a.splits != splits) return HF_ERR_ARG;  // ask hf_conv2d_nhwc_plan first
   if (out_c) a.out_c = (int)out_c;
   launch_one(direction, a, blocks, (hipStream_t)stream);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_conv2d_nhwc_slabs_unpack(void* out, const void* act, const void* mat, int64_t n, int64_t h, int64_t w,
+                                int64_t c, int64_t k, int64_t r, int64_t s, int64_t stride_h, int64_t stride_w,
+                                int64_t pad_h, int64_t pad_w, int64_t act_ld, int64_t mat_ld, int splits,
+                                int64_t slab_stride, const void* usrc, void* const* udsts, const int64_t* usrc_offs,
+                                const int64_t* unumels, const int64_t* uslabs, const int64_t* uinners,
+                                const int64_t* ulive, const int64_t* uhalves, int n_tensors, int dtype,
+                                void* stream) {
+  if (splits < 1 || slab_stride < 0 || mat_ld < 0 || dtype != HF_F32) return HF_ERR_ARG;
+  if (!usrc || !udsts || !usrc_offs || !unumels || !uslabs || !uinners || n_tensors < 1) return HF_ERR_ARG;
+  alignas(16) float dummy_ws[4];
+  const int rc = check_common(out, act, mat, dummy_ws, dummy_ws, dtype, n, h, w, c, k, r, s, stride_h, stride_w,
+                              pad_h, pad_w);
+  if (rc) return rc;
+  ConvArgs a;
+  const int64_t blocks = setup(a, 0, out, act, mat, n, h, w, c, k, r, s, stride_h, stride_w, pad_h, pad_w, act_ld,
+                               nullptr, 0, nullptr, 0, 0, splits, slab_stride, mat_ld);
+  if (blocks <= 0) return (int)blocks;
+  if (a.splits != splits || a.big || a.ncls > 0) return HF_ERR_ARG;  // (small-map launches only: ask the plan first)
+  hf_shared::UnpackArgs u;
+  int ublocks = 0;
+  const int next = hf_shared::fill_unpack_args<float>(u, &ublocks, 0, udsts, usrc_offs, unumels, uslabs, uinners,
+                                                      ulive, uhalves, n_tensors);
+  if (next < 0) return next;
+  if (next != n_tensors || ublocks < 1) return HF_ERR_ARG;  // more tensors than one argument block holds
+  seal(a, 0);
+  const dim3 grid((unsigned)(blocks + ublocks)), block(CT);
+  if (a.scalar)
+    hipLaunchKernelGGL((k_conv_nt_unpack<true, Small>), grid, block, 0, (hipStream_t)stream, a, u, (const float*)usrc,
+                       (int)blocks);
+  else
+    hipLaunchKernelGGL((k_conv_nt_unpack<false, Small>), grid, block, 0, (hipStream_t)stream, a, u,
+                       (const float*)usrc, (int)blocks);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }

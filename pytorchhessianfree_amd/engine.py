@@ -605,6 +605,7 @@ class FusedGGNEngine(_Operator):
                 u.tout, u.tout_ld, u.yout2 = torch.empty_like(u.y), 0, None
         self._xcats = xcats
         self._slot_list = list(self._tangent_slots.values())
+        self._carry_ok = os.environ.get("HF_CARRY_SCATTER", "1") != "0"  # (the stem's launch carries the v_W scatter)
         # (I, H, W, O) copies: the weights (once per step) and, for Hessian products, V (per product)
         self._wt_slots = [(self._offs[u.pw], u.wT, u.x.shape[1]) for u in self.units if not u.im2col and not u.first]
         self._vt_slots = [(self._offs[u.pw], u.vT, u.x.shape[1]) for u in self.units
@@ -775,8 +776,7 @@ class FusedGGNEngine(_Operator):
         v = v.detach()
         if not v.is_contiguous():
             v = v.contiguous()
-        _lib.unpack_tangent(v, self._slot_list)  # v_W halves of all [W | v_W] operands: one launch
-        self._tangent_stem(v)
+        self._tangent_stem(v, carry_scatter=True)  # + the v_W halves of all [W | v_W] operands, same launch
         self._tangent_blocks(v)
         g_last, g_fw, g_fb = self._head(v)
         pool_srcs = self._adjoint_blocks(g_last)
@@ -824,8 +824,7 @@ class FusedGGNEngine(_Operator):
         determine (``out[offset:]``)."""
         cut, first, offset = split
         v = v.detach()
-        _lib.unpack_tangent(v, self._slot_list)
-        self._tangent_stem(v)
+        self._tangent_stem(v, carry_scatter=True)
         self._tangent_blocks(v)
         g_last, g_fw, g_fb = self._head(v)
         self._phase_state = self._adjoint_blocks(g_last, last_block=cut)
@@ -864,10 +863,26 @@ class FusedGGNEngine(_Operator):
         pn, _, ph, pw = self.stem.y.shape
         return pn, ph, pw, self.pool_out.shape[2], self.pool_out.shape[3], self.pool_out.shape[1]
 
-    def _tangent_stem(self, v):
+    def _tangent_stem(self, v, carry_scatter=False):
+        """Stem: conv(x, v_W) as a 1x1 convolution on the im2col'd input (the input has no tangent; v_W is a
+        slice of ``v`` itself).  ``carry_scatter``: the launch also carries the scatter of every other layer's v_W
+        into its ``[W | v_W]`` operand (``hf_conv2d_nhwc_slabs_unpack``) -- nothing in the stem reads those."""
         s = self.stem
         vw = v[self._offs[s.pw]: self._offs[s.pw] + s.conv.weight.numel()]
-        self._conv_slabs(0, s.tbuf, s.cols, vw, s.geo, s.sT)  # input has no tangent: conv(x, v_W) as 1x1 on im2col
+        if carry_scatter and self._carry_ok:
+            n, h, w, c, k, r, s_, st, pd = s.geo
+            rc = _lib.load().hf_conv2d_nhwc_slabs_unpack(
+                _ptr(s.tbuf), _ptr(s.cols), _ptr(vw), n, h, w, c, k, r, s_, st[0], st[1], pd[0], pd[1], 0, 0, s.sT,
+                s.tbuf.shape[1], _ptr(v), *_lib.unpack_table(v, self._slot_list), _lib.HF_F32,
+                _lib.current_stream_ptr(self.dev))
+            if rc == _lib.HF_ERR_ARG:  # (a geometry / tensor count the merged launch does not take)
+                self._carry_ok = False
+            else:
+                _lib.check(rc, "hf_conv2d_nhwc_slabs_unpack")
+        if carry_scatter and not self._carry_ok:
+            _lib.unpack_tangent(v, self._slot_list)  # v_W halves of all [W | v_W] operands: one launch
+        if not (carry_scatter and self._carry_ok):
+            self._conv_slabs(0, s.tbuf, s.cols, vw, s.geo, s.sT)
         self._bn_tangent(s, v, None, 0)
         pn, ph, pw, poh, pow_, c0 = self._pool_geometry()
         _lib.check(_lib.load().hf_maxpool_tangent_nhwc(

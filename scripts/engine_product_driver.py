@@ -65,6 +65,17 @@ class Recorder:
         return [(("k_conv_tn" if direction == 2 else "k_conv_nt") + ("<true>" if scalar else "<false>"), rd, wr, fl)]
 
     @staticmethod
+    def _cost_hf_conv2d_nhwc_slabs_unpack(out, act, mat, n, h, w, c, k, r, s, sh, sw, ph, pw, act_ld, mat_ld, splits,
+                                          slab, usrc, dsts, offs, numels, slabs, inners, live, halves, nt, dtype, stream):
+        rd, wr, fl = conv_cost(0, n, h, w, c, k, r, s, sh, sw, ph, pw, splits)
+        tot = 0
+        for t in range(nt):
+            hwc = slabs[t] // inners[t] if inners[t] else 1
+            frac = bin(live[t]).count("1") / hwc if (live and live[t]) else 1.0
+            tot += int(4 * numels[t] * frac)
+        return [("k_conv_nt_unpack", rd + tot, wr + tot, fl)]  # the stem's convolution + the v_W scatter it carries
+
+    @staticmethod
     def _cost_hf_conv2d_nhwc_backward_slabs(dx, dw, dy, x, wt, n, h, w, c, k, r, s, sh, sw, ph, pw, sd, ld, sw_, lw,
                                             dtype, stream):
         r1, w1, f1 = conv_cost(1, n, h, w, c, k, r, s, sh, sw, ph, pw, sd)
