@@ -401,13 +401,21 @@ class FusedGGNEngine(_Operator):
         n, h, w, c, k, r, s, st, pd = u.geo
         self._conv_slabs(0, u.tbuf, u.x, u.wcat, u.geo, u.sF, mat_ld=2 * c)
 
-    def forward_own(self):
+    def forward_own(self, refresh=False):
         """The network's forward pass on the engine's static buffers, own kernels only: every
         activation lands where the sweeps read it (dense output = ReLU mask / weight-gradient operand
         / residual, and the x half of the consumer's [t_x | x] operand), max-pool positions, logits
-        and -- for a softmax cross-entropy -- probabilities and the loss value."""
+        and -- for a softmax cross-entropy -- probabilities and the loss value.  ``refresh``: first bring
+        the W halves of all [W | v_W] operands up to the current parameters (``refresh_weights()``) -- carried
+        by the stem's convolution launch where possible (the stem reads its weight from the parameter)."""
         s = self.stem
-        self._conv_forward(s)
+        flat = self._flat_params
+        carried = (refresh and flat is not None and flat.data_ptr() == self.params[0].data_ptr()
+                   and self._conv_carrying_scatter(s, s.conv.weight.detach(), s.sF, flat, 0))
+        if not carried:
+            if refresh:
+                self.refresh_weights()
+            self._conv_forward(s)
         self._bn_forward(s, s.sF)
         ks, st_, pd, _dl, _cm = self.pool_args
         pn, ph, pw, poh, pow_, c0 = self._pool_geometry()
@@ -658,6 +666,25 @@ class FusedGGNEngine(_Operator):
             mat_ld, out_c, splits, out.shape[1] if out.dim() == 2 else 0, _lib.HF_F32,
             _lib.current_stream_ptr(self.dev)), "hf_conv2d_nhwc_slabs")
 
+    def _conv_carrying_scatter(self, u, mat, splits, src, half):
+        """The im2col'd first layer's convolution (its weight operand ``mat`` is a slice of a flat vector, no
+        scattered operand is read) in ONE launch with the scatter of ``src`` into the v_W (``half=1``) / W
+        (``half=0``) halves of every other layer's operand (``hf_conv2d_nhwc_slabs_unpack``): the scatter hides
+        behind the latency-bound convolution.  False: not taken (switched off, no scatter to carry, or a
+        geometry / tensor count the merged launch refuses) -- the caller issues the two launches."""
+        if not (self._carry_ok and u.im2col and self._slot_list):
+            return False
+        n, h, w, c, k, r, s_, st, pd = u.geo
+        rc = _lib.load().hf_conv2d_nhwc_slabs_unpack(
+            _ptr(u.tbuf), _ptr(u.cols), _ptr(mat), n, h, w, c, k, r, s_, st[0], st[1], pd[0], pd[1], 0, 0, splits,
+            u.tbuf.shape[1], _ptr(src), *_lib.unpack_table(src, self._slot_list, half=half), _lib.HF_F32,
+            _lib.current_stream_ptr(self.dev))
+        if rc == _lib.HF_ERR_ARG:
+            self._carry_ok = False
+            return False
+        _lib.check(rc, "hf_conv2d_nhwc_slabs_unpack")
+        return True
+
     def _train_coeffs(self, u, vq, vr):
         """Per-channel vectors of the elementwise pass of a train-mode BatchNorm from the partial sums in
         ``u.gw`` / ``u.gb`` (sum xhat*a', sum a' over the batch): see ``hf_bn_train_coeffs``."""
@@ -869,19 +896,9 @@ class FusedGGNEngine(_Operator):
         into its ``[W | v_W]`` operand (``hf_conv2d_nhwc_slabs_unpack``) -- nothing in the stem reads those."""
         s = self.stem
         vw = v[self._offs[s.pw]: self._offs[s.pw] + s.conv.weight.numel()]
-        if carry_scatter and self._carry_ok:
-            n, h, w, c, k, r, s_, st, pd = s.geo
-            rc = _lib.load().hf_conv2d_nhwc_slabs_unpack(
-                _ptr(s.tbuf), _ptr(s.cols), _ptr(vw), n, h, w, c, k, r, s_, st[0], st[1], pd[0], pd[1], 0, 0, s.sT,
-                s.tbuf.shape[1], _ptr(v), *_lib.unpack_table(v, self._slot_list), _lib.HF_F32,
-                _lib.current_stream_ptr(self.dev))
-            if rc == _lib.HF_ERR_ARG:  # (a geometry / tensor count the merged launch does not take)
-                self._carry_ok = False
-            else:
-                _lib.check(rc, "hf_conv2d_nhwc_slabs_unpack")
-        if carry_scatter and not self._carry_ok:
-            _lib.unpack_tangent(v, self._slot_list)  # v_W halves of all [W | v_W] operands: one launch
-        if not (carry_scatter and self._carry_ok):
+        if not (carry_scatter and self._conv_carrying_scatter(s, vw, s.sT, v, 1)):
+            if carry_scatter:
+                _lib.unpack_tangent(v, self._slot_list)  # v_W halves of all [W | v_W] operands: one launch
             self._conv_slabs(0, s.tbuf, s.cols, vw, s.geo, s.sT)
         self._bn_tangent(s, v, None, 0)
         pn, ph, pw, poh, pow_, c0 = self._pool_geometry()
@@ -1370,9 +1387,15 @@ class PlainStackEngine(FusedGGNEngine):
             raise _Unsupported("more than 1024 classes")
 
     # ---- forward -----------------------------------------------------------------------------
-    def forward_own(self):
+    def forward_own(self, refresh=False):
+        first, flat = self.units[0], self._flat_params
+        carried = (refresh and flat is not None and flat.data_ptr() == self.params[0].data_ptr()
+                   and self._conv_carrying_scatter(first, first.conv.weight.detach(), first.sF, flat, 0))
+        if refresh and not carried:
+            self.refresh_weights()
         for u in self.units:
-            self._conv_forward(u)
+            if not (carried and u is first):
+                self._conv_forward(u)
             self._bn_forward(u, u.sF)
         torch.mean(self.tail.y, dim=(2, 3), out=self.logits)
         if getattr(self, "loss_spec", None) is not None:
@@ -1381,12 +1404,18 @@ class PlainStackEngine(FusedGGNEngine):
 
     # ---- product ------------------------------------------------------------------------------
     def _tangent_sweep(self, v):
-        if self._slot_list:
+        first = self.units[0]
+        carried = False
+        if first.im2col:  # (the first layer's launch carries the v_W scatter of all the others)
+            vw = v[self._offs[first.pw]: self._offs[first.pw] + first.conv.weight.numel()]
+            carried = self._conv_carrying_scatter(first, vw, first.sT, v, 1)
+        if self._slot_list and not carried:
             _lib.unpack_tangent(v, self._slot_list)  # v_W halves of all [W | v_W] operands: one launch
         for u in self.units:
             if u.im2col:  # no input tangent: conv(x, v_W) as a 1x1 product over the im2col
                 vw = v[self._offs[u.pw]: self._offs[u.pw] + u.conv.weight.numel()]
-                self._conv_slabs(0, u.tbuf, u.cols, vw, u.geo, u.sT)
+                if not (carried and u is first):
+                    self._conv_slabs(0, u.tbuf, u.cols, vw, u.geo, u.sT)
             else:
                 self._conv_slabs(0, u.tbuf, u.xcat, u.wcat, self._tgeo(u), u.sT)
             self._bn_tangent(u, v, None, 0)

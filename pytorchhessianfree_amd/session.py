@@ -96,7 +96,7 @@ class EngineSession:
         self.stream.synchronize()
         with torch.no_grad():
             self.g_wT = self._capture(lambda: eng.refresh_weights(transposed=True))
-            self.g_fwd = self._capture(lambda: (eng.refresh_weights(), eng.forward_own()))
+            self.g_fwd = self._capture(lambda: eng.forward_own(refresh=True))
             self.g_grad = self._capture(lambda: eng.gradient(self.grad_buffer))
             self.graph = self._capture(lambda: eng.local(self.input_buffer, out=self.output_buffer), keep=True)
         cur.wait_stream(self.stream)
