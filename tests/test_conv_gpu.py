@@ -171,3 +171,54 @@ def test_more_output_tiles_than_tickets_runs_unsplit():
     assert float((got.double() - ref).abs().max() / ref.abs().max()) < 2e-5
     (g,) = torch.autograd.grad(got.sum(), conv.weight)
     assert torch.isfinite(g).all()
+
+
+def test_convolution_launch_carrying_the_weight_scatter_equals_the_two_launches():
+    """``hf_conv2d_nhwc_slabs_unpack``: a forward convolution over an im2col'd input (weight operand = a slice
+    of the flat vector, as the stem's tangent convolution) whose launch carries ``hf_unpack_weights`` of other
+    tensors as extra workgroups -- bitwise what ``hf_conv2d_nhwc_slabs`` + ``hf_unpack_weights`` write, for a
+    vector (16-byte) and a scalar (C = 49) geometry, with a dead-tap mask on one scattered tensor; a geometry
+    the merged launch does not take (128-wide tiles) is refused with HF_ERR_ARG, not run."""
+    gen = torch.Generator(device=DEV).manual_seed(31)
+    lib, P = _lib.load(), _lib.c_void_p
+    for rows, c, k in ((6272, 49, 64), (1568, 52, 64)):
+        cols = torch.randn(rows, c, device=DEV, generator=gen)  # [rows, 1, 1, c] NHWC
+        k2, c2 = 24, 16
+        n_vec = k * c + 5 + k2 * c2 * 9 + k2 * c2
+        v = torch.randn(n_vec, device=DEV, generator=gen)
+        vw = v[:k * c]  # the convolution's own weight operand: a slice of the vector
+        off3, off1 = k * c + 5, k * c + 5 + k2 * c2 * 9
+        sp = _lib.conv_plan(0, rows, 1, 1, c, k, 1, 1, (1, 1), (0, 0))
+
+        def buffers():
+            b3 = _cl(torch.full((k2, 2 * c2, 3, 3), 7.0, device=DEV))
+            b1 = _cl(torch.full((k2, 2 * c2, 1, 1), 7.0, device=DEV))
+            return [(off3, b3, c2, 0b000111010), (off1, b1, c2, 0)], torch.full((sp, rows * k), -1.0, device=DEV)
+
+        slots_a, out_a = buffers()
+        _lib.conv2d_nhwc_slabs(0, out_a, cols, vw, rows, 1, 1, c, k, 1, 1, (1, 1), (0, 0), sp)
+        _lib.unpack_tangent(v, slots_a)
+        slots_b, out_b = buffers()
+        st = _lib.current_stream_ptr(v.device)
+        rc = lib.hf_conv2d_nhwc_slabs_unpack(
+            P(out_b.data_ptr()), P(cols.data_ptr()), P(vw.data_ptr()), rows, 1, 1, c, k, 1, 1, 1, 1, 0, 0, 0, 0, sp,
+            out_b.shape[1], P(v.data_ptr()), *_lib.unpack_table(v, slots_b), _lib.HF_F32, st)
+        assert rc == 0
+        assert torch.equal(out_a, out_b)
+        for (_, ba, _, _), (_, bb, _, _) in zip(slots_a, slots_b):
+            assert torch.equal(ba, bb)
+        got = out_b.sum(0).view(rows, k).double()
+        want = cols.double() @ vw.view(k, c).double().t()
+        assert float((got - want).abs().max() / want.abs().max()) < 2e-5
+        assert not torch.equal(slots_b[0][1], torch.full_like(slots_b[0][1], 7.0))  # (the scatter really ran)
+    # a large-map geometry runs the 128-wide configuration: the merged launch declines it
+    n, h, c, k = 32, 32, 96, 96
+    x = _cl(torch.randn(n, c, h, h, device=DEV, generator=gen))
+    w = _cl(torch.randn(k, c, 3, 3, device=DEV, generator=gen))
+    sp = _lib.conv_plan(0, n, h, h, c, k, 3, 3, (1, 1), (1, 1))
+    out = torch.empty((sp, n * h * h * k), device=DEV)
+    slots, _ = buffers()
+    rc = lib.hf_conv2d_nhwc_slabs_unpack(
+        P(out.data_ptr()), P(x.data_ptr()), P(w.data_ptr()), n, h, h, c, k, 3, 3, 1, 1, 1, 1, 0, 0, sp, out.shape[1],
+        P(v.data_ptr()), *_lib.unpack_table(v, slots), _lib.HF_F32, _lib.current_stream_ptr(v.device))
+    assert rc == _lib.HF_ERR_ARG
