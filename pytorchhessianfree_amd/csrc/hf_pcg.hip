@@ -1112,6 +1112,39 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
     const T rs = rstd ? rstd[c] : (T)1, mu = mean ? mean[c] : (T)0;
     const T s = (w ? w[c] : (T)1) * rs;
     const I per = N * HW;
+    if (per <= (I)TPC) {
+      // at most ONE element per lane (the 32-row maps of the last stage, whose cotangents arrive as ~32 slabs):
+      // sixteen slabs in flight per pass -- one at a time is a dependent round trip per slab, ~5 us per launch
+      if ((I)lane < per) {
+        const I n = HW == 1 ? (I)lane : (I)lane / HW;
+        const I idx = (n * C + c) * HW + ((I)lane - n * HW);
+        T g = gy[idx], h = gy2 ? gy2[idx] : (T)0;
+        const T m = mask_src ? mask_src[idx] : (T)1, xv = x ? x[idx] : (T)0;
+        for (int sp = 1; sp < s1; sp += 16) {
+          T v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = gy[(long long)(sp + u < s1 ? sp + u : 0) * l1 + idx];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) g += sp + u < s1 ? v[u] : (T)0;
+        }
+        if (gy2) {
+          for (int sp = 1; sp < s2; sp += 16) {
+            T v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = gy2[(long long)(sp + u < s2 ? sp + u : 0) * l2 + idx];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) h += sp + u < s2 ? v[u] : (T)0;
+          }
+        }
+        T gg = g;
+        if (gy2) gg = gg + h;
+        if (mask_src) gg = m > (T)0 ? gg : (T)0;
+        if (gx) gx[idx] = gg * s;
+        if (gres) gres[idx] = gg;
+        if (x) acc[0] += (double)gg * (double)(T)((xv - mu) * rs);
+        acc[1] += (double)gg;
+      }
+    } else {
     // ITER elements per thread with all loads issued before the first use (latency-bound)
     constexpr int ITER = 8;
     for (I e0 = lane; e0 < per; e0 += (I)TPC * ITER) {
@@ -1152,6 +1185,7 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_bwd(
           acc[1] += (double)gg;
         }
       }
+    }
     }
   }
   if (TPC == 64) {
