@@ -66,6 +66,11 @@ def test_resnet18_engine_product_matches_float64(batch):
         assert torch.equal(op(v), got)  # the reference's _test_mvp_deterministic, bitwise
     want = _float64_product(tp.resnet18_mnist, v, batch_size=batch)
     assert float((got.double() - want).abs().max() / want.abs().max()) < 5e-7
+    # the stem's launch carries the v_W scatter (hf_conv2d_nhwc_slabs_unpack): same bits as the two launches
+    assert op._carry_ok
+    op._carry_ok = False
+    assert torch.equal(op(v), got)
+    op._carry_ok = True
     # linear in v, symmetric operator: <u, G v> == <v, G u>
     u = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
     a, b = float(u.double() @ got.double()), float(v.double() @ op(u).double())
