@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 5
+#define HF_ABI_VERSION 6
 
 enum hf_dtype { HF_F32 = 0, HF_F64 = 1 };
 
@@ -307,6 +307,17 @@ typedef struct hf_bn_adjoint_problem {
   int row_blocks;
 } hf_bn_adjoint_problem;
 int hf_chan_affine_bwd_pair(const hf_bn_adjoint_problem* problems /* [2] */, int dtype, void* stream);
+
+/* Batch statistics of a train-mode BatchNorm layer for the engine's OWN forward pass (the forward pass of
+ * /root/reference/hessianfree/optimizer.py:216-229 and of every tfunc call, :288-294, on a model that was not put in
+ * eval mode -- examples/run_resnet18_mnist.py:19-35): from `nparts` partial per-channel sums c elements apart (what
+ * hf_chan_affine_bwd_ex leaves in gb / gw), added in order in fp64.
+ *   stage 0: mean = sum(part) / count                      (part: sums of a)
+ *   stage 1: var = sum(part) / count, rstd = 1/sqrt(var + eps)   (part: sums of a*(a - mean), mean as written by
+ *            stage 0); momentum >= 0: running_mean / running_var (nullable) move as torch.nn.BatchNorm2d's forward
+ *            moves them: r <- (1 - momentum) r + momentum * {mean, var * count/(count - 1)}. */
+int hf_bn_batch_stats(void* mean, void* rstd, void* running_mean, void* running_var, const void* part, int nparts,
+                      double count, double eps, double momentum, int stage, int64_t c, int dtype, void* stream);
 
 /*
  * Forward pass of conv -> (eval-BatchNorm | bias) (+ residual) (+ ReLU) from the convolution's split-K

@@ -1536,6 +1536,32 @@ __global__ __launch_bounds__(BLOCK) void k_bn_forward(
 //     q[c] = vq[c] - w[c]*rstd[c] * S_x[c]/m ,   r[c] = vr[c] - w[c]*rstd[c] * S_1[c]/m
 // with S_x = sum(xhat * a'), S_1 = sum(a') given as `nparts` partial sums (the row shares of k_bn_adjoint_rows),
 // added up here in order.  One tiny launch per layer and sweep.
+// Batch statistics of a train-mode BatchNorm from per-row-block partial sums (what hf_chan_affine_bwd_ex leaves in
+// gb / gw), added in order in fp64.  stage 0: mean = sum(part) / count.  stage 1: part holds sum a*(a - mean):
+// var = sum / count (biased, what the layer normalises with), rstd = 1 / sqrt(var + eps), and -- momentum >= 0 -- the
+// running statistics move as torch.nn.BatchNorm2d's forward moves them (unbiased variance).
+__global__ __launch_bounds__(BLOCK) void k_bn_batch_stats(float* __restrict__ mean, float* __restrict__ rstd,
+                                                         float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                         const float* __restrict__ part, int nparts, double count,
+                                                         float eps, float momentum, int stage, int C) {
+  const int c = blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int k = 0; k < nparts; ++k) s += (double)part[(size_t)k * C + c];
+  if (stage == 0) {
+    mean[c] = (float)(s / count);
+    return;
+  }
+  double var = s / count;
+  if (var < 0.0) var = 0.0;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (momentum >= 0.f && run_mean && run_var) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    run_mean[c] = (float)((1.0 - (double)momentum) * (double)run_mean[c] + (double)momentum * (double)mean[c]);
+    run_var[c] = (float)((1.0 - (double)momentum) * (double)run_var[c] + (double)momentum * unbiased);
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_bn_train_coeffs(float* __restrict__ q_out, float* __restrict__ r_out,
                                                            const float* __restrict__ part_x,
                                                            const float* __restrict__ part_1, int nparts,
@@ -2457,6 +2483,18 @@ int hf_bn_train_coeffs(void* q_out, void* r_out, const void* part_x, const void*
   hipLaunchKernelGGL(k_bn_train_coeffs, dim3((unsigned)((c + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
                      (float*)q_out, (float*)r_out, (const float*)part_x, (const float*)part_1, nparts, (const float*)w,
                      (const float*)rstd, (const float*)vq, (const float*)vr, (float)(1.0 / count), (int)c);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_bn_batch_stats(void* mean, void* rstd, void* running_mean, void* running_var, const void* part, int nparts,
+                      double count, double eps, double momentum, int stage, int64_t c, int dtype, void* stream) {
+  if (dtype != HF_F32 || !mean || !part || nparts < 1 || c < 1 || !(count > 0) || stage < 0 || stage > 1)
+    return HF_ERR_ARG;
+  if (stage == 1 && (!rstd || !(eps >= 0))) return HF_ERR_ARG;
+  hipLaunchKernelGGL(k_bn_batch_stats, dim3((unsigned)((c + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     (float*)mean, (float*)rstd, (float*)running_mean, (float*)running_var, (const float*)part, nparts,
+                     count, (float)eps, (float)momentum, stage, (int)c);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }

@@ -143,10 +143,18 @@ class FusedGGNEngine(_Operator):
         self._allocate()
         self.set_batch(getattr(outputs, "_hf_input").detach(), None)
         self.refresh_weights(transposed=True)
+        self.train_own = False
         if self.train_bn:
             # train-mode BatchNorm: the engine linearises at the activations and batch statistics the MODEL's
-            # forward pass recorded (no own forward pass, no persistent session: every forward of such a model
-            # also moves its running statistics)
+            # forward pass recorded.  Its own forward pass (batch statistics by own kernels, running statistics
+            # moved as the layers' forward moves them) lets a persistent session serve such a model too -- if it
+            # reproduces the model's output here (with the running statistics left alone)
+            if (os.environ.get("HF_TRAIN_SESSION", "1") != "0"
+                    and all(u.bn.momentum is not None and u.bn.track_running_stats for u in self.units if u.train)):
+                self.forward_own(update_running=False)
+                want = outputs.detach()
+                err = float((self.logits - want).abs().max() / want.abs().max().clamp_min(1e-30))
+                self.train_own = err < 1e-4
             self._load_recorded(outputs)
         else:
             # own forward pass on the engine's static buffers; it must reproduce the model's output
@@ -210,7 +218,9 @@ class FusedGGNEngine(_Operator):
                 if rec is None or len(rec) != 6 or group_is_set:
                     raise _Unsupported(f"{name}: train-mode BatchNorm without a record (or under data "
                                        "parallelism: batch statistics couple the samples of a shard)")
-                bx, bres, by, brelu, rstd, u.mean_t = rec
+                bx, bres, by, brelu, rstd, mean_t = rec
+                # (engine-owned static buffers: the own forward pass of a session rewrites them per batch)
+                rstd, u.mean_t = rstd.clone(), mean_t.clone()
                 u.train = True
             else:
                 bx, bres, by, brelu, rstd = io(bn, 5)
@@ -301,7 +311,7 @@ class FusedGGNEngine(_Operator):
         # loss, probabilities and d loss / d logits itself, on its own forward pass -- which is what
         # lets ONE engine serve many steps and trial points (``session.EngineSession``)
         self.loss_spec = None
-        if self._ce is not None and not self.train_bn:
+        if self._ce is not None and (not self.train_bn or self.train_own):
             spec = ce_loss_spec(loss, outputs)
             if spec is not None:
                 self.loss_spec = spec
@@ -385,11 +395,40 @@ class FusedGGNEngine(_Operator):
                     if not u.im2col and not u.first:
                         u.wT.copy_(self.params[u.pw].detach().permute(1, 2, 3, 0))
 
-    def _bn_forward(self, u, splits):
+    def _ones(self, k):
+        cache = self.__dict__.setdefault("_ones_cache", {})
+        if k not in cache:
+            cache[k] = torch.ones(k, dtype=torch.float32, device=self.dev)
+        return cache[k]
+
+    def _bn_forward(self, u, splits, update_running=True):
         n, k, oh, ow = u.a.shape
         res = u.res
+        if u.train:
+            # batch statistics by two passes of the adjoint's reduction kernel over the convolution's output
+            # (sum a -> mean; sum a*(a - mean) -> biased variance), each followed by a per-channel finalisation;
+            # the first pass also sums the convolution's slabs into ``a``
+            lib, st, bn = _lib.load(), _lib.current_stream_ptr(self.dev), u.bn
+            count = float(n * oh * ow)
+            _lib.check(lib.hf_chan_affine_bwd_ex(
+                None, None, _ptr(u.gb), _ptr(u.a), _ptr(u.tbuf), splits, u.tbuf.shape[1], None, 1, 0, None, None,
+                None, None, None, n, k, oh * ow, 1, u.rb, _lib.HF_F32, st), "hf_chan_affine_bwd_ex")
+            _lib.check(lib.hf_bn_batch_stats(_ptr(u.mean_t), None, None, None, _ptr(u.gb), u.rb, count, 0.0, -1.0, 0,
+                                             k, _lib.HF_F32, st), "hf_bn_batch_stats")
+            _lib.check(lib.hf_chan_affine_bwd_ex(
+                None, _ptr(u.gw), _ptr(u.gb), None, _ptr(u.a), 1, 0, None, 1, 0, _ptr(u.a), _ptr(u.mean_t),
+                _ptr(self._ones(k)), None, None, n, k, oh * ow, 1, u.rb, _lib.HF_F32, st), "hf_chan_affine_bwd_ex")
+            move = update_running and bn.track_running_stats
+            _lib.check(lib.hf_bn_batch_stats(
+                _ptr(u.mean_t), _ptr(u.rstd), _ptr(bn.running_mean) if move else None,
+                _ptr(bn.running_var) if move else None, _ptr(u.gw), u.rb, count, float(bn.eps),
+                float(bn.momentum) if move else -1.0, 1, k, _lib.HF_F32, st), "hf_bn_batch_stats")
+            if move:
+                bn.num_batches_tracked.add_(1)
+            splits = 1  # (``a`` is summed)
         _lib.check(_lib.load().hf_bn_forward(
-            _ptr(u.y), _ptr(u.yout2), 2 * k if u.yout2 is not None else 0, _ptr(u.a), _ptr(u.tbuf), splits,
+            _ptr(u.y), _ptr(u.yout2), 2 * k if u.yout2 is not None else 0, _ptr(u.a),
+            _ptr(u.a if u.train else u.tbuf), splits,
             u.tbuf.shape[1], _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.shift),
             _ptr(res), 0, 1 if u.relu else 0, n * oh * ow, k, _lib.HF_F32, _lib.current_stream_ptr(self.dev)),
             "hf_bn_forward")
@@ -401,7 +440,7 @@ class FusedGGNEngine(_Operator):
         n, h, w, c, k, r, s, st, pd = u.geo
         self._conv_slabs(0, u.tbuf, u.x, u.wcat, u.geo, u.sF, mat_ld=2 * c)
 
-    def forward_own(self, refresh=False):
+    def forward_own(self, refresh=False, update_running=True):
         """The network's forward pass on the engine's static buffers, own kernels only: every
         activation lands where the sweeps read it (dense output = ReLU mask / weight-gradient operand
         / residual, and the x half of the consumer's [t_x | x] operand), max-pool positions, logits
@@ -416,7 +455,7 @@ class FusedGGNEngine(_Operator):
             if refresh:
                 self.refresh_weights()
             self._conv_forward(s)
-        self._bn_forward(s, s.sF)
+        self._bn_forward(s, s.sF, update_running)
         ks, st_, pd, _dl, _cm = self.pool_args
         pn, ph, pw, poh, pow_, c0 = self._pool_geometry()
         (kh, kw), (sh, sw), (pph, ppw) = _pair(ks), _pair(st_ if st_ is not None else ks), _pair(pd)
@@ -427,10 +466,10 @@ class FusedGGNEngine(_Operator):
         for chain, ds, _x in self.blocks:
             if ds is not None:
                 self._conv_forward(ds)
-                self._bn_forward(ds, ds.sF)
+                self._bn_forward(ds, ds.sF, update_running)
             for u in chain:
                 self._conv_forward(u)
-                self._bn_forward(u, u.sF)
+                self._bn_forward(u, u.sF, update_running)
         tail = self.tail
         if self._head_hw > 1:
             torch.mean(tail.y, dim=(2, 3), out=self.feat)
@@ -1279,6 +1318,8 @@ class FusedGGNEngine(_Operator):
             self.weight = weight
             if not self.train_bn:
                 self.forward_own()  # back to the engine's own activations
+            elif self.train_own:
+                self.forward_own(update_running=False)
         want = GGNOperator(loss, self.outputs, self.params).local(v)
         err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
         if not err < FusedGGNEngine.verify_tol:
@@ -1387,7 +1428,7 @@ class PlainStackEngine(FusedGGNEngine):
             raise _Unsupported("more than 1024 classes")
 
     # ---- forward -----------------------------------------------------------------------------
-    def forward_own(self, refresh=False):
+    def forward_own(self, refresh=False, update_running=True):  # (no BatchNorm in a plain stack: nothing to move)
         first, flat = self.units[0], self._flat_params
         carried = (refresh and flat is not None and flat.data_ptr() == self.params[0].data_ptr()
                    and self._conv_carrying_scatter(first, first.conv.weight.detach(), first.sF, flat, 0))

@@ -90,13 +90,18 @@ class EngineSession:
             self.losses = torch.zeros(64, **f32)
             # warm-up of everything that will be captured (allocator, lazy initialisations)
             eng.refresh_weights(transposed=True)
-            eng.forward_own()
+            eng.forward_own(update_running=False)
             eng.gradient(self.grad_buffer)
             eng.local(self.input_buffer, out=self.output_buffer)
         self.stream.synchronize()
         with torch.no_grad():
             self.g_wT = self._capture(lambda: eng.refresh_weights(transposed=True))
             self.g_fwd = self._capture(lambda: eng.forward_own(refresh=True))
+            # train-mode BatchNorm: a forward pass moves the running statistics.  The step that CREATES the
+            # session has already run the model itself (the stock layers moved them): its refresh replays a
+            # twin of the graph that leaves them alone
+            self.g_fwd_still = (self._capture(lambda: eng.forward_own(refresh=True, update_running=False))
+                                if eng.train_bn else self.g_fwd)
             self.g_grad = self._capture(lambda: eng.gradient(self.grad_buffer))
             self.graph = self._capture(lambda: eng.local(self.input_buffer, out=self.output_buffer), keep=True)
         cur.wait_stream(self.stream)
@@ -128,7 +133,7 @@ class EngineSession:
         ref = getattr(outputs, "_hf_model", None)
         model = ref() if ref is not None else None
         x = getattr(outputs, "_hf_input", None)
-        if model is not eng.model_ref or x is None or model.training or group is not self.group:
+        if model is not eng.model_ref or x is None or model.training != eng.train_bn or group is not self.group:
             return None
         if tuple(x.shape) != tuple(eng.x_in.shape) or x.dtype != torch.float32 or x.device != eng.x_in.device:
             return None
@@ -154,7 +159,7 @@ class EngineSession:
         the logits as a leaf that requires grad, or ``None`` when this call is not the session's
         (another model / shape / mode) and the model must run itself."""
         eng = self.engine
-        if (model is not eng.model_ref or model.training or not torch.is_grad_enabled()
+        if (model is not eng.model_ref or model.training != eng.train_bn or not torch.is_grad_enabled()
                 or not isinstance(x, torch.Tensor) or tuple(x.shape) != tuple(eng.x_in.shape)
                 or x.dtype != torch.float32 or x.device != eng.x_in.device
                 or eng._flat_params is None or eng._flat_params.data_ptr() != eng.params[0].data_ptr()):
@@ -182,7 +187,7 @@ class EngineSession:
             else:
                 eng.set_batch(getattr(outputs, "_hf_input").detach(), spec["targets"])
                 self.g_wT.replay()
-                self.g_fwd.replay()
+                self.g_fwd_still.replay()  # (the model's own forward pass produced `outputs`)
         self._override_out = None
         self._cache = {}
         self.steps += 1

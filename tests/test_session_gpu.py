@@ -188,3 +188,55 @@ def test_session_is_refused_for_other_losses_and_models():
         opt.step(fwd)
         opt.step(fwd)
     assert opt._session is None
+
+
+def _run_train_mode_steps(steps, session):
+    model, _, lossf = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=SEEDS[0])
+    model.train()
+    modelprep.prepare_model(model, channels_last=True)
+    opt = hf.HessianFree(model.parameters(), graph_matvec=True)
+    if not session:
+        opt._session_off = True
+    finals = []
+    for i in range(steps):
+        _, (x, t), _ = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=SEEDS[i])
+
+        def forward():
+            out = model(x)
+            return lossf(out, t), out
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            finals.append(opt.step(forward))
+    return opt, finals, model
+
+
+def test_train_mode_batchnorm_session_equals_generic_path():
+    """TRAIN-mode BatchNorm (what the reference's ResNet example runs, examples/run_resnet18_mnist.py:19-35: no
+    ``model.eval()``): the persistent session serves such a model with its own batch-statistics forward pass
+    (``hf_bn_batch_stats``) -- three default steps on fresh batches against this package's generic path (stock
+    train-mode layers, engine rebuilt per step).  Stated tolerance: first step's losses 1e-5 / 1e-4, same damping
+    schedule, iteration counts +-2; the second step's losses 1e-3; the third step starts from parameters that
+    differ like any two fp32 train-mode runs (products scatter ~1e-3 between two forward passes, DESIGN.md
+    section 5; measured: initial losses 4e-5, final losses 1.2 % apart): 2e-3 / 5e-2.  The running statistics move on
+    both paths -- every evaluated point moves them, as every ``forward()`` of the reference does; the session
+    evaluates fewer points (cached trial values) -- and stay within a quarter of their range of each other."""
+    a, fa, ma = _run_train_mode_steps(3, session=True)
+    assert a._session is not None and a._session.steps == 3 and a._session.engine.train_own
+    b, fb, mb = _run_train_mode_steps(3, session=False)
+    assert b._session is None
+    assert abs(a.state["init_losses"][0] - b.state["init_losses"][0]) <= 1e-5 * abs(b.state["init_losses"][0])
+    assert abs(fa[0] - fb[0]) <= 1e-4 * abs(fb[0])
+    assert a.state["dampings"] == b.state["dampings"]
+    for x, y in zip(a.state["num_cg_iters"], b.state["num_cg_iters"]):
+        assert abs(x - y) <= 2
+    ia, ib = a.state["init_losses"], b.state["init_losses"]
+    assert abs(ia[1] - ib[1]) <= 1e-3 * abs(ib[1]) and abs(fa[1] - fb[1]) <= 1e-3 * abs(fb[1])
+    assert abs(ia[2] - ib[2]) <= 2e-3 * abs(ib[2]) and abs(fa[2] - fb[2]) <= 5e-2 * abs(fb[2])
+    for x, y in zip(fa, ia):
+        assert x < y  # every step reduced its batch's loss
+    ra, rb = ma.bn1.running_mean, mb.bn1.running_mean
+    assert float(ra.abs().max()) > 0 and int(ma.bn1.num_batches_tracked) > 3
+    assert float((ra - rb).abs().max()) <= 0.25 * float(rb.abs().max())
+    va, vb = ma.layers[4].bn1.running_var, mb.layers[4].bn1.running_var
+    assert float((va - vb).abs().max()) <= 0.25 * float(vb.abs().max())
