@@ -136,13 +136,16 @@ def test_session_steps_match_reference_cpu_path():
 
 def test_session_equals_generic_path_and_is_faster_to_restart():
     """Session vs this package's generic path (engine rebuilt + re-captured every step, eager trial
-    forwards): same iteration counts, learning rates, damping schedule.  The first step's losses agree
+    forwards): iteration counts +-1, same learning rates and damping schedule.  The first step's losses agree
     to 1e-6; later steps start from parameters that differ like any two fp32 runs (back-tracking picks
     between iterates whose losses tie to 1e-6): 1e-3."""
     a, fa = _run_steps(DEV, 3, session=True)
     b, fb = _run_steps(DEV, 3, session=False)
     assert a._session is not None and b._session is None
-    assert a.state["num_cg_iters"] == b.state["num_cg_iters"]
+    # (Martens' criterion is a threshold on fp32 quantities: the generic path's eager forward passes are not
+    # bitwise repeatable, one run in three stops a solve one iteration earlier or later)
+    for x, y in zip(a.state["num_cg_iters"], b.state["num_cg_iters"]):
+        assert abs(x - y) <= 1
     assert a.state["learning_rates"] == b.state["learning_rates"]
     assert a.state["dampings"] == b.state["dampings"]
     assert abs(a.state["init_losses"][0] - b.state["init_losses"][0]) <= 1e-6 * abs(b.state["init_losses"][0])
