@@ -336,7 +336,14 @@ def main():
             return curvature.hessian_operator(loss, out, params, weight=weight, group=None)
         return curvature.ggn_operator(loss, out, params, weight=weight, group=None)
 
+    state = {"group": None, "opt": None}
+
     def build_operator(channels_last, overlap=False):
+        """The operator ``HessianFree.step()`` itself hands to ``cg()`` for this problem -- obtained from
+        ``HessianFree.linearise`` (same code path, same process group), not built here: the persistent engine
+        session where the model family is covered (single GPU: one product graph cloned into the iteration
+        graph; data parallel: two product graphs, the all-reduce chunked by stage and overlapped), else the
+        engine / autograd operator as a hipGraph."""
         model, x, t, lossf = problem(device)
         if args.fuse_bn:
             modelprep.fuse_eval_batchnorm(model)
@@ -346,33 +353,38 @@ def main():
             modelprep.fuse_residual_blocks(model)  # relu(bn(.)) / relu(bn(.) + identity) as one layer
             modelprep.fuse_bn_relu(model)          # relu(bn(.)) outside residual blocks (the stem)
             modelprep.skip_identity_pools(model)   # AdaptiveAvgPool2d(1) of a 1x1 map
-            modelprep._install_engine_hooks(model)  # lets curvature.ggn_operator use the fused engine
+            modelprep._install_engine_hooks(model)  # lets the optimizer use the fused engine / session
         params = [p for p in model.parameters() if p.requires_grad]
-        # local gradient first (its graph is freed again: nothing may tie the parameters
-        # to the default stream while the product is captured, see GraphedOperator)
-        grad = curvature.flatten_into(torch.autograd.grad(lossf(model(x), t), params), params,
-                                      scale=weight)
+        group = state["group"]
         diag = None
         if args.precond:  # per-sample autograd path, preconditioners.py:63-105
             diag = preconditioners.diag_EF_autograd(model, lossf, x, t, "mean") * weight
+            if group is not None:
+                torch.distributed.all_reduce(diag, group=group)
 
-        def builder():  # forward graph + recorded J^T / H_L maps (once per Newton step)
+        def forward():
             out = model(x)
-            return make_operator(lossf(out, t), out, params)
+            return lossf(out, t), out
 
-        op = None
         if args.graph and overlap and not hessian:
-            os.environ["HF_ENGINE"] = "0"  # the two-graph split is a split of the autograd sweeps
-            op = curvature.OverlappedGraphedOperator(builder, params=params)
-        elif args.graph and chunk_on and not hessian and args.engine:
-            from pytorchhessianfree_amd.session import ChunkedEngineOperator
+            # EXPERIMENTAL (--overlap 1 only): the two-graph split of the AUTOGRAD sweeps, built here
+            os.environ["HF_ENGINE"] = "0"
 
-            try:
-                op = ChunkedEngineOperator(builder, params=params)
-            except TypeError as exc:  # (no engine / no suffix split for this model: the single-graph operator)
-                print(f"[bench] chunked all-reduce not available: {exc}", file=sys.stderr, flush=True)
-        if op is None:
-            op = curvature.maybe_graphed(builder, enable=bool(args.graph), params=params)
+            def builder():
+                out = model(x)
+                return curvature.ggn_operator(lossf(out, t), out, params, weight=weight, group=group)
+
+            grad = curvature.flatten_into(torch.autograd.grad(lossf(model(x), t), params), params, scale=weight)
+            if group is not None:
+                torch.distributed.all_reduce(grad, group=group)
+            op = curvature.OverlappedGraphedOperator(builder, params=params)
+            return op, grad, diag, sum(p.numel() for p in params)
+        opt = hf.HessianFree(model.parameters(), curvature_opt=args.curvature, graph_matvec=bool(args.graph),
+                             process_group=group, shard_weight=weight if group is not None else None)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            op, grad, _loss, _sess = opt.linearise(forward)
+        state["opt"], state["model"] = opt, model  # (the session lives as long as its optimizer)
         return op, grad, diag, sum(p.numel() for p in params)
 
     def stock_product(v, dtype, masks=None, record=None):
@@ -452,11 +464,12 @@ def main():
 
         FusedGGNEngine.verify_tol = check["tol"]
 
-    def checked(channels_last):
+    def checked(channels_last, overlap=False):
         if "want" not in check:
             reference_products()
-        op, grad, diag, n = build_operator(channels_last)
-        got = op(check["v"]).double()
+        op, grad, diag, n = build_operator(channels_last, overlap)
+        # (this rank's own weighted product: the float64 reference below is of this rank's shard)
+        got = op.local(check["v"]).double().clone()
         masks = relu_decisions(op)
         ref = check["want"] if masks is None else stock_product(check["v"], torch.float64, masks=masks)
         err = float((got - ref).abs().max()) / check["scale"]
@@ -467,35 +480,8 @@ def main():
         check["tol_eff"] = check["tol"] if masks is not None else max(1e-5, 5.0 * check["stock_err_plain"])
         del masks, ref
         # the reference's own check (optimizer.py:414-448): the same product twice
-        check["deterministic"] = bool(torch.equal(op(check["v"]).double(), got))
+        check["deterministic"] = bool(torch.equal(op.local(check["v"]).double(), got))
         return op, grad, diag, n, err
-
-    op, grad, diag, n, err = checked(bool(args.channels_last))
-    def note_text(err):
-        if check.get("masked"):
-            return ("max-norm error against float64 stock autograd on this operator's own ReLU decisions {:.1e} "
-                    "(on the float64 network's decisions {:.1e}); stock fp32 autograd likewise {:.1e} ({:.1e})"
-                    ).format(err, check["err_plain"], check["stock_err"], check["stock_err_plain"])
-        return "max-norm error against float64 stock autograd {:.1e}, stock fp32 autograd {:.1e}".format(
-            err, check["stock_err_plain"])
-
-    class _Note:  # (keeps the two call sites below unchanged)
-        @staticmethod
-        def format(err, _unused):
-            return note_text(err)
-
-    note = _Note
-    layout = ("NHWC" if args.channels_last else "NCHW") + " (" + note.format(err, check["stock_err"]) + ")"
-    if not err < check["tol_eff"] and args.channels_last:
-        print(f"[bench] NHWC product off by {err:.2e} (float64 reference); using NCHW",
-              file=sys.stderr, flush=True)
-        del op
-        args.channels_last = 0
-        op, grad, diag, n, err = checked(False)
-        layout = "NCHW (NHWC failed its check; " + note.format(err, check["stock_err"]) + ")"
-    if not err < check["tol_eff"]:
-        raise SystemExit(f"bench: the curvature product is off by {err:.2e} against float64 stock autograd")
-    del check["want"], check["v"]
 
     group, allreduce_ms, comm_path = None, None, "none"
     if dist_on:
@@ -537,10 +523,43 @@ def main():
             os.close(saved_fd)
         group = dist.group.WORLD
         world = dist.get_world_size(group)  # what the backend reports is what gets printed
+        state["group"] = group
+        if os.environ.get("HF_BENCH_FAIL_RANK") == str(rank):  # test hook: a rank that dies mid-run
+            os._exit(3)
+        if not chunk_on:
+            os.environ["HF_CHUNKED_ALLREDUCE"] = "0"
+    args.overlap = max(args.overlap, 0)  # (the autograd two-graph split: only on request)
+    op, grad, diag, n, err = checked(bool(args.channels_last), overlap=bool(args.overlap))
+    def note_text(err):
+        if check.get("masked"):
+            return ("max-norm error against float64 stock autograd on this operator's own ReLU decisions {:.1e} "
+                    "(on the float64 network's decisions {:.1e}); stock fp32 autograd likewise {:.1e} ({:.1e})"
+                    ).format(err, check["err_plain"], check["stock_err"], check["stock_err_plain"])
+        return "max-norm error against float64 stock autograd {:.1e}, stock fp32 autograd {:.1e}".format(
+            err, check["stock_err_plain"])
+
+    class _Note:  # (keeps the two call sites below unchanged)
+        @staticmethod
+        def format(err, _unused):
+            return note_text(err)
+
+    note = _Note
+    layout = ("NHWC" if args.channels_last else "NCHW") + " (" + note.format(err, check["stock_err"]) + ")"
+    if not err < check["tol_eff"] and args.channels_last:
+        print(f"[bench] NHWC product off by {err:.2e} (float64 reference); using NCHW",
+              file=sys.stderr, flush=True)
+        del op
+        args.channels_last = 0
+        op, grad, diag, n, err = checked(False)
+        layout = "NCHW (NHWC failed its check; " + note.format(err, check["stock_err"]) + ")"
+    if not err < check["tol_eff"]:
+        raise SystemExit(f"bench: the curvature product is off by {err:.2e} against float64 stock autograd")
+    del check["want"], check["v"]
+
+    if group is not None:
         # one-off timing of THE collective of this path: the operator's own reduction of a product
         # (all-reduce of the 4N-byte vector; the engine moves only the entries that can be non-zero)
         probe = torch.zeros(n, device=device)
-        op.group = group
         for _ in range(3):
             op.reduce(probe)
         torch.cuda.synchronize()
@@ -549,29 +568,10 @@ def main():
             op.reduce(probe)
         torch.cuda.synchronize()
         tt = torch.tensor([(time.perf_counter() - t0) / 10 * 1e3], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)  # one number, one decision, on every rank
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)  # one number, on every rank
         allreduce_ms = float(tt.item())
         comm_path = hfdist.path_name(probe, group)
         del probe
-        # policy: the two-graph overlap costs ~0.2 ms per product on its own,
-        # so it is only worth switching on when the exposed all-reduce is slower than that
-        # ... and only for the AUTOGRAD operator: the fused engine keeps its own path (engine product
-        # graph -> compact all-reduce -> K1-K3 graph) whatever the collective costs, so that a
-        # functional multi-rank run on one device (slow gloo) exercises exactly what an 8-GPU RCCL run
-        # takes; `--overlap 1` forces the two-graph autograd split
-        engine_on = "engine" in getattr(op, "mode", "")
-        if args.overlap < 0:
-            args.overlap = int(world > 1 and allreduce_ms > 0.6 and bool(args.graph) and not hessian
-                               and not engine_on)
-        if args.overlap and not isinstance(op, curvature.OverlappedGraphedOperator):
-            del op
-            op, grad, diag, n = build_operator(bool(args.channels_last), overlap=True)
-    op.group = group  # one all-reduce (sum) of the 4N-byte partial product per matvec
-
-    if group is not None:
-        torch.distributed.all_reduce(grad, group=group)
-        if diag is not None:
-            torch.distributed.all_reduce(diag, group=group)
     b = -grad
     A = hf.DampedCurvature(op, args.damping)
     M = hf.DiagonalPreconditioner(diag, args.damping, 0.75) if diag is not None else None
@@ -658,9 +658,15 @@ def main():
                 "iteration": ("one hipGraph launch per PCG iteration (product -> K1 -> K2 -> K3)" if fused and group is None
                               else "product graph A -> [all-reduce of the late layers' share on a second communicator] "
                                    "|| product graph B -> all-reduce of the rest -> scatter -> K1-K3 graph"
-                              if fused and hasattr(op, "replay_and_reduce")
+                              if fused and getattr(op, "split", None) is not None
                               else "product graph -> all-reduce -> K1-K3 graph" if fused
                               else "product, then K1, K2, K3 as separate launches"),
+                "operator_source": ("HessianFree.linearise(forward): the operator step() itself hands to cg() "
+                                    "(persistent engine session)" if state["opt"] is not None
+                                    and getattr(state["opt"], "_session", None) is op
+                                    else "HessianFree.linearise(forward): the operator step() itself hands to cg() "
+                                         "(generic path)" if state["opt"] is not None
+                                    else "built by bench.py (--overlap 1, experimental)"),
                 "termination": reason,
                 "allreduce": None if allreduce_ms is None else {
                     "path": comm_path, "bytes": int(getattr(getattr(op, "op", op), "reduce_bytes", 4 * n)),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 6
+#define HF_ABI_VERSION 7
 
 enum hf_dtype { HF_F32 = 0, HF_F64 = 1 };
 
@@ -551,6 +551,11 @@ int hf_comm_destroy(hf_comm_t* c);
 /* In-place sum all-reduce of the GGN.v partial (the `+=` of optimizer.py:677-684
  * across ranks), enqueued on `stream`. */
 int hf_allreduce_sum(hf_comm_t* c, void* buf, int64_t n, int dtype, void* stream);
+/* The same for `count` (<= 16) disjoint pieces of one product (the in-place dense runs of the vector and
+ * the compact staging vector of the entries that can be non-zero), issued between ncclGroupStart /
+ * ncclGroupEnd: ONE collective launch instead of `count`. */
+int hf_allreduce_sum_multi(hf_comm_t* c, void* const* bufs, const int64_t* ns, int count, int dtype,
+                           void* stream);
 
 #ifdef __cplusplus
 }

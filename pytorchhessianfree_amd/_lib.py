@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HF_PCG_LIB") or os.path.join(_HERE, "csrc", "libhfpcg.so")
 
 HF_F32, HF_F64 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 HF_ERR_ARG = -1  # hf_status of include/hf_pcg.h: null / negative / inconsistent argument
 HF_M_NONE, HF_M_DIAG, HF_M_EXTERNAL = 0, 1, 2
 REASONS = {
@@ -151,6 +151,8 @@ SIGNATURES = {
     "hf_comm_create": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_char_p, c_int, c_int]),
     "hf_comm_destroy": (c_int, [c_void_p]),
     "hf_allreduce_sum": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "hf_allreduce_sum_multi": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), c_int, c_int,
+                                       c_void_p]),
 }
 
 _lib = None

@@ -2820,3 +2820,28 @@ int hf_allreduce_sum(hf_comm_t* c, void* buf, int64_t n, int dtype, void* stream
   return rc ? 1000 + rc : HF_OK;
 }
 
+int hf_allreduce_sum_multi(hf_comm_t* c, void* const* bufs, const int64_t* ns, int count, int dtype,
+                           void* stream) {
+  if (!c || !c->comm || !bufs || !ns || count < 1 || count > 16) return HF_ERR_ARG;
+  if (dtype != HF_F32 && dtype != HF_F64) return HF_ERR_ARG;
+  for (int i = 0; i < count; ++i)
+    if (!bufs[i] || ns[i] <= 0) return HF_ERR_ARG;
+  if (count == 1) return hf_allreduce_sum(c, bufs[0], ns[0], dtype, stream);
+  typedef int (*fn_group)(void);
+  fn_allreduce f = (fn_allreduce)rccl_sym("ncclAllReduce");
+  fn_group gs = (fn_group)rccl_sym("ncclGroupStart");
+  fn_group ge = (fn_group)rccl_sym("ncclGroupEnd");
+  if (!f || !gs || !ge) return HF_ERR_NOSYMBOL;
+  const int nccl_dtype = dtype == HF_F32 ? 7 : 8;
+  int rc = gs();
+  if (rc) return 1000 + rc;
+  int first = 0;
+  for (int i = 0; i < count; ++i) {
+    rc = f(bufs[i], bufs[i], (size_t)ns[i], nccl_dtype, 0, c->comm, (hipStream_t)stream);
+    if (rc && !first) first = rc;
+  }
+  rc = ge();  // (always closed: an open group would swallow every later collective of the communicator)
+  if (first) return 1000 + first;
+  return rc ? 1000 + rc : HF_OK;
+}
+

@@ -66,6 +66,20 @@ class _DirectComm:
             "hf_allreduce_sum")
         return t
 
+    def all_reduce_sum_multi(self, pieces):
+        """Several disjoint pieces of one product as ONE grouped collective launch
+        (``hf_allreduce_sum_multi``: ncclGroupStart ... ncclGroupEnd)."""
+        if len(pieces) == 1:
+            return self.all_reduce_sum(pieces[0])
+        k = len(pieces)
+        bufs = (_lib.c_void_p * k)(*[t.data_ptr() for t in pieces])
+        ns = (_lib.c_int64 * k)(*[t.numel() for t in pieces])
+        _lib.check(
+            self.lib.hf_allreduce_sum_multi(self.handle, bufs, ns, k, _lib.dtype_code(pieces[0].dtype),
+                                            _lib.current_stream_ptr(pieces[0].device)),
+            "hf_allreduce_sum_multi")
+        return pieces
+
 
 def _wants_direct(t, group):
     if os.environ.get("HF_RCCL_DIRECT", "1") == "0" or not (t.is_cuda and t.is_contiguous()):
@@ -124,6 +138,22 @@ def path_name(t, group):
     if _wants_direct(t, group) and _direct_comm(group) is not None:
         return "ncclAllReduce (RCCL) enqueued on the compute stream (hf_allreduce_sum)"
     return f"torch.distributed.all_reduce ({torch.distributed.get_backend(group)})"
+
+
+def all_reduce_sum_multi(pieces, group):
+    """In-place sum over ``group`` of every tensor of ``pieces`` (the disjoint parts of one product that
+    travel): one grouped RCCL launch on the direct path, one collective per piece otherwise."""
+    pieces = [t for t in pieces if t.numel() > 0]
+    if group is None or not pieces:
+        return pieces
+    if (len(pieces) <= 16 and all(_wants_direct(t, group) for t in pieces)
+            and len({t.dtype for t in pieces}) == 1 and os.environ.get("HF_RCCL_GROUPED", "1") != "0"):
+        comm = _direct_comm(group)
+        if comm is not None:
+            return comm.all_reduce_sum_multi(pieces)
+    for t in pieces:
+        all_reduce_sum(t, group)
+    return pieces
 
 
 def all_reduce_sum(t, group):

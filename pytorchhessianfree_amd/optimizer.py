@@ -149,7 +149,7 @@ class HessianFree(torch.optim.Optimizer):
     # ------------------------------------------------------------------------
     # step
     # ------------------------------------------------------------------------
-    def step(self, forward, grad=None, mvp=None, M_func=None, test_deterministic=False):
+    def step(self, forward, grad=None, mvp=None, M_func=None, test_deterministic=False, *, _session=None):
         """One Hessian-free update; arguments as optimizer.py:126-180.  ``forward()``
         returns ``(loss, outputs)``; ``grad`` / ``mvp`` / ``M_func`` optionally
         override the gradient vector, the curvature product ``x -> B x`` and the
@@ -173,49 +173,7 @@ class HessianFree(torch.optim.Optimizer):
             self._test_forward_determinisitc(forward)
 
         # ---- loss, gradient, curvature operator (optimizer.py:216-247) ---------
-        curvature_opt = self._group["curvature_opt"]
-        user_grad, user_mvp = grad is not None, mvp is not None
-        holder = {}
-
-        def setup():
-            """Forward pass (+ gradient, + curvature operator).  Runs on the capture
-            stream when the matvec is to be replayed as a hipGraph."""
-            with torch.no_grad() if (user_grad and user_mvp) else nullcontext():
-                loss, outputs = forward()
-            holder["loss"] = loss
-            grads = None
-            if not user_grad:
-                grads = torch.autograd.grad(
-                    loss, self._params_list, create_graph=(curvature_opt == "hessian"),
-                    retain_graph=True, allow_unused=True,
-                )
-                holder["grad"] = self._reduce_vector(self._flat(grads))
-            if user_mvp:
-                return None
-            if curvature_opt == "hessian":
-                return curvature.hessian_operator(
-                    loss, outputs, self._params_list,
-                    grad_with_graph=None if (grads is None or any(g is None for g in grads)) else grads,
-                    weight=self.shard_weight, group=self.process_group)
-            return curvature.ggn_operator(loss, outputs, self._params_list,
-                                          weight=self.shard_weight, group=self.process_group)
-
-        sess = None
-        if (self.graph_matvec and not user_mvp and not user_grad
-                and self.device.type == "cuda" and not self._session_off and self._cg is cg):
-            sess, init_loss = self._session_step(forward)
-        if sess is not None:
-            mvp = sess
-            grad = self._reduce_vector(sess.gradient())
-        else:
-            if self.graph_matvec and not user_mvp and self.device.type == "cuda":
-                mvp = curvature.maybe_graphed(setup, params=self._params_list)
-            else:
-                op = setup()
-                mvp = mvp if user_mvp else op
-            if not user_grad:
-                grad = holder["grad"]
-            init_loss = self._reduce_scalar(holder["loss"].item())
+        mvp, grad, init_loss, sess = self.linearise(forward, grad, mvp, _session=_session)
         self._log(f"\nInitial loss = {init_loss:.6f}")
         state["init_losses"].append(init_loss)
 
@@ -310,6 +268,62 @@ class HessianFree(torch.optim.Optimizer):
         return final_loss
 
     # ------------------------------------------------------------------------
+    def linearise(self, forward, grad=None, mvp=None, *, _session=None):
+        """Loss, gradient and curvature operator of one step (optimizer.py:216-247) -- exactly what ``step``
+        hands to ``cg()``: returns ``(mvp, grad, initial loss, session)`` with ``session`` the persistent
+        engine session when it serves this step (``mvp`` is then the session itself: product graph(s), the
+        data-parallel all-reduce chunked and overlapped), else ``None`` (``mvp``: engine / autograd operator,
+        hipGraph-replayed with ``graph_matvec``).  Public so that a caller who drives ``cg()`` himself
+        (``bench.py``) measures the operator ``step`` uses, not one he built."""
+        self._ensure_arena()
+        curvature_opt = self._group["curvature_opt"]
+        user_grad, user_mvp = grad is not None, mvp is not None
+        holder = {}
+
+        def setup():
+            """Forward pass (+ gradient, + curvature operator).  Runs on the capture
+            stream when the matvec is to be replayed as a hipGraph."""
+            with torch.no_grad() if (user_grad and user_mvp) else nullcontext():
+                loss, outputs = forward()
+            holder["loss"] = loss
+            grads = None
+            if not user_grad:
+                grads = torch.autograd.grad(
+                    loss, self._params_list, create_graph=(curvature_opt == "hessian"),
+                    retain_graph=True, allow_unused=True,
+                )
+                holder["grad"] = self._reduce_vector(self._flat(grads))
+            if user_mvp:
+                return None
+            if curvature_opt == "hessian":
+                return curvature.hessian_operator(
+                    loss, outputs, self._params_list,
+                    grad_with_graph=None if (grads is None or any(g is None for g in grads)) else grads,
+                    weight=self.shard_weight, group=self.process_group)
+            return curvature.ggn_operator(loss, outputs, self._params_list,
+                                          weight=self.shard_weight, group=self.process_group)
+
+        sess = _session  # (acc_step: the accumulated session has already been brought to this step's data)
+        if sess is not None:
+            return sess, sess.gradient(), sess.base_loss, sess
+        if (self.graph_matvec and not user_mvp and not user_grad
+                and self.device.type == "cuda" and not self._session_off and self._cg is cg):
+            sess, init_loss = self._session_step(forward)
+        if sess is not None:
+            mvp = sess
+            grad = self._reduce_vector(sess.gradient())
+        else:
+            if self.graph_matvec and not user_mvp and self.device.type == "cuda":
+                mvp = curvature.maybe_graphed(setup, params=self._params_list)
+            else:
+                op = setup()
+                mvp = mvp if user_mvp else op
+            if not user_grad:
+                grad = holder["grad"]
+            init_loss = self._reduce_scalar(holder["loss"].item())
+        return mvp, grad, init_loss, sess
+
+    # ------------------------------------------------------------------------
     def _session_step(self, forward):
         """Start a step on the persistent engine session (session.py), creating it on first use.
         Runs the caller's ``forward()`` ONCE: its loss value is the step's initial loss and must be
@@ -323,8 +337,10 @@ class HessianFree(torch.optim.Optimizer):
             ok = torch.tensor([1 if sess is not None else 0], dtype=torch.int32, device=self.device)
             torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
             if int(ok.item()) == 0:
-                if sess is not None:
-                    self._session, self._session_off = None, True
+                # EVERY rank switches the session off, whether it had one or not: a rank whose session was
+                # merely refused this once would otherwise issue this all-reduce again on the next step while
+                # its peers go straight to the generic path's gradient all-reduce
+                self._session, self._session_off = None, True
                 return None, None
         if sess is None:
             return None, None

@@ -39,7 +39,110 @@ from .curvature import GraphedOperator
 from .engine import FusedGGNEngine, ce_loss_spec
 
 
-class EngineSession:
+class _TwoPhaseProduct:
+    """The data-parallel engine product as TWO hipGraphs with the all-reduce chunked by stage and overlapped
+    with the sweep (the ``result += N * mb_result`` of optimizer.py:677-684 across GPUs, once per PCG iteration):
+
+        G_a  tangent sweep, head, adjoint sweep of the late blocks, gather of their gradients
+             -> the vector's suffix is final; its staged part (live taps of tensors with dead ones) is gathered
+        side stream / second communicator:   all-reduce(tail pieces: the dense run in place + the staging
+                                             vector, ~80 % of the bytes; ONE grouped launch)   <- overlaps G_b
+        G_b  the rest of the adjoint sweep
+        compute stream:                      all-reduce(head pieces: in place in the full vector)
+        wait for the side stream; scatter the staged sums back into the full vector; K1-K3 graph
+
+    Two plain hipGraphs and events BETWEEN graph launches (fork / join nodes inside one graph cost ~45 us
+    each on this stack).  On 2 ranks the result is bitwise the single all-reduce's (a + b in either
+    order); on more ranks every rank still receives identical sums -- which is all the lockstep rule of
+    ``cg()`` needs.  ResNet-18 on 28x28 inputs: layer3 + layer4 + fc are 14.2 of the 16.9 MB that travel and
+    are final after ~60 % of the product, so ~0.3 ms of sweep remain to hide their all-reduce.
+
+    Shared by ``EngineSession`` (what ``HessianFree.step(process_group=...)`` runs) and
+    ``ChunkedEngineOperator`` (the bare operator).  Needs ``engine, input_buffer, output_buffer, stream,
+    group`` on the instance."""
+
+    split = None
+    _side = None
+
+    @staticmethod
+    def plan_phases(eng, tail_fraction=None):
+        """``(cut block, first late parameter, flat offset)`` when the engine's product splits into an early
+        part and a late suffix AND has a compact layout of the entries that travel; else ``None`` (the
+        engine is left as it was: single graph, single compact / plain all-reduce)."""
+        if tail_fraction is None:
+            tail_fraction = float(os.environ.get("HF_CHUNK_TAIL", "0.7"))
+        if os.environ.get("HF_CHUNKED_ALLREDUCE", "1") == "0" or not hasattr(eng, "phase_split"):
+            return None
+        if getattr(eng, "hessian", False) or getattr(eng, "train_bn", False):
+            return None
+        split = eng.phase_split(tail_fraction)
+        if split is None:
+            return None
+        had = eng.__dict__.pop("_live_segs", None), getattr(eng, "_seg_break", None)
+        eng._seg_break = split[1]
+        if eng._live_segments() is None or eng._seg_cut is None:
+            eng._seg_break = had[1]
+            eng.__dict__.pop("_live_segs", None)
+            return None
+        return split
+
+    def _phase_a(self):
+        eng = self.engine
+        eng.local_phase_a(self.input_buffer, self.output_buffer, self.split)
+        eng._live_copy(self.output_buffer, False, part="tail")
+
+    def _phase_b(self):
+        eng = self.engine
+        eng.local_phase_b(self.output_buffer, self.split)
+        eng._live_copy(self.output_buffer, False, part="head")
+
+    def _capture_phases(self):
+        """(on ``self.stream``, warmed up) the two graphs of one product."""
+        self.g_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_a, stream=self.stream):
+            self._phase_a()
+        self.g_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_b, stream=self.stream, pool=self.g_a.pool()):
+            self._phase_b()
+
+    def replay_phases(self):
+        self.g_a.replay()
+        self.g_b.replay()
+
+    def reduce_phases(self):
+        """One data-parallel product: reads ``input_buffer``, leaves the summed product in ``output_buffer``."""
+        from . import distributed as hfdist
+
+        eng, group = self.engine, self.group
+        if group is None:
+            return self.replay_phases()
+        head = eng._reduce_pieces(self.output_buffer, "head")
+        tail = eng._reduce_pieces(self.output_buffer, "tail")
+        cur = torch.cuda.current_stream()
+        side_comm = hfdist.side_comm(tail[0], group)
+        self.g_a.replay()
+        works = []
+        if side_comm is not None:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+                self._ev_a, self._ev_t = torch.cuda.Event(), torch.cuda.Event()
+            self._ev_a.record(cur)
+            self._side.wait_event(self._ev_a)
+            with torch.cuda.stream(self._side):
+                side_comm.all_reduce_sum_multi(tail)
+                self._ev_t.record(self._side)
+        else:
+            works = [torch.distributed.all_reduce(piece, group=group, async_op=True) for piece in tail]
+        self.g_b.replay()
+        hfdist.all_reduce_sum_multi(head, group)
+        if side_comm is not None:
+            cur.wait_event(self._ev_t)
+        for work in works:
+            work.wait()
+        eng._live_copy(self.output_buffer, True)
+
+
+class EngineSession(_TwoPhaseProduct):
     mode = ("persistent session: hipGraph replay of the " + FusedGGNEngine.mode
             + "; engine, product graph and PCG iteration graph kept across steps, forward pass / "
               "gradient / trial losses as graph replays on static buffers")
@@ -88,11 +191,18 @@ class EngineSession:
             self.output_buffer = torch.empty(self.n, **f32)
             self.grad_buffer = torch.empty(self.n, **f32)
             self.losses = torch.zeros(64, **f32)
+            # data parallel: the product as two graphs, its all-reduce chunked by stage and overlapped
+            self.split = self.plan_phases(eng) if eng.group is not None else None
             # warm-up of everything that will be captured (allocator, lazy initialisations)
             eng.refresh_weights(transposed=True)
             eng.forward_own(update_running=False)
             eng.gradient(self.grad_buffer)
-            eng.local(self.input_buffer, out=self.output_buffer)
+            if self.split is None:
+                eng.local(self.input_buffer, out=self.output_buffer)
+            else:
+                for _ in range(2):
+                    self._phase_a()
+                    self._phase_b()
         self.stream.synchronize()
         with torch.no_grad():
             self.g_wT = self._capture(lambda: eng.refresh_weights(transposed=True))
@@ -103,7 +213,11 @@ class EngineSession:
             self.g_fwd_still = (self._capture(lambda: eng.forward_own(refresh=True, update_running=False))
                                 if eng.train_bn else self.g_fwd)
             self.g_grad = self._capture(lambda: eng.gradient(self.grad_buffer))
-            self.graph = self._capture(lambda: eng.local(self.input_buffer, out=self.output_buffer), keep=True)
+            if self.split is None:
+                self.graph = self._capture(lambda: eng.local(self.input_buffer, out=self.output_buffer), keep=True)
+            else:
+                self.graph = None
+                self._capture_phases()
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
         self.calls = 0
@@ -206,18 +320,34 @@ class EngineSession:
 
     # ---- operator interface of cg() (see curvature.GraphedOperator) -------------------------
     def raw_graph(self):
-        return self.graph.raw_cuda_graph()
+        # (two graphs under data parallelism: cg() then fuses K1-K3 only, which needs no product graph)
+        return self.graph.raw_cuda_graph() if self.graph is not None else None
 
     def replay_local(self):
-        self.graph.replay()
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.replay_phases()
+
+    def replay_and_reduce(self):
+        """One product over all ranks: ``input_buffer`` -> summed product in ``output_buffer``."""
+        if self.graph is not None:
+            self.graph.replay()
+            self.engine.reduce(self.output_buffer, self.group)
+        else:
+            self.reduce_phases()
 
     def reduce(self, t):
         return self.engine.reduce(t, self.group)
 
+    @property
+    def reduce_bytes(self):
+        return self.engine.reduce_bytes
+
     def local(self, v, out=None):
         if v.data_ptr() != self.input_buffer.data_ptr():
             self.input_buffer.copy_(v)
-        self.graph.replay()
+        self.replay_local()
         if out is not None:
             out.copy_(self.output_buffer)
             return out
@@ -225,30 +355,25 @@ class EngineSession:
 
     def __call__(self, v, out=None):
         self.calls += 1
-        return self.reduce(self.local(v, out))
+        if self.group is None:
+            return self.local(v, out)
+        if v.data_ptr() != self.input_buffer.data_ptr():
+            self.input_buffer.copy_(v)
+        self.replay_and_reduce()
+        if out is not None:
+            out.copy_(self.output_buffer)
+            return out
+        return self.output_buffer
 
 
 def _quadratic_signature(spec):
     return tuple((float(c), tuple(id(w) for w in ws)) for c, ws in (spec.get("quadratic") or ()))
 
 
-class ChunkedEngineOperator:
-    """Data-parallel engine product with the all-reduce CHUNKED BY STAGE and overlapped with the sweep
-    (the ``result += N * mb_result`` of optimizer.py:677-684 across GPUs, once per PCG iteration):
-
-        G_a  tangent sweep, head, adjoint sweep of the late blocks, gather of their gradients
-             -> the vector's suffix is final; its staged part (live taps of tensors with dead ones) is gathered
-        side stream / second communicator:   all-reduce(tail pieces: the dense run in place + the staging
-                                             vector, ~80 % of the bytes)       <- overlaps G_b
-        G_b  the rest of the adjoint sweep
-        compute stream:                      all-reduce(head pieces: in place in the full vector)
-        wait for the side stream; scatter the staged sums back into the full vector; K1-K3 graph
-
-    Two plain hipGraphs and events BETWEEN graph launches (fork / join nodes inside one graph cost ~45 us
-    each on this stack).  On 2 ranks the result is bitwise the single all-reduce's (a + b in either
-    order); on more ranks every rank still receives identical sums -- which is all the lockstep rule of
-    ``cg()`` needs.  ResNet-18 on 28x28 inputs: layer3 + layer4 + fc are 14.2 of the 16.9 MB that travel and
-    are final after ~60 % of the product, so ~0.3 ms of sweep remain to hide their all-reduce."""
+class ChunkedEngineOperator(_TwoPhaseProduct):
+    """The bare data-parallel engine operator with the chunked / overlapped all-reduce (``_TwoPhaseProduct``) for
+    callers that drive ``cg()`` themselves; ``HessianFree.step(process_group=...)`` gets the same product from
+    its ``EngineSession``."""
 
     mode = ("2 hipGraphs per product over the " + FusedGGNEngine.mode + "; all-reduce chunked by stage, the late "
             "layers' share overlapped with the rest of the adjoint sweep")
@@ -264,14 +389,11 @@ class ChunkedEngineOperator:
             eng = builder()
             if not isinstance(eng, FusedGGNEngine):
                 raise TypeError("ChunkedEngineOperator needs the fused curvature engine")
-            split = eng.phase_split(tail_fraction)
-            if split is None:
-                raise TypeError("the model's parameters do not split into an early part and a late suffix")
-            eng._seg_break = split[1]
-            if eng._live_segments() is None or eng._seg_cut is None:
-                raise TypeError("no compact layout for this model")
+            self.split = self.plan_phases(eng, tail_fraction)
+            if self.split is None:
+                raise TypeError("the model's parameters do not split into an early part and a late suffix with a "
+                                "compact layout")
             self.op = self.engine = eng
-            self.split = split
             self.n, self.group, self.params = eng.n, eng.group, eng.params
             f32 = dict(dtype=torch.float32, device=eng.dev)
             self.input_buffer = torch.zeros(self.n, **f32)
@@ -282,26 +404,10 @@ class ChunkedEngineOperator:
                     self._phase_b()
         self.stream.synchronize()
         with torch.no_grad():
-            self.g_a = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_a, stream=self.stream):
-                self._phase_a()
-            self.g_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_b, stream=self.stream, pool=self.g_a.pool()):
-                self._phase_b()
+            self._capture_phases()
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
         self.calls = 0
-        self._side = None
-
-    def _phase_a(self):
-        eng = self.engine
-        eng.local_phase_a(self.input_buffer, self.output_buffer, self.split)
-        eng._live_copy(self.output_buffer, False, part="tail")
-
-    def _phase_b(self):
-        eng = self.engine
-        eng.local_phase_b(self.output_buffer, self.split)
-        eng._live_copy(self.output_buffer, False, part="head")
 
     @property
     def reduce_bytes(self):
@@ -311,42 +417,13 @@ class ChunkedEngineOperator:
         return None
 
     def replay_local(self):
-        self.g_a.replay()
-        self.g_b.replay()
+        self.replay_phases()
 
     def reduce(self, t):
         return self.engine.reduce(t, self.group)
 
     def replay_and_reduce(self):
-        """One data-parallel product: reads ``input_buffer``, leaves the summed product in ``output_buffer``."""
-        from . import distributed as hfdist
-
-        eng, group = self.engine, self.group
-        if group is None:
-            return self.replay_local()
-        head = eng._reduce_pieces(self.output_buffer, "head")
-        tail = eng._reduce_pieces(self.output_buffer, "tail")
-        cur = torch.cuda.current_stream()
-        side_comm = hfdist.side_comm(tail[0], group)
-        self.g_a.replay()
-        works = []
-        if side_comm is not None:
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-            self._side.wait_stream(cur)
-            with torch.cuda.stream(self._side):
-                for piece in tail:
-                    side_comm.all_reduce_sum(piece)
-        else:
-            works = [torch.distributed.all_reduce(piece, group=group, async_op=True) for piece in tail]
-        self.g_b.replay()
-        for piece in head:
-            hfdist.all_reduce_sum(piece, group)
-        if side_comm is not None:
-            cur.wait_stream(self._side)
-        for work in works:
-            work.wait()
-        eng._live_copy(self.output_buffer, True)
+        self.reduce_phases()
 
     def local(self, v, out=None):
         if v.data_ptr() != self.input_buffer.data_ptr():

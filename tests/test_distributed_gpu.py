@@ -130,3 +130,155 @@ def test_bench_gpus_2_starts_two_ranks_itself():
     assert rec["config"]["allreduce"]["overlap_two_graphs"] is False
     assert "product graph A" in rec["config"]["iteration"]
     assert rec["config"]["allreduce"]["bytes"] < 0.5 * 4 * 11175370
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The drop-in API under data parallelism: HessianFree(prepared ResNet-18, graph_matvec=True,
+# process_group=...).step -> fused engine + persistent session + chunked / overlapped all-reduce
+# ---------------------------------------------------------------------------------------------------------
+def _launch_session_ranks(out, world, mode="steps", backend="gloo", timeout=900):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(HERE, "gpu_workers", "dp_session_ranks.py"), str(out), mode, backend],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    logs = [p.communicate(timeout=timeout) for p in procs]
+    for p, (so, se) in zip(procs, logs):
+        assert p.returncode == 0, (so[-2000:], se[-3000:])
+    return [np.load(out / f"rank{r}.npz") for r in range(world)]
+
+
+_CPU_REF = {}
+
+
+def _cpu_whole_batch_steps(n_steps=2):
+    """The single-process CPU path on the whole 32-sample batches: stock model, torch autograd, host logic with
+    the oracle PCG (the reference's algorithm, pinned bit for bit by tests/golden/make_golden.py)."""
+    if n_steps in _CPU_REF:
+        return _CPU_REF[n_steps]
+    import warnings
+
+    import torch
+
+    import pytorchhessianfree_amd as hf
+    from oracle import pcg as oracle
+    from pytorchhessianfree_amd import testproblems as tp
+
+    seeds = tp.RESNET18_B32_SEPARATED_SEEDS
+    model, _, lossf = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=seeds[0])
+    opt = hf.HessianFree(model.parameters())
+    opt._cg = oracle.pcg
+    finals = []
+    for i in range(n_steps):
+        _, (x, t), _ = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=seeds[i])
+
+        def forward():
+            o = model(x)
+            return lossf(o, t), o
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            finals.append(opt.step(forward))
+    params = torch.cat([p.detach().reshape(-1) for p in opt._params_list]).numpy().copy()
+    _CPU_REF[n_steps] = (opt.state, finals, params)
+    return _CPU_REF[n_steps]
+
+
+def _check_against_cpu(r0, tol_final=1e-4):
+    st, finals, params = _cpu_whole_batch_steps()
+    np.testing.assert_allclose(r0["init_losses"], st["init_losses"], rtol=1e-5)
+    assert [str(x) for x in r0["reasons"]] == [str(x) for x in st["cg_reasons"]]
+    assert r0["learning_rates"].tolist() == st["learning_rates"]
+    np.testing.assert_allclose(r0["dampings"], st["dampings"], rtol=1e-12)
+    for a, b in zip(r0["num_cg_iters"].tolist(), st["num_cg_iters"]):
+        assert abs(a - b) <= 2
+    np.testing.assert_allclose(r0["finals"], finals, rtol=tol_final)
+
+
+@pytest.fixture(scope="module")
+def session_two_ranks(tmp_path_factory):
+    return _launch_session_ranks(tmp_path_factory.mktemp("dps2"), 2)
+
+
+def test_step_two_ranks_engine_session_equals_cpu_whole_batch(session_two_ranks):
+    """Two rank processes, shards of 16 + 16 of each 32-sample batch, two default ``step()`` calls through the
+    drop-in API: both ranks take the persistent session in its two-phase mode (chunked / overlapped
+    all-reduce), stay bitwise identical, and reproduce the single-process CPU path on the whole batch
+    (stated tolerance: initial losses 1e-5, learning rates / damping schedule / reasons identical, iteration
+    counts +-2, final losses 1e-4).  Lockstep: every rank issues exactly n_iters + lag + 1 products per solve
+    (lag = 1 for graph-replayed iterations: A(x0), the iterations, one speculative product)."""
+    r0, r1 = session_two_ranks
+    assert r0["session_mode"].tolist() == [2, 2] and r1["session_mode"].tolist() == [2, 2]
+    assert np.array_equal(r0["params"], r1["params"])
+    assert r0["num_cg_iters"].tolist() == r1["num_cg_iters"].tolist()
+    for r in (r0, r1):
+        assert r["session_calls"].tolist() == [n + 1 + 1 for n in r["num_cg_iters"].tolist()]
+        assert bool(r["product_equals_plain_allreduce"][0])
+    assert np.array_equal(r0["product_checksum"], r1["product_checksum"])
+    moved, full = (int(x) for x in r0["reduce_bytes"])
+    assert moved < 0.5 * full
+    _check_against_cpu(r0)
+
+
+def test_step_eight_ranks_on_one_device(tmp_path):
+    """world = 8 (BASELINE configs[2]'s world size) as eight rank processes on ONE MI355X over gloo, shards of
+    4 samples: the path an 8-GPU run takes -- `phase_split`, two product graphs, the lag rule, compact
+    pieces -- functionally.  All ranks bitwise identical; the result equals the whole-batch CPU path within
+    the stated tolerances; lockstep call counts on every rank."""
+    ranks = _launch_session_ranks(tmp_path, 8, timeout=1500)
+    r0 = ranks[0]
+    for r in ranks:
+        assert r["session_mode"].tolist() == [2, 2]
+        assert np.array_equal(r["params"], r0["params"])
+        assert r["num_cg_iters"].tolist() == r0["num_cg_iters"].tolist()
+        assert r["session_calls"].tolist() == [n + 1 + 1 for n in r["num_cg_iters"].tolist()]
+        assert np.array_equal(r["product_checksum"], r0["product_checksum"])
+        # (8 addends: the collective's summation order depends on the message layout -- equal to rounding)
+        assert float(r["product_rel_err"][0]) < 1e-6
+    _check_against_cpu(r0)
+
+
+def test_step_two_ranks_one_session_refused_falls_back_together(tmp_path):
+    """One rank's session creation fails on the first step (the decision must be symmetric): BOTH
+    ranks switch the session off for good, take the generic path (engine + compact all-reduce, re-captured per
+    step) and still match each other bitwise and the CPU whole-batch path."""
+    r0, r1 = _launch_session_ranks(tmp_path, 2, mode="asym")
+    assert r0["session_mode"].tolist() == [0, 0] and r1["session_mode"].tolist() == [0, 0]
+    assert int(r0["session_off"][0]) == 1 and int(r1["session_off"][0]) == 1
+    assert np.array_equal(r0["params"], r1["params"])
+    _check_against_cpu(r0)
+
+
+def test_step_one_rank_rccl_engine_session(tmp_path):
+    """The same path over a real RCCL communicator (1-rank ``nccl`` group, channels_last): direct communicator
+    on the compute stream, second communicator on the side stream, grouped launch of the tail pieces; the
+    session is in its two-phase mode and the steps equal the CPU whole-batch path (a 1-rank shard IS the
+    whole batch)."""
+    (r0,) = _launch_session_ranks(tmp_path, 1, backend="nccl")
+    assert r0["session_mode"].tolist() == [2, 2]
+    assert "hf_allreduce_sum" in str(r0["comm_path"][0]) and int(r0["side_comm"][0]) == 1
+    assert bool(r0["product_equals_plain_allreduce"][0])
+    assert r0["session_calls"].tolist() == [n + 1 + 1 for n in r0["num_cg_iters"].tolist()]
+    _check_against_cpu(r0)
+
+
+def test_bench_launcher_ends_siblings_when_a_rank_dies():
+    """``bench.py --gpus 2`` without a launcher: rank 1 exits non-zero after the process group is up (test hook
+    ``HF_BENCH_FAIL_RANK``); the parent must end rank 0 (blocked in its next collective) and return non-zero
+    within a bounded time -- fresh child processes only, nothing re-exec'ed."""
+    import time
+
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HF_BENCH_FAIL_RANK"] = "1"
+    t0 = time.time()
+    p = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+         "--iters", "30", "--no-cpu-baseline", "--watchdog", "240"],
+        env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert time.time() - t0 < 300
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
