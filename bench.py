@@ -91,6 +91,10 @@ def parse():
     ap.add_argument("--precond", type=int, default=0,
                     help="1: diagonal empirical-Fisher preconditioner, exponent 0.75, per-sample autograd "
                          "path (preconditioners.py:63-127), fused into K2/K3 (56 N bytes per iteration)")
+    ap.add_argument("--acc", default="",
+                    help="comma-separated chunk sizes (e.g. 16,16; they must add up to --batch): drive "
+                         "HessianFree.acc_step's path (optimizer.py:519-606) -- loss / gradient / products "
+                         "accumulated over the chunks by the accumulated engine session -- instead of step's")
     ap.add_argument("--l2", type=float, default=-1.0,
                     help="L2 regularisation weight added to the loss as in examples/example_utils.py:77-81 "
                          "(-1: 5e-4 for --workload allcnnc with --curvature hessian, else 0)")
@@ -259,11 +263,19 @@ def full_step_timing(args, device, n_steps=8, warmup=2):
             out = model(x)
             return lossf(out, t), out
 
+        acc_sizes = [int(v) for v in args.acc.split(",") if v.strip()]
+        chunks, o = [], 0
+        for sz in acc_sizes:
+            chunks.append((x[o:o + sz].contiguous(), t[o:o + sz].contiguous()))
+            o += sz
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            opt.step(forward)
+            if chunks:
+                opt.acc_step(model, lossf, chunks, reduction="mean")
+            else:
+                opt.step(forward)
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t0) * 1e3)
     timed = times[warmup:]
@@ -276,6 +288,8 @@ def full_step_timing(args, device, n_steps=8, warmup=2):
         "loss_first_to_last": [st["init_losses"][0], st["init_losses"][-1]],
         "mode": ("persistent engine session (engine + graphs kept across steps, graph-replayed forward / "
                  "gradient / trial losses)" if getattr(opt, "_session", None) is not None
+                 else "accumulated engine session (acc_step: one engine per chunk, graphs kept across calls)"
+                 if getattr(opt, "_acc_session", None) is not None
                  else "generic path (operator rebuilt and re-captured per step, eager trial forwards)"),
         "settings": "HessianFree defaults: damping 1.0 + LM, cg_max_iter 250, Martens' criterion, "
                     "CG-backtracking, line search; a fresh batch per step",
@@ -320,6 +334,9 @@ def main():
     l2 = args.l2 if args.l2 >= 0 else (5e-4 if (args.workload == "allcnnc" and args.curvature == "hessian") else 0.0)
     hessian = args.curvature == "hessian"
     dist_on = world > 1 or bool(args.force_dist)
+    acc_sizes = [int(v) for v in args.acc.split(",") if v.strip()]
+    if acc_sizes and sum(acc_sizes) != args.batch:
+        raise SystemExit(f"bench --acc {args.acc}: the chunks must add up to --batch {args.batch}")
     chunk_on = bool(args.chunk) if args.chunk >= 0 else world > 1
 
     def problem(dev, dtype=torch.float32):
@@ -383,7 +400,17 @@ def main():
                              process_group=group, shard_weight=weight if group is not None else None)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            op, grad, _loss, _sess = opt.linearise(forward)
+            if acc_sizes:
+                chunks, o = [], 0
+                for sz in acc_sizes:
+                    chunks.append((x[o:o + sz].contiguous(), t[o:o + sz].contiguous()))
+                    o += sz
+                _fwd, grad, op, sess = opt.acc_linearise(model, lossf, chunks, reduction="mean")
+                if sess is None:
+                    raise SystemExit("bench --acc: the accumulated engine session does not cover this workload")
+                op, grad = sess, sess.gradient()
+            else:
+                op, grad, _loss, _sess = opt.linearise(forward)
         state["opt"], state["model"] = opt, model  # (the session lives as long as its optimizer)
         return op, grad, diag, sum(p.numel() for p in params)
 
@@ -430,6 +457,9 @@ def main():
     def relu_decisions(op):
         """The ReLU sign decisions of a fused-engine operator, in the model's call order (``None`` for
         operators that do not expose them: the plain float64 product is the reference then)."""
+        engines = getattr(op, "engines", None)
+        if engines:  # (accumulated session: one engine per chunk, the chunks in batch order)
+            return [torch.cat([(e.units[i].y > 0) for e in engines]) for i, u in enumerate(engines[0].units) if u.relu]
         eng = getattr(op, "engine", None) or getattr(op, "op", op)
         units = getattr(eng, "units", None)
         if not units or "engine" not in getattr(eng, "mode", ""):
@@ -641,7 +671,8 @@ def main():
                             f"({matvecs} operator calls in {args.steps} steps, max_iter {args.iters}), "
                             f"damping {args.damping}, {args.bn}-mode BN, CE-mean"
                             + (f" + L2 {l2:g}" if l2 > 0 else "") + ", x0=0, tol=0"
-                            + (", diag empirical-Fisher preconditioner ^-0.75 (per-sample autograd)" if M is not None else ""),
+                            + (", diag empirical-Fisher preconditioner ^-0.75 (per-sample autograd)" if M is not None else "")
+                            + (f", acc_step path: chunks {acc_sizes} accumulated" if acc_sizes else ""),
                 "parallelism": f"dp{world} (batch sharded, {args.batch} samples per GPU, one all-reduce per matvec: the "
                                "4N-byte vector, or only its entries that can be non-zero with the fused engine -- "
                                "config.allreduce.bytes; `value` counts SHARD products: every rank's operator call "
@@ -661,7 +692,10 @@ def main():
                               if fused and getattr(op, "split", None) is not None
                               else "product graph -> all-reduce -> K1-K3 graph" if fused
                               else "product, then K1, K2, K3 as separate launches"),
-                "operator_source": ("HessianFree.linearise(forward): the operator step() itself hands to cg() "
+                "operator_source": ("HessianFree.acc_linearise(model, loss, chunks): what acc_step() itself hands to "
+                                    "step() / cg() (accumulated engine session)" if state["opt"] is not None
+                                    and getattr(state["opt"], "_acc_session", None) is op
+                                    else "HessianFree.linearise(forward): the operator step() itself hands to cg() "
                                     "(persistent engine session)" if state["opt"] is not None
                                     and getattr(state["opt"], "_session", None) is op
                                     else "HessianFree.linearise(forward): the operator step() itself hands to cg() "

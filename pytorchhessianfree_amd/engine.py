@@ -303,6 +303,12 @@ class FusedGGNEngine(_Operator):
         if used != set(range(len(self.params))):
             raise _Unsupported("the parameter list has entries the engine's layers do not cover")
 
+    def layer_signature(self):
+        """What the captured graphs of a session bake in about the model's layers besides shapes: module
+        identities and every BatchNorm's mode / eps / momentum (kernel arguments).  Compared per step."""
+        return tuple((id(u.conv), id(u.bn), None if u.bn is None else (u.bn.training, u.bn.eps, u.bn.momentum))
+                     for u in self.units) + (bool(self.model_ref.training) if not self.units[0].bn is None else None,)
+
     # ---- loss Hessian (same contract as GGNOperator) -------------------------------------
     def _loss_setup(self, loss, outputs):
         (self._dl,) = torch.autograd.grad(loss, outputs, create_graph=True, retain_graph=True)

@@ -107,6 +107,10 @@ class HessianFree(torch.optim.Optimizer):
         self._session = None
         self._session_failures = 0
         self._session_off = False
+        # ... and its acc_step counterpart (session.AccumulatedSession: one engine per data chunk)
+        self._acc_session = None
+        self._acc_session_failures = 0
+        self._acc_session_off = False
 
     # ------------------------------------------------------------------------
     # helpers
@@ -351,7 +355,16 @@ class HessianFree(torch.optim.Optimizer):
         from .modelprep import session_forward
         from .session import EngineSession
 
-        with session_forward(self._session):  # (an existing session answers the model's forward pass)
+        import os
+
+        # From its second step on the session answers the model's forward pass itself, so comparing the caller's
+        # loss with the session's says nothing about the forward pass any more.  Every K-th step (K =
+        # ``HF_SESSION_VERIFY_EVERY``, default 16; ``HF_SESSION_VERIFY=1``: every step) the model therefore runs
+        # its OWN forward pass and the session must reproduce its logits (1e-4) and loss (1e-5): a layer swapped,
+        # frozen or re-configured behind the captured graphs shows up here instead of never
+        every = 1 if os.environ.get("HF_SESSION_VERIFY") == "1" else int(os.environ.get("HF_SESSION_VERIFY_EVERY", "16"))
+        verify = self._session is not None and every > 0 and self._session.steps % every == 0
+        with session_forward(None if verify else self._session):  # (an existing session answers the forward pass)
             loss, outputs = forward()
         if not isinstance(outputs, torch.Tensor) or loss.grad_fn is None:
             self._session_off = True
@@ -364,6 +377,7 @@ class HessianFree(torch.optim.Optimizer):
         spec = sess.accepts(*args) if sess is not None else None
         if spec is None:
             self._session = sess = None
+            verify = False
             if getattr(outputs, "_hf_model", None) is not None:
                 sess = EngineSession.try_create(*args, hessian=hessian)
             spec = sess.accepts(*args) if sess is not None else None
@@ -374,11 +388,16 @@ class HessianFree(torch.optim.Optimizer):
                 return None, None, None
             self._session = sess
         own = sess.begin_step(outputs, spec)
-        a, b, bad = torch.stack([loss.detach().float().reshape(()), own.reshape(()),
-                                 sess.engine.bad_targets.float().reshape(())]).tolist()
-        if bad or not abs(a - b) <= 1e-5 * max(1.0, abs(a)):
-            warn(f"persistent engine session: its forward pass gives loss {b!r}, `forward()` gives {a!r}; "
-                 "using the generic path from now on")
+        drift = torch.zeros((), device=own.device)
+        if verify:
+            want = outputs.detach()
+            drift = (sess.engine.logits - want).abs().max() / want.abs().max().clamp_min(1e-30)
+        a, b, bad, drift = torch.stack([loss.detach().float().reshape(()), own.reshape(()),
+                                        sess.engine.bad_targets.float().reshape(()), drift.float().reshape(())]).tolist()
+        if bad or not abs(a - b) <= 1e-5 * max(1.0, abs(a)) or not drift <= 1e-4:
+            warn(f"persistent engine session: its forward pass gives loss {b!r}, `forward()` gives {a!r}"
+                 + (f" (logits differ by {drift:.1e} from the model's own forward pass)" if verify else "")
+                 + "; using the generic path from now on")
             self._session, self._session_off = None, True
             return None, None, None
         self._session_failures = 0
@@ -459,6 +478,26 @@ class HessianFree(torch.optim.Optimizer):
                  M_func=None, reduction="mean", test_deterministic=False):
         """optimizer.py:519-606.  With a process group every rank passes ITS data
         lists; ``mean`` weights are then ``N_chunk / N_total over all ranks``."""
+        forward, grad, mvp, sess = self.acc_linearise(model, loss_func, loss_datalist, grad_datalist, mvp_datalist,
+                                                      reduction)
+        # `step` must not re-weight what `_acc` already reduced over ranks
+        saved = (self.process_group, self.shard_weight)
+        self.process_group, self.shard_weight = None, 1.0
+        self._acc_comm_active = self._acc_comm is not None
+        try:
+            return self.step(forward=forward, grad=grad, mvp=mvp, M_func=M_func,
+                             test_deterministic=test_deterministic, _session=sess)
+        finally:
+            self.process_group, self.shard_weight = saved
+            self._acc_comm_active = False
+            self._acc_counts = {}
+
+    def acc_linearise(self, model, loss_func, loss_datalist, grad_datalist=None, mvp_datalist=None,
+                      reduction="mean"):
+        """What ``acc_step`` hands to ``step``: ``(forward, grad, mvp, session)`` (optimizer.py:519-606).  With the
+        accumulated engine session (``session`` not ``None``) loss, gradient, trial losses and products are graph
+        replays over one fused engine per chunk and ``grad`` / ``mvp`` are ``None`` (``step`` takes them from the
+        session); else the generic accumulation.  Public for callers who drive ``cg()`` themselves (bench.py)."""
         grad_datalist = loss_datalist if grad_datalist is None else grad_datalist
         mvp_datalist = loss_datalist if mvp_datalist is None else mvp_datalist
         curvature_opt = self._group["curvature_opt"]
@@ -469,8 +508,11 @@ class HessianFree(torch.optim.Optimizer):
         def forward():
             return self._acc_loss(model, loss_func, loss_datalist, reduction), None
 
+        sess = self._acc_session_step(model, loss_func, (loss_datalist, grad_datalist, mvp_datalist), reduction,
+                                      curvature_opt)
+        if sess is not None:
+            return forward, None, None, sess
         grad = self._acc_grad(model, loss_func, grad_datalist, reduction)
-
         if self.cache_acc_graphs:
             mvp = self._acc_mvp_cached(model, loss_func, mvp_datalist, curvature_opt, reduction)
         else:
@@ -480,18 +522,71 @@ class HessianFree(torch.optim.Optimizer):
 
             if self._acc_comm is not None:
                 mvp.collective = True
+        return forward, grad, mvp, None
 
-        # `step` must not re-weight what `_acc` already reduced over ranks
-        saved = (self.process_group, self.shard_weight)
-        self.process_group, self.shard_weight = None, 1.0
-        self._acc_comm_active = self._acc_comm is not None
+    def _acc_session_step(self, model, loss_func, lists, reduction, curvature_opt):
+        """The accumulated engine session for this ``acc_step`` call, brought to its data (created on first use,
+        reused while model, loss, list structure and chunk shapes stay the same), or ``None`` -- then the generic
+        accumulation runs (and after repeated refusals the session is not tried again).  Under data
+        parallelism the decision is taken for all ranks together (one MIN all-reduce)."""
+        if not (self.graph_matvec and self.device.type == "cuda" and not self._acc_session_off and self._cg is cg):
+            return None
+        sess = self._acc_session_step_local(model, loss_func, lists, reduction, curvature_opt)
+        if self._acc_comm is not None:
+            ok = torch.tensor([1 if sess is not None else 0], dtype=torch.int32, device=self.device)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=self._acc_comm)
+            if int(ok.item()) == 0:
+                self._acc_session, self._acc_session_off = None, True
+                return None
+            if sess is not None:  # (the count-weighted loss summed over the ranks)
+                sess.base_loss = sess.reduce_losses(sess.loss_buf.reshape(1)).tolist()[0]
+        return sess
+
+    def _acc_session_step_local(self, model, loss_func, lists, reduction, curvature_opt):
+        import os
+
+        from .session import AccumulatedSession, _NoEngine
+
+        self._ensure_arena()
+        memo = {}
+
+        def dev(t):  # (chunks the lists share stay shared: the session keys its engines on tensor identity)
+            if id(t) not in memo:
+                memo[id(t)] = t.to(self.device)
+            return memo[id(t)]
+
         try:
-            return self.step(forward=forward, grad=grad, mvp=mvp, M_func=M_func,
-                             test_deterministic=test_deterministic)
-        finally:
-            self.process_group, self.shard_weight = saved
-            self._acc_comm_active = False
-            self._acc_counts = {}
+            dlists = tuple([(dev(x), dev(t)) for x, t in dl] for dl in lists)
+        except (TypeError, ValueError, AttributeError):
+            self._acc_session_off = True
+            return None
+        counts = [self._total_count(dl) for dl in lists]
+        hessian = curvature_opt == "hessian"
+        args = (model, loss_func, dlists, self._params_list, reduction, counts, hessian, self._acc_comm)
+        sess = self._acc_session
+        slots = sess.accepts(*args) if sess is not None else None
+        if slots is None:
+            self._acc_session = sess = None
+            sess = AccumulatedSession.try_create(model, loss_func, dlists, self._params_list, reduction, counts,
+                                                 hessian=hessian, group=self._acc_comm)
+            slots = sess.accepts(*args) if sess is not None else None
+            if slots is None:
+                self._acc_session_failures += 1
+                if self._acc_session_failures >= 2:
+                    self._acc_session_off = True
+                return None
+            self._acc_session = sess
+        every = 1 if os.environ.get("HF_SESSION_VERIFY") == "1" else int(os.environ.get("HF_SESSION_VERIFY_EVERY", "16"))
+        try:
+            sess.begin_step(slots, verify=every > 0 and sess.steps > 0 and sess.steps % every == 0,
+                            reduce=self._acc_comm is None)
+        except _NoEngine:
+            warn("accumulated engine session: it no longer reproduces the model (or a target is outside the "
+                 "classes); using the generic accumulation from now on")
+            self._acc_session, self._acc_session_off = None, True
+            return None
+        self._acc_session_failures = 0
+        return sess
 
     def _count_samples(self, *datalists):
         """Samples per data list, summed over the ranks of a data-parallel run -- ONCE
@@ -700,7 +795,10 @@ class _SessionTrials:
             return
         vals = self.sess.losses[: len(self.pending)]
         opt = self.opt
-        if opt.process_group is not None:  # weighted sum over the ranks' shards, all values at once
+        reducer = getattr(self.sess, "reduce_losses", None)
+        if reducer is not None:  # (acc_step: count-weighted over the chunks already; summed over the ranks here)
+            vals = reducer(vals)
+        elif opt.process_group is not None:  # weighted sum over the ranks' shards, all values at once
             vals = vals.double() * opt.shard_weight
             torch.distributed.all_reduce(vals, group=opt.process_group)
         for (key, _), val in zip(self.pending, vals.tolist()):

@@ -224,6 +224,7 @@ class EngineSession(_TwoPhaseProduct):
         self.steps = 0
         self._cache = {}
         self._signature = self._signature_of(eng)
+        self._layers = eng.layer_signature()
 
     def _capture(self, fn, keep=False):
         g = torch.cuda.CUDAGraph(keep_graph=True) if keep else torch.cuda.CUDAGraph()
@@ -247,8 +248,10 @@ class EngineSession(_TwoPhaseProduct):
         ref = getattr(outputs, "_hf_model", None)
         model = ref() if ref is not None else None
         x = getattr(outputs, "_hf_input", None)
-        if model is not eng.model_ref or x is None or model.training != eng.train_bn or group is not self.group:
+        if model is not eng.model_ref or x is None or group is not self.group:
             return None
+        if eng.layer_signature() != self._layers:
+            return None  # (a BatchNorm switched mode, eps / momentum changed, a layer was swapped)
         if tuple(x.shape) != tuple(eng.x_in.shape) or x.dtype != torch.float32 or x.device != eng.x_in.device:
             return None
         if len(params) != len(eng.params) or any(a is not b for a, b in zip(params, eng.params)):
@@ -273,7 +276,7 @@ class EngineSession(_TwoPhaseProduct):
         the logits as a leaf that requires grad, or ``None`` when this call is not the session's
         (another model / shape / mode) and the model must run itself."""
         eng = self.engine
-        if (model is not eng.model_ref or model.training != eng.train_bn or not torch.is_grad_enabled()
+        if (model is not eng.model_ref or eng.layer_signature() != self._layers or not torch.is_grad_enabled()
                 or not isinstance(x, torch.Tensor) or tuple(x.shape) != tuple(eng.x_in.shape)
                 or x.dtype != torch.float32 or x.device != eng.x_in.device
                 or eng._flat_params is None or eng._flat_params.data_ptr() != eng.params[0].data_ptr()):
@@ -445,6 +448,335 @@ class ChunkedEngineOperator(_TwoPhaseProduct):
             out.copy_(self.output_buffer)
             return out
         return self.output_buffer
+
+
+class AccumulatedSession:
+    """``HessianFree.acc_step()`` on the fused engine (reference optimizer.py:519-606, :608-684, :767-814): loss,
+    gradient and every curvature product accumulated over lists of data chunks, without building a forward
+    graph per chunk and product as the reference does (it says so itself, optimizer.py:537-540).
+
+    One fused curvature engine per DISTINCT chunk of the three data lists (chunks that the lists share -- the
+    default: one list for everything -- share their engine), every buffer static, and FOUR hipGraphs for the
+    whole lists, kept across ``acc_step`` calls while the lists keep their shapes:
+
+        G_wT    the (I, H, W, O) weight copies of every engine                              (per step)
+        G_fwd   forward pass + loss of every chunk of the LOSS list (and of the chunks whose activations the
+                gradient / curvature lists need), loss = sum_k N_k loss_k / sum_k N_k        (per step, per trial point)
+        G_grad  one adjoint sweep per chunk of the GRADIENT list, summed                   (per step)
+        G_prod  one product per chunk of the CURVATURE list, each already weighted N_k / sum N (mean) or 1
+                (sum), summed by one gather launch -- cloned into ``cg()``'s one-launch-per-iteration graph
+
+    The chunks' sweeps are independent until the final sum: they are captured on parallel branches of the
+    graph (fork / join by events during capture), so that two latency-bound sweeps of half the batch overlap
+    instead of queueing (``HF_ACC_PARALLEL=0``: one after the other; train-mode BatchNorm always runs the
+    chunks in sequence -- they all move the same running statistics).  Everything is the package's own
+    deterministic kernels: two ``acc_step`` calls on the same data are bitwise equal.
+
+    Under data parallelism (``process_group``) every rank holds ITS lists; the counts are totals over all ranks
+    and the summed product / gradient / losses are all-reduced once more (compact layout of the engine)."""
+
+    mode = ("accumulated engine session: one fused curvature engine per data chunk on parallel graph branches, "
+            "weighted sum by one gather launch; engine, graphs and PCG iteration graph kept across acc_step calls")
+
+    # ------------------------------------------------------------------------------------
+    @classmethod
+    def try_create(cls, model, loss_func, lists, params, reduction, counts, hessian=False, group=None):
+        """``lists = (loss_datalist, grad_datalist, mvp_datalist)`` on the device; ``counts`` their total sample
+        counts (over all ranks).  ``None`` when the engine does not cover the model / loss."""
+        if os.environ.get("HF_ACC_SESSION", "1") == "0" or not torch.cuda.is_available():
+            return None
+        if not getattr(model, "_hf_engine_hooks", False):
+            return None
+        sess = cls.__new__(cls)
+        try:
+            sess._build(model, loss_func, lists, list(params), reduction, counts, hessian, group)
+        except _NoEngine:
+            return None
+        return sess
+
+    @staticmethod
+    def _plan(lists):
+        """Distinct chunks (by identity of their tensors) and the slots each list uses."""
+        slots, index, roles = [], {}, []
+        for dl in lists:
+            idx = []
+            for inputs, targets in dl:
+                key = (id(inputs), id(targets))
+                if key not in index:
+                    index[key] = len(slots)
+                    slots.append((inputs, targets))
+                idx.append(index[key])
+            roles.append(tuple(idx))
+        return slots, roles
+
+    def _build(self, model, loss_func, lists, params, reduction, counts, hessian, group):
+        slots, roles = self._plan(lists)
+        if not slots or any(len(r) == 0 for r in roles):
+            raise _NoEngine()
+        self.model, self.loss_func, self.reduction, self.hessian = model, loss_func, reduction, bool(hessian)
+        self.roles, self.counts = roles, tuple(float(c) for c in counts)
+        self.shapes = [tuple(x.shape) for x, _ in slots]
+        self.group, self.params = group, params
+        cur = torch.cuda.current_stream()
+        dev = torch.cuda.current_device()
+        if dev not in GraphedOperator._streams:
+            GraphedOperator._streams[dev] = torch.cuda.Stream()
+        self.stream = GraphedOperator._streams[dev]
+        self.stream.wait_stream(cur)
+        engines = []
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            for x, t in slots:
+                if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and t.dim() == 1):
+                    cur.wait_stream(self.stream)
+                    raise _NoEngine()
+                with torch.enable_grad():
+                    out = model(x)
+                    loss = loss_func(out, t)
+                    spec = ce_loss_spec(loss, out) if isinstance(out, torch.Tensor) and out.dim() == 2 else None
+                    eng = None
+                    if spec is not None and spec["reduction"] == reduction:
+                        # (group=None: the ranks' sum is taken once, after the chunks' sum)
+                        eng = FusedGGNEngine.try_build(loss, out, params, weight=1.0, group=None, hessian=hessian)
+                if eng is None or eng.loss_spec is None:
+                    cur.wait_stream(self.stream)
+                    raise _NoEngine()
+                engines.append(eng)
+                del out, loss
+            self.engines = engines
+            e0 = engines[0]
+            self.engine = e0
+            self.n, self.dev = e0.n, e0.dev
+            self.train_bn = any(e.train_bn for e in engines)
+            self.parallel = (os.environ.get("HF_ACC_PARALLEL", "1") != "0" and len(engines) > 1
+                             and not self.train_bn)
+            f32 = dict(dtype=torch.float32, device=self.dev)
+            k_all = len(engines)
+            self.input_buffer = torch.zeros(self.n, **f32)
+            self.output_buffer = torch.empty(self.n, **f32)
+            self.grad_buffer = torch.empty(self.n, **f32)
+            self._parts = torch.empty((k_all, self.n), **f32)   # per-chunk partial products / gradients
+            self._loss_ks = list(dict.fromkeys(roles[0]))  # (trial points: only these engines run)
+            self._lossvec = torch.zeros(len(self._loss_ks), **f32)
+            w = torch.zeros(len(self._loss_ks), **f32)
+            for k in roles[0]:
+                w[self._loss_ks.index(k)] += float(self.shapes[k][0]) if reduction == "mean" else 1.0
+            self._loss_w = w
+            self.loss_buf = torch.zeros((), **f32)
+            self.losses = torch.zeros(64, **f32)
+            self._side = [torch.cuda.Stream() for _ in range(k_all - 1)] if self.parallel else []
+            self._events = [torch.cuda.Event() for _ in range(2 * k_all)]
+            # which engines each graph touches
+            grad_set = list(dict.fromkeys(roles[1]))
+            if hessian:  # (a Hessian engine's products read the first-order cotangents its gradient sweep keeps)
+                grad_set += [k for k in dict.fromkeys(roles[2]) if k not in grad_set]
+            self._grad_set, self._mvp_set = grad_set, list(dict.fromkeys(roles[2]))
+            self._fwd_set = list(range(k_all))
+
+            def role_weights(role):  # (a chunk listed twice in one list counts twice)
+                out = {}
+                for k in roles[role]:
+                    wk = float(self.shapes[k][0]) / self.counts[role] if reduction == "mean" else 1.0
+                    out[k] = out.get(k, 0.0) + wk
+                return out
+
+            self._w_grad, self._w_mvp = role_weights(1), role_weights(2)
+            # warm-up of everything that will be captured
+            self._refresh()
+            self._forward(self._fwd_set, update_running=False)
+            self._gradient()
+            self._product()
+        self.stream.synchronize()
+        with torch.no_grad():
+            self.g_wT = self._capture(self._refresh)
+            # every engine (a step's linearisation point) / the loss list's engines only (trial points)
+            self.g_fwd_all = self._capture(lambda: self._forward(self._fwd_set, update_running=True))
+            self.g_fwd = (self.g_fwd_all if len(self._loss_ks) == k_all
+                          else self._capture(lambda: self._forward(self._loss_ks, update_running=True)))
+            self.g_fwd_still = (self._capture(lambda: self._forward(self._fwd_set, update_running=False))
+                                if self.train_bn else self.g_fwd_all)
+            self.g_grad = self._capture(self._gradient)
+            self.graph = self._capture(self._product, keep=True)
+        cur.wait_stream(self.stream)
+        torch.cuda.synchronize()
+        self.calls = 0
+        self.steps = 0
+        self.base_loss = None
+        self._fresh = True  # (the model's own forward passes of the creating step have moved the running statistics)
+
+    def _capture(self, fn, keep=False):
+        g = torch.cuda.CUDAGraph(keep_graph=True) if keep else torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=self.stream):
+            fn()
+        if keep:
+            g.instantiate()
+        return g
+
+    # ---- the four bodies ---------------------------------------------------------------------
+    def _fork_join(self, ks, fn):
+        """``fn(k)`` for every engine index of ``ks``: on parallel branches (the current stream + side streams,
+        forked and joined by events -- inside a capture these become the graph's branches) or in sequence."""
+        ks = list(ks)
+        if not self.parallel or len(ks) < 2:
+            for k in ks:
+                fn(k)
+            return
+        cur = torch.cuda.current_stream()
+        fork = self._events[0]
+        fork.record(cur)
+        for j, k in enumerate(ks[1:]):
+            st = self._side[j]
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                fn(k)
+                self._events[1 + j].record(st)
+        fn(ks[0])
+        for j in range(len(ks) - 1):
+            cur.wait_event(self._events[1 + j])
+
+    def _refresh(self):
+        self._fork_join(self._fwd_set, lambda k: self.engines[k].refresh_weights(transposed=True))
+
+    def _forward(self, ks, update_running=True):
+        self._fork_join(ks, lambda k: self.engines[k].forward_own(refresh=True, update_running=update_running))
+        torch.stack([self.engines[k].loss_buf for k in self._loss_ks], out=self._lossvec)
+        val = torch.dot(self._lossvec, self._loss_w)
+        if self.reduction == "mean":
+            val = val / self.counts[0]
+        self.loss_buf.copy_(val)
+
+    def _sum_parts(self, ks, out):
+        """``out = sum of the leading rows of the parts``: one gather launch (fixed order: repeatable)."""
+        _lib.pack_ex(out, [self._parts[0]], {}, {0: (len(list(ks)), self.n)}, scale=1.0)
+
+    def _gradient(self):
+        order = self._grad_set  # (gradient-list chunks first: their parts are the leading rows)
+
+        def one(j):
+            eng = self.engines[order[j]]
+            eng.weight = self._w_grad.get(order[j], 1.0)
+            eng.gradient(self._parts[j])
+
+        n_sum = len(dict.fromkeys(self.roles[1]))
+        if n_sum == 1:  # (one chunk: straight into the result)
+            eng = self.engines[order[0]]
+            eng.weight = self._w_grad.get(order[0], 1.0)
+            eng.gradient(self.grad_buffer)
+            for j in range(1, len(order)):
+                one(j)
+            return
+        self._fork_join(range(len(order)), one)
+        self._sum_parts(range(n_sum), self.grad_buffer)
+
+    def _product(self):
+        order = self._mvp_set
+
+        def one(j):
+            eng = self.engines[order[j]]
+            eng.weight = self._w_mvp[order[j]]
+            eng.local(self.input_buffer, out=self._parts[j])
+
+        if len(order) == 1:
+            eng = self.engines[order[0]]
+            eng.weight = self._w_mvp[order[0]]
+            eng.local(self.input_buffer, out=self.output_buffer)
+            return
+        self._fork_join(range(len(order)), one)
+        self._sum_parts(range(len(order)), self.output_buffer)
+
+    # ---- validity ------------------------------------------------------------------------------
+    def accepts(self, model, loss_func, lists, params, reduction, counts, hessian, group):
+        slots, roles = self._plan(lists)
+        if (model is not self.model or loss_func is not self.loss_func or reduction != self.reduction
+                or bool(hessian) != self.hessian or group is not self.group or roles != self.roles
+                or tuple(float(c) for c in counts) != self.counts or model.training != self.train_bn):
+            return None
+        if [tuple(x.shape) for x, _ in slots] != self.shapes:
+            return None
+        if len(params) != len(self.params) or any(a is not b for a, b in zip(params, self.params)):
+            return None
+        e0 = self.engines[0]
+        if e0._flat_params is None or e0._flat_params.data_ptr() != e0.params[0].data_ptr():
+            return None
+        for (x, t), eng in zip(slots, self.engines):
+            if not x.is_cuda or x.dtype != torch.float32 or tuple(t.shape) != tuple(eng._targets.shape):
+                return None
+        return slots
+
+    # ---- per step ----------------------------------------------------------------------------
+    def begin_step(self, slots, verify=False, reduce=True):
+        """New data + current parameters into every engine; returns the accumulated loss (``reduce``: summed over
+        the ranks here; else the caller does it -- after the ranks have agreed to use the session at all)."""
+        with torch.no_grad():
+            for (x, t), eng in zip(slots, self.engines):
+                eng.set_batch(x.detach(), t)
+            self.g_wT.replay()
+            (self.g_fwd_still if self._fresh else self.g_fwd_all).replay()
+            self._fresh = False
+            bad = torch.stack([eng.bad_targets.float().reshape(()) for eng in self.engines]).sum()
+            vals = torch.stack([self.loss_buf.float().reshape(()), bad]).tolist()
+        if vals[1]:
+            raise _NoEngine()
+        if verify:
+            self._verify(slots)
+        self.steps += 1
+        self.base_loss = self.reduce_losses(self.loss_buf.reshape(1)).tolist()[0] if reduce else vals[0]
+        return self.base_loss
+
+    def _verify(self, slots):
+        """The captured graphs still describe the model: its STOCK forward pass on the first chunk against the
+        engine's logits (1e-4); raises ``_NoEngine`` otherwise."""
+        x, _ = slots[0]
+        with torch.no_grad():
+            want = self.model._hf_stock_model_forward(x)
+        got = self.engines[0].logits
+        err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
+        if not err < 1e-4:
+            raise _NoEngine()
+
+    def reduce_losses(self, vals):
+        """Sum over ranks of (already count-weighted) loss values, as float64."""
+        vals = vals.double()
+        if self.group is not None:
+            torch.distributed.all_reduce(vals, group=self.group)
+        return vals
+
+    def gradient(self):
+        self.g_grad.replay()
+        if self.group is not None:
+            self.engine.reduce(self.grad_buffer, self.group)
+        return self.grad_buffer
+
+    def forward_loss(self, slot):
+        self.g_fwd.replay()
+        self.losses[slot].copy_(self.loss_buf)
+        return self.losses[slot]
+
+    # ---- operator interface of cg() ------------------------------------------------------------
+    def raw_graph(self):
+        return self.graph.raw_cuda_graph()
+
+    def replay_local(self):
+        self.graph.replay()
+
+    def reduce(self, t):
+        return self.engine.reduce(t, self.group)
+
+    @property
+    def reduce_bytes(self):
+        return self.engine.reduce_bytes
+
+    def local(self, v, out=None):
+        if v.data_ptr() != self.input_buffer.data_ptr():
+            self.input_buffer.copy_(v)
+        self.graph.replay()
+        if out is not None:
+            out.copy_(self.output_buffer)
+            return out
+        return self.output_buffer
+
+    def __call__(self, v, out=None):
+        self.calls += 1
+        return self.reduce(self.local(v, out))
 
 
 class _NoEngine(Exception):

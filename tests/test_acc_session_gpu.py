@@ -1,0 +1,167 @@
+"""GPU: ``HessianFree.acc_step()`` on the fused engine (``session.AccumulatedSession``) -- loss, gradient and every
+curvature product accumulated over lists of data chunks (reference ``/root/reference/hessianfree/optimizer.py:
+519-606, :608-684, :767-814``), one engine per chunk, the chunks' sweeps on parallel branches of ONE product
+graph inside ``cg()``'s iteration graph, trial losses as graph replays.
+
+Oracles: (1) the reference's own statement of chunk additivity (``/root/reference/tests/test_optimizer_acc.py:
+116-175``: accumulated == whole batch, ``1e-4``) against this package's ``step`` on the whole batch, and (2) the
+CPU path -- stock model, torch autograd, generic accumulation, host logic with ``oracle.pcg`` (the reference's PCG
+restated, pinned bit for bit by tests/golden/make_golden.py).  Tolerances are stated at the assertions."""
+
+import warnings
+
+import pytest
+import torch
+
+import pytorchhessianfree_amd as hf
+from pytorchhessianfree_amd import modelprep
+from pytorchhessianfree_amd import testproblems as tp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SEEDS = tp.RESNET18_B32_SEPARATED_SEEDS
+
+
+def _flat(opt):
+    return torch.cat([p.detach().reshape(-1) for p in opt._params_list])
+
+
+def _chunks(x, t, sizes):
+    out, o = [], 0
+    for n in sizes:
+        out.append((x[o:o + n].contiguous(), t[o:o + n].contiguous()))
+        o += n
+    return out
+
+
+def _resnet_runs(kind, steps, sizes=(16, 16), **kw):
+    """``kind``: "step" (whole batch through the session), "acc" (chunks through the accumulated session), "cpu"
+    (chunks through the generic accumulation on the CPU with the oracle PCG)."""
+    dev = "cpu" if kind == "cpu" else DEV
+    model, _, lossf = tp.resnet18_mnist(batch_size=32, device=dev, data_seed=SEEDS[0])
+    if dev != "cpu":
+        modelprep.prepare_model(model, channels_last=True)
+    opt = hf.HessianFree(model.parameters(), graph_matvec=(dev != "cpu"), **kw)
+    if kind == "cpu":
+        from oracle import pcg as oracle
+
+        opt._cg = oracle.pcg
+    finals = []
+    for i in range(steps):
+        _, (x, t), _ = tp.resnet18_mnist(batch_size=32, device=dev, data_seed=SEEDS[i])
+
+        def forward():
+            out = model(x)
+            return lossf(out, t), out
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if kind == "step":
+                finals.append(opt.step(forward))
+            else:
+                finals.append(opt.acc_step(model, lossf, _chunks(x, t, sizes), reduction="mean"))
+    return opt, finals
+
+
+def _same_trace(a, fa, b, fb, loss_tol=1e-5, final_tol=1e-4, iters=2):
+    sa, sb = a.state, b.state
+    for x, y in zip(sa["init_losses"], sb["init_losses"]):
+        assert abs(x - y) <= loss_tol * abs(y)
+    assert sa["cg_reasons"] == sb["cg_reasons"]
+    assert sa["learning_rates"] == sb["learning_rates"]
+    assert sa["dampings"] == sb["dampings"]
+    for x, y in zip(sa["num_cg_iters"], sb["num_cg_iters"]):
+        assert abs(x - y) <= iters
+    for x, y in zip(fa, fb):
+        assert abs(x - y) <= final_tol * abs(y)
+
+
+def test_acc_step_on_engine_equals_step_on_whole_batch_and_is_repeatable():
+    """ResNet-18 (config 2), eval-mode BatchNorm: ``acc_step`` on chunks [16, 16] equals ``step`` on the 32-sample
+    batch -- the reference's own bar for this equivalence is 1e-4 (test_optimizer_acc.py:175).  Two steps on
+    fresh batches; stated tolerance: initial losses 1e-5, learning rates / damping schedule / reasons identical,
+    iteration counts +-2, final losses 1e-4, parameters after the first step 1e-4 of their max-norm.  The
+    accumulated session serves both steps, and a second run of the same two calls is BITWISE equal."""
+    acc, fa = _resnet_runs("acc", 2)
+    sess = acc._acc_session
+    assert sess is not None and sess.steps == 2 and len(sess.engines) == 2
+    assert "engine" in sess.mode
+    whole, fw = _resnet_runs("step", 2)
+    assert whole._session is not None
+    _same_trace(acc, fa, whole, fw)
+    again, fa2 = _resnet_runs("acc", 2)
+    assert fa2 == fa and torch.equal(_flat(again), _flat(acc))
+    assert again.state["num_cg_iters"] == acc.state["num_cg_iters"]
+
+
+def test_acc_step_on_engine_matches_cpu_reference_path_with_ragged_chunks():
+    """Chunks of unequal sizes [20, 12] (weights N_k / sum N, optimizer.py:677-684): two ``acc_step`` calls
+    against the CPU path (stock model, generic accumulation, oracle PCG).  Tolerances as above."""
+    acc, fa = _resnet_runs("acc", 2, sizes=(20, 12))
+    assert acc._acc_session is not None and acc._acc_session.shapes[0][0] == 20
+    cpu, fc = _resnet_runs("cpu", 2, sizes=(20, 12))
+    _same_trace(acc, fa, cpu, fc)
+
+
+def test_acc_product_gradient_and_loss_equal_generic_accumulation():
+    """The session's accumulated loss / gradient / product against the generic ``_acc_*`` accumulation (autograd
+    operators per chunk) on the same lists, with DISTINCT loss / gradient / curvature lists (README.md:147-150 of
+    the reference): 1e-6 / 2e-6 / 2e-6 (max-norm relative), and the product is bitwise repeatable."""
+    model, _, lossf = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=SEEDS[0])
+    modelprep.prepare_model(model, channels_last=True)
+    opt = hf.HessianFree(model.parameters(), graph_matvec=True)
+    data = [tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=SEEDS[i])[1] for i in range(3)]
+    loss_dl = _chunks(*data[0], (16, 16))
+    grad_dl = _chunks(*data[1], (12, 20))
+    mvp_dl = _chunks(*data[2], (8, 8))  # (a smaller curvature batch: 16 of the 32 samples)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        forward, grad, mvp, sess = opt.acc_linearise(model, lossf, loss_dl, grad_dl, mvp_dl, "mean")
+    assert sess is not None and grad is None and mvp is None and len(sess.engines) == 6
+    want_loss = float(opt._acc_loss(model, lossf, loss_dl, "mean"))
+    assert abs(sess.base_loss - want_loss) <= 1e-6 * abs(want_loss)
+    want_grad = opt._acc_grad(model, lossf, grad_dl, "mean")
+    got_grad = sess.gradient()
+    assert float((got_grad - want_grad).abs().max() / want_grad.abs().max()) < 2e-6
+    v = torch.randn(sess.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    want = opt._acc_mvp(model, lossf, mvp_dl, "ggn", "mean", v)
+    got = sess(v).clone()
+    assert float((got - want).abs().max() / want.abs().max()) < 2e-6
+    assert torch.equal(sess(v), got)
+
+
+def test_acc_step_allcnnc_hessian_with_l2_on_engine_equals_step():
+    """BASELINE configs[3]'s model through ``acc_step``: All-CNN-C, Hessian curvature, tagged L2 term, chunks
+    [16, 16] against ``step`` on the whole batch (both on the plain-stack engine): same tolerances."""
+    runs = []
+    for kind in ("acc", "step"):
+        model, (x, t), lossf = tp.allcnnc_cifar100(batch_size=32, device=DEV, data_seed=7)
+        lossf = tp.l2_regularized(lossf, model, 5e-4)
+        modelprep.prepare_model(model, channels_last=True)
+        opt = hf.HessianFree(model.parameters(), curvature_opt="hessian", graph_matvec=True, cg_max_iter=30)
+
+        def forward():
+            out = model(x)
+            return lossf(out, t), out
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if kind == "acc":
+                final = opt.acc_step(model, lossf, _chunks(x, t, (16, 16)), reduction="mean")
+                assert opt._acc_session is not None and opt._acc_session.hessian
+            else:
+                final = opt.step(forward)
+                assert opt._session is not None and opt._session.engine.hessian
+        runs.append((opt, [final]))
+    _same_trace(*runs[0], *runs[1])
+
+
+def test_acc_step_falls_back_for_models_the_engine_does_not_cover():
+    """An MLP with an MSE loss (the reference's own acc tests): no engine, the generic accumulation runs."""
+    model, (x, t), lossf = tp.small_nn(device=DEV)
+    opt = hf.HessianFree(model.parameters(), graph_matvec=True, cg_max_iter=5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        opt.acc_step(model, lossf, _chunks(x, t, (16, 16)), reduction="mean")
+        opt.acc_step(model, lossf, _chunks(x, t, (16, 16)), reduction="mean")
+    assert opt._acc_session is None
