@@ -70,9 +70,11 @@ def parse():
                          "so it only pays when the all-reduce itself takes > ~0.6 ms; -1 = decided from a one-off "
                          "timing of the all-reduce at start-up)")
     ap.add_argument("--chunk", type=int, default=-1,
-                    help="data parallel + fused engine: two hipGraphs per product, the all-reduce chunked by stage "
+                    help="data parallel + fused engine: 1 = two hipGraphs per product, the all-reduce chunked by stage "
                          "and the late layers' share (ResNet-18: 14 of 17 MB) overlapped with the rest of the adjoint "
-                         "sweep on a second communicator (session.ChunkedEngineOperator); -1 = on for > 1 rank")
+                         "sweep on a second communicator; 0 = one product graph + one compact all-reduce; -1 = the "
+                         "session times both on this communicator at creation and keeps the faster (what "
+                         "HessianFree.step(process_group=...) does by default)")
     ap.add_argument("--force-dist", type=int, default=0,
                     help="create the process group even for WORLD_SIZE=1 (exercises the RCCL path on one GPU)")
     ap.add_argument("--conv", default="", choices=["", "auto", "own", "miopen"],
@@ -91,6 +93,10 @@ def parse():
     ap.add_argument("--precond", type=int, default=0,
                     help="1: diagonal empirical-Fisher preconditioner, exponent 0.75, per-sample autograd "
                          "path (preconditioners.py:63-127), fused into K2/K3 (56 N bytes per iteration)")
+    ap.add_argument("--min-calls", type=int, default=1000,
+                    help="when a solve ends before --iters (Martens' criterion / round-off on the preconditioned "
+                         "Hessian system of config 4), a step repeats the solve back to back until the timed region "
+                         "holds at least this many operator calls")
     ap.add_argument("--acc", default="",
                     help="comma-separated chunk sizes (e.g. 16,16; they must add up to --batch): drive "
                          "HessianFree.acc_step's path (optimizer.py:519-606) -- loss / gradient / products "
@@ -237,6 +243,36 @@ def cpu_baseline(args):
     }
 
 
+def beyond_cache_roofline(device, n=64 * 1024 * 1024, iters=48):
+    """K2 (and K1, K3) on vectors far beyond the 256 MiB Infinity Cache (six vectors of 256 MiB): the headline's
+    six 44.7 MB vectors (268 MB) sit at its edge, so part of the headline fraction is served on-die -- this is
+    the plain HBM figure of the same kernels, measured in this run (HIP events inside libhfpcg)."""
+    import pytorchhessianfree_amd as hf
+    from pytorchhessianfree_amd.cg import enable_kernel_timing, read_kernel_timing
+
+    gen = torch.Generator(device=device).manual_seed(0)
+    d = torch.rand(n, device=device, generator=gen) * 100.0 + 1e-3
+    b = torch.randn(n, device=device, generator=gen)
+    out = torch.empty(n, device=device)
+    A = hf.DampedCurvature(lambda v: torch.mul(d, v, out=out), 1e-3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hf.cg(A, b, max_iter=8, tol=0.0, store_x_at_iters=[0])
+        ws = enable_kernel_timing(device, n, torch.float32, True)
+        hf.cg(A, b, max_iter=iters, tol=0.0, store_x_at_iters=[0])
+    t = read_kernel_timing(ws)
+    enable_kernel_timing(device, n, torch.float32, False)
+    res = {"n": n, "vector_MiB": n * 4 / 2**20, "launches_timed": t["n"]}
+    for k, by in (("k1", 8), ("k2", 28), ("k3", 12)):
+        res[k + "_ms"] = t[k + "_ms"]
+        res[k + "_frac"] = by * n / (t[k + "_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if t[k + "_ms"] > 0 else 0.0
+    tot = t["k1_ms"] + t["k2_ms"] + t["k3_ms"]
+    res["all_frac"] = 48.0 * n / (tot * 1e-3) / 1e9 / HBM_PEAK_GBS if tot > 0 else 0.0
+    del d, b, out
+    torch.cuda.empty_cache()
+    return res
+
+
 def full_step_timing(args, device, n_steps=8, warmup=2):
     """Wall time of complete default ``HessianFree.step()`` calls (optimizer.py:126-363: forward,
     gradient, PCG to Martens' criterion, LM damping, CG-backtracking, line search, update) on the
@@ -252,9 +288,12 @@ def full_step_timing(args, device, n_steps=8, warmup=2):
     model, _, lossf = make(batch_size=args.batch, seed=0, device=device, data_seed=seeds[0])
     if args.bn == "train":
         model.train()
+    l2 = args.l2 if args.l2 >= 0 else (5e-4 if (args.workload == "allcnnc" and args.curvature == "hessian") else 0.0)
+    if l2 > 0:
+        lossf = tp.l2_regularized(lossf, model, l2)
     modelprep.prepare_model(model, channels_last=bool(args.channels_last))
     batches = [make(batch_size=args.batch, seed=0, device=device, data_seed=sd)[1] for sd in seeds]
-    opt = hf.HessianFree(model.parameters(), graph_matvec=bool(args.graph))
+    opt = hf.HessianFree(model.parameters(), curvature_opt=args.curvature, graph_matvec=bool(args.graph))
     times = []
     for i in range(warmup + n_steps):
         x, t = batches[i % len(batches)]
@@ -272,10 +311,13 @@ def full_step_timing(args, device, n_steps=8, warmup=2):
         t0 = time.perf_counter()
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
+            # (config 4: the diagonal empirical-Fisher preconditioner is rebuilt per step at the current
+            # damping, per-sample autograd path -- inside the timed step, as a user of the reference pays it)
+            M = (opt.get_preconditioner(model, lossf, x, t, "mean", use_backpack=False) if args.precond else None)
             if chunks:
-                opt.acc_step(model, lossf, chunks, reduction="mean")
+                opt.acc_step(model, lossf, chunks, M_func=M, reduction="mean")
             else:
-                opt.step(forward)
+                opt.step(forward, M_func=M)
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t0) * 1e3)
     timed = times[warmup:]
@@ -292,7 +334,9 @@ def full_step_timing(args, device, n_steps=8, warmup=2):
                  if getattr(opt, "_acc_session", None) is not None
                  else "generic path (operator rebuilt and re-captured per step, eager trial forwards)"),
         "settings": "HessianFree defaults: damping 1.0 + LM, cg_max_iter 250, Martens' criterion, "
-                    "CG-backtracking, line search; a fresh batch per step",
+                    "CG-backtracking, line search; a fresh batch per step"
+                    + ("; diag empirical-Fisher preconditioner rebuilt per step (per-sample autograd, timed)"
+                       if args.precond else ""),
     }
 
 
@@ -337,7 +381,6 @@ def main():
     acc_sizes = [int(v) for v in args.acc.split(",") if v.strip()]
     if acc_sizes and sum(acc_sizes) != args.batch:
         raise SystemExit(f"bench --acc {args.acc}: the chunks must add up to --batch {args.batch}")
-    chunk_on = bool(args.chunk) if args.chunk >= 0 else world > 1
 
     def problem(dev, dtype=torch.float32):
         model, (x, t), lossf = build_problem(args, dev, rank)
@@ -556,8 +599,10 @@ def main():
         state["group"] = group
         if os.environ.get("HF_BENCH_FAIL_RANK") == str(rank):  # test hook: a rank that dies mid-run
             os._exit(3)
-        if not chunk_on:
-            os.environ["HF_CHUNKED_ALLREDUCE"] = "0"
+        # the data-parallel product: --chunk 1 two-phase (chunked / overlapped all-reduce), 0 single graph + one
+        # compact all-reduce, -1 (default) whichever the session measures to be faster on this communicator
+        if args.chunk >= 0:
+            os.environ["HF_CHUNKED_ALLREDUCE"] = "1" if args.chunk else "0"
     args.overlap = max(args.overlap, 0)  # (the autograd two-graph split: only on request)
     op, grad, diag, n, err = checked(bool(args.channels_last), overlap=bool(args.overlap))
     def note_text(err):
@@ -617,14 +662,27 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    calls_w = op.calls
     for _ in range(args.warmup):
-        solve()
+        xs_w, _, reason_w = solve()
+    # A solve that cannot sustain --iters iterations (config 4: fp32 round-off ends the preconditioned Hessian
+    # solve at tol = 0 in "Divergence" after ~21 iterations) is replaced by what the optimizer actually runs --
+    # Martens-terminated solves -- repeated back to back so that the timed region holds >= --min-calls calls
+    sustained = args.warmup == 0 or len(xs_w) - 1 >= args.iters
+    timed_martens = not sustained
+    solves_per_step = 1
+    if not sustained:
+        c0 = op.calls
+        solve(martens=True)
+        per = max(1, op.calls - c0)
+        solves_per_step = max(1, -(-args.min_calls // (per * max(1, args.steps))))
     ws = enable_kernel_timing(device, n, torch.float32, not os.environ.get("HF_BENCH_NO_TIMING"))
     calls0 = op.calls
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        xs, _, reason = solve()
+        for _r in range(solves_per_step):
+            xs, _, reason = solve(martens=timed_martens)
     barrier()
     dt = time.perf_counter() - t0
     timing = read_kernel_timing(ws)
@@ -668,8 +726,15 @@ def main():
             "config": {
                 "workload": f"{args.workload} {args.curvature.upper()} PCG solve: N={n} fp32 parameters, "
                             f"batch {args.batch}/GPU, {iters_done} PCG iterations in the last step "
-                            f"({matvecs} operator calls in {args.steps} steps, max_iter {args.iters}), "
-                            f"damping {args.damping}, {args.bn}-mode BN, CE-mean"
+                            f"({matvecs} operator calls in {args.steps} steps"
+                            + (f" of {solves_per_step} Martens-terminated solves each" if timed_martens else "")
+                            + f", max_iter {args.iters}), "
+                            f"damping {args.damping}"
+                            + (" (SURVEY.md 8(d) states 1.0: with 1.0 this random-init problem is at fp32 round-off "
+                               "after ~15 iterations and 250 iterations cannot be sustained; the Martens-terminated leg "
+                               "`cg_to_martens` and `step_ms` run the optimizer's default 1.0)"
+                               if args.damping != 1.0 and not hessian else "")
+                            + f", {args.bn}-mode BN, CE-mean"
                             + (f" + L2 {l2:g}" if l2 > 0 else "") + ", x0=0, tol=0"
                             + (", diag empirical-Fisher preconditioner ^-0.75 (per-sample autograd)" if M is not None else "")
                             + (f", acc_step path: chunks {acc_sizes} accumulated" if acc_sizes else ""),
@@ -705,9 +770,14 @@ def main():
                 "allreduce": None if allreduce_ms is None else {
                     "path": comm_path, "bytes": int(getattr(getattr(op, "op", op), "reduce_bytes", 4 * n)),
                     "ms": allreduce_ms,
-                    "overlap_two_graphs": bool(args.overlap)},
+                    "overlap_two_graphs": bool(args.overlap),
+                    "product_mode": ("two-phase (chunked / overlapped)" if getattr(op, "split", None) is not None
+                                     else "single graph + one compact all-reduce"),
+                    "product_mode_timing_ms": getattr(op, "mode_timing", None),
+                    "product_mode_policy": {-1: "auto (measured at session creation)", 0: "forced single",
+                                            1: "forced two-phase"}.get(args.chunk)},
             },
-            "cg_iters_per_s": world * args.steps * iters_done / dt,
+            "cg_iters_per_s": world * args.steps * solves_per_step * iters_done / dt,
             "cg_to_martens": {"iters": len(xs_m) - 1, "reason": reason_m,
                               "iters_per_s": (len(xs_m) - 1) / dt_m},
             "roofline": {
@@ -745,7 +815,18 @@ def main():
                         "command on this stack), not re-measured in this run")
             except Exception:
                 pass
-        if world == 1 and not dist_on and not hessian and not args.precond and not args.no_step_timing:
+        if world == 1 and not dist_on:
+            try:
+                bc = beyond_cache_roofline(device)
+                line["roofline"]["frac_beyond_l3"] = bc["k2_frac"]
+                line["roofline"]["beyond_l3"] = bc
+                line["roofline"]["note"] = (
+                    f"frac: K2 at this workload's N = {n} (six {4 * n / 1e6:.1f} MB vectors = "
+                    f"{6 * 4 * n / 2**20:.0f} MiB, at the edge of the 256 MiB Infinity Cache: partly served on-die); "
+                    "frac_beyond_l3: the same kernel on 256 MiB vectors, measured in this run -- the plain HBM figure")
+            except Exception as exc:  # noqa: BLE001
+                line["roofline"]["beyond_l3"] = {"error": repr(exc)}
+        if world == 1 and not dist_on and not args.no_step_timing:
             try:
                 line["step_ms"] = full_step_timing(args, device)
             except Exception as exc:  # noqa: BLE001  (the headline number must not depend on this leg)

@@ -255,6 +255,19 @@ __global__ __launch_bounds__(BLOCK) void k_init_finalize(DevState* __restrict__ 
 // else (the done flag, the re-reduction of the previous kernel's partials): at small N
 // (All-CNN-C: 5.5 MB vectors, one tile per block) that prologue used to sit in front of
 // the first load and cost more than the streaming itself.
+// (tuning knob, scripts/experiments/k1_variants.sh: HF_K1_NT=1 reads both streams with non-temporal loads)
+#ifndef HF_K1_NT
+#define HF_K1_NT 0
+#endif
+#if HF_K1_NT
+#define HF_K1_LD(dst, ptr)                                                                  \
+  {                                                                                         \
+    NV t_ = __builtin_nontemporal_load(reinterpret_cast<const NV*>(ptr));                   \
+    __builtin_memcpy(&(dst), &t_, sizeof(NV));                                              \
+  }
+#else
+#define HF_K1_LD(dst, ptr) (dst) = *(ptr);
+#endif
 template <typename T, int UNROLL>
 __global__ __launch_bounds__(BLOCK) void k_curvature(const DevState* __restrict__ st,
                                                      double* __restrict__ part1, int stride,
@@ -263,6 +276,7 @@ __global__ __launch_bounds__(BLOCK) void k_curvature(const DevState* __restrict_
                                                      long long n) {
   constexpr int W = VecOf<T>::W;
   typedef typename VecOf<T>::type V;
+  typedef T NV __attribute__((ext_vector_type(W)));
   __shared__ double lds[WAVES];
   double acc[1] = {0.0};
   const long long nvec = n / W;
@@ -273,8 +287,8 @@ __global__ __launch_bounds__(BLOCK) void k_curvature(const DevState* __restrict_
   _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                       \
     const long long i = base + u * BLOCK + threadIdx.x;                     \
     if (i < nvec) {                                                         \
-      vp[u].v = reinterpret_cast<const V*>(p)[i];                           \
-      vg[u].v = reinterpret_cast<const V*>(Bp)[i];                          \
+      HF_K1_LD(vp[u].v, reinterpret_cast<const V*>(p) + i)                  \
+      HF_K1_LD(vg[u].v, reinterpret_cast<const V*>(Bp) + i)                 \
     }                                                                       \
   }
   HF_K1_LOAD();
@@ -643,8 +657,17 @@ __global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackA
             for (int c = 0; c < W; ++c) acc.e[c] += tt[u].e[c];
         }
         if (staged) {
+          // Lanes of a wave hold consecutive input-channel quads of one (o, hw) row: their LDS words are
+          // 4*HW = 36 apart for a 3x3 kernel, i.e. lanes l, l+16, l+32, l+48 met in one bank (4-way conflicts:
+          // two thirds of this kernel's LDS cycles, profiles/r03_engine_kernel_counters.json).  Their word
+          // indices differ by multiples of 9*64, so bits 6..7 tell them apart: XOR those into the position
+          // INSIDE the 16-byte quad -- quads stay whole and aligned for the 16-byte reads below, which undo
+          // the swap in registers.
 #pragma unroll
-          for (int c = 0; c < W; ++c) tile[jd - (unsigned)j0 + c * step] = acc.e[c];
+          for (int c = 0; c < W; ++c) {
+            const unsigned q = jd - (unsigned)j0 + c * step;
+            tile[(q & ~3u) | ((q ^ (q >> 6)) & 3u)] = acc.e[c];
+          }
         } else if (I == 0 && OP == 0 && (((uintptr_t)(out + jd)) & 15) == 0) {
 #pragma unroll
           for (int c = 0; c < W; ++c) acc.e[c] = pack_op<T, OP>((T)0, acc.e[c], scale);
@@ -660,6 +683,13 @@ __global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackA
         for (unsigned t = threadIdx.x * 4; t < len; t += BLOCK * 4) {
           VU<T> v, d;
           v.v = *reinterpret_cast<const V*>(tile + t);
+          if constexpr (W == 4) {  // undo the in-quad swap of the staging stores (sw = bits 6..7 of the word index)
+            const unsigned sw = (t >> 6) & 3u;
+            T e0 = v.e[0], e1 = v.e[1], e2 = v.e[2], e3 = v.e[3];
+            if (sw & 1u) { T x0 = e0; e0 = e1; e1 = x0; T x2 = e2; e2 = e3; e3 = x2; }
+            if (sw & 2u) { T x0 = e0; e0 = e2; e2 = x0; T x1 = e1; e1 = e3; e3 = x1; }
+            v.e[0] = e0; v.e[1] = e1; v.e[2] = e2; v.e[3] = e3;
+          }
           if (OP == 1) d.v = *reinterpret_cast<const V*>(out + j0 + t);
 #pragma unroll
           for (int c = 0; c < W; ++c) v.e[c] = pack_op<T, OP>(OP == 1 ? d.e[c] : (T)0, v.e[c], scale);

@@ -124,11 +124,17 @@ class FusedGGNEngine(_Operator):
                 return None
         return None
 
-    supports_hessian = False
+    # Hessian products (optimizer.py:450-455) by forward-over-reverse on the same kernels; residual nets with
+    # EVAL-mode BatchNorm (the layer is a per-channel affine map; ReLU masks and max-pool positions are
+    # piecewise constant): per unit, besides the GGN's terms, conv_D(g, V) and conv_W(t_x, g) (g: the step's
+    # first-order cotangent, kept by the gradient sweep) as MORE SLABS of the same buffers, and the BatchNorm
+    # scale's own second-order terms  g_a' += g_z * rstd * v_gamma ,  g_gamma' += sum g_z * rstd * t_a .
+    supports_hessian = True
 
     def __init__(self, model, loss, outputs, params, weight, group, hessian=False):
         super().__init__(params, weight, group)
         self.hessian = bool(hessian)
+        self._second = False  # (inside the adjoint sweep of a Hessian product)
         self._l2 = None
         self.outputs = outputs
         self.dev = outputs.device
@@ -140,6 +146,12 @@ class FusedGGNEngine(_Operator):
         self._offs = offs
         self.train_bn = False
         self._layout(model)
+        if self.hessian and self.train_bn:
+            raise _Unsupported("Hessian products with train-mode BatchNorm (batch statistics couple the samples: "
+                               "cross terms the engine does not carry)")
+        if self.hessian:
+            for u in self.units:
+                u.needs_g = True  # (the first-order masked cotangent of every unit is kept)
         self._allocate()
         self.set_batch(getattr(outputs, "_hf_input").detach(), None)
         self.refresh_weights(transposed=True)
@@ -326,6 +338,10 @@ class FusedGGNEngine(_Operator):
                 self._loss_head()
                 self._ce = (self._p, self._ce[1])  # the static buffer the own forward pass refreshes
                 self._dl = None                     # (nothing of this step's autograd graph is kept)
+        if self.hessian:
+            if self.loss_spec is None:
+                raise _Unsupported("Hessian products on the engine need a plain softmax cross-entropy loss")
+            self.gradient()  # fills the first-order cotangents the Hessian products read
 
     def _set_quadratic(self, terms):
         """``loss = cross-entropy + sum_j 0.5 * coef_j * ||w_j||^2`` (the L2 term of the reference's
@@ -512,12 +528,28 @@ class FusedGGNEngine(_Operator):
         g_fw = g.t() @ self.feat
         g_fb = g.sum(0) if self.pfb is not None else None
         g_feat = g @ fw
-        pool_srcs = self._adjoint_blocks(self._feature_cotangent(g_feat))
-        self._adjoint_stem(pool_srcs)
-        self._gather(out, g_fw, g_fb)
+        if self.hessian:
+            # the first-order cotangents stay for the step's Hessian products: the sweep below writes the units'
+            # g1 / ga1 instead of g / ga (buffers swapped for its duration)
+            if getattr(self, "_gl1", None) is None:
+                self._gl1 = torch.empty_like(g)
+            self._gl1.copy_(g)
+            self._swap_first_order()
+        try:
+            pool_srcs = self._adjoint_blocks(self._feature_cotangent(g_feat))
+            self._adjoint_stem(pool_srcs)
+        finally:
+            if self.hessian:
+                self._swap_first_order()
+        self._gather(out, g_fw, g_fb, first_order=True)
         if self._l2 is not None:
             out.addcmul_(self._l2, self._theta(), value=self.weight)
         return out
+
+    def _swap_first_order(self):
+        for u in self.units:
+            u.g, u.g1 = u.g1, u.g
+            u.ga, u.ga1 = u.ga1, u.ga
 
     def _feature_cotangent(self, g_feat):
         tail = self.tail
@@ -626,6 +658,9 @@ class FusedGGNEngine(_Operator):
                 u.dbuf = torch.empty((u.nD, u.x.numel()), dtype=f32, device=dev)
             if self.hessian:
                 u.ga1 = torch.empty_like(u.a)  # first-order cotangent of the convolution output (per step)
+                if u.bn is not None:
+                    u.g1 = torch.empty_like(u.a)   # ... and of the BatchNorm output (masked), per step
+                    u.gah = torch.empty_like(u.a)  # g_a' + g_z * rstd * v_gamma: what the convolutions' adjoints read
                 if u.sD:
                     u.vT = torch.empty((c, r, s, k), dtype=f32, device=dev)  # V as (I, H, W, O), per product
             u.g = torch.empty_like(u.a) if u.needs_g else None  # masked cotangent of the unit's output
@@ -645,7 +680,9 @@ class FusedGGNEngine(_Operator):
                 u.rb = -(-u.rows // per)
                 if u.rb < 2:
                     u.rb = 1
-            u.gw = torch.empty((u.rb, k), dtype=f32, device=dev)
+            # (Hessian: the scale's second-order term arrives as `rb` more partial rows for hf_pack_ex to add)
+            u.gw_rows = u.rb * (2 if (self.hessian and u.bn is not None) else 1)
+            u.gw = torch.empty((u.gw_rows, k), dtype=f32, device=dev)
             u.gb = torch.empty((u.rb, k), dtype=f32, device=dev)
         # where each unit's output goes besides its own dense buffer: the [t_x | x] operand of its
         # consumer -- the tangent into the first half, the value (forward pass) into the second
@@ -794,7 +831,41 @@ class FusedGGNEngine(_Operator):
     def _adjoint_unit(self, u, srcs):
         """srcs: up to two (tensor, splits, slab_stride) cotangents of the unit's output."""
         self._bn_adjoint(u, srcs)
-        self._conv_adjoint(u)
+        if not (self._second and u.bn is not None):
+            self._conv_adjoint(u)
+            return
+        # ---- Hessian product: the tangent of the backward sweep through this unit --------------------------
+        lib, st = _lib.load(), _lib.current_stream_ptr(self.dev)
+        n, k, oh, ow = u.a.shape
+        v = self._v
+        v_gamma = v[self._offs[u.pg]: self._offs[u.pg] + k]
+        # the scale's gradient also moves with the convolution's tangent:  sum_rows g_z * rstd * t_a  (t_a = the
+        # sum of the tangent convolution's slabs, still in place) -> `rb` more partial rows of the same buffer
+        _lib.check(lib.hf_chan_affine_bwd_ex(
+            None, _ptr(u.gw[u.rb:]), None, None, _ptr(u.tbuf), u.sT, u.tbuf.shape[1], None, 1, 0, _ptr(u.g1),
+            _ptr(self._zeros(k)), _ptr(u.rstd), None, None, n, k, oh * ow, 1, u.rb, _lib.HF_F32, st),
+            "hf_chan_affine_bwd_ex")
+        # the convolution's cotangent tangent:  g_a' + g_z * rstd * v_gamma
+        _lib.check(lib.hf_chan_affine_ex(
+            _ptr(u.gah), _ptr(u.g1), None, None, _ptr(u.rstd), _ptr(v_gamma), None, None, _ptr(u.ga), None, 0, n, k,
+            oh * ow, 1, 0, 0, 1, 0, _lib.HF_F32, st), "hf_chan_affine_ex")
+        self._conv_adjoint(u, u.gah)
+        if not u.im2col and not u.first:
+            # conv_D(g_a, V) and conv_W(t_x, g_a) with the step's first-order cotangent: MORE SLABS of the same
+            # buffers (the consumers sum them anyway)
+            c = u.x.shape[1]
+            _lib.conv_dw_slabs((1, u.dbuf[u.sD:], u.ga1, u.vT, u.geo, u.sD, 0, 0),
+                               (2, u.wbuf[u.sW:], u.xcat, u.ga1, u.geo, u.sW, 2 * c, 0), self.dev)
+
+    def _zeros(self, k):
+        cache = self.__dict__.setdefault("_zeros_cache", {})
+        if k not in cache:
+            cache[k] = torch.zeros(k, dtype=torch.float32, device=self.dev)
+        return cache[k]
+
+    def _dslabs(self, u):
+        """How many data-gradient slabs the consumers of ``u``'s input cotangent must sum in the current sweep."""
+        return u.nD if self._second else u.sD
 
     def _bn_adjoint(self, u, srcs, ga=None):
         ga = u.ga if ga is None else ga
@@ -850,10 +921,20 @@ class FusedGGNEngine(_Operator):
             v = v.contiguous()
         self._tangent_stem(v, carry_scatter=True)  # + the v_W halves of all [W | v_W] operands, same launch
         self._tangent_blocks(v)
-        g_last, g_fw, g_fb = self._head(v)
-        pool_srcs = self._adjoint_blocks(g_last)
-        self._adjoint_stem(pool_srcs)
-        return self._gather(out, g_fw, g_fb)
+        if self.hessian:
+            if self._vt_slots:
+                _lib.unpack_tangent(v, self._vt_slots, half=2)  # V as (I, H, W, O): the operand of conv_D(g, V)
+            self._second, self._v = True, v
+        try:
+            g_last, g_fw, g_fb = self._head(v)
+            pool_srcs = self._adjoint_blocks(g_last)
+            self._adjoint_stem(pool_srcs)
+        finally:
+            self._second, self._v = False, None
+        self._gather(out, g_fw, g_fb)
+        if self.hessian and self._l2 is not None:  # the regulariser's Hessian: coef on its tensors' entries
+            out.addcmul_(self._l2, v, value=self.weight)
+        return out
 
     # ---- the product in two phases, for overlapping the all-reduce with the rest of the sweep ----
     def phase_split(self, tail_fraction=0.7):
@@ -994,6 +1075,20 @@ class FusedGGNEngine(_Operator):
         nf = fw.numel()
         v_fw = v[self._offs[self.pfw]: self._offs[self.pfw] + nf].view_as(fw)
         v_fb = None if self.pfb is None else v[self._offs[self.pfb]: self._offs[self.pfb] + fw.shape[0]]
+        if self.hessian:
+            # forward-over-reverse through the linear head: besides H_L J v, the first-order cotangent g of the
+            # logits meets the tangents of the layer's two operands (g V -> features, g^T t_feat -> weight)
+            t_feat = t_last.flatten(1) if hw == 1 else t_last.mean(dim=(2, 3))
+            if self.pfb is not None:
+                Jv = torch.addmm(v_fb, t_feat, fw.detach().t())
+            else:
+                Jv = t_feat @ fw.detach().t()
+            Jv = torch.addmm(Jv, self.feat, v_fw.t())
+            HJv = self._loss_hessian(Jv)
+            g_fw = torch.addmm(self._gl1.t() @ t_feat, HJv.t(), self.feat)
+            g_fb = HJv.sum(0) if self.pfb is not None else None
+            g_feat = torch.addmm(self._gl1 @ v_fw, HJv, fw.detach())
+            return self._feature_cotangent(g_feat), g_fw, g_fb
         if self._head_fused(hw, v_fw):
             # ONE launch: logits' tangent, softmax-CE Hessian, the three gradients
             g_feat, g_fw, g_fb = self._head_bufs
@@ -1048,13 +1143,13 @@ class FusedGGNEngine(_Operator):
                 else:
                     self._adjoint_unit(u, incoming.pop(id(u)))
                 if k > 0:
-                    incoming.setdefault(id(chain[k - 1]), []).append((u.dbuf, u.sD, u.dbuf.shape[1]))
+                    incoming.setdefault(id(chain[k - 1]), []).append((u.dbuf, self._dslabs(u), u.dbuf.shape[1]))
             # the block input receives conv1's data gradient and the residual branch's cotangent
-            srcs = [(head.dbuf, head.sD, head.dbuf.shape[1])]
+            srcs = [(head.dbuf, self._dslabs(head), head.dbuf.shape[1])]
             if ds is not None:
                 if not group:
                     self._adjoint_unit(ds, [(last.g, 1, 0)])
-                srcs.append((ds.dbuf, ds.sD, ds.dbuf.shape[1]))
+                srcs.append((ds.dbuf, self._dslabs(ds), ds.dbuf.shape[1]))
             else:
                 srcs.append((last.g, 1, 0))
             if bi > 0:
@@ -1079,9 +1174,9 @@ class FusedGGNEngine(_Operator):
             "hf_maxpool_adjoint_nhwc")
         self._adjoint_unit(s, [(g_stem, 1, 0)])
 
-    def _gather(self, out, g_fw, g_fb):
+    def _gather(self, out, g_fw, g_fb, first_order=False):
         """All parameter gradients into the flat vector (weight-gradient slabs summed on the way)."""
-        tensors, perms, splits = self._pack_args()
+        tensors, perms, splits = self._pack_args(first_order)
         tensors = list(tensors)
         if g_fw.dim() == 3:  # the head kernel's per-workgroup partial sums: slabs for hf_pack_ex
             splits = dict(splits)
@@ -1098,7 +1193,8 @@ class FusedGGNEngine(_Operator):
         return out
 
     def _grouping(self):
-        return os.environ.get("HF_ENGINE_GROUP", "1") != "0"
+        # (Hessian products carry extra terms per unit: the plain one-unit launches)
+        return os.environ.get("HF_ENGINE_GROUP", "1") != "0" and not self.hessian
 
     def _head_fused(self, hw, v_fw):
         """Whether ``hf_linear_ce_head`` applies: closed-form softmax-CE Hessian, a 1x1 final map
@@ -1135,6 +1231,11 @@ class FusedGGNEngine(_Operator):
                         splits[u.pw] = (u.sW, u.wbuf.shape[1])
                     else:
                         splits.pop(u.pw, None)
+                if u.pg is not None and u.gw_rows != u.rb:
+                    if u.rb > 1:
+                        splits[u.pg] = (u.rb, u.cout)
+                    else:
+                        splits.pop(u.pg, None)
             return tensors, perms, splits
         if getattr(self, "_pack", None) is None:
             tensors, perms, splits = [None] * len(self.params), {}, {}
@@ -1149,11 +1250,11 @@ class FusedGGNEngine(_Operator):
                             self._pack_live[u.pw] = u.live
                 if u.nW > 1:
                     splits[u.pw] = (u.nW, u.wbuf.shape[1])
-                for pi, buf in ((u.pg, u.gw), (u.pb, u.gb)):
+                for pi, buf, rows in ((u.pg, u.gw, u.gw_rows), (u.pb, u.gb, u.rb)):
                     if pi is not None:
                         tensors[pi] = buf[0]
-                        if u.rb > 1:
-                            splits[pi] = (u.rb, u.cout)
+                        if rows > 1:
+                            splits[pi] = (rows, u.cout)
             self._pack = (tensors, perms, splits)
         return self._pack
 
@@ -1310,7 +1411,8 @@ class FusedGGNEngine(_Operator):
         """First product of every (model, shape) signature against the autograd operator, both on the
         activations the model's own forward pass recorded (``_load_recorded``)."""
         policy = os.environ.get("HF_ENGINE_VERIFY", "first")
-        key = (id(self.model_ref), tuple(type(m).__name__ for m in self.model_ref.modules()), self.n,
+        key = ("hessian" if self.hessian else "ggn", id(self.model_ref),
+               tuple(type(m).__name__ for m in self.model_ref.modules()), self.n,
                tuple(tuple(p.shape) for p in self.params), tuple(self.logits.shape), tuple(self.x_in.shape),
                str(self.dev))
         if policy == "never" or (policy != "always" and key in FusedGGNEngine._verified):
@@ -1320,6 +1422,8 @@ class FusedGGNEngine(_Operator):
         weight, self.weight = self.weight, 1.0
         self._load_recorded(self.outputs)
         try:
+            if self.hessian:
+                self.gradient()  # first-order cotangents at the recorded activations
             got = self.local(v).clone()
         finally:
             self.weight = weight
@@ -1327,10 +1431,17 @@ class FusedGGNEngine(_Operator):
                 self.forward_own()  # back to the engine's own activations
             elif self.train_own:
                 self.forward_own(update_running=False)
-        want = GGNOperator(loss, self.outputs, self.params).local(v)
+            if self.hessian:
+                self.gradient()
+        if self.hessian:
+            from .curvature import HessianOperator
+
+            want = HessianOperator(loss, self.params).local(v)
+        else:
+            want = GGNOperator(loss, self.outputs, self.params).local(v)
         err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
         if not err < FusedGGNEngine.verify_tol:
-            exc = _Unsupported(f"engine product differs from the autograd product by {err:.2e} "
+            exc = _Unsupported(f"engine {'Hessian ' if self.hessian else ''}product differs from the autograd product by {err:.2e} "
                                f"(tolerance {FusedGGNEngine.verify_tol:.1e}); using the autograd operator")
             exc.loud = True
             raise exc
@@ -1529,38 +1640,6 @@ class PlainStackEngine(FusedGGNEngine):
         FusedGGNEngine._loss_setup(self, loss, outputs)
         if self.loss_spec is None:
             raise _Unsupported("the plain-stack engine needs a plain softmax cross-entropy loss")
-        if self.hessian:
-            self.gradient()  # fills the first-order cotangents the Hessian products read
-
-    def _verify(self, loss):
-        if not self.hessian:
-            return FusedGGNEngine._verify(self, loss)
-        from .curvature import HessianOperator
-
-        policy = os.environ.get("HF_ENGINE_VERIFY", "first")
-        key = ("hessian", id(self.model_ref), self.n, tuple(tuple(p.shape) for p in self.params),
-               tuple(self.x_in.shape), str(self.dev))
-        if policy == "never" or (policy != "always" and key in FusedGGNEngine._verified):
-            return
-        gen = torch.Generator(device=self.dev).manual_seed(4321)
-        v = torch.randn(self.n, device=self.dev, generator=gen)
-        weight, self.weight = self.weight, 1.0
-        self._load_recorded(self.outputs)
-        try:
-            self.gradient()  # first-order cotangents at the recorded activations
-            got = self.local(v).clone()
-        finally:
-            self.weight = weight
-            self.forward_own()
-            self.gradient()
-        want = HessianOperator(loss, self.params).local(v)
-        err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
-        if not err < FusedGGNEngine.verify_tol:
-            exc = _Unsupported(f"engine Hessian product differs from the autograd product by {err:.2e} "
-                               f"(tolerance {FusedGGNEngine.verify_tol:.1e}); using the autograd operator")
-            exc.loud = True
-            raise exc
-        FusedGGNEngine._verified.add(key)
 
 
 class _Unsupported(Exception):

@@ -348,6 +348,8 @@ class HessianFree(torch.optim.Optimizer):
                 return None, None
         if sess is None:
             return None, None
+        if getattr(sess, "mode_pending", False):  # (data parallel, once: single graph or chunked all-reduce)
+            sess.choose_product_mode()
         sess.base_loss = self._reduce_scalar(b)
         return sess, self._reduce_scalar(a)
 

@@ -71,7 +71,7 @@ class _TwoPhaseProduct:
         engine is left as it was: single graph, single compact / plain all-reduce)."""
         if tail_fraction is None:
             tail_fraction = float(os.environ.get("HF_CHUNK_TAIL", "0.7"))
-        if os.environ.get("HF_CHUNKED_ALLREDUCE", "1") == "0" or not hasattr(eng, "phase_split"):
+        if os.environ.get("HF_CHUNKED_ALLREDUCE", "auto") == "0" or not hasattr(eng, "phase_split"):
             return None
         if getattr(eng, "hessian", False) or getattr(eng, "train_bn", False):
             return None
@@ -197,9 +197,8 @@ class EngineSession(_TwoPhaseProduct):
             eng.refresh_weights(transposed=True)
             eng.forward_own(update_running=False)
             eng.gradient(self.grad_buffer)
-            if self.split is None:
-                eng.local(self.input_buffer, out=self.output_buffer)
-            else:
+            eng.local(self.input_buffer, out=self.output_buffer)
+            if self.split is not None:
                 for _ in range(2):
                     self._phase_a()
                     self._phase_b()
@@ -213,11 +212,13 @@ class EngineSession(_TwoPhaseProduct):
             self.g_fwd_still = (self._capture(lambda: eng.forward_own(refresh=True, update_running=False))
                                 if eng.train_bn else self.g_fwd)
             self.g_grad = self._capture(lambda: eng.gradient(self.grad_buffer))
-            if self.split is None:
-                self.graph = self._capture(lambda: eng.local(self.input_buffer, out=self.output_buffer), keep=True)
-            else:
-                self.graph = None
+            # (always the single product graph; under data parallelism also the two-phase pair, and
+            # ``choose_product_mode`` keeps whichever is faster with THIS communicator on THIS machine)
+            self.graph = self._capture(lambda: eng.local(self.input_buffer, out=self.output_buffer), keep=True)
+            self._split_plan = self.split
+            if self.split is not None:
                 self._capture_phases()
+        self.mode_pending = self.split is not None and os.environ.get("HF_CHUNKED_ALLREDUCE", "auto") == "auto"
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
         self.calls = 0
@@ -323,22 +324,56 @@ class EngineSession(_TwoPhaseProduct):
 
     # ---- operator interface of cg() (see curvature.GraphedOperator) -------------------------
     def raw_graph(self):
-        # (two graphs under data parallelism: cg() then fuses K1-K3 only, which needs no product graph)
-        return self.graph.raw_cuda_graph() if self.graph is not None else None
+        return self.graph.raw_cuda_graph()
 
     def replay_local(self):
-        if self.graph is not None:
+        if self.split is None:
             self.graph.replay()
         else:
             self.replay_phases()
 
     def replay_and_reduce(self):
         """One product over all ranks: ``input_buffer`` -> summed product in ``output_buffer``."""
-        if self.graph is not None:
+        if self.split is None:
             self.graph.replay()
             self.engine.reduce(self.output_buffer, self.group)
         else:
             self.reduce_phases()
+
+    def choose_product_mode(self, reps=8):
+        """Data parallel, ``HF_CHUNKED_ALLREDUCE=auto`` (default): time a few products with the single graph +
+        one compact all-reduce and with the two-phase chunked / overlapped all-reduce -- on THIS communicator,
+        THIS machine -- and keep the faster (two-phase only if it gains >= 3 %).  The chunked form hides most of
+        the all-reduce behind the sweep but costs a graph launch, a stream hand-over and a gather more; which
+        wins depends on the link (measured on one MI355X with a 1-rank RCCL group: single 1 438-1 452 matvecs/s,
+        two-phase 1 296; projected at 8 GPUs over xGMI: two-phase).  COLLECTIVE: every rank
+        of the group must call it at the same point (``HessianFree`` does, after the ranks have agreed to use
+        the session); all ranks reach the same decision (MAX all-reduce of the timings)."""
+        import time
+
+        self.mode_pending = False
+        if self._split_plan is None or self.group is None:
+            return self.split is not None
+        dist = torch.distributed
+        sync = torch.zeros(2, dtype=torch.float64, device=self.engine.dev)
+        times = []
+        for two in (False, True):
+            self.split = self._split_plan if two else None
+            for _ in range(3):
+                self.replay_and_reduce()
+            dist.all_reduce(sync, group=self.group)  # (every rank starts the timed replays together)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                self.replay_and_reduce()
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) / reps)
+        t = torch.tensor(times, dtype=torch.float64, device=self.engine.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        single, two_phase = t.tolist()
+        self.mode_timing = {"single_graph_ms": single * 1e3, "two_phase_ms": two_phase * 1e3}
+        self.split = self._split_plan if two_phase < 0.97 * single else None
+        return self.split is not None
 
     def reduce(self, t):
         return self.engine.reduce(t, self.group)

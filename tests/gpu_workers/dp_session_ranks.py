@@ -10,7 +10,8 @@ curvature is a plain sum over samples, so shards of 16 + 16 equal one batch of 3
 
     RANK=r WORLD_SIZE=W MASTER_ADDR=127.0.0.1 MASTER_PORT=p python dp_session_ranks.py <outdir> [mode] [backend]
 
-mode: ``steps`` (default) | ``asym`` (rank 1's session creation is forced to fail on the first step: every
+mode: ``steps`` (default; the two-phase product forced) | ``auto`` (the session's measured choice between the
+single-graph and the two-phase product) | ``asym`` (rank 1's session creation is forced to fail on the first step: every
 rank must fall back together) | ``die`` (the last rank exits mid-run: the others must not hang
 for good -- used through bench.py's launcher test instead).
 """
@@ -41,6 +42,8 @@ N_STEPS = 2
 
 def main(outdir, mode="steps", backend="gloo"):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if mode != "auto":  # (the two-phase product is what these runs are about; "auto": the measured choice)
+        os.environ.setdefault("HF_CHUNKED_ALLREDUCE", "1")
     torch.cuda.set_device(0)
     import datetime
 
@@ -99,6 +102,8 @@ def main(outdir, mode="steps", backend="gloo"):
             from pytorchhessianfree_amd import distributed as hfdist
 
             out["reduce_bytes"] = np.array([sess.reduce_bytes, 4 * sess.n])
+            timing = getattr(sess, "mode_timing", None)
+            out["mode_timing"] = np.array([timing["single_graph_ms"], timing["two_phase_ms"]] if timing else [0.0, 0.0])
             out["comm_path"] = np.array([hfdist.path_name(sess.output_buffer, group)])
             out["side_comm"] = np.array([int(hfdist.side_comm(sess.output_buffer, group) is not None)])
             # the session's product over all ranks against the plain all-reduce of the local products

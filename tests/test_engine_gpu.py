@@ -211,6 +211,91 @@ def test_allcnnc_engine_hessian_product_matches_float64_and_cpu_oracle(l2):
     assert abs(float(op.loss_buf) - float(closs)) <= 1e-6 * abs(float(closs))
 
 
+@pytest.mark.parametrize("batch", [32, 6])
+def test_resnet18_engine_hessian_product_matches_float64_and_cpu_oracle(batch):
+    """The HESSIAN product (``curvature_opt="hessian"``, reference optimizer.py:450-455) of the ResNet-18 of
+    examples/run_resnet18_mnist.py with eval-mode BatchNorm on the fused engine: forward-over-reverse on the own
+    kernels -- per unit the plain stack's ``conv_D(g, V)`` / ``conv_W(t_x, g)`` plus the BatchNorm scale's own
+    second-order terms, residual adds, the max-pool and the linear head.  Against float64 autograd double-backward
+    of the STOCK model on the engine's ReLU / pooling decisions (2e-6 max-norm relative), against the CPU oracle
+    (BackPACK's ``hessian_vector_product`` restated: 1e-5), bitwise repeatable, symmetric."""
+    from oracle import backpack_restated as bp
+    from pytorchhessianfree_amd.utils import vector_to_parameter_list
+
+    seed = tp.RESNET18_B32_SEPARATED_SEEDS[0]
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=batch, device=DEV, data_seed=seed)
+    modelprep.prepare_model(model, channels_last=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    op = curvature.hessian_operator(lossf(out, t), out, params)
+    assert isinstance(op, FusedGGNEngine) and op.hessian and type(op) is FusedGGNEngine
+    v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(13))
+    got = op(v).clone()
+    for _ in range(2):
+        assert torch.equal(op(v), got)
+    masks = [(u.y > 0) for u in op.units if u.relu]
+    m64, (x64, t64), l64 = tp.resnet18_mnist(batch_size=batch, device=DEV, data_seed=seed)
+    m64 = m64.double()
+    _replay_relu_decisions(m64, masks)
+    p64 = [p for p in m64.parameters() if p.requires_grad]
+    want = curvature.HessianOperator(l64(m64(x64.double()), t64), p64)(v.double())
+    err = float((got.double() - want).abs().max() / want.abs().max())
+    worst, off = [], 0
+    for name, p in model.named_parameters():
+        a, b = got[off:off + p.numel()].double(), want[off:off + p.numel()]
+        worst.append((float((a - b).abs().max() / want.abs().max()), name))
+        off += p.numel()
+    assert err < 2e-6, (err, sorted(worst, reverse=True)[:6])
+    u = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(14))
+    a, b = float(u.double() @ got.double()), float(v.double() @ op(u).double())
+    assert abs(a - b) <= 1e-5 * abs(a)
+    cm, (cx, ct), cl = tp.resnet18_mnist(batch_size=batch, device="cpu", data_seed=seed)
+    cp = [p for p in cm.parameters() if p.requires_grad]
+    closs = cl(cm(cx), ct)
+    ref = torch.cat([g.reshape(-1) for g in bp.hessian_vector_product(closs, cp, vector_to_parameter_list(v.cpu(), cp))])
+    assert float((got.cpu() - ref).abs().max() / ref.abs().max()) < 1e-5
+    grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(closs, cp)])
+    assert float((op.gradient().cpu() - grad).abs().max() / grad.abs().max()) < 2e-6
+    # the GGN product of the same engine family is untouched by the Hessian bookkeeping
+    out2 = model(x)
+    ggn = curvature.ggn_operator(lossf(out2, t), out2, params)
+    assert isinstance(ggn, FusedGGNEngine) and not ggn.hessian
+
+
+def test_resnet18_hessian_step_through_the_session_matches_cpu_path():
+    """One default ``HessianFree.step()`` with ``curvature_opt="hessian"`` on the ResNet-18 workload through the
+    persistent session over the Hessian engine, against the CPU path (stock model, double backward, oracle PCG):
+    initial loss 1e-5, damping / learning rate / reason identical, iterations +-2, final loss 1e-4."""
+    from oracle import pcg as oracle
+
+    seed = tp.RESNET18_B32_SEPARATED_SEEDS[0]
+    res = {}
+    for dev in ("cpu", DEV):
+        model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device=dev, data_seed=seed)
+        if dev != "cpu":
+            modelprep.prepare_model(model, channels_last=True)
+        opt = hf.HessianFree(model.parameters(), curvature_opt="hessian", graph_matvec=(dev != "cpu"))
+        if dev == "cpu":
+            opt._cg = oracle.pcg
+
+        def forward():
+            o = model(x)
+            return lossf(o, t), o
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            final = opt.step(forward)
+        if dev != "cpu":
+            assert opt._session is not None and opt._session.engine.hessian
+        res[dev] = (opt.state, final)
+    (sc, fc), (sg, fg) = res["cpu"], res[DEV]
+    assert abs(sg["init_losses"][0] - sc["init_losses"][0]) <= 1e-5 * abs(sc["init_losses"][0])
+    assert sg["dampings"] == sc["dampings"] and sg["learning_rates"] == sc["learning_rates"]
+    assert sg["cg_reasons"] == sc["cg_reasons"]
+    assert abs(sg["num_cg_iters"][0] - sc["num_cg_iters"][0]) <= 2
+    assert abs(fg - fc) <= 1e-4 * abs(fc)
+
+
 def test_train_mode_batchnorm_engine_product_matches_cpu_oracle_and_float64():
     """What ``examples/run_resnet18_mnist.py:19-35`` actually runs -- no ``model.eval()``: BatchNorm normalises
     with BATCH statistics and the GGN couples the samples.  The engine takes such a model (single GPU): tangent

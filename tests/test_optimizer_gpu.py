@@ -844,14 +844,18 @@ def test_resnet18_newton_solve_matches_reference_cpu_path(mode):
 
 
 
+@pytest.mark.parametrize("path", ["engine", "autograd"])
 @pytest.mark.parametrize("lam", [1.0, 0.01])
-def test_config4_allcnnc_hessian_diag_fisher_solve_matches_reference_cpu_path(lam):
+def test_config4_allcnnc_hessian_diag_fisher_solve_matches_reference_cpu_path(lam, path):
     """BASELINE.json ``configs[3]`` as stated: All-CNN-C, batch 32, ``curvature_opt="hessian"``,
     diagonal empirical-Fisher preconditioner (exponent 0.75) built with the per-sample autograd
     path (preconditioners.py:63-127), cross-entropy + the L2 term of examples/example_utils.py:
     77-81, damping 1.0 (optimizer.py default).  CPU: stock model, BackPACK's published Hessian
     product (oracle), the reference's preconditioner re-evaluated per call, reference-order PCG.
-    GPU: prepared model, hipGraph Hessian product, ``HF_M_DIAG`` kernels.  Stated fp32
+    GPU: prepared model, hipGraph Hessian product, ``HF_M_DIAG`` kernels -- ``path="engine"``: NHWC, the
+    plain-stack engine's forward-over-reverse on own kernels (what ``bench.py --workload allcnnc --curvature
+    hessian`` times), equal iteration count and a bitwise second solve demanded; ``path="autograd"``: NCHW,
+    double backward over MIOpen (``curvature.HessianOperator``).  Stated fp32
     tolerance: gradient and diagonal 1e-5; iterates k <= 10 rel-l2 1e-4; m_k rel 1e-4; same
     termination reason; iteration count +-1; non-positive-curvature warnings in the same
     iterations.  Damping 0.01 makes H + damping*I indefinite on this random-init net: CG then
@@ -890,7 +894,7 @@ def test_config4_allcnnc_hessian_diag_fisher_solve_matches_reference_cpu_path(la
                       if "Directional curvature" in str(w.message))
 
     gm, (gx_, gt_), glossf0 = tp.allcnnc_cifar100(batch_size=B, device=DEV)
-    modelprep.prepare_model(gm)
+    modelprep.prepare_model(gm, channels_last=(path == "engine"))
     glossf = tp.l2_regularized(glossf0, gm, l2)
     gp = list(gm.parameters())
     ggrad = curvature.flatten_into(torch.autograd.grad(glossf(gm(gx_), gt_), gp), gp)
@@ -902,12 +906,24 @@ def test_config4_allcnnc_hessian_diag_fisher_solve_matches_reference_cpu_path(la
 
     def builder():
         o = gm(gx_)
+        if path == "engine":
+            return curvature.hessian_operator(glossf(o, gt_), o, gp)
         return curvature.HessianOperator(glossf(o, gt_), gp)
 
     op = curvature.maybe_graphed(builder, params=gp)
+    if path == "engine":
+        from pytorchhessianfree_amd.engine import PlainStackEngine
+
+        assert isinstance(op.op, PlainStackEngine) and op.op.hessian and "engine" in op.mode
     with warnings.catch_warnings(record=True) as wg:
         warnings.simplefilter("always")
         gx, gmm, greason = hf.cg(hf.DampedCurvature(op, lam), -ggrad, M=M, **kw)
+    if path == "engine":  # own kernels only: the solve is bitwise repeatable
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            gx2, gmm2, greason2 = hf.cg(hf.DampedCurvature(op, lam), -ggrad, M=M, **kw)
+        assert greason2 == greason and len(gx2) == len(gx) and torch.equal(gx2[-1], gx[-1])
+        assert all(float(a) == float(b) for a, b in zip(gmm, gmm2))
     g_nonpos = sorted(str(w.message).split("iteration ")[1].split(".")[0] for w in wg
                       if "Directional curvature" in str(w.message))
     diag_msg = (greason, oreason, len(gx), len(ox), g_nonpos, o_nonpos)
@@ -915,7 +931,7 @@ def test_config4_allcnnc_hessian_diag_fisher_solve_matches_reference_cpu_path(la
     assert k > 3, diag_msg
     if definite:
         assert greason == oreason, diag_msg
-        assert abs(len(gx) - len(ox)) <= 1, diag_msg
+        assert abs(len(gx) - len(ox)) <= (0 if path == "engine" else 1), diag_msg
         assert g_nonpos == o_nonpos == [], diag_msg
         last, tol = min(k, 11), 1e-4
     else:
@@ -1120,3 +1136,46 @@ def test_deterministic_mode_products_are_bitwise_repeatable():
     ro = ref_model(x.double())
     want = curvature.GGNOperator(lossf(ro, t), ro, rp)(v.double())
     assert float((first.double() - want).abs().max() / want.abs().max()) < 2e-6
+
+
+def test_config4_default_step_with_diag_fisher_on_the_hessian_engine_matches_cpu_host_logic():
+    """BASELINE configs[3] through the drop-in API: ONE default ``HessianFree.step(forward, M_func=diag-EF)`` on
+    All-CNN-C (+ L2) with ``curvature_opt="hessian"`` -- on the GPU the persistent session over
+    ``PlainStackEngine(hessian=True)`` with the preconditioner fused into K2 / K3 -- against the CPU host logic
+    (stock model, double backward, ``M_func`` re-evaluated per call) with the oracle PCG.  Stated tolerance: initial
+    loss 1e-5, damping / learning rate / reason identical, iteration count +-1, final loss 1e-4, step direction
+    (parameter change) cosine > 0.999."""
+    from oracle import pcg as oracle
+    from pytorchhessianfree_amd import modelprep
+    from pytorchhessianfree_amd.engine import PlainStackEngine
+
+    res = {}
+    for dev in ("cpu", DEV):
+        model, (x, t), lossf0 = tp.allcnnc_cifar100(batch_size=32, device=dev, data_seed=21)
+        lossf = tp.l2_regularized(lossf0, model, 5e-4)
+        if dev != "cpu":
+            modelprep.prepare_model(model, channels_last=True)
+        opt = hf.HessianFree(model.parameters(), curvature_opt="hessian", graph_matvec=(dev != "cpu"))
+        if dev == "cpu":
+            opt._cg = oracle.pcg
+        before = trainable_vec(model).detach().cpu().clone()
+
+        def forward():
+            out = model(x)
+            return lossf(out, t), out
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            M = opt.get_preconditioner(model, lossf, x, t, "mean", use_backpack=False)
+            final = opt.step(forward, M_func=M)
+        if dev != "cpu":
+            assert opt._session is not None and isinstance(opt._session.engine, PlainStackEngine)
+            assert opt._session.engine.hessian
+        res[dev] = (opt.state, final, trainable_vec(model).detach().cpu() - before)
+    (sc, fc, dc), (sg, fg, dg) = res["cpu"], res[DEV]
+    assert abs(sg["init_losses"][0] - sc["init_losses"][0]) <= 1e-5 * abs(sc["init_losses"][0])
+    assert sg["dampings"] == sc["dampings"] and sg["learning_rates"] == sc["learning_rates"]
+    assert sg["cg_reasons"] == sc["cg_reasons"]
+    assert abs(sg["num_cg_iters"][0] - sc["num_cg_iters"][0]) <= 1
+    assert abs(fg - fc) <= 1e-4 * abs(fc)
+    assert float(dg @ dc / (dg.norm() * dc.norm())) > 0.999

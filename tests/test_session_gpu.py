@@ -243,3 +243,127 @@ def test_train_mode_batchnorm_session_equals_generic_path():
     assert float((ra - rb).abs().max()) <= 0.25 * float(rb.abs().max())
     va, vb = ma.layers[4].bn1.running_var, mb.layers[4].bn1.running_var
     assert float((va - vb).abs().max()) <= 0.25 * float(vb.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Sessions of the other engine families the bench reports: All-CNN-C GGN, All-CNN-C
+# Hessian + L2 + diagonal empirical-Fisher preconditioner (BASELINE configs[3]), the Bottleneck net
+# ---------------------------------------------------------------------------------------------------------
+def _run_family(make, device, steps, curv="ggn", l2=0.0, precond=False, seeds=(11, 12, 13), cg_max_iter=250, **mk):
+    """``steps`` default ``HessianFree.step()`` calls on fresh batches.  GPU: prepared NHWC model, persistent
+    session.  CPU: stock model, torch autograd, host logic with the oracle PCG (reference order)."""
+    from oracle import pcg as oracle
+
+    model, _, lossf = make(device=device, data_seed=seeds[0], **mk)
+    if l2:
+        lossf = tp.l2_regularized(lossf, model, l2)
+    if device != "cpu":
+        modelprep.prepare_model(model, channels_last=True)
+    opt = hf.HessianFree(model.parameters(), curvature_opt=curv, graph_matvec=(device != "cpu"),
+                         cg_max_iter=cg_max_iter)
+    if device == "cpu":
+        opt._cg = oracle.pcg
+    finals = []
+    for i in range(steps):
+        _, (x, t), _ = make(device=device, data_seed=seeds[i], **mk)
+
+        def forward():
+            out = model(x)
+            return lossf(out, t), out
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            M = opt.get_preconditioner(model, lossf, x, t, "mean", use_backpack=False) if precond else None
+            finals.append(opt.step(forward, M_func=M))
+    return opt, finals
+
+
+def _compare_family(gpu, g_final, cpu, c_final, loss_tol=1e-5, final_tol=1e-4, iters=2):
+    sg, sc = gpu.state, cpu.state
+    for a, b in zip(sg["init_losses"], sc["init_losses"]):
+        assert abs(a - b) <= loss_tol * abs(b), (sg["init_losses"], sc["init_losses"])
+    assert sg["cg_reasons"] == sc["cg_reasons"]
+    assert sg["learning_rates"] == sc["learning_rates"]
+    assert sg["dampings"] == sc["dampings"]
+    for a, b in zip(sg["num_cg_iters"], sc["num_cg_iters"]):
+        assert abs(a - b) <= iters, (sg["num_cg_iters"], sc["num_cg_iters"])
+    for a, b in zip(g_final, c_final):
+        assert abs(a - b) <= final_tol * abs(b), (g_final, c_final)
+
+
+def test_allcnnc_ggn_session_steps_match_reference_cpu_path():
+    """All-CNN-C / CIFAR-100 shapes (N = 1 387 108), GGN: three default steps on fresh batches through the
+    plain-stack engine's persistent session against the CPU path.  Stated tolerance: initial losses 1e-5,
+    learning rates / damping schedule / reasons identical, iteration counts +-2, final losses 1e-4."""
+    from pytorchhessianfree_amd.engine import PlainStackEngine
+
+    gpu, g_final = _run_family(tp.allcnnc_cifar100, DEV, 3, batch_size=32)
+    assert gpu._session is not None and gpu._session.steps == 3
+    assert isinstance(gpu._session.engine, PlainStackEngine) and not gpu._session.engine.hessian
+    cpu, c_final = _run_family(tp.allcnnc_cifar100, "cpu", 3, batch_size=32)
+    _compare_family(gpu, g_final, cpu, c_final)
+
+
+def test_allcnnc_hessian_l2_preconditioned_session_steps_match_reference_cpu_path():
+    """BASELINE configs[3] as stated -- All-CNN-C, ``curvature_opt="hessian"``, the L2 term of
+    examples/example_utils.py:77-81, diagonal empirical-Fisher preconditioner (exponent 0.75, per-sample autograd
+    path, rebuilt per step at the current damping) -- three default steps through the Hessian engine's session
+    (``PlainStackEngine(hessian=True)``, ``HF_M_DIAG`` kernels inside the one-launch iteration graph) against the
+    CPU path (double backward of the stock model, ``M_func`` re-evaluated per call, oracle PCG).  Same
+    tolerances; iteration counts +-2."""
+    from pytorchhessianfree_amd.engine import PlainStackEngine
+
+    kw = dict(curv="hessian", l2=5e-4, precond=True, batch_size=32)
+    gpu, g_final = _run_family(tp.allcnnc_cifar100, DEV, 3, **kw)
+    assert gpu._session is not None and gpu._session.steps == 3
+    assert isinstance(gpu._session.engine, PlainStackEngine) and gpu._session.engine.hessian
+    cpu, c_final = _run_family(tp.allcnnc_cifar100, "cpu", 3, **kw)
+    _compare_family(gpu, g_final, cpu, c_final)
+
+
+def test_bottleneck_net_session_steps_match_reference_cpu_path():
+    """The Bottleneck (ResNet-50 topology, N = 25 557 032) net on 32x32 images, batch 4: two default steps through
+    the session against the CPU path.  A deep random-init net: a handful of its pre-activations lie within fp32
+    rounding of zero, so from the second step on the two fp32 trajectories differ like any
+    two fp32 runs: initial losses 1e-5 / 1e-4, iteration counts +-3, final losses 1e-3; learning rates, damping
+    schedule and reasons identical."""
+    kw = dict(batch_size=4, image=32)
+    gpu, g_final = _run_family(tp.resnet50_small_images, DEV, 2, **kw)
+    assert gpu._session is not None and gpu._session.steps == 2
+    cpu, c_final = _run_family(tp.resnet50_small_images, "cpu", 2, **kw)
+    assert abs(gpu.state["init_losses"][0] - cpu.state["init_losses"][0]) <= 1e-5 * abs(cpu.state["init_losses"][0])
+    _compare_family(gpu, g_final, cpu, c_final, loss_tol=1e-4, final_tol=1e-3, iters=3)
+
+
+def test_session_is_reverified_against_the_models_own_forward(monkeypatch):
+    """From its second step on the session answers the model's forward pass itself, so the loss cross-check
+    compares the session with itself.  With ``HF_SESSION_VERIFY=1`` (default: every 16th
+    step) the model runs its OWN forward pass and the session must reproduce its logits: a layer changed behind
+    the captured graphs -- here a convolution whose padding is altered after the first step, same shapes, same
+    parameters -- is caught on the next step, the optimizer warns and continues on the generic path."""
+    monkeypatch.setenv("HF_SESSION_VERIFY", "1")
+    model, _, lossf = tp.resnet18_mnist(batch_size=8, device=DEV, data_seed=SEEDS[0])
+    modelprep.prepare_model(model, channels_last=True)
+    opt = hf.HessianFree(model.parameters(), graph_matvec=True, cg_max_iter=6)
+
+    def step(i):
+        _, (x, t), _ = tp.resnet18_mnist(batch_size=8, device=DEV, data_seed=SEEDS[i])
+
+        def forward():
+            out = model(x)
+            return lossf(out, t), out
+
+        return opt.step(forward)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        step(0)
+        step(1)
+    assert opt._session is not None and opt._session.steps == 2  # verified step: still the session
+    # same module, same parameter, same shapes: a dilated 3x3 kernel with matching padding keeps the map size
+    conv = model.layers[1].conv1
+    conv.dilation, conv.padding = (2, 2), (2, 2)
+    with pytest.warns(UserWarning, match="persistent engine session"):
+        final = step(2)
+    assert opt._session is None and opt._session_off
+    assert final < opt.state["init_losses"][-1]
