@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 7
+#define HF_ABI_VERSION 8
 
 enum hf_dtype { HF_F32 = 0, HF_F64 = 1 };
 
@@ -348,6 +348,32 @@ int hf_bn_forward(void* y, void* y2, int64_t y2_ld, void* a_out, const void* a, 
 int hf_bn_train_coeffs(void* q_out, void* r_out, const void* part_x, const void* part_1, int nparts, const void* w,
                        const void* rstd, const void* vq, const void* vr, double count, int64_t c, int dtype,
                        void* stream);
+
+/*
+ * hf_chan_affine_bwd_ex (row-major NHWC fp32 kernel, row_blocks >= 2) and hf_bn_train_coeffs in ONE launch: the
+ * last workgroup to publish its partial sums (ticket word `ticket`: one zero-initialised uint32 per layer, resets
+ * itself) adds all partial rows up in order and writes  q = vq - final_w*rstd*S_x/count,
+ * r = vr - final_w*rstd*S_1/count  (final_w, vq, vr nullable).  One launch less per train-mode BatchNorm layer and
+ * sweep of every curvature product (examples/run_resnet18_mnist.py:19-35 with optimizer.py:457-462).
+ */
+int hf_bn_adjoint_rows_train(void* gx, void* gw, void* gb, void* gres, const void* gy, int gy_splits,
+                             int64_t gy_slab, const void* gy2, int gy2_splits, int64_t gy2_slab, const void* x,
+                             const void* mean, const void* rstd, const void* w, const void* mask_src, int64_t n,
+                             int64_t c, int64_t hw, int row_blocks, void* ticket, void* q_out, void* r_out,
+                             const void* final_w, const void* vq, const void* vr, double count, int dtype,
+                             void* stream);
+
+/*
+ * One-pass batch statistics of a train-mode BatchNorm in the engine's own forward pass (optimizer.py:216-229,
+ * :288-294 on a model in train mode): a_out (nullable) = sum of `splits` slabs of a (split order), per-channel
+ * sum a and sum a^2 in fp64 (`part`: [row_blocks, 2, c] doubles, scratch), finalised by the last workgroup
+ * (`ticket`: zero-initialised uint32, resets itself): mean, rstd = 1/sqrt(E[a^2] - mean^2 + eps), and -- momentum >= 0,
+ * running_mean / running_var not NULL -- the running statistics as torch.nn.BatchNorm2d's forward moves them.
+ * Replaces two reduction launches + two hf_bn_batch_stats launches per layer.
+ */
+int hf_bn_stats_rows(void* a_out, const void* a, int splits, int64_t slab_stride, void* part, void* ticket,
+                     void* mean, void* rstd, void* running_mean, void* running_var, double count, double eps,
+                     double momentum, int64_t rows, int64_t c, int row_blocks, int dtype, void* stream);
 
 /* Elementwise adjoint pre-pass of a fused BatchNorm(+add+ReLU) layer, NHWC [rows, c]:
  *   g = (sum of gy_a's slabs + sum of gy_b's slabs) * [mask_src > 0];  g_out = g (nullable);

@@ -1480,6 +1480,134 @@ __global__ __launch_bounds__(BLOCK) void k_bn_adjoint_rows(
                        rows_per_block, blockIdx.x, red);
 }
 
+// ---- train-mode BatchNorm: the per-channel finalisation inside the reduction's launch -----------------------
+// Every block publishes its partial row, draws a ticket; the LAST arriver re-reads all rows (agent-scope loads,
+// fixed order: the same sums whichever block comes last) and writes the per-channel result.  The ticket word
+// resets itself.  Replaces one tiny dependent launch (hf_bn_train_coeffs / hf_bn_batch_stats) per layer and sweep.
+__device__ __forceinline__ bool last_block_arrives(unsigned* ticket, unsigned* s_last) {
+  __threadfence();  // publish this block's partial sums (agent scope)
+  __syncthreads();
+  if (threadIdx.x == 0) *s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+  __syncthreads();
+  if (!*s_last) return false;
+  __threadfence();  // acquire the other blocks' partial sums
+  return true;
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct TrainFinal {
+  unsigned* ticket;
+  float *q_out, *r_out;
+  const float *fw, *vq, *vr;  // the layer's scale (nullable: 1) and the parameter tangents (nullable)
+  float inv_m;
+};
+
+// k_bn_adjoint_rows + hf_bn_train_coeffs in one launch (q = vq - w*rstd*S_x/m, r = vr - w*rstd*S_1/m).
+__global__ __launch_bounds__(BLOCK) void k_bn_adjoint_rows_train(
+    float* __restrict__ gx, float* gw, float* gb, float* __restrict__ gres,
+    const float* __restrict__ gy, int s1, long long l1, const float* __restrict__ gy2, int s2, long long l2,
+    const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ w, const float* __restrict__ mask_src, unsigned rows, unsigned C,
+    unsigned rows_per_block, const TrainFinal f) {
+  __shared__ double red[BLOCK * 8];
+  __shared__ unsigned s_last;
+  bn_adjoint_rows_body(gx, gw, gb, gres, gy, s1, l1, gy2, s2, l2, x, mean, rstd, w, mask_src, rows, C,
+                       rows_per_block, blockIdx.x, red);
+  if (!last_block_arrives(f.ticket, &s_last)) return;
+  for (unsigned c = threadIdx.x; c < C; c += BLOCK) {
+    double sx = 0.0, sone = 0.0;
+    for (unsigned p = 0; p < gridDim.x; ++p) {
+      sx += (double)ld_agent(gw + (size_t)p * C + c);
+      sone += (double)ld_agent(gb + (size_t)p * C + c);
+    }
+    const float k = (f.fw ? f.fw[c] : 1.f) * rstd[c] * f.inv_m;
+    f.q_out[c] = (f.vq ? f.vq[c] : 0.f) - k * (float)sx;
+    f.r_out[c] = (f.vr ? f.vr[c] : 0.f) - k * (float)sone;
+  }
+  if (threadIdx.x == 0) *f.ticket = 0u;
+}
+
+// One-pass batch statistics of a train-mode BatchNorm's forward: sums the convolution's split-K slabs into
+// a_out (row-major walk as k_bn_adjoint_rows), per-channel sum a and sum a^2 in fp64 per thread / block /
+// (last block) over the blocks; then mean, biased variance = E[a^2] - mean^2 (fp64: 1e-16 * mean^2/var relative,
+// far below fp32 for any layer a network can train), rstd, and -- momentum >= 0 -- the running statistics as
+// torch.nn.BatchNorm2d's forward moves them.  part: [gridDim.x, 2, C] doubles.
+__global__ __launch_bounds__(BLOCK) void k_bn_stats_rows(
+    float* __restrict__ a_out, const float* __restrict__ a, int splits, long long slab, double* part,
+    unsigned* ticket, float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
+    float* __restrict__ run_var, double count, float eps, float momentum, unsigned rows, unsigned C,
+    unsigned rows_per_block) {
+  struct alignas(16) Col { float e[4]; };
+  __shared__ double red[BLOCK * 8];
+  __shared__ unsigned s_last;
+  const unsigned quads = C / 4, RP = BLOCK / quads;
+  const unsigned tx = threadIdx.x % quads, ty = threadIdx.x / quads;
+  const unsigned c0 = tx * 4;
+  const bool live = ty < RP;
+  double acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+  const unsigned row_lo = blockIdx.x * rows_per_block;
+  const unsigned row_hi = row_lo + rows_per_block < rows ? row_lo + rows_per_block : rows;
+  if (live) {
+    for (unsigned r = row_lo + ty; r < row_hi; r += RP) {
+      const unsigned idx = r * C + c0;
+      Col v = *reinterpret_cast<const Col*>(a + idx);
+      for (int sp = 1; sp < splits; sp += 8) {  // eight slabs in flight, added in split order
+        Col t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          t[u] = *reinterpret_cast<const Col*>(a + (long long)(sp + u < splits ? sp + u : 0) * slab + idx);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v.e[k] += sp + u < splits ? t[u].e[k] : 0.f;
+      }
+      if (a_out) *reinterpret_cast<Col*>(a_out + idx) = v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc[2 * k] += (double)v.e[k];
+        acc[2 * k + 1] += (double)v.e[k] * (double)v.e[k];
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[(k * RP + ty) * quads + tx] = acc[k];
+  }
+  __syncthreads();
+  for (unsigned idx = threadIdx.x; idx < 8 * quads; idx += BLOCK) {
+    const unsigned k = idx / quads, col = idx - k * quads;
+    double sum = 0.0;
+    for (unsigned t = 0; t < RP; ++t) sum += red[(k * RP + t) * quads + col];  // fixed order over ty
+    part[((size_t)blockIdx.x * 2 + (k & 1)) * C + col * 4 + (k >> 1)] = sum;
+  }
+  if (!last_block_arrives(ticket, &s_last)) return;
+  for (unsigned c = threadIdx.x; c < C; c += BLOCK) {
+    double s = 0.0, sq = 0.0;
+    for (unsigned p = 0; p < gridDim.x; ++p) {
+      s += ld_agent(part + ((size_t)p * 2) * C + c);
+      sq += ld_agent(part + ((size_t)p * 2 + 1) * C + c);
+    }
+    const double m = s / count;
+    double var = sq / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (momentum >= 0.f && run_mean && run_var) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      run_mean[c] = (float)((1.0 - (double)momentum) * (double)run_mean[c] + (double)momentum * (double)(float)m);
+      run_var[c] = (float)((1.0 - (double)momentum) * (double)run_var[c] + (double)momentum * unbiased);
+    }
+  }
+  if (threadIdx.x == 0) *ticket = 0u;
+}
+
 // Two independent layers' adjoints in ONE launch (see k_chan_affine_pair).
 struct BnAdjArgs {
   float *gx, *gw, *gb, *gres;
@@ -2777,6 +2905,51 @@ int hf_chan_affine_bwd_ex(void* gx, void* gw, void* gb, void* gres, const void* 
                                    channels_last, gy_splits, gy_slab, gy2_splits, gy2_slab, row_blocks);
   else
     return HF_ERR_ARG;
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_bn_adjoint_rows_train(void* gx, void* gw, void* gb, void* gres, const void* gy, int gy_splits,
+                             int64_t gy_slab, const void* gy2, int gy2_splits, int64_t gy2_slab, const void* x,
+                             const void* mean, const void* rstd, const void* w, const void* mask_src, int64_t n,
+                             int64_t c, int64_t hw, int row_blocks, void* ticket, void* q_out, void* r_out,
+                             const void* final_w, const void* vq, const void* vr, double count, int dtype,
+                             void* stream) {
+  if (!gy || !gw || !gb || !x || !mean || !rstd || !ticket || !q_out || !r_out || n <= 0 || c <= 0 || hw <= 0 ||
+      gy_splits < 1 || gy2_splits < 1 || row_blocks < 2 || count <= 0.0 || dtype != HF_F32)
+    return HF_ERR_ARG;
+  if (!(c % 4 == 0 && c / 4 <= BLOCK)) return HF_ERR_ARG;
+  if ((gy_splits > 1 && gy_slab <= 0) || (gy2 && gy2_splits > 1 && gy2_slab <= 0)) return HF_ERR_ARG;
+  const int64_t rows = n * hw;
+  if (rows * c > 0x7fffffffLL) return HF_ERR_ARG;
+  if (!aligned16(gy) || (gy2 && !aligned16(gy2)) || !aligned16(x) || (mask_src && !aligned16(mask_src)) ||
+      (gx && !aligned16(gx)) || (gres && !aligned16(gres)))
+    return HF_ERR_ALIGN;
+  const unsigned rpb = (unsigned)((rows + row_blocks - 1) / row_blocks);
+  TrainFinal f{(unsigned*)ticket, (float*)q_out, (float*)r_out, (const float*)final_w, (const float*)vq,
+               (const float*)vr, (float)(1.0 / count)};
+  hipLaunchKernelGGL(k_bn_adjoint_rows_train, dim3((unsigned)row_blocks), dim3(BLOCK), 0, (hipStream_t)stream,
+                     (float*)gx, (float*)gw, (float*)gb, (float*)gres, (const float*)gy, gy_splits,
+                     (long long)gy_slab, (const float*)gy2, gy2_splits, (long long)gy2_slab, (const float*)x,
+                     (const float*)mean, (const float*)rstd, (const float*)w, (const float*)mask_src,
+                     (unsigned)rows, (unsigned)c, rpb, f);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_bn_stats_rows(void* a_out, const void* a, int splits, int64_t slab_stride, void* part, void* ticket,
+                     void* mean, void* rstd, void* running_mean, void* running_var, double count, double eps,
+                     double momentum, int64_t rows, int64_t c, int row_blocks, int dtype, void* stream) {
+  if (!a || !part || !ticket || !mean || !rstd || splits < 1 || (splits > 1 && slab_stride <= 0) || rows <= 0 ||
+      c <= 0 || row_blocks < 1 || count <= 0.0 || dtype != HF_F32)
+    return HF_ERR_ARG;
+  if (!(c % 4 == 0 && c / 4 <= BLOCK) || rows * c > 0x7fffffffLL) return HF_ERR_ARG;
+  if (!aligned16(a) || (a_out && !aligned16(a_out)) || (slab_stride & 3)) return HF_ERR_ALIGN;
+  const unsigned rpb = (unsigned)((rows + row_blocks - 1) / row_blocks);
+  hipLaunchKernelGGL(k_bn_stats_rows, dim3((unsigned)row_blocks), dim3(BLOCK), 0, (hipStream_t)stream,
+                     (float*)a_out, (const float*)a, splits, (long long)slab_stride, (double*)part,
+                     (unsigned*)ticket, (float*)mean, (float*)rstd, (float*)running_mean, (float*)running_var,
+                     count, (float)eps, (float)momentum, (unsigned)rows, (unsigned)c, rpb);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }

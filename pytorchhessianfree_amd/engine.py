@@ -426,7 +426,20 @@ class FusedGGNEngine(_Operator):
     def _bn_forward(self, u, splits, update_running=True):
         n, k, oh, ow = u.a.shape
         res = u.res
-        if u.train:
+        if u.train and u.fold:
+            # ONE pass: the convolution's slabs summed into ``a``, per-channel sum a / sum a^2 in fp64, finalised by
+            # the launch's last workgroup (mean, rstd, running statistics) -- 3 launches per unit instead of 6
+            bn = u.bn
+            move = update_running and bn.track_running_stats
+            _lib.check(_lib.load().hf_bn_stats_rows(
+                _ptr(u.a), _ptr(u.tbuf), splits, u.tbuf.shape[1], _ptr(u.stat_part), _ptr(u.ticket), _ptr(u.mean_t),
+                _ptr(u.rstd), _ptr(bn.running_mean) if move else None, _ptr(bn.running_var) if move else None,
+                float(n * oh * ow), float(bn.eps), float(bn.momentum) if move else -1.0, n * oh * ow, k, u.rb,
+                _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_bn_stats_rows")
+            if move:
+                bn.num_batches_tracked.add_(1)
+            splits = 1  # (``a`` is summed)
+        elif u.train:
             # batch statistics by two passes of the adjoint's reduction kernel over the convolution's output
             # (sum a -> mean; sum a*(a - mean) -> biased variance), each followed by a per-channel finalisation;
             # the first pass also sums the convolution's slabs into ``a``
@@ -684,6 +697,12 @@ class FusedGGNEngine(_Operator):
             u.gw_rows = u.rb * (2 if (self.hessian and u.bn is not None) else 1)
             u.gw = torch.empty((u.gw_rows, k), dtype=f32, device=dev)
             u.gb = torch.empty((u.rb, k), dtype=f32, device=dev)
+            if u.train:
+                # in-launch finalisation of the per-channel sums (hf_bn_adjoint_rows_train / hf_bn_stats_rows): a
+                # self-resetting ticket word and the one-pass statistics' fp64 partial sums
+                u.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+                u.stat_part = torch.empty((u.rb, 2, k), dtype=torch.float64, device=dev)
+                u.fold = u.rb > 1 and os.environ.get("HF_BN_FOLD", "1") != "0"
         # where each unit's output goes besides its own dense buffer: the [t_x | x] operand of its
         # consumer -- the tangent into the first half, the value (forward pass) into the second
         for u in self.units:
@@ -780,7 +799,15 @@ class FusedGGNEngine(_Operator):
         n, k, oh, ow = u.a.shape
         vg = v[self._offs[u.pg]: self._offs[u.pg] + k] if u.pg is not None else None
         vb = v[self._offs[u.pb]: self._offs[u.pb] + k] if u.pb is not None else None
-        if u.train:
+        if u.train and u.fold:
+            # ... reduction and folding in ONE launch (the last workgroup finalises the per-channel vectors)
+            _lib.check(_lib.load().hf_bn_adjoint_rows_train(
+                None, _ptr(u.gw), _ptr(u.gb), None, _ptr(u.tbuf), u.sT, u.tbuf.shape[1], None, 1, 0, _ptr(u.a),
+                _ptr(u.mean), _ptr(u.rstd), None, None, n, k, oh * ow, u.rb, _ptr(u.ticket), _ptr(u.cq), _ptr(u.cr),
+                _ptr(u.scale), _ptr(vg), _ptr(vb), float(n * oh * ow), _lib.HF_F32,
+                _lib.current_stream_ptr(self.dev)), "hf_bn_adjoint_rows_train")
+            vg, vb = u.cq, u.cr
+        elif u.train:
             # batch statistics move with the input: sums of a' and xhat*a' over the batch (the adjoint's
             # reduction kernel on the tangent slabs), folded into the per-channel vectors of the same pass
             lib, st = _lib.load(), _lib.current_stream_ptr(self.dev)
@@ -879,11 +906,18 @@ class FusedGGNEngine(_Operator):
             # pass 1: g = mask * (sum of the cotangents' slabs) and its per-channel sums (the parameter
             # gradients); pass 2: g_a = rstd*w * [g - mean(g) - xhat * mean(xhat*g)] (the batch statistics'
             # share), by the elementwise kernel with the corrections folded into its per-channel vectors
-            _lib.check(lib.hf_chan_affine_bwd_ex(
-                None, _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a), _ptr(u.mean),
-                _ptr(u.rstd), _ptr(u.scale), _ptr(u.y) if u.relu else None, n, k, oh * ow, 1, u.rb, _lib.HF_F32, st),
-                "hf_chan_affine_bwd_ex")
-            self._train_coeffs(u, None, None)
+            if u.fold:  # (pass 1 finalises those vectors itself: its last workgroup)
+                _lib.check(lib.hf_bn_adjoint_rows_train(
+                    None, _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a),
+                    _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.y) if u.relu else None, n, k, oh * ow, u.rb,
+                    _ptr(u.ticket), _ptr(u.cq), _ptr(u.cr), _ptr(u.scale), None, None, float(n * oh * ow),
+                    _lib.HF_F32, st), "hf_bn_adjoint_rows_train")
+            else:
+                _lib.check(lib.hf_chan_affine_bwd_ex(
+                    None, _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a),
+                    _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.y) if u.relu else None, n, k, oh * ow, 1,
+                    u.rb, _lib.HF_F32, st), "hf_chan_affine_bwd_ex")
+                self._train_coeffs(u, None, None)
             _lib.check(lib.hf_chan_affine_ex(
                 _ptr(ga), _ptr(u.g), _ptr(u.a), _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.cq), _ptr(u.cr),
                 None, None, 0, n, k, oh * ow, 1, 0, 0, 1, 0, _lib.HF_F32, st), "hf_chan_affine_ex")

@@ -349,6 +349,55 @@ def test_train_mode_batchnorm_engine_product_matches_cpu_oracle_and_float64():
     assert final < opt.state["init_losses"][0]
 
 
+def test_train_mode_folded_kernels_equal_the_separate_launches():
+    """Train-mode BatchNorm with the per-channel finalisation INSIDE the reduction's launch (last workgroup by
+    ticket: ``hf_bn_adjoint_rows_train``, ``hf_bn_stats_rows``) against the separate reduction + finalisation
+    launches (``HF_BN_FOLD=0`` path): the curvature product is BITWISE the same (same partial sums, same order);
+    the one-pass forward statistics (E[a^2] - mean^2 in fp64 instead of a second pass over a - mean) reproduce
+    logits to 2e-6, batch statistics and moved running statistics to 1e-6 (max-norm relative)."""
+    seed = tp.RESNET18_B32_SEPARATED_SEEDS[2]
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=16, device=DEV, data_seed=seed)
+    model.train()
+    modelprep.prepare_model(model, channels_last=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    op = curvature.ggn_operator(lossf(out, t), out, params)
+    assert isinstance(op, FusedGGNEngine) and op.train_bn and op.train_own
+    folded = [u for u in op.units if u.train and u.fold]
+    assert len(folded) >= 10
+    v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(41))
+    got = op(v).clone()
+    assert torch.equal(op(v), got)
+    for u in folded:
+        u.fold = False
+    assert torch.equal(op(v), got)
+    # forward pass: both variants from the same running statistics
+    saved = [(u.bn.running_mean.clone(), u.bn.running_var.clone(), u.bn.num_batches_tracked.clone()) for u in op.units]
+
+    def restore():
+        for u, (m, var, nb) in zip(op.units, saved):
+            u.bn.running_mean.copy_(m)
+            u.bn.running_var.copy_(var)
+            u.bn.num_batches_tracked.copy_(nb)
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+    op.forward_own(update_running=True)
+    ref = (op.logits.clone(), [(u.mean_t.clone(), u.rstd.clone(), u.bn.running_mean.clone(), u.bn.running_var.clone())
+                               for u in op.units])
+    restore()
+    for u in folded:
+        u.fold = True
+    op.forward_own(update_running=True)
+    assert rel(op.logits, ref[0]) < 2e-6
+    for u, (m, r, rm, rv) in zip(op.units, ref[1]):
+        assert rel(u.mean_t, m) < 1e-6 and rel(u.rstd, r) < 1e-6
+        assert rel(u.bn.running_mean, rm) < 1e-6 and rel(u.bn.running_var, rv) < 1e-6
+    assert int(op.units[0].bn.num_batches_tracked) == int(saved[0][2]) + 1
+    restore()
+
+
 def test_resnet18_engine_product_matches_cpu_oracle_at_batch_32():
     """The engine's product DIRECTLY against the CPU oracle (oracle/backpack_restated.py: BackPACK's
     ``ggn_vector_product_from_plist`` restated; reference call site optimizer.py:457-462) at
