@@ -193,11 +193,22 @@ def load():
     return lib
 
 
+class Refused(RuntimeError):
+    """The library REFUSED its arguments (``HF_ERR_ARG`` / ``HF_ERR_ALIGN`` / ``HF_ERR_CAPACITY``: a geometry,
+    alignment or size it does not cover) -- nothing was launched; callers with another implementation of the same
+    operation may fall back to it.  Any other non-zero status (a HIP launch error, a call-order violation) is a
+    plain ``RuntimeError`` and must not be swallowed."""
+
+
+_REFUSALS = (-1, -2, -5)  # HF_ERR_ARG, HF_ERR_ALIGN, HF_ERR_CAPACITY of include/hf_pcg.h
+
+
 def check(code, what=""):
     if code != 0:
         msg = load().hf_error_string(code)
         msg = msg.decode() if msg else "?"
-        raise RuntimeError(f"libhfpcg {what} failed with code {code}: {msg}")
+        kind = Refused if code in _REFUSALS else RuntimeError
+        raise kind(f"libhfpcg {what} failed with code {code}: {msg}")
 
 
 def dtype_code(dtype):

@@ -36,7 +36,7 @@ def cg_efficient_backtracking(f, steps_list, verbose=False):
     order = [idx for idx in range(len(steps_list) - 1, -1, -1) if steps_list[idx] is not None]
     for pos, idx in enumerate(order):
         if prefetch is not None:
-            prefetch([(steps_list[i], 1.0) for i in order[pos:pos + 2]])
+            prefetch([(steps_list[i], 1.0) for i in order[pos:pos + 2]], needed=1)  # (the second: speculative)
         val = f(steps_list[idx])
         seen[idx] = val
         if val < best_val:

@@ -255,16 +255,31 @@ __global__ __launch_bounds__(BLOCK) void k_init_finalize(DevState* __restrict__ 
 // else (the done flag, the re-reduction of the previous kernel's partials): at small N
 // (All-CNN-C: 5.5 MB vectors, one tile per block) that prologue used to sit in front of
 // the first load and cost more than the streaming itself.
-// (tuning knob, scripts/experiments/k1_variants.sh: HF_K1_NT=1 reads both streams with non-temporal loads)
+// Non-temporal access to streams that are not read again before ~0.5 ms of other traffic has passed (measured,
+// profiles/r04_pcg_nt_variants.jsonl: K1 at N = 100 M 151.8 -> 138.1 us, at N = 11.2 M 17.7 -> 17.2 us).
+// HF_K1_NT: K1's two read streams; HF_K2_NT: K2's x / b / Bp loads and its x store; HF_K3_NT: K3's r load.
 #ifndef HF_K1_NT
-#define HF_K1_NT 0
+#define HF_K1_NT 1
 #endif
-#if HF_K1_NT
-#define HF_K1_LD(dst, ptr)                                                                  \
+#ifndef HF_K2_NT
+#define HF_K2_NT 0
+#endif
+#ifndef HF_K3_NT
+#define HF_K3_NT 0
+#endif
+#define HF_NT_LD(dst, ptr)                                                                  \
   {                                                                                         \
     NV t_ = __builtin_nontemporal_load(reinterpret_cast<const NV*>(ptr));                   \
     __builtin_memcpy(&(dst), &t_, sizeof(NV));                                              \
   }
+#define HF_NT_ST(ptr, src)                                                                  \
+  {                                                                                         \
+    NV t_;                                                                                  \
+    __builtin_memcpy(&t_, &(src), sizeof(NV));                                              \
+    __builtin_nontemporal_store(t_, reinterpret_cast<NV*>(ptr));                            \
+  }
+#if HF_K1_NT
+#define HF_K1_LD(dst, ptr) HF_NT_LD(dst, ptr)
 #else
 #define HF_K1_LD(dst, ptr) (dst) = *(ptr);
 #endif
@@ -329,6 +344,14 @@ __global__ __launch_bounds__(BLOCK) void k_update_xr(
     T* __restrict__ slab, long long slab_stride, long long n) {
   constexpr int W = VecOf<T>::W;
   typedef typename VecOf<T>::type V;
+  typedef T NV __attribute__((ext_vector_type(W)));
+#if HF_K2_NT
+#define HF_K2_LD(dst, ptr) HF_NT_LD(dst, ptr)
+#define HF_K2_STX(ptr, src) HF_NT_ST(ptr, src)
+#else
+#define HF_K2_LD(dst, ptr) (dst) = *(ptr);
+#define HF_K2_STX(ptr, src) *(ptr) = (src);
+#endif
   __shared__ double lds[3 * WAVES];
   const long long nvec = n / W;
   const long long tile = (long long)BLOCK * UNROLL;
@@ -338,11 +361,11 @@ __global__ __launch_bounds__(BLOCK) void k_update_xr(
   _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                       \
     const long long i = base + u * BLOCK + threadIdx.x;                     \
     if (i < nvec) {                                                         \
-      vx[u].v = reinterpret_cast<const V*>(x)[i];                           \
+      HF_K2_LD(vx[u].v, reinterpret_cast<const V*>(x) + i)                  \
       vr[u].v = reinterpret_cast<const V*>(r)[i];                           \
       vp[u].v = reinterpret_cast<const V*>(p)[i];                           \
-      vg[u].v = reinterpret_cast<const V*>(Bp)[i];                          \
-      vb[u].v = reinterpret_cast<const V*>(b)[i];                           \
+      HF_K2_LD(vg[u].v, reinterpret_cast<const V*>(Bp) + i)                 \
+      HF_K2_LD(vb[u].v, reinterpret_cast<const V*>(b) + i)                  \
       if (MODE == HF_M_DIAG) vm[u].v = reinterpret_cast<const V*>(minv)[i]; \
     }                                                                       \
   }
@@ -391,7 +414,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_xr(
           acc[1] += (double)rn * (double)rn;
           acc[2] += (double)(T)(rn - vb[u].e[c]) * (double)xn;  // dot(r-b, x)  cg.py:97
         }
-        reinterpret_cast<V*>(x)[i] = vx[u].v;
+        HF_K2_STX(reinterpret_cast<V*>(x) + i, vx[u].v)
         reinterpret_cast<V*>(r)[i] = vr[u].v;
         if (snap) reinterpret_cast<V*>(snap)[i] = vx[u].v;
       }
@@ -465,6 +488,12 @@ __global__ __launch_bounds__(BLOCK) void k_update_p(
     T* __restrict__ m_hist, long long max_iter, int* host_flag, long long n) {
   constexpr int W = VecOf<T>::W;
   typedef typename VecOf<T>::type V;
+  typedef T NV __attribute__((ext_vector_type(W)));
+#if HF_K3_NT
+#define HF_K3_LD(dst, ptr) HF_NT_LD(dst, ptr)
+#else
+#define HF_K3_LD(dst, ptr) (dst) = *(ptr);
+#endif
   __shared__ double lds[3 * WAVES];
   const long long nvec = n / W;
   const long long tile = (long long)BLOCK * UNROLL;
@@ -475,7 +504,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_p(
     const long long i = base + u * BLOCK + threadIdx.x;                     \
     if (i < nvec) {                                                         \
       if (MODE == HF_M_EXTERNAL) vr[u].v = reinterpret_cast<const V*>(yext)[i]; \
-      else vr[u].v = reinterpret_cast<const V*>(r)[i];                      \
+      else HF_K3_LD(vr[u].v, reinterpret_cast<const V*>(r) + i)             \
       vp[u].v = reinterpret_cast<const V*>(p)[i];                           \
       if (MODE == HF_M_DIAG) vm[u].v = reinterpret_cast<const V*>(minv)[i]; \
     }                                                                       \
@@ -1507,6 +1536,33 @@ struct TrainFinal {
   float inv_m;
 };
 
+// Column sums of `nrows` partial rows [nrows, C] (C % 4 == 0, C / 4 <= BLOCK) by ONE workgroup, all threads busy:
+// thread (quad tx, group ty) adds rows ty, ty + G, ... (16-byte loads, all in flight), the groups are combined through
+// LDS in a fixed order.  out: LDS [C] doubles.  scratch: LDS 4 * BLOCK doubles.
+__device__ __forceinline__ void final_column_sums(const float* rows, unsigned nrows, unsigned C, double* scratch,
+                                                  double* out) {
+  const unsigned quads = C / 4, G = BLOCK / quads;
+  const unsigned tx = threadIdx.x % quads, ty = threadIdx.x / quads;
+  if (ty < G) {
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (unsigned p = ty; p < nrows; p += G) {
+      const F4 v = ld4(rows + (size_t)p * C + 4 * tx);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] += (double)v.e[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) scratch[(k * G + ty) * quads + tx] = a[k];
+  }
+  __syncthreads();
+  for (unsigned idx = threadIdx.x; idx < 4 * quads; idx += BLOCK) {
+    const unsigned k = idx / quads, col = idx - k * quads;
+    double sum = 0.0;
+    for (unsigned t = 0; t < G; ++t) sum += scratch[(k * G + t) * quads + col];
+    out[col * 4 + k] = sum;
+  }
+  __syncthreads();
+}
+
 // k_bn_adjoint_rows + hf_bn_train_coeffs in one launch (q = vq - w*rstd*S_x/m, r = vr - w*rstd*S_1/m).
 __global__ __launch_bounds__(BLOCK) void k_bn_adjoint_rows_train(
     float* __restrict__ gx, float* gw, float* gb, float* __restrict__ gres,
@@ -1515,19 +1571,17 @@ __global__ __launch_bounds__(BLOCK) void k_bn_adjoint_rows_train(
     const float* __restrict__ w, const float* __restrict__ mask_src, unsigned rows, unsigned C,
     unsigned rows_per_block, const TrainFinal f) {
   __shared__ double red[BLOCK * 8];
+  __shared__ double fin[2 * 4 * BLOCK];  // the two finished column sums, C <= 4 * BLOCK channels each
   __shared__ unsigned s_last;
   bn_adjoint_rows_body(gx, gw, gb, gres, gy, s1, l1, gy2, s2, l2, x, mean, rstd, w, mask_src, rows, C,
                        rows_per_block, blockIdx.x, red);
   if (!last_block_arrives(f.ticket, &s_last)) return;
+  final_column_sums(gw, gridDim.x, C, red, fin);
+  final_column_sums(gb, gridDim.x, C, red, fin + 4 * BLOCK);
   for (unsigned c = threadIdx.x; c < C; c += BLOCK) {
-    double sx = 0.0, sone = 0.0;
-    for (unsigned p = 0; p < gridDim.x; ++p) {
-      sx += (double)ld_agent(gw + (size_t)p * C + c);
-      sone += (double)ld_agent(gb + (size_t)p * C + c);
-    }
     const float k = (f.fw ? f.fw[c] : 1.f) * rstd[c] * f.inv_m;
-    f.q_out[c] = (f.vq ? f.vq[c] : 0.f) - k * (float)sx;
-    f.r_out[c] = (f.vr ? f.vr[c] : 0.f) - k * (float)sone;
+    f.q_out[c] = (f.vq ? f.vq[c] : 0.f) - k * (float)fin[c];
+    f.r_out[c] = (f.vr ? f.vr[c] : 0.f) - k * (float)fin[4 * BLOCK + c];
   }
   if (threadIdx.x == 0) *f.ticket = 0u;
 }
@@ -1590,9 +1644,18 @@ __global__ __launch_bounds__(BLOCK) void k_bn_stats_rows(
   if (!last_block_arrives(ticket, &s_last)) return;
   for (unsigned c = threadIdx.x; c < C; c += BLOCK) {
     double s = 0.0, sq = 0.0;
-    for (unsigned p = 0; p < gridDim.x; ++p) {
-      s += ld_agent(part + ((size_t)p * 2) * C + c);
-      sq += ld_agent(part + ((size_t)p * 2 + 1) * C + c);
+    for (unsigned p0 = 0; p0 < gridDim.x; p0 += 8) {  // eight rows in flight, added in row order
+      double ts[8], tq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned p = p0 + u < gridDim.x ? p0 + u : p0;
+        ts[u] = part[((size_t)p * 2) * C + c];
+        tq[u] = part[((size_t)p * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (p0 + u < gridDim.x) { s += ts[u]; sq += tq[u]; }
+      }
     }
     const double m = s / count;
     double var = sq / count - m * m;
@@ -1662,8 +1725,8 @@ __global__ __launch_bounds__(BLOCK) void k_bn_adjoint_pre(
 // NHWC [rows, C]; one element per thread (activation-sized, latency-bound).  The rounding sequence
 // is chan_affine_body's forward: ((s - mean)*rstd)*w, + b, + res.
 __global__ __launch_bounds__(BLOCK) void k_bn_forward(
-    float* __restrict__ y, float* __restrict__ y2, unsigned y2_ld, float* __restrict__ a_out,
-    const float* __restrict__ a, int splits, long long slab, const float* __restrict__ mean,
+    float* __restrict__ y, float* __restrict__ y2, unsigned y2_ld, float* a_out,
+    const float* a, int splits, long long slab, const float* __restrict__ mean,  // (a_out may alias a: in place)
     const float* __restrict__ rstd, const float* __restrict__ w, const float* __restrict__ b,
     const float* __restrict__ res, unsigned res_ld, int relu, unsigned total, unsigned C) {
   for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < total; i += gridDim.x * BLOCK) {

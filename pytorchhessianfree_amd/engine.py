@@ -119,7 +119,7 @@ class FusedGGNEngine(_Operator):
                     warnings.warn(f"fused curvature engine ({kind.__name__}) not used: {exc}")
                 if getattr(exc, "loud", False):
                     return None
-            except RuntimeError as exc:  # a kernel refused its arguments (alignment, size limits ...)
+            except _lib.Refused as exc:  # a kernel refused its arguments (alignment, size limits ...)
                 warnings.warn(f"fused curvature engine ({kind.__name__}) not used: {exc}")
                 return None
         return None
@@ -182,6 +182,9 @@ class FusedGGNEngine(_Operator):
         self._rec_pool = None
         if self.loss_spec is not None:
             self.outputs = None  # nothing of the step's autograd graph stays alive in the engine
+            from .modelprep import release_records
+
+            release_records(model)  # (the layers' records pinned this pass's activations until the next one)
 
     # ---- topology ---------------------------------------------------------------------
     def _param(self, p):

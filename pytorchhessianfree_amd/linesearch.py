@@ -53,7 +53,7 @@ def simple_linesearch(f, f_grad_0, step, init_alpha=1.0, beta=0.8, c=1e-2, max_i
             return alpha, trial
         alpha *= beta
         if prefetch is not None:  # this candidate and the next: one read-back for two values
-            prefetch([(step, alpha), (step, alpha * beta)])
+            prefetch([(step, alpha), (step, alpha * beta)], needed=1)  # (the second: speculative)
         trial = value_at(alpha)
         tries += 1
 

@@ -845,7 +845,7 @@ class _Conv(torch.autograd.Function):
             try:
                 y = _own_conv_forward(xf, wf, stride, padding)
                 return y if b is None else y + b.view(1, -1, 1, 1)
-            except RuntimeError:
+            except _lib.Refused:  # (a size / alignment the library does not cover; real faults propagate)
                 pass
         elif _tiny_cin(xf, w, cl) and _use_own(mode, "F", rows):
             try:
@@ -855,7 +855,7 @@ class _Conv(torch.autograd.Function):
                     memory_format=torch.channels_last)
                 _lib.conv2d_nhwc(0, y, cols, w, n_ * oh * ow, 1, 1, j_, k_, 1, 1, (1, 1), (0, 0))
                 return y if b is None else y + b.view(1, -1, 1, 1)
-            except RuntimeError:
+            except _lib.Refused:
                 ctx.cols = None
         c = _point(xf, wf, padding, dilation, cl)
         if c is not None:
@@ -896,7 +896,7 @@ class _Conv(torch.autograd.Function):
             if own_dw or own_w:
                 try:
                     gx, gw = _own_backward(ctx, gy, xf, wf, stride, padding, own_dw, own_d)
-                except RuntimeError:  # refused by the library (size limits): MIOpen below
+                except _lib.Refused:  # refused by the library (size limits): MIOpen below
                     gx = gw = None
             elif tiny:
                 # weight gradient of a tiny-Cin layer: gW[k, j] = sum_m gy[m, k] * cols[m, j]
@@ -976,6 +976,14 @@ def skip_identity_pools(model):
             m.forward = types.MethodType(_pool_forward, m)
             count += 1
     return count
+
+
+def release_records(model):
+    """Drop the activation records of the last forward pass (``_hf_io`` of every layer): the engine has copied
+    what it needs, and a record keeps its activation alive until the next forward pass."""
+    for m in model.modules():
+        if getattr(m, "_hf_io", None) is not None:
+            m._hf_io = None
 
 
 def _record_io(module, inputs, output):

@@ -774,14 +774,21 @@ class _SessionTrials:
         self.opt, self.sess, self.arena, self.base = opt, sess, arena, params_vec
         self.cache = {(0, 0.0): sess.base_loss}  # alpha = 0: the loss at theta0 (this step's forward replay)
         self.pending = []
+        self._keep = []
 
     @staticmethod
     def _key(step, alpha):
         return (0, 0.0) if alpha == 0.0 else (step.data_ptr(), float(alpha))
 
     @torch.no_grad()
-    def prefetch(self, points):
-        """Enqueue the evaluation of ``[(step, alpha), ...]`` (no host synchronisation)."""
+    def prefetch(self, points, needed=None):
+        """Enqueue the evaluation of ``[(step, alpha), ...]`` (no host synchronisation).  ``needed``: only the
+        first ``needed`` points are certainly consumed, the rest is speculation (the next back-tracking / Armijo
+        candidate).  With train-mode BatchNorm every evaluated point moves the running statistics -- as every
+        ``forward()`` of the reference does -- so there only the points the reference itself would evaluate
+        are evaluated (no speculation)."""
+        if needed is not None and getattr(getattr(self.sess, "engine", None), "train_bn", False):
+            points = points[:needed]
         for step, alpha in points:
             key = self._key(step, alpha)
             if step is None or key in self.cache or any(k == key for k, _ in self.pending):
@@ -791,6 +798,7 @@ class _SessionTrials:
             self.arena.write(self.base, step, alpha)
             self.sess.forward_loss(len(self.pending))
             self.pending.append((key, len(self.pending)))
+            self._keep.append(step)  # (the key is the vector's address: it must not be recycled within the step)
 
     def flush(self):
         if not self.pending:

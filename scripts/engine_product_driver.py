@@ -120,6 +120,18 @@ class Recorder:
         return [(name, rd, wr, 8.0 * n * c * hw)]
 
     @staticmethod
+    def _cost_hf_bn_adjoint_rows_train(gx, gw, gb, gres, gy, s1, l1, gy2, s2, l2, x, mean, rstd, w, mask, n, c, hw, rb,
+                                       ticket, q_out, r_out, fw, vq, vr, count, dtype, stream):
+        tot = 4 * n * c * hw
+        rd = tot * (s1 + (s2 if gy2 else 0) + (1 if x else 0) + (1 if mask else 0))
+        wr = tot * ((1 if gx else 0) + (1 if gres else 0))
+        return [("k_bn_adjoint_rows_train", rd, wr, 8.0 * n * c * hw)]
+
+    @staticmethod
+    def _cost_hf_bn_train_coeffs(q_out, r_out, px, p1, nparts, w, rstd, vq, vr, count, c, dtype, stream):
+        return [("k_bn_train_coeffs", 4 * 2 * nparts * c, 4 * 2 * c, 0.0)]
+
+    @staticmethod
     def _cost_hf_chan_affine_bwd_pair(problems, dtype, stream):
         arr = _lib.ctypes.cast(problems, _lib.ctypes.POINTER(_lib.BnAdjointProblem * 2)).contents
         rd = wr = 0
@@ -178,6 +190,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--workload", default="resnet18", choices=["resnet18", "allcnnc", "resnet50"])
     ap.add_argument("--curvature", default="ggn", choices=["ggn", "hessian"])
+    ap.add_argument("--bn", default="eval", choices=["eval", "train"])
     args = ap.parse_args()
     hf.configure()
     dev = "cuda"
@@ -187,6 +200,8 @@ def main():
         model, (x, t), lossf = tp.allcnnc_cifar100(batch_size=32, device=dev)
     else:
         model, (x, t), lossf = tp.resnet50_small_images(batch_size=32, device=dev)
+    if args.bn == "train":
+        model.train()
     modelprep.prepare_model(model, channels_last=True)
     params = [p for p in model.parameters() if p.requires_grad]
     out = model(x)

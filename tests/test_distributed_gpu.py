@@ -115,7 +115,7 @@ def test_bench_gpus_2_starts_two_ranks_itself():
            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run(
         [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-         "--iters", "30", "--no-cpu-baseline"],
+         "--iters", "30", "--no-cpu-baseline", "--chunk", "1"],
         env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

@@ -80,6 +80,27 @@ def test_trial_values_are_exact_cached_and_batched():
         assert abs(v - _direct(base, target, s, al)) < 1e-5 * max(1.0, abs(v))
 
 
+def test_train_mode_session_evaluates_no_speculative_points():
+    """Train-mode BatchNorm: every evaluated trial point moves the running statistics, as every ``forward()`` of
+    the reference does (optimizer.py:288-294) -- so the speculative second candidate of a back-tracking / Armijo
+    pair (``needed=1``) is NOT evaluated there, while an eval-mode session evaluates both with one read-back."""
+    for train, forwards in ((False, 2), (True, 1)):
+        arena, base, target, sess, trials, flushes = _setup()
+
+        class _Eng:
+            train_bn = train
+
+        sess.engine = _Eng()
+        steps = [torch.randn(12, generator=torch.Generator().manual_seed(i)) for i in range(2)]
+        trials.prefetch([(steps[0], 1.0), (steps[1], 1.0)], needed=1)
+        assert sess.forwards == forwards
+        v = trials.value(steps[0], 1.0)
+        assert abs(v - _direct(base, target, steps[0], 1.0)) < 1e-5 * abs(v)
+        # the LM pair (both values certainly consumed) is evaluated in full either way
+        trials.prefetch([(steps[0], 0.5), (steps[1], 0.5)])
+        assert sess.forwards == forwards + 2
+
+
 def test_backtracking_with_prefetch_equals_reference_walk():
     """The reference's toy sequence (tests/test_cg_backtracking.py:8-44): walk from the last stored step
     backwards, stop at the first non-improvement.  With the prefetch hook the same index / value come out, at
@@ -98,7 +119,7 @@ def test_backtracking_with_prefetch_equals_reference_walk():
             reads[0] += 1
         return values[idx]
 
-    def prefetch(points):
+    def prefetch(points, needed=None):
         for step, alpha in points:
             idx = int(step[0])
             if idx not in evaluated:
