@@ -368,7 +368,8 @@ def cg(
         if verbose:
             print(f"  cg-iteration {it}")
         if fused is not None:
-            timed = fused.timing and it % _TIMING_SAMPLE == 0
+            # (every 16th iteration -- and the 3rd, so that short Martens-terminated solves are sampled too)
+            timed = fused.timing and (it % _TIMING_SAMPLE == 0 or it == 3)
             if timed and timed_pending:
                 fused.collect()  # iteration it-16: long finished, does not stall the pipeline
             if group is None:

@@ -255,35 +255,35 @@ __global__ __launch_bounds__(BLOCK) void k_init_finalize(DevState* __restrict__ 
 // else (the done flag, the re-reduction of the previous kernel's partials): at small N
 // (All-CNN-C: 5.5 MB vectors, one tile per block) that prologue used to sit in front of
 // the first load and cost more than the streaming itself.
-// Non-temporal access to streams that are not read again before ~0.5 ms of other traffic has passed (measured,
-// profiles/r04_pcg_nt_variants.jsonl: K1 at N = 100 M 151.8 -> 138.1 us, at N = 11.2 M 17.7 -> 17.2 us).
-// HF_K1_NT: K1's two read streams; HF_K2_NT: K2's x / b / Bp loads and its x store; HF_K3_NT: K3's r load.
-#ifndef HF_K1_NT
-#define HF_K1_NT 1
-#endif
-#ifndef HF_K2_NT
-#define HF_K2_NT 0
-#endif
-#ifndef HF_K3_NT
-#define HF_K3_NT 0
-#endif
-#define HF_NT_LD(dst, ptr)                                                                  \
+// Non-temporal access to the solver's streams (template flag NT of K1 / K2 / K3, chosen per handle at run time:
+// vectors of >= HF_PCG_NT_MIN elements, default 4 M).  Between two uses of the same vector element lie a whole
+// curvature product (~0.5 GB of other traffic on the ResNet-18 workload) or five other vector streams, so nothing
+// these kernels read survives in a cache anyway -- non-temporal loads / stores just do not evict what does:
+// measured in the bench (profiles/r04_pcg_nt_variants.jsonl): 1 499 -> 1 534 matvecs/s, K2 55.4 -> 52.4 us; at
+// N = 100 M K1 151.8 -> 137.2, K2 466.9 -> 440.0, K3 211.1 -> 204.6 us (all three 0.736 -> 0.770 of 8 TB/s).  Small
+// vectors (All-CNN-C: 5.5 MB, L2-resident between kernels) keep the default policy.
+// NT covers: K1 both read streams; K2 the x / b / Bp loads and the x store (r and p are re-read by K3 right
+// after); K3 the r load.
+#define HF_LD(NTFLAG, dst, ptr)                                                             \
   {                                                                                         \
-    NV t_ = __builtin_nontemporal_load(reinterpret_cast<const NV*>(ptr));                   \
-    __builtin_memcpy(&(dst), &t_, sizeof(NV));                                              \
+    if constexpr (NTFLAG) {                                                                 \
+      NV t_ = __builtin_nontemporal_load(reinterpret_cast<const NV*>(ptr));                 \
+      __builtin_memcpy(&(dst), &t_, sizeof(NV));                                            \
+    } else {                                                                                \
+      (dst) = *(ptr);                                                                       \
+    }                                                                                       \
   }
-#define HF_NT_ST(ptr, src)                                                                  \
+#define HF_ST(NTFLAG, ptr, src)                                                             \
   {                                                                                         \
-    NV t_;                                                                                  \
-    __builtin_memcpy(&t_, &(src), sizeof(NV));                                              \
-    __builtin_nontemporal_store(t_, reinterpret_cast<NV*>(ptr));                            \
+    if constexpr (NTFLAG) {                                                                 \
+      NV t_;                                                                                \
+      __builtin_memcpy(&t_, &(src), sizeof(NV));                                            \
+      __builtin_nontemporal_store(t_, reinterpret_cast<NV*>(ptr));                          \
+    } else {                                                                                \
+      *(ptr) = (src);                                                                       \
+    }                                                                                       \
   }
-#if HF_K1_NT
-#define HF_K1_LD(dst, ptr) HF_NT_LD(dst, ptr)
-#else
-#define HF_K1_LD(dst, ptr) (dst) = *(ptr);
-#endif
-template <typename T, int UNROLL>
+template <typename T, int UNROLL, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_curvature(const DevState* __restrict__ st,
                                                      double* __restrict__ part1, int stride,
                                                      const T* __restrict__ p,
@@ -302,8 +302,8 @@ __global__ __launch_bounds__(BLOCK) void k_curvature(const DevState* __restrict_
   _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                       \
     const long long i = base + u * BLOCK + threadIdx.x;                     \
     if (i < nvec) {                                                         \
-      HF_K1_LD(vp[u].v, reinterpret_cast<const V*>(p) + i)                  \
-      HF_K1_LD(vg[u].v, reinterpret_cast<const V*>(Bp) + i)                 \
+      HF_LD(NT, vp[u].v, reinterpret_cast<const V*>(p) + i)                 \
+      HF_LD(NT, vg[u].v, reinterpret_cast<const V*>(Bp) + i)                \
     }                                                                       \
   }
   HF_K1_LOAD();
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(BLOCK) void k_curvature(const DevState* __restrict_
 // K2: alpha; x += alpha p; r += alpha (Bp + lambda p); snapshot; partials
 //   part2[0] r.y   part2[1] r.r   part2[2] (r-b).x         28N (32N with minv)
 // ---------------------------------------------------------------------------
-template <typename T, int MODE, int UNROLL>
+template <typename T, int MODE, int UNROLL, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_update_xr(
     DevState* __restrict__ st, const double* __restrict__ part1, double* __restrict__ part2,
     int nparts, int stride, T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p,
@@ -345,13 +345,6 @@ __global__ __launch_bounds__(BLOCK) void k_update_xr(
   constexpr int W = VecOf<T>::W;
   typedef typename VecOf<T>::type V;
   typedef T NV __attribute__((ext_vector_type(W)));
-#if HF_K2_NT
-#define HF_K2_LD(dst, ptr) HF_NT_LD(dst, ptr)
-#define HF_K2_STX(ptr, src) HF_NT_ST(ptr, src)
-#else
-#define HF_K2_LD(dst, ptr) (dst) = *(ptr);
-#define HF_K2_STX(ptr, src) *(ptr) = (src);
-#endif
   __shared__ double lds[3 * WAVES];
   const long long nvec = n / W;
   const long long tile = (long long)BLOCK * UNROLL;
@@ -361,11 +354,11 @@ __global__ __launch_bounds__(BLOCK) void k_update_xr(
   _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                       \
     const long long i = base + u * BLOCK + threadIdx.x;                     \
     if (i < nvec) {                                                         \
-      HF_K2_LD(vx[u].v, reinterpret_cast<const V*>(x) + i)                  \
+      HF_LD(NT, vx[u].v, reinterpret_cast<const V*>(x) + i)                 \
       vr[u].v = reinterpret_cast<const V*>(r)[i];                           \
       vp[u].v = reinterpret_cast<const V*>(p)[i];                           \
-      HF_K2_LD(vg[u].v, reinterpret_cast<const V*>(Bp) + i)                 \
-      HF_K2_LD(vb[u].v, reinterpret_cast<const V*>(b) + i)                  \
+      HF_LD(NT, vg[u].v, reinterpret_cast<const V*>(Bp) + i)                \
+      HF_LD(NT, vb[u].v, reinterpret_cast<const V*>(b) + i)                 \
       if (MODE == HF_M_DIAG) vm[u].v = reinterpret_cast<const V*>(minv)[i]; \
     }                                                                       \
   }
@@ -414,7 +407,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_xr(
           acc[1] += (double)rn * (double)rn;
           acc[2] += (double)(T)(rn - vb[u].e[c]) * (double)xn;  // dot(r-b, x)  cg.py:97
         }
-        HF_K2_STX(reinterpret_cast<V*>(x) + i, vx[u].v)
+        HF_ST(NT, reinterpret_cast<V*>(x) + i, vx[u].v)
         reinterpret_cast<V*>(r)[i] = vr[u].v;
         if (snap) reinterpret_cast<V*>(snap)[i] = vx[u].v;
       }
@@ -480,7 +473,7 @@ __global__ __launch_bounds__(BLOCK) void k_dot_ry(const DevState* __restrict__ s
 // K3: finalise ||r||, m_i; termination tests (cg.py:95-115); beta; p = -y + beta p
 //                                                           12N (16N with minv)
 // ---------------------------------------------------------------------------
-template <typename T, int MODE, int UNROLL>
+template <typename T, int MODE, int UNROLL, bool NT>
 __global__ __launch_bounds__(BLOCK) void k_update_p(
     DevState* __restrict__ st, const double* __restrict__ part2,
     const double* __restrict__ part3, int nparts, int stride, const T* __restrict__ r,
@@ -489,11 +482,6 @@ __global__ __launch_bounds__(BLOCK) void k_update_p(
   constexpr int W = VecOf<T>::W;
   typedef typename VecOf<T>::type V;
   typedef T NV __attribute__((ext_vector_type(W)));
-#if HF_K3_NT
-#define HF_K3_LD(dst, ptr) HF_NT_LD(dst, ptr)
-#else
-#define HF_K3_LD(dst, ptr) (dst) = *(ptr);
-#endif
   __shared__ double lds[3 * WAVES];
   const long long nvec = n / W;
   const long long tile = (long long)BLOCK * UNROLL;
@@ -504,7 +492,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_p(
     const long long i = base + u * BLOCK + threadIdx.x;                     \
     if (i < nvec) {                                                         \
       if (MODE == HF_M_EXTERNAL) vr[u].v = reinterpret_cast<const V*>(yext)[i]; \
-      else HF_K3_LD(vr[u].v, reinterpret_cast<const V*>(r) + i)             \
+      else HF_LD(NT, vr[u].v, reinterpret_cast<const V*>(r) + i)            \
       vp[u].v = reinterpret_cast<const V*>(p)[i];                           \
       if (MODE == HF_M_DIAG) vm[u].v = reinterpret_cast<const V*>(minv)[i]; \
     }                                                                       \
@@ -1392,7 +1380,7 @@ __device__ __forceinline__ void bn_adjoint_rows_body(
     const float* __restrict__ gy, int s1, long long l1, const float* __restrict__ gy2, int s2, long long l2,
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ w, const float* __restrict__ mask_src, unsigned rows, unsigned C,
-    unsigned rows_per_block, unsigned bid, double* red) {
+    unsigned rows_per_block, unsigned bid, double* red, const bool publish = false) {
   struct alignas(16) Col { float e[4]; };
   const unsigned quads = C / 4, RP = BLOCK / quads;
   const unsigned tx = threadIdx.x % quads, ty = threadIdx.x / quads;
@@ -1494,7 +1482,11 @@ __device__ __forceinline__ void bn_adjoint_rows_body(
     double sum = 0.0;
     for (unsigned t = 0; t < RP; ++t) sum += red[(k * RP + t) * quads + col];  // fixed order over ty
     float* dst = (k & 1) ? gb : gw;
-    if (dst) dst[bid * C + col * 4 + (k >> 1)] = (float)sum;
+    if (dst) {
+      // publish: write-through (sc1) store -- visible device-wide once drained, no release fence (in-launch readers)
+      if (publish) __hip_atomic_store(dst + bid * C + col * 4 + (k >> 1), (float)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else dst[bid * C + col * 4 + (k >> 1)] = (float)sum;
+    }
   }
 }
 
@@ -1514,13 +1506,24 @@ __global__ __launch_bounds__(BLOCK) void k_bn_adjoint_rows(
 // fixed order: the same sums whichever block comes last) and writes the per-channel result.  The ticket word
 // resets itself.  Replaces one tiny dependent launch (hf_bn_train_coeffs / hf_bn_batch_stats) per layer and sweep.
 __device__ __forceinline__ bool last_block_arrives(unsigned* ticket, unsigned* s_last) {
-  __threadfence();  // publish this block's partial sums (agent scope)
+  // (cdna_hip_programming.md, in-launch reduction, write-through form -- as hf_conv.hip's split-K tickets: the
+  // partial sums were stored write-through (sc1); every wave drains them, ONE lane draws the ticket, the last
+  // arriver acquires once (drops stale lines) and then reads the rows with plain loads.  A release FENCE here
+  // instead would write this workgroup's share of the activation-sized outputs back out of L2 first.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) *s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned last = old == gridDim.x - 1u ? 1u : 0u;
+    if (last) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *s_last = last;
+  }
   __syncthreads();
-  if (!*s_last) return false;
-  __threadfence();  // acquire the other blocks' partial sums
-  return true;
+  return *s_last != 0u;
 }
 __device__ __forceinline__ float ld_agent(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1574,7 +1577,7 @@ __global__ __launch_bounds__(BLOCK) void k_bn_adjoint_rows_train(
   __shared__ double fin[2 * 4 * BLOCK];  // the two finished column sums, C <= 4 * BLOCK channels each
   __shared__ unsigned s_last;
   bn_adjoint_rows_body(gx, gw, gb, gres, gy, s1, l1, gy2, s2, l2, x, mean, rstd, w, mask_src, rows, C,
-                       rows_per_block, blockIdx.x, red);
+                       rows_per_block, blockIdx.x, red, true);
   if (!last_block_arrives(f.ticket, &s_last)) return;
   final_column_sums(gw, gridDim.x, C, red, fin);
   final_column_sums(gb, gridDim.x, C, red, fin + 4 * BLOCK);
@@ -1583,7 +1586,6 @@ __global__ __launch_bounds__(BLOCK) void k_bn_adjoint_rows_train(
     f.q_out[c] = (f.vq ? f.vq[c] : 0.f) - k * (float)fin[c];
     f.r_out[c] = (f.vr ? f.vr[c] : 0.f) - k * (float)fin[4 * BLOCK + c];
   }
-  if (threadIdx.x == 0) *f.ticket = 0u;
 }
 
 // One-pass batch statistics of a train-mode BatchNorm's forward: sums the convolution's split-K slabs into
@@ -1639,7 +1641,8 @@ __global__ __launch_bounds__(BLOCK) void k_bn_stats_rows(
     const unsigned k = idx / quads, col = idx - k * quads;
     double sum = 0.0;
     for (unsigned t = 0; t < RP; ++t) sum += red[(k * RP + t) * quads + col];  // fixed order over ty
-    part[((size_t)blockIdx.x * 2 + (k & 1)) * C + col * 4 + (k >> 1)] = sum;
+    __hip_atomic_store(part + ((size_t)blockIdx.x * 2 + (k & 1)) * C + col * 4 + (k >> 1), sum, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);  // (write-through: see last_block_arrives)
   }
   if (!last_block_arrives(ticket, &s_last)) return;
   for (unsigned c = threadIdx.x; c < C; c += BLOCK) {
@@ -1668,7 +1671,6 @@ __global__ __launch_bounds__(BLOCK) void k_bn_stats_rows(
       run_var[c] = (float)((1.0 - (double)momentum) * (double)run_var[c] + (double)momentum * unbiased);
     }
   }
-  if (threadIdx.x == 0) *ticket = 0u;
 }
 
 // Two independent layers' adjoints in ONE launch (see k_chan_affine_pair).
@@ -1881,6 +1883,13 @@ int grid_for(const hf_pcg* h, int unroll) {
   if (tiles <= SMALL_TILES && tiles <= h->grid_cap) return (int)tiles;
   return (int)(tiles < h->grid ? tiles : h->grid);
 }
+
+// non-temporal streams for vectors that cannot stay cached between their uses (see HF_LD)
+bool nt_streams(const hf_pcg* h) {
+  static long long min_n = -1;
+  if (min_n < 0) { const char* e = getenv("HF_PCG_NT_MIN"); min_n = e ? atoll(e) : 4000000LL; }
+  return h->n >= min_n;
+}
 }  // namespace
 
 // C linkage comes from the declarations in hf_pcg.h
@@ -2077,7 +2086,7 @@ template <> void* lam_slot<double>(KLaunch& k, double damping) { k.lam_d = dampi
 
 template <typename T>
 static void build_k1(hf_pcg* h, const void* Bp, double damping, KLaunch& k) {
-  k.func = (const void*)&k_curvature<T, U1>;
+  k.func = nt_streams(h) ? (const void*)&k_curvature<T, U1, true> : (const void*)&k_curvature<T, U1, false>;
   k.grid = grid_for(h, U1);
   k.st = h->d_state; k.pw = part_ptr(h, 1); k.i0 = h->grid_cap;
   k.v0 = h->p; k.v1 = const_cast<void*>(Bp); k.i1 = damping != 0.0 ? 1 : 0; k.l0 = h->n;
@@ -2087,10 +2096,11 @@ static void build_k1(hf_pcg* h, const void* Bp, double damping, KLaunch& k) {
 
 template <typename T>
 static void build_k2(hf_pcg* h, const void* Bp, double damping, KLaunch& k) {
+  const bool nt = nt_streams(h);
   switch (h->precond) {
-    case HF_M_NONE: k.func = (const void*)&k_update_xr<T, HF_M_NONE, U2>; break;
-    case HF_M_DIAG: k.func = (const void*)&k_update_xr<T, HF_M_DIAG, U2>; break;
-    default: k.func = (const void*)&k_update_xr<T, HF_M_EXTERNAL, U2>; break;
+    case HF_M_NONE: k.func = nt ? (const void*)&k_update_xr<T, HF_M_NONE, U2, true> : (const void*)&k_update_xr<T, HF_M_NONE, U2, false>; break;
+    case HF_M_DIAG: k.func = nt ? (const void*)&k_update_xr<T, HF_M_DIAG, U2, true> : (const void*)&k_update_xr<T, HF_M_DIAG, U2, false>; break;
+    default: k.func = nt ? (const void*)&k_update_xr<T, HF_M_EXTERNAL, U2, true> : (const void*)&k_update_xr<T, HF_M_EXTERNAL, U2, false>; break;
   }
   k.grid = grid_for(h, U2);
   k.st = h->d_state; k.pa = part_ptr(h, 1); k.pw = part_ptr(h, 2);
@@ -2107,10 +2117,11 @@ static void build_k2(hf_pcg* h, const void* Bp, double damping, KLaunch& k) {
 
 template <typename T>
 static void build_k3(hf_pcg* h, const void* yext, KLaunch& k) {
+  const bool nt = nt_streams(h);
   switch (h->precond) {
-    case HF_M_NONE: k.func = (const void*)&k_update_p<T, HF_M_NONE, U3>; break;
-    case HF_M_DIAG: k.func = (const void*)&k_update_p<T, HF_M_DIAG, U3>; break;
-    default: k.func = (const void*)&k_update_p<T, HF_M_EXTERNAL, U3>; break;
+    case HF_M_NONE: k.func = nt ? (const void*)&k_update_p<T, HF_M_NONE, U3, true> : (const void*)&k_update_p<T, HF_M_NONE, U3, false>; break;
+    case HF_M_DIAG: k.func = nt ? (const void*)&k_update_p<T, HF_M_DIAG, U3, true> : (const void*)&k_update_p<T, HF_M_DIAG, U3, false>; break;
+    default: k.func = nt ? (const void*)&k_update_p<T, HF_M_EXTERNAL, U3, true> : (const void*)&k_update_p<T, HF_M_EXTERNAL, U3, false>; break;
   }
   k.grid = grid_for(h, U3);
   k.st = h->d_state; k.pa = part_ptr(h, 2); k.pb = part_ptr(h, 0);

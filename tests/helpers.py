@@ -57,3 +57,42 @@ def lowrank_operator(g, key, device, dtype=torch.float32):
         return B(v) + damping * v
 
     return A, B, damping
+
+
+_CPU_STEPS = {}
+
+
+def cpu_resnet18_default_steps(n_steps):
+    """``n_steps`` default ``HessianFree.step()`` calls of the single-process CPU path on the 32-sample ResNet-18
+    batches of ``RESNET18_B32_SEPARATED_SEEDS`` -- stock model, torch autograd, host logic with the oracle PCG (the
+    reference's algorithm, pinned bit for bit by tests/golden/make_golden.py).  Returns ``(state, finals, params)``
+    truncated to ``n_steps``; computed once per pytest process (the longest run so far serves the shorter ones:
+    the steps are sequential)."""
+    import warnings
+
+    import pytorchhessianfree_amd as hf
+    from oracle import pcg as oracle
+    from pytorchhessianfree_amd import testproblems as tp
+
+    run = _CPU_STEPS.get("run")
+    if run is None:
+        seeds = tp.RESNET18_B32_SEPARATED_SEEDS
+        model, _, lossf = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=seeds[0])
+        opt = hf.HessianFree(model.parameters())
+        opt._cg = oracle.pcg
+        run = _CPU_STEPS["run"] = dict(model=model, lossf=lossf, opt=opt, finals=[], params=[])
+    model, lossf, opt = run["model"], run["lossf"], run["opt"]
+    while len(run["finals"]) < n_steps:  # (continue the same run: the steps are sequential)
+        i = len(run["finals"])
+        _, (x, t), _ = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=tp.RESNET18_B32_SEPARATED_SEEDS[i])
+
+        def forward():
+            o = model(x)
+            return lossf(o, t), o
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            run["finals"].append(opt.step(forward))
+        run["params"].append(torch.cat([p.detach().reshape(-1) for p in opt._params_list]).numpy().copy())
+    state = {k: list(v[:n_steps]) for k, v in opt.state.items() if isinstance(v, list)}
+    return state, run["finals"][:n_steps], run["params"][n_steps - 1]

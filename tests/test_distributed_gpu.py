@@ -151,40 +151,11 @@ def _launch_session_ranks(out, world, mode="steps", backend="gloo", timeout=900)
     return [np.load(out / f"rank{r}.npz") for r in range(world)]
 
 
-_CPU_REF = {}
-
-
 def _cpu_whole_batch_steps(n_steps=2):
-    """The single-process CPU path on the whole 32-sample batches: stock model, torch autograd, host logic with
-    the oracle PCG (the reference's algorithm, pinned bit for bit by tests/golden/make_golden.py)."""
-    if n_steps in _CPU_REF:
-        return _CPU_REF[n_steps]
-    import warnings
+    """The single-process CPU path on the whole 32-sample batches (tests/helpers.py: computed once per process)."""
+    from helpers import cpu_resnet18_default_steps
 
-    import torch
-
-    import pytorchhessianfree_amd as hf
-    from oracle import pcg as oracle
-    from pytorchhessianfree_amd import testproblems as tp
-
-    seeds = tp.RESNET18_B32_SEPARATED_SEEDS
-    model, _, lossf = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=seeds[0])
-    opt = hf.HessianFree(model.parameters())
-    opt._cg = oracle.pcg
-    finals = []
-    for i in range(n_steps):
-        _, (x, t), _ = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=seeds[i])
-
-        def forward():
-            o = model(x)
-            return lossf(o, t), o
-
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            finals.append(opt.step(forward))
-    params = torch.cat([p.detach().reshape(-1) for p in opt._params_list]).numpy().copy()
-    _CPU_REF[n_steps] = (opt.state, finals, params)
-    return _CPU_REF[n_steps]
+    return cpu_resnet18_default_steps(n_steps)
 
 
 def _check_against_cpu(r0, tol_final=1e-4):

@@ -26,6 +26,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+_CPU_ORACLE = {}  # CPU-oracle solves shared by the parametrisations of one test (computed once per process)
+
+
 def check_state(opt, g, prefix, n_steps):
     st = opt.state
     np.testing.assert_allclose(st["init_losses"], g[prefix + "init_losses"][:n_steps], rtol=1e-5)
@@ -784,21 +787,24 @@ def test_resnet18_newton_solve_matches_reference_cpu_path(mode):
     # correct fp32 forward passes (CPU / GPU) may otherwise disagree on one ReLU sign, which alone
     # moves the gradient by 2e-4 (testproblems.relu_margin; ~every third random batch has one)
     seed = tp.RESNET18_B32_SEPARATED_SEEDS[0]
-    model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=seed)
-    assert tp.relu_margin(copy.deepcopy(model).double(), x.double()) > 8e-7
-    params = list(model.parameters())
-    out = model(x)
-    loss = lossf(out, t)
-    grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, params, retain_graph=True)])
-
-    def mvp(v):
-        Gv = bp.ggn_vector_product_from_plist(loss, out, params, vector_to_parameter_list(v, params))
-        return torch.cat([g.reshape(-1) for g in Gv]).detach()
-
     kw = dict(max_iter=80, martens_conv_crit=True, store_x_at_iters=None)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        ox, om, oreason = oracle.pcg(lambda v: mvp(v) + lam * v, -grad, **kw)
+    if "newton" not in _CPU_ORACLE:  # (the CPU oracle's solve is the same for the three modes: once per process)
+        model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=seed)
+        assert tp.relu_margin(copy.deepcopy(model).double(), x.double()) > 8e-7
+        params = list(model.parameters())
+        out = model(x)
+        loss = lossf(out, t)
+        grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, params, retain_graph=True)])
+
+        def mvp(v):
+            Gv = bp.ggn_vector_product_from_plist(loss, out, params, vector_to_parameter_list(v, params))
+            return torch.cat([g.reshape(-1) for g in Gv]).detach()
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _CPU_ORACLE["newton"] = (grad.detach(),) + tuple(oracle.pcg(lambda v: mvp(v) + lam * v, -grad, **kw))
+    grad, ox, om, oreason = _CPU_ORACLE["newton"]
+    lossf = torch.nn.CrossEntropyLoss()
 
     gm, (gx_, gt_), _ = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=seed)
     # deterministic: every convolution on the package's own fixed-order kernels (NHWC)
@@ -869,29 +875,32 @@ def test_config4_allcnnc_hessian_diag_fisher_solve_matches_reference_cpu_path(la
 
     B, l2 = 32, 5e-4
     definite = lam >= 1.0
-    model, (x, t), lossf0 = tp.allcnnc_cifar100(batch_size=B, device="cpu")
-    lossf = tp.l2_regularized(lossf0, model, l2)
-    params = list(model.parameters())
-    out = model(x)
-    loss = lossf(out, t)
-    grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, params, retain_graph=True)])
-    diag = torch.zeros_like(grad)
-    for x_i, t_i in zip(x, t):  # preconditioners.py:91-99
-        g_i = torch.autograd.grad(lossf(model(x_i), t_i), params)
-        diag += torch.cat([g.reshape(-1) for g in g_i]) ** 2
-    diag /= B
-
-    def Hv(v):
-        H = bp.hessian_vector_product(loss, params, vector_to_parameter_list(v, params))
-        return torch.cat([h.reshape(-1) for h in H]).detach()
-
     kw = dict(max_iter=40, martens_conv_crit=True, store_x_at_iters=list(range(41)))
-    with warnings.catch_warnings(record=True) as wo:
-        warnings.simplefilter("always")
-        ox, om, oreason = oracle.pcg(lambda v: Hv(v) + lam * v, -grad,
-                                     M=lambda v: (diag + lam) ** -0.75 * v, **kw)
-    o_nonpos = sorted(str(w.message).split("iteration ")[1].split(".")[0] for w in wo
-                      if "Directional curvature" in str(w.message))
+    if ("config4", lam) not in _CPU_ORACLE:  # (the CPU oracle's solve serves both GPU paths: once per process)
+        model, (x, t), lossf0 = tp.allcnnc_cifar100(batch_size=B, device="cpu")
+        lossf = tp.l2_regularized(lossf0, model, l2)
+        params = list(model.parameters())
+        out = model(x)
+        loss = lossf(out, t)
+        grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, params, retain_graph=True)])
+        diag = torch.zeros_like(grad)
+        for x_i, t_i in zip(x, t):  # preconditioners.py:91-99
+            g_i = torch.autograd.grad(lossf(model(x_i), t_i), params)
+            diag += torch.cat([g.reshape(-1) for g in g_i]) ** 2
+        diag /= B
+
+        def Hv(v):
+            H = bp.hessian_vector_product(loss, params, vector_to_parameter_list(v, params))
+            return torch.cat([h.reshape(-1) for h in H]).detach()
+
+        with warnings.catch_warnings(record=True) as wo:
+            warnings.simplefilter("always")
+            ox, om, oreason = oracle.pcg(lambda v: Hv(v) + lam * v, -grad,
+                                         M=lambda v: (diag + lam) ** -0.75 * v, **kw)
+        o_nonpos = sorted(str(w.message).split("iteration ")[1].split(".")[0] for w in wo
+                          if "Directional curvature" in str(w.message))
+        _CPU_ORACLE[("config4", lam)] = (grad.detach(), diag, ox, om, oreason, o_nonpos)
+    grad, diag, ox, om, oreason, o_nonpos = _CPU_ORACLE[("config4", lam)]
 
     gm, (gx_, gt_), glossf0 = tp.allcnnc_cifar100(batch_size=B, device=DEV)
     modelprep.prepare_model(gm, channels_last=(path == "engine"))

@@ -119,10 +119,12 @@ def test_session_steps_match_reference_cpu_path():
     reference-order PCG): the session must serve steps 2 and 3 without being rebuilt.  Stated
     tolerance: initial losses 1e-5 (steps 2+ start from fp32-different parameters), learning rates,
     damping schedule and termination reasons identical, iteration counts +-2, final losses 1e-4."""
+    from helpers import cpu_resnet18_default_steps
+
     gpu, g_final = _run_steps(DEV, 3)
     assert gpu._session is not None and gpu._session.steps == 3
-    cpu, c_final = _run_steps("cpu", 3)
-    sg, sc = gpu.state, cpu.state
+    sc, c_final, _ = cpu_resnet18_default_steps(3)  # (computed once per pytest process, shared with the 2-/8-rank tests)
+    sg = gpu.state
     for a, b in zip(sg["init_losses"], sc["init_losses"]):
         assert abs(a - b) <= 1e-5 * abs(b)
     assert sg["cg_reasons"] == sc["cg_reasons"]
@@ -324,17 +326,18 @@ def test_allcnnc_hessian_l2_preconditioned_session_steps_match_reference_cpu_pat
 
 
 def test_bottleneck_net_session_steps_match_reference_cpu_path():
-    """The Bottleneck (ResNet-50 topology, N = 25 557 032) net on 32x32 images, batch 4: two default steps through
-    the session against the CPU path.  A deep random-init net: a handful of its pre-activations lie within fp32
+    """The Bottleneck (ResNet-50 topology, N = 25 557 032) net on 32x32 images, batch 4: two steps (default
+    settings, ``cg_max_iter=6`` -- the CPU side of this 25 M-parameter net costs ~1.5 s per product) through the
+    session against the CPU path.  A deep random-init net: a handful of its pre-activations lie within fp32
     rounding of zero, so from the second step on the two fp32 trajectories differ like any
-    two fp32 runs: initial losses 1e-5 / 1e-4, iteration counts +-3, final losses 1e-3; learning rates, damping
-    schedule and reasons identical."""
-    kw = dict(batch_size=4, image=32)
+    two fp32 runs: initial losses 1e-5 / 1e-4, final losses 1e-3; learning rates, damping schedule, reasons and
+    iteration counts identical."""
+    kw = dict(batch_size=4, image=32, cg_max_iter=6)
     gpu, g_final = _run_family(tp.resnet50_small_images, DEV, 2, **kw)
     assert gpu._session is not None and gpu._session.steps == 2
     cpu, c_final = _run_family(tp.resnet50_small_images, "cpu", 2, **kw)
     assert abs(gpu.state["init_losses"][0] - cpu.state["init_losses"][0]) <= 1e-5 * abs(cpu.state["init_losses"][0])
-    _compare_family(gpu, g_final, cpu, c_final, loss_tol=1e-4, final_tol=1e-3, iters=3)
+    _compare_family(gpu, g_final, cpu, c_final, loss_tol=1e-4, final_tol=1e-3, iters=0)
 
 
 def test_session_is_reverified_against_the_models_own_forward(monkeypatch):
