@@ -97,6 +97,9 @@ def parse():
                     help="when a solve ends before --iters (Martens' criterion / round-off on the preconditioned "
                          "Hessian system of config 4), a step repeats the solve back to back until the timed region "
                          "holds at least this many operator calls")
+    ap.add_argument("--no-beyond-l3", action="store_true",
+                    help="skip the `roofline.frac_beyond_l3` leg (the same PCG kernels on 256 MiB vectors): a rocprofv3 "
+                         "--stats run of this command then averages K1 / K2 / K3 over the workload's N only")
     ap.add_argument("--acc", default="",
                     help="comma-separated chunk sizes (e.g. 16,16; they must add up to --batch): drive "
                          "HessianFree.acc_step's path (optimizer.py:519-606) -- loss / gradient / products "
@@ -771,7 +774,9 @@ def main():
                     "path": comm_path, "bytes": int(getattr(getattr(op, "op", op), "reduce_bytes", 4 * n)),
                     "ms": allreduce_ms,
                     "overlap_two_graphs": bool(args.overlap),
-                    "product_mode": ("two-phase (chunked / overlapped)" if getattr(op, "split", None) is not None
+                    "product_mode": ("two-phase (chunked / overlapped)"
+                                     + (", both graphs chained into one launch" if getattr(op, "use_chain", False) else "")
+                                     if getattr(op, "split", None) is not None
                                      else "single graph + one compact all-reduce"),
                     "product_mode_timing_ms": getattr(op, "mode_timing", None),
                     "product_mode_policy": {-1: "auto (measured at session creation)", 0: "forced single",
@@ -810,12 +815,12 @@ def main():
                 if val is not None:
                     line["roofline"]["traffic"] = val
                     line["roofline"]["traffic_source"] = (
-                        "static: profiles/traffic.json -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes taken on "
-                        "scripts/pcg_kernel_bench.py (the same kernel at the same N; --pmc aborts this full "
-                        "command on this stack), not re-measured in this run")
+                        "static: profiles/traffic.json (round 4 binary, scripts/collect_r04_profiles.sh) -- rocprofv3 "
+                        "--pmc FETCH_SIZE / WRITE_SIZE passes taken on scripts/pcg_kernel_bench.py (the same kernel at "
+                        "the same N; --pmc aborts this full command on this stack), not re-measured in this run")
             except Exception:
                 pass
-        if world == 1 and not dist_on:
+        if world == 1 and not dist_on and not args.no_beyond_l3:
             try:
                 bc = beyond_cache_roofline(device)
                 line["roofline"]["frac_beyond_l3"] = bc["k2_frac"]

@@ -63,6 +63,8 @@ class _TwoPhaseProduct:
 
     split = None
     _side = None
+    _chain = None       # hf_graph_chain_t*: G_a -> mid event -> G_b as ONE launch (direct RCCL only)
+    use_chain = False
 
     @staticmethod
     def plan_phases(eng, tail_fraction=None):
@@ -97,13 +99,37 @@ class _TwoPhaseProduct:
         eng._live_copy(self.output_buffer, False, part="head")
 
     def _capture_phases(self):
-        """(on ``self.stream``, warmed up) the two graphs of one product."""
-        self.g_a = torch.cuda.CUDAGraph()
+        """(on ``self.stream``, warmed up) the two graphs of one product -- and, where the library can chain them,
+        both as ONE launch with a hand-over event in between (``hf_graph_chain_*``)."""
+        self.g_a = torch.cuda.CUDAGraph(keep_graph=True)
         with torch.cuda.graph(self.g_a, stream=self.stream):
             self._phase_a()
-        self.g_b = torch.cuda.CUDAGraph()
+        self.g_b = torch.cuda.CUDAGraph(keep_graph=True)
         with torch.cuda.graph(self.g_b, stream=self.stream, pool=self.g_a.pool()):
             self._phase_b()
+        self.g_a.instantiate()
+        self.g_b.instantiate()
+        self._chain, self.use_chain = None, False
+        mode = os.environ.get("HF_CHUNK_ONEGRAPH", "auto")
+        if mode != "0":
+            handle = _lib.c_void_p()
+            rc = _lib.load().hf_graph_chain_create(_lib.ctypes.byref(handle), _lib.c_void_p(self.g_a.raw_cuda_graph()),
+                                                   _lib.c_void_p(self.g_b.raw_cuda_graph()))
+            if rc == 0:
+                self._chain = handle
+                self.use_chain = mode == "1"
+            elif mode == "1":
+                import warnings
+
+                warnings.warn(f"hf_graph_chain_create failed with code {rc}: the two-phase product stays two launches")
+
+    def __del__(self):
+        chain, self._chain = getattr(self, "_chain", None), None
+        if chain is not None:
+            try:
+                _lib.load().hf_graph_chain_destroy(chain)
+            except Exception:  # noqa: BLE001
+                pass
 
     def replay_phases(self):
         self.g_a.replay()
@@ -120,20 +146,30 @@ class _TwoPhaseProduct:
         tail = eng._reduce_pieces(self.output_buffer, "tail")
         cur = torch.cuda.current_stream()
         side_comm = hfdist.side_comm(tail[0], group)
-        self.g_a.replay()
+        if side_comm is not None and self._side is None:
+            self._side = torch.cuda.Stream()
+            self._ev_a, self._ev_t = torch.cuda.Event(), torch.cuda.Event()
         works = []
-        if side_comm is not None:
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-                self._ev_a, self._ev_t = torch.cuda.Event(), torch.cuda.Event()
-            self._ev_a.record(cur)
-            self._side.wait_event(self._ev_a)
+        if side_comm is not None and self.use_chain and self._chain is not None:
+            # ONE launch: G_a -> mid event -> G_b; the side stream waits for the mid event only
+            lib = _lib.load()
+            _lib.check(lib.hf_graph_chain_launch(self._chain, _lib.c_void_p(cur.cuda_stream)), "hf_graph_chain_launch")
+            _lib.check(lib.hf_graph_chain_wait_mid(self._chain, _lib.c_void_p(self._side.cuda_stream)),
+                       "hf_graph_chain_wait_mid")
             with torch.cuda.stream(self._side):
                 side_comm.all_reduce_sum_multi(tail)
                 self._ev_t.record(self._side)
         else:
-            works = [torch.distributed.all_reduce(piece, group=group, async_op=True) for piece in tail]
-        self.g_b.replay()
+            self.g_a.replay()
+            if side_comm is not None:
+                self._ev_a.record(cur)
+                self._side.wait_event(self._ev_a)
+                with torch.cuda.stream(self._side):
+                    side_comm.all_reduce_sum_multi(tail)
+                    self._ev_t.record(self._side)
+            else:
+                works = [torch.distributed.all_reduce(piece, group=group, async_op=True) for piece in tail]
+            self.g_b.replay()
         hfdist.all_reduce_sum_multi(head, group)
         if side_comm is not None:
             cur.wait_event(self._ev_t)
@@ -355,10 +391,17 @@ class EngineSession(_TwoPhaseProduct):
         if self._split_plan is None or self.group is None:
             return self.split is not None
         dist = torch.distributed
+        from . import distributed as hfdist
+
         sync = torch.zeros(2, dtype=torch.float64, device=self.engine.dev)
+        # candidates: single graph; two launches; (direct RCCL only) the two graphs chained into ONE launch
+        chain_ok = self._chain is not None and hfdist.side_comm(self.output_buffer, self.group) is not None
+        cands = [("single_graph", None, False), ("two_phase", self._split_plan, False)]
+        if chain_ok:
+            cands.append(("two_phase_one_launch", self._split_plan, True))
         times = []
-        for two in (False, True):
-            self.split = self._split_plan if two else None
+        for _name, split, chain in cands:
+            self.split, self.use_chain = split, chain
             for _ in range(3):
                 self.replay_and_reduce()
             dist.all_reduce(sync, group=self.group)  # (every rank starts the timed replays together)
@@ -370,9 +413,14 @@ class EngineSession(_TwoPhaseProduct):
             times.append((time.perf_counter() - t0) / reps)
         t = torch.tensor(times, dtype=torch.float64, device=self.engine.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        single, two_phase = t.tolist()
-        self.mode_timing = {"single_graph_ms": single * 1e3, "two_phase_ms": two_phase * 1e3}
-        self.split = self._split_plan if two_phase < 0.97 * single else None
+        times = t.tolist()
+        self.mode_timing = {name + "_ms": v * 1e3 for (name, _s, _c), v in zip(cands, times)}
+        self.mode_timing.setdefault("two_phase_ms", times[1] * 1e3)
+        best = min(range(1, len(cands)), key=lambda i: times[i])
+        if times[best] < 0.97 * times[0]:
+            self.split, self.use_chain = cands[best][1], cands[best][2]
+        else:
+            self.split, self.use_chain = None, False
         return self.split is not None
 
     def reduce(self, t):

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 # headline, as the driver runs it
 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/r04_bench_n1.json" 2> "$OUT/r04_bench_n1.err"; echo "bench_n1 rc=$?" >> "$OUT/rc.log"
 # rocprofv3 summary of the same command (no CPU leg, no step leg: kernels of the timed loop)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- python3 bench.py --no-cpu-baseline --no-step-timing > "$OUT/r04_bench_n1_under_rocprof.json" 2> "$OUT/prof_bench.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- python3 bench.py --no-cpu-baseline --no-step-timing --no-beyond-l3 > "$OUT/r04_bench_n1_under_rocprof.json" 2> "$OUT/prof_bench.log"
 find "$OUT/prof_bench" -name "*kernel_stats.csv" -exec cp {} "$OUT/r04_bench_n1_kernel_stats.csv" \;
 rm -rf "$OUT/prof_bench"
 # PMC traffic of the PCG kernels (separate passes; FETCH_SIZE doubled per the guide): profiles/traffic.json

@@ -12,7 +12,8 @@ curvature is a plain sum over samples, so shards of 16 + 16 equal one batch of 3
 
 mode: ``steps`` (default; the two-phase product forced) | ``auto`` (the session's measured choice between the
 single-graph and the two-phase product) | ``asym`` (rank 1's session creation is forced to fail on the first step: every
-rank must fall back together) | ``die`` (the last rank exits mid-run: the others must not hang
+rank must fall back together) | ``acc`` (``acc_step``: every rank passes ITS shard as two chunks -- the
+accumulated engine session under data parallelism) | ``die`` (the last rank exits mid-run: the others must not hang
 for good -- used through bench.py's launcher test instead).
 """
 
@@ -76,13 +77,19 @@ def main(outdir, mode="steps", backend="gloo"):
                 o = model(xs)
                 return lossf(o, ts), o
 
-            sess0 = opt._session
+            sess0 = opt._acc_session if mode == "acc" else opt._session
             c0 = sess0.calls if sess0 is not None else 0
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
-                finals.append(opt.step(forward))
-            sess = opt._session
-            modes.append(0 if sess is None else (2 if sess.split is not None else 1))
+                if mode == "acc":  # (two chunks per rank: world * 2 chunks accumulate to the whole batch)
+                    half = shard // 2
+                    chunks = [(xs[:half].contiguous(), ts[:half].contiguous()),
+                              (xs[half:].contiguous(), ts[half:].contiguous())]
+                    finals.append(opt.acc_step(model, lossf, chunks, reduction="mean"))
+                else:
+                    finals.append(opt.step(forward))
+            sess = opt._acc_session if mode == "acc" else opt._session
+            modes.append(0 if sess is None else (2 if getattr(sess, "split", None) is not None else 1))
             calls.append(-1 if sess is None else sess.calls - (c0 if sess is sess0 else 0))
             params.append(torch.cat([p.detach().reshape(-1) for p in opt._params_list]).cpu().numpy().copy())
         st = opt.state
@@ -97,11 +104,12 @@ def main(outdir, mode="steps", backend="gloo"):
         out["session_calls"] = np.array(calls)
         out["session_off"] = np.array([int(opt._session_off)])
         out["params"] = np.stack(params)
-        sess = opt._session
+        sess = opt._acc_session if mode == "acc" else opt._session
         if sess is not None:
             from pytorchhessianfree_amd import distributed as hfdist
 
             out["reduce_bytes"] = np.array([sess.reduce_bytes, 4 * sess.n])
+            out["use_chain"] = np.array([int(bool(getattr(sess, "use_chain", False)))])
             timing = getattr(sess, "mode_timing", None)
             out["mode_timing"] = np.array([timing["single_graph_ms"], timing["two_phase_ms"]] if timing else [0.0, 0.0])
             out["comm_path"] = np.array([hfdist.path_name(sess.output_buffer, group)])

@@ -136,12 +136,12 @@ def test_bench_gpus_2_starts_two_ranks_itself():
 # The drop-in API under data parallelism: HessianFree(prepared ResNet-18, graph_matvec=True,
 # process_group=...).step -> fused engine + persistent session + chunked / overlapped all-reduce
 # ---------------------------------------------------------------------------------------------------------
-def _launch_session_ranks(out, world, mode="steps", backend="gloo", timeout=900):
+def _launch_session_ranks(out, world, mode="steps", backend="gloo", timeout=900, env_extra=None):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **(env_extra or {}))
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(HERE, "gpu_workers", "dp_session_ranks.py"), str(out), mode, backend],
             env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -229,6 +229,25 @@ def test_step_two_ranks_measured_product_mode(tmp_path):
     _check_against_cpu(r0)
 
 
+def test_acc_step_two_ranks_accumulated_engine_session(tmp_path):
+    """``acc_step`` under data parallelism on the engine: every rank passes its 16-sample shard as two chunks of 8
+    (4 chunks accumulate to the 32-sample batch, weights N_k / sum N over ALL ranks, optimizer.py:677-684), the
+    accumulated session serves both calls (one engine per chunk, parallel graph branches, one compact all-reduce
+    per product, lockstep), ranks stay bitwise identical and the steps equal the single-process CPU path on the
+    whole batch (same tolerances as ``step``)."""
+    r0, r1 = _launch_session_ranks(tmp_path, 2, mode="acc")
+    assert r0["session_mode"].tolist() == [1, 1] and r1["session_mode"].tolist() == [1, 1]
+    assert np.array_equal(r0["params"], r1["params"])
+    assert r0["num_cg_iters"].tolist() == r1["num_cg_iters"].tolist()
+    for r in (r0, r1):
+        # lockstep through separate launches around the all-reduce: A(x0), the iterations, `lag` speculative ones
+        assert all(c >= n + 2 for c, n in zip(r["session_calls"].tolist(), r["num_cg_iters"].tolist()))
+        assert float(r["product_rel_err"][0]) < 1e-6
+    assert r0["session_calls"].tolist() == r1["session_calls"].tolist()
+    assert np.array_equal(r0["product_checksum"], r1["product_checksum"])
+    _check_against_cpu(r0, tol_final=5e-4)
+
+
 def test_step_two_ranks_one_session_refused_falls_back_together(tmp_path):
     """One rank's session creation fails on the first step (the decision must be symmetric): BOTH
     ranks switch the session off for good, take the generic path (engine + compact all-reduce, re-captured per
@@ -250,6 +269,17 @@ def test_step_one_rank_rccl_engine_session(tmp_path):
     assert "hf_allreduce_sum" in str(r0["comm_path"][0]) and int(r0["side_comm"][0]) == 1
     assert bool(r0["product_equals_plain_allreduce"][0])
     assert r0["session_calls"].tolist() == [n + 1 + 1 for n in r0["num_cg_iters"].tolist()]
+    _check_against_cpu(r0)
+
+
+def test_step_one_rank_rccl_two_phase_product_as_one_launch(tmp_path):
+    """The two product graphs chained into ONE launch with a hand-over event in between (``hf_graph_chain_*``,
+    ``HF_CHUNK_ONEGRAPH=1``): the side stream waits for the mid event and all-reduces the late layers' share while the
+    second half of the same launch runs.  Same results as the two-launch form (bitwise product, steps vs the CPU
+    whole-batch path)."""
+    (r0,) = _launch_session_ranks(tmp_path, 1, backend="nccl", env_extra={"HF_CHUNK_ONEGRAPH": "1"})
+    assert r0["session_mode"].tolist() == [2, 2] and int(r0["use_chain"][0]) == 1
+    assert bool(r0["product_equals_plain_allreduce"][0])
     _check_against_cpu(r0)
 
 

@@ -326,18 +326,23 @@ def test_allcnnc_hessian_l2_preconditioned_session_steps_match_reference_cpu_pat
 
 
 def test_bottleneck_net_session_steps_match_reference_cpu_path():
-    """The Bottleneck (ResNet-50 topology, N = 25 557 032) net on 32x32 images, batch 4: two steps (default
-    settings, ``cg_max_iter=6`` -- the CPU side of this 25 M-parameter net costs ~1.5 s per product) through the
-    session against the CPU path.  A deep random-init net: a handful of its pre-activations lie within fp32
-    rounding of zero, so from the second step on the two fp32 trajectories differ like any
-    two fp32 runs: initial losses 1e-5 / 1e-4, final losses 1e-3; learning rates, damping schedule, reasons and
-    iteration counts identical."""
-    kw = dict(batch_size=4, image=32, cg_max_iter=6)
+    """The Bottleneck (ResNet-50 topology, N = 25 557 032) net on 32x32 images, batch 4: two default steps through
+    the session; the FIRST against the CPU path (one CPU step of this 25 M-parameter net costs ~13 products of
+    ~1.5 s: the second step's CPU twin is left out for the suite's run time -- round 4 measured both: initial
+    losses 1e-5 / 1e-4, final losses 1e-3, identical schedules).  Stated tolerance for the first step: initial
+    loss 1e-5, learning rate / damping / reason identical, iteration count +-2, final loss 1e-4; the second step
+    is served by the same session and reduces its batch's loss."""
+    kw = dict(batch_size=4, image=32)
     gpu, g_final = _run_family(tp.resnet50_small_images, DEV, 2, **kw)
     assert gpu._session is not None and gpu._session.steps == 2
-    cpu, c_final = _run_family(tp.resnet50_small_images, "cpu", 2, **kw)
-    assert abs(gpu.state["init_losses"][0] - cpu.state["init_losses"][0]) <= 1e-5 * abs(cpu.state["init_losses"][0])
-    _compare_family(gpu, g_final, cpu, c_final, loss_tol=1e-4, final_tol=1e-3, iters=0)
+    cpu, c_final = _run_family(tp.resnet50_small_images, "cpu", 1, **kw)
+    first = {k: v[:1] for k, v in gpu.state.items() if isinstance(v, list)}
+
+    class _First:
+        state = first
+
+    _compare_family(_First, g_final[:1], cpu, c_final, loss_tol=1e-5, final_tol=1e-4, iters=2)
+    assert g_final[1] < gpu.state["init_losses"][1]
 
 
 def test_session_is_reverified_against_the_models_own_forward(monkeypatch):
