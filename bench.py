@@ -325,7 +325,24 @@ def full_step_timing(args, device, n_steps=8, warmup=2):
         times.append((time.perf_counter() - t0) * 1e3)
     timed = times[warmup:]
     st = opt.state
+    precond_ms = None
+    if args.precond:  # what the preconditioner's construction alone costs, both ways the reference offers
+        from pytorchhessianfree_amd import preconditioners
+
+        x, t = batches[0]
+        precond_ms = {}
+        for name, fn in (("per_sample_autograd (preconditioners.py:63-105; inside every timed step)",
+                          preconditioners.diag_EF_autograd),
+                         ("batched per-sample gradients (the role of BackPACK's SumGradSquared, preconditioners.py:11-60)",
+                          preconditioners.diag_EF_backpack)):
+            fn(model, lossf, x, t, "mean")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn(model, lossf, x, t, "mean")
+            torch.cuda.synchronize()
+            precond_ms[name] = (time.perf_counter() - t0) * 1e3
     return {
+        "precond_build_ms": precond_ms,
         "mean": sum(timed) / len(timed), "min": min(timed), "max": max(timed), "steps": n_steps,
         "warmup_steps": warmup, "first_step_ms": times[0],
         "cg_iters": st["num_cg_iters"][warmup:], "best_cg_iters": [int(b) for b in st["best_cg_iters"][warmup:]],
