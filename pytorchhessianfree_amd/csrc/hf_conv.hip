@@ -1196,6 +1196,9 @@ int hf_conv2d_nhwc_slabs_unpack(void* out, const void* act, const void* mat, int
                                 void* stream) {
   if (splits < 1 || slab_stride < 0 || mat_ld < 0 || dtype != HF_F32) return HF_ERR_ARG;
   if (!usrc || !udsts || !usrc_offs || !unumels || !uslabs || !uinners || n_tensors < 1) return HF_ERR_ARG;
+  if (uhalves)  // (transposed copies run as LDS-tiled workgroups of hf_unpack_weights' own kernel only)
+    for (int t_ = 0; t_ < n_tensors; ++t_)
+      if (uhalves[t_] == 2) return HF_ERR_ARG;
   alignas(16) float dummy_ws[4];
   const int rc = check_common(out, act, mat, dummy_ws, dummy_ws, dtype, n, h, w, c, k, r, s, stride_h, stride_w,
                               pad_h, pad_w);

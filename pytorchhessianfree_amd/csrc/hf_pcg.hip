@@ -881,6 +881,8 @@ using hf_shared::UnpackArgs;
 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_unpack_tangent(const T* __restrict__ src_base, const UnpackArgs a) {
+  __shared__ T tile[hf_shared::TT * (hf_shared::TT + 1)];  // (transposed copies only)
+  if (hf_shared::unpack_transposed_block<T>(src_base, a, blockIdx.x, tile)) return;
   hf_shared::unpack_block<T>(src_base, a, blockIdx.x);
 }
 

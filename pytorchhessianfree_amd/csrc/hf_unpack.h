@@ -58,17 +58,7 @@ __device__ __forceinline__ void unpack_block(const T* __restrict__ src_base, con
   constexpr int W = VecOf<T>::W;
   typedef typename VecOf<T>::type V;
   const bool al = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
-  if (half == 2) {
-    // transposed copy: dst stored (I, H, W, O) dense -- the operand of a data-gradient convolution:
-    // dst[(i*HW + hw)*O + o] = src[(o*I + i)*HW + hw]; walked in source order (coalesced reads)
-    const unsigned HW = slab / I, O = (unsigned)(numel / slab);
-    for (long long j = j0 + threadIdx.x; j < j1; j += BLOCK) {
-      const unsigned o = (unsigned)(j / slab), rem = (unsigned)(j - (long long)o * slab);
-      const unsigned i = rem / HW, hw = rem - i * HW;
-      dst[((long long)i * HW + hw) * O + o] = src[j];
-    }
-    return;
-  }
+  if (half == 2) return;  // (transposed copies: unpack_transposed_block, k_unpack_tangent only)
   if (I == 0) {  // dst[o*2*slab + half*slab + r] = src[o*slab + r]
     if (al && slab % W == 0) {
       for (long long j = j0 + (long long)threadIdx.x * W; j < j1; j += (long long)BLOCK * W) {
@@ -111,6 +101,43 @@ __device__ __forceinline__ void unpack_block(const T* __restrict__ src_base, con
 }
 
 
+// Transposed copy (half == 2): dst stored (I, H, W, O) dense -- the operand of a data-gradient convolution --,
+// dst[r*O + o] = src[o*R + r] with r = i*HW + hw, R = I*HW: a [O, R] -> [R, O] matrix transpose, one TT x TT tile per
+// workgroup through LDS (coalesced 256-byte rows on both sides; the element-wise walk this replaces scattered 4-byte
+// stores O floats apart: 157 us for the 44.7 MB of a ResNet-18 vector, once per Hessian product).
+// Returns false when workgroup `bid` belongs to a tensor of another kind.  lds: TT * (TT + 1) elements.
+constexpr int TT = 64;
+template <typename T>
+__device__ __forceinline__ bool unpack_transposed_block(const T* __restrict__ src_base, const UnpackArgs& a,
+                                                        unsigned bid, T* lds) {
+  int lo = 0, hi = a.nt;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.blk_start[mid] <= (int)bid) lo = mid; else hi = mid;
+  }
+  if (a.half[lo] != 2) return false;
+  const T* __restrict__ src = src_base + a.src_off[lo];
+  T* __restrict__ dst = reinterpret_cast<T*>(a.dst[lo]);
+  const unsigned R = (unsigned)a.slab[lo], O = (unsigned)(a.numel[lo] / a.slab[lo]);
+  const unsigned tiles_o = (O + TT - 1) / TT;
+  const unsigned tile = bid - (unsigned)a.blk_start[lo];
+  const unsigned o0 = (tile % tiles_o) * TT, r0 = (tile / tiles_o) * TT;
+  const unsigned tx = threadIdx.x % TT, ty = threadIdx.x / TT;  // BLOCK / TT = 4 rows per pass
+#pragma unroll 4
+  for (unsigned k = 0; k < TT; k += BLOCK / TT) {
+    const unsigned o = o0 + ty + k, r = r0 + tx;
+    if (o < O && r < R) lds[(ty + k) * (TT + 1) + tx] = src[(size_t)o * R + r];
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (unsigned k = 0; k < TT; k += BLOCK / TT) {
+    const unsigned r = r0 + ty + k, o = o0 + tx;
+    if (o < O && r < R) dst[(size_t)r * O + o] = lds[tx * (TT + 1) + ty + k];
+  }
+  return true;
+}
+
+
 // Fills ONE argument block for tensors t0 ... (at most PACK_MAXT non-empty ones); returns the next tensor index,
 // the number of workgroups in *blocks, or a negative error code.
 template <typename T>
@@ -139,7 +166,10 @@ inline int fill_unpack_args(UnpackArgs& a, int* blocks_out, int t, void* const* 
       // reads into LDS, lane = channel on the way out -- 21.2 vs 14.3 us, scripts/experiments/unpack_time.py)
       a.chunk[k] = PACK_CHUNK;
       a.blk_start[k] = blocks;
-      blocks += (int)((numels[t] + a.chunk[k] - 1) / a.chunk[k]);
+      if (a.half[k] == 2)  // one TT x TT tile of the [O, slab] -> [slab, O] transpose per workgroup
+        blocks += (int)(((numels[t] / slab + TT - 1) / TT) * ((slab + TT - 1) / TT));
+      else
+        blocks += (int)((numels[t] + a.chunk[k] - 1) / a.chunk[k]);
       ++k;
     }
     ++t;

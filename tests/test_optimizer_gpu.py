@@ -266,6 +266,30 @@ def test_unpack_tangent_scatters_like_copy(dtype):
         _lib.unpack_tangent(v, [(v.numel() - 3, torch.empty(2, 2, 1, 2, device=DEV, dtype=dtype), 1)])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_unpack_transposed_copies_equal_permute(dtype):
+    """hf_unpack_weights, half = 2: weight-shaped slices of the flat vector [O, I, H, W] as dense (I, H, W, O)
+    copies -- the operand of the data-gradient convolutions (``W^T`` per step, ``V^T`` per Hessian product,
+    optimizer.py:450-455) -- by the LDS-tiled transpose: bitwise ``permute(1, 2, 3, 0)``, for tile-aligned and
+    ragged shapes (O, I*H*W not multiples of 64), many tensors in one launch."""
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    shapes = [(64, 64, 3, 3), (128, 64, 1, 1), (512, 256, 3, 3), (100, 192, 1, 1), (96, 3, 3, 3), (5, 6, 2, 3),
+              (1, 4, 1, 1), (70, 130, 1, 1)] + [(3, 2, 1, 2)] * 70
+    sizes = [int(np.prod(sh)) for sh in shapes]
+    pad = 3
+    v = torch.randn(sum(sizes) + pad * len(shapes), device=DEV, dtype=dtype, generator=gen)
+    slots, want, off = [], [], 0
+    for sh, size in zip(shapes, sizes):
+        o, i, h, w = sh
+        buf = torch.full((i, h, w, o), 7.0, device=DEV, dtype=dtype)
+        slots.append((off, buf, i))
+        want.append(v[off:off + size].view(sh).permute(1, 2, 3, 0).contiguous())
+        off += size + pad
+    _lib.unpack_tangent(v, slots, half=2)
+    for (_, buf, _), ref in zip(slots, want):
+        assert torch.equal(buf, ref)
+
+
 @pytest.mark.parametrize("cl", [False, True])
 def test_tangent_scatter_product_equals_per_layer_copies(cl):
     """The first product of an operator fills the conv layers' v_W operands with one
