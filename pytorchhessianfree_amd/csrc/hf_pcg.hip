@@ -263,7 +263,8 @@ __global__ __launch_bounds__(BLOCK) void k_init_finalize(DevState* __restrict__ 
 // N = 100 M K1 151.8 -> 137.2, K2 466.9 -> 440.0, K3 211.1 -> 204.6 us (all three 0.736 -> 0.770 of 8 TB/s).  Small
 // vectors (All-CNN-C: 5.5 MB, L2-resident between kernels) keep the default policy.
 // NT covers: K1 both read streams; K2 the x / b / Bp loads and the x store (r and p are re-read by K3 right
-// after); K3 the r load.
+// after).  K3 keeps the default policy: its r was written by K2 a moment ago and is still on-die (a non-temporal
+// r load cost K3 24.8 -> 26.9 us in the same A/B, profiles/r04_pcg_nt_variants.jsonl).
 #define HF_LD(NTFLAG, dst, ptr)                                                             \
   {                                                                                         \
     if constexpr (NTFLAG) {                                                                 \
@@ -2119,7 +2120,8 @@ static void build_k2(hf_pcg* h, const void* Bp, double damping, KLaunch& k) {
 
 template <typename T>
 static void build_k3(hf_pcg* h, const void* yext, KLaunch& k) {
-  const bool nt = nt_streams(h);
+  const bool nt = false;  // (see HF_LD: K3's operands are on-die)
+  (void)nt_streams;
   switch (h->precond) {
     case HF_M_NONE: k.func = nt ? (const void*)&k_update_p<T, HF_M_NONE, U3, true> : (const void*)&k_update_p<T, HF_M_NONE, U3, false>; break;
     case HF_M_DIAG: k.func = nt ? (const void*)&k_update_p<T, HF_M_DIAG, U3, true> : (const void*)&k_update_p<T, HF_M_DIAG, U3, false>; break;

@@ -869,23 +869,70 @@ class FusedGGNEngine(_Operator):
         n, k, oh, ow = u.a.shape
         v = self._v
         v_gamma = v[self._offs[u.pg]: self._offs[u.pg] + k]
-        # the scale's gradient also moves with the convolution's tangent:  sum_rows g_z * rstd * t_a  (t_a = the
-        # sum of the tangent convolution's slabs, still in place) -> `rb` more partial rows of the same buffer
-        _lib.check(lib.hf_chan_affine_bwd_ex(
-            None, _ptr(u.gw[u.rb:]), None, None, _ptr(u.tbuf), u.sT, u.tbuf.shape[1], None, 1, 0, _ptr(u.g1),
-            _ptr(self._zeros(k)), _ptr(u.rstd), None, None, n, k, oh * ow, 1, u.rb, _lib.HF_F32, st),
-            "hf_chan_affine_bwd_ex")
+        if not self._extras_parallel:
+            self._hessian_extras(u)
         # the convolution's cotangent tangent:  g_a' + g_z * rstd * v_gamma
         _lib.check(lib.hf_chan_affine_ex(
             _ptr(u.gah), _ptr(u.g1), None, None, _ptr(u.rstd), _ptr(v_gamma), None, None, _ptr(u.ga), None, 0, n, k,
             oh * ow, 1, 0, 0, 1, 0, _lib.HF_F32, st), "hf_chan_affine_ex")
         self._conv_adjoint(u, u.gah)
+
+    def _hessian_extras(self, u):
+        """The terms of a Hessian product that do NOT depend on the adjoint chain -- only on the tangent sweep's
+        results and the step's first-order cotangents: the scale's  sum_rows g_z * rstd * t_a  (t_a = the sum of the
+        tangent convolution's slabs, still in place) as `rb` more partial rows of the gw buffer, and conv_D(g_a, V) /
+        conv_W(t_x, g_a) as MORE SLABS of the same buffers (the consumers sum them anyway)."""
+        if u.bn is not None:
+            n, k, oh, ow = u.a.shape
+            _lib.check(_lib.load().hf_chan_affine_bwd_ex(
+                None, _ptr(u.gw[u.rb:]), None, None, _ptr(u.tbuf), u.sT, u.tbuf.shape[1], None, 1, 0, _ptr(u.g1),
+                _ptr(self._zeros(k)), _ptr(u.rstd), None, None, n, k, oh * ow, 1, u.rb, _lib.HF_F32,
+                _lib.current_stream_ptr(self.dev)), "hf_chan_affine_bwd_ex")
         if not u.im2col and not u.first:
-            # conv_D(g_a, V) and conv_W(t_x, g_a) with the step's first-order cotangent: MORE SLABS of the same
-            # buffers (the consumers sum them anyway)
             c = u.x.shape[1]
             _lib.conv_dw_slabs((1, u.dbuf[u.sD:], u.ga1, u.vT, u.geo, u.sD, 0, 0),
                                (2, u.wbuf[u.sW:], u.xcat, u.ga1, u.geo, u.sW, 2 * c, 0), self.dev)
+
+    # Those extras are half of a Hessian product's launches and none of them is on the adjoint sweep's dependency
+    # chain: they are issued on a SECOND STREAM forked off after the tangent sweep (inside a hipGraph capture: a
+    # parallel branch of the graph), in the adjoint's unit order; the chain waits per unit for the data-gradient
+    # slabs it is about to sum (an event per unit) and once, before the gather, for the rest.
+    _extras_parallel = False
+
+    def _extras_fork(self):
+        self._extras_parallel = os.environ.get("HF_HESSIAN_PARALLEL", "1") != "0"
+        if not self._extras_parallel:
+            return
+        if getattr(self, "_xside", None) is None:
+            self._xside = torch.cuda.Stream(device=self.dev)
+            self._xfork, self._xjoin = torch.cuda.Event(), torch.cuda.Event()
+            self._xev = {id(u): torch.cuda.Event() for u in self.units}
+        cur = torch.cuda.current_stream(self.dev)
+        self._xfork.record(cur)
+        self._xside.wait_event(self._xfork)
+        self._xwait = {}
+        with torch.cuda.stream(self._xside):
+            for u in reversed(self.units):
+                self._hessian_extras(u)
+                if getattr(u, "sD", 0) and not u.im2col and not u.first:
+                    ev = self._xev[id(u)]
+                    ev.record(self._xside)
+                    self._xwait[u.dbuf.data_ptr()] = ev
+            self._xjoin.record(self._xside)
+
+    def _extras_wait(self, srcs):
+        """Before a unit sums data-gradient slabs: the side branch's share of them must be there."""
+        if self._extras_parallel and self._second:
+            cur = torch.cuda.current_stream(self.dev)
+            for buf, _n, _l in srcs:
+                ev = self._xwait.get(buf.data_ptr())
+                if ev is not None:
+                    cur.wait_event(ev)
+
+    def _extras_join(self):
+        if self._extras_parallel:
+            torch.cuda.current_stream(self.dev).wait_event(self._xjoin)
+            self._extras_parallel = False
 
     def _zeros(self, k):
         cache = self.__dict__.setdefault("_zeros_cache", {})
@@ -901,6 +948,7 @@ class FusedGGNEngine(_Operator):
         ga = u.ga if ga is None else ga
         if not 1 <= len(srcs) <= 2:
             raise RuntimeError(f"{u.name}: {len(srcs)} consumers")
+        self._extras_wait(srcs)
         (a, sa, la) = srcs[0]
         (b, sb, lb) = srcs[1] if len(srcs) == 2 else (None, 1, 0)
         lib, st = _lib.load(), _lib.current_stream_ptr(self.dev)
@@ -962,10 +1010,13 @@ class FusedGGNEngine(_Operator):
             if self._vt_slots:
                 _lib.unpack_tangent(v, self._vt_slots, half=2)  # V as (I, H, W, O): the operand of conv_D(g, V)
             self._second, self._v = True, v
+            self._extras_fork()
         try:
             g_last, g_fw, g_fb = self._head(v)
             pool_srcs = self._adjoint_blocks(g_last)
             self._adjoint_stem(pool_srcs)
+            if self.hessian:
+                self._extras_join()
         finally:
             self._second, self._v = False, None
         self._gather(out, g_fw, g_fb)
@@ -1202,6 +1253,7 @@ class FusedGGNEngine(_Operator):
         ks, st_, pd, dl, cm = self.pool_args
         pn, ph, pw, poh, pow_, c0 = self._pool_geometry()
         (a, sa, la), (b, sb, lb) = pool_srcs
+        self._extras_wait(pool_srcs)
         # slab sums of both cotangents and the max-pool adjoint (gather form) in one launch
         g_stem = self._g_stem
         (kh, kw), (sh, sw), (pph, ppw) = _pair(ks), _pair(st_ if st_ is not None else ks), _pair(pd)
@@ -1621,17 +1673,18 @@ class PlainStackEngine(FusedGGNEngine):
         otherwise the product's sweep -- for a Hessian engine with the two extra convolutions per layer."""
         second = self.hessian and not first_order
         srcs = [(g_last, 1, 0)]
+        self._second = second  # (the chain waits for the side branch's slabs, _extras_wait)
         for u in reversed(self.units):
             ga = u.ga1 if (self.hessian and first_order) else u.ga
             self._bn_adjoint(u, srcs, ga)
             if second and not u.im2col and not u.first:
-                n_, h, w, c, k_, r, s, sd, pd = u.geo
                 # (two launches of two problems each; four in one grouped launch ran 3x slower -- with four
-                # by-value problem descriptions hipcc spills them to scratch memory)
+                # by-value problem descriptions hipcc spills them to scratch memory.  The second one -- conv_D(g, V),
+                # conv_W(t_x, g): no dependence on this chain -- runs on the side branch, see _extras_fork)
                 _lib.conv_dw_slabs((1, u.dbuf, ga, u.wT, u.geo, u.sD, 0, 0), (2, u.wbuf, u.x, ga, u.geo, u.sW, 0, 0),
                                    self.dev)
-                _lib.conv_dw_slabs((1, u.dbuf[u.sD:], u.ga1, u.vT, u.geo, u.sD, 0, 0),
-                                   (2, u.wbuf[u.sW:], u.xcat, u.ga1, u.geo, u.sW, 2 * c, 0), self.dev)
+                if not self._extras_parallel:
+                    self._hessian_extras(u)
             else:
                 self._conv_adjoint(u, ga)
             if u.sD:
@@ -1650,7 +1703,14 @@ class PlainStackEngine(FusedGGNEngine):
         _lib.check(_lib.load().hf_pool_ce_head(
             _ptr(self._g_last), None, _ptr(self.tail.tout), _ptr(self._ce[0]), float(self._ce[1]), n, self._head_hw, k,
             _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_pool_ce_head")
-        self._adjoint_sweep(self._g_last)
+        if self.hessian:
+            self._extras_fork()
+        try:
+            self._adjoint_sweep(self._g_last)
+            if self.hessian:
+                self._extras_join()
+        finally:
+            self._second = False
         self._gather(out, None, None)
         if self.hessian and self._l2 is not None:  # the regulariser's Hessian: coef on its tensors' entries
             out.addcmul_(self._l2, v, value=self.weight)

@@ -331,7 +331,8 @@ def test_bottleneck_net_session_steps_match_reference_cpu_path():
     ~1.5 s: the second step's CPU twin is left out for the suite's run time -- round 4 measured both: initial
     losses 1e-5 / 1e-4, final losses 1e-3, identical schedules).  Stated tolerance for the first step: initial
     loss 1e-5, learning rate / damping / reason identical, iteration count +-2, final loss 1e-4; the second step
-    is served by the same session and reduces its batch's loss."""
+    is served by the same session and does not increase its batch's loss (on this net its line search ends at
+    lr = 0 -- on the CPU path too, round-4 measurement: the step is then rejected and the loss stays)."""
     kw = dict(batch_size=4, image=32)
     gpu, g_final = _run_family(tp.resnet50_small_images, DEV, 2, **kw)
     assert gpu._session is not None and gpu._session.steps == 2
@@ -342,7 +343,7 @@ def test_bottleneck_net_session_steps_match_reference_cpu_path():
         state = first
 
     _compare_family(_First, g_final[:1], cpu, c_final, loss_tol=1e-5, final_tol=1e-4, iters=2)
-    assert g_final[1] < gpu.state["init_losses"][1]
+    assert g_final[1] <= gpu.state["init_losses"][1]
 
 
 def test_session_is_reverified_against_the_models_own_forward(monkeypatch):
