@@ -255,16 +255,17 @@ __global__ __launch_bounds__(BLOCK) void k_init_finalize(DevState* __restrict__ 
 // else (the done flag, the re-reduction of the previous kernel's partials): at small N
 // (All-CNN-C: 5.5 MB vectors, one tile per block) that prologue used to sit in front of
 // the first load and cost more than the streaming itself.
-// Non-temporal access to the solver's streams (template flag NT of K1 / K2 / K3, chosen per handle at run time:
-// vectors of >= HF_PCG_NT_MIN elements, default 4 M).  Between two uses of the same vector element lie a whole
-// curvature product (~0.5 GB of other traffic on the ResNet-18 workload) or five other vector streams, so nothing
-// these kernels read survives in a cache anyway -- non-temporal loads / stores just do not evict what does:
-// measured in the bench (profiles/r04_pcg_nt_variants.jsonl): 1 499 -> 1 534 matvecs/s, K2 55.4 -> 52.4 us; at
-// N = 100 M K1 151.8 -> 137.2, K2 466.9 -> 440.0, K3 211.1 -> 204.6 us (all three 0.736 -> 0.770 of 8 TB/s).  Small
-// vectors (All-CNN-C: 5.5 MB, L2-resident between kernels) keep the default policy.
+// Non-temporal access to the solver's streams (template flag NT of K1 / K2, chosen per handle at run time: vectors
+// of >= HF_PCG_NT_MIN elements, default 16 M = six fp32 vectors of 1.5 x the 256 MiB Infinity Cache).  Beyond the
+// cache nothing these kernels read survives until its next use, and non-temporal loads / stores stream faster
+// (profiles/r04_pcg_nt_variants.jsonl, N = 100 M: K1 151.8 -> 137.2, K2 466.9 -> 440.0 us; all three kernels 0.70 ->
+// 0.77 of 8 TB/s; N = 25.6 M: 0.71 -> 0.79).  At the ResNet-18 size (six vectors = 256 MiB, the cache's edge) the
+// same-box A/B of the whole bench is inside its own noise (+1.8 % / +1.8 % in one batch, -3.0 % / +1.5 % in the
+// next) while K2 / K3 themselves get ~1 us slower: default policy there, and for small vectors (All-CNN-C: 5.5 MB,
+// L2-resident between kernels).
 // NT covers: K1 both read streams; K2 the x / b / Bp loads and the x store (r and p are re-read by K3 right
 // after).  K3 keeps the default policy: its r was written by K2 a moment ago and is still on-die (a non-temporal
-// r load cost K3 24.8 -> 26.9 us in the same A/B, profiles/r04_pcg_nt_variants.jsonl).
+// r load cost K3 24.8 -> 26.9 us at N = 11.2 M).
 #define HF_LD(NTFLAG, dst, ptr)                                                             \
   {                                                                                         \
     if constexpr (NTFLAG) {                                                                 \
@@ -1890,7 +1891,7 @@ int grid_for(const hf_pcg* h, int unroll) {
 // non-temporal streams for vectors that cannot stay cached between their uses (see HF_LD)
 bool nt_streams(const hf_pcg* h) {
   static long long min_n = -1;
-  if (min_n < 0) { const char* e = getenv("HF_PCG_NT_MIN"); min_n = e ? atoll(e) : 4000000LL; }
+  if (min_n < 0) { const char* e = getenv("HF_PCG_NT_MIN"); min_n = e ? atoll(e) : 16000000LL; }
   return h->n >= min_n;
 }
 }  // namespace

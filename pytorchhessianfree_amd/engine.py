@@ -900,7 +900,11 @@ class FusedGGNEngine(_Operator):
     _extras_parallel = False
 
     def _extras_fork(self):
-        self._extras_parallel = os.environ.get("HF_HESSIAN_PARALLEL", "1") != "0"
+        # (``_extras_allowed = False``: the caller already runs this engine on one of several parallel branches --
+        # session.AccumulatedSession -- and a fork inside a forked capture branch crashes hipStreamEndCapture
+        # on this stack: segfault in capture_end, round-4 batch r4f)
+        self._extras_parallel = (os.environ.get("HF_HESSIAN_PARALLEL", "1") != "0"
+                                 and getattr(self, "_extras_allowed", True))
         if not self._extras_parallel:
             return
         if getattr(self, "_xside", None) is None:

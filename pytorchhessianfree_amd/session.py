@@ -632,6 +632,9 @@ class AccumulatedSession:
             self.train_bn = any(e.train_bn for e in engines)
             self.parallel = (os.environ.get("HF_ACC_PARALLEL", "1") != "0" and len(engines) > 1
                              and not self.train_bn)
+            if self.parallel:  # (one level of graph branches: the chunks'; no fork inside a forked branch)
+                for e in engines:
+                    e._extras_allowed = False
             f32 = dict(dtype=torch.float32, device=self.dev)
             k_all = len(engines)
             self.input_buffer = torch.zeros(self.n, **f32)
