@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round-4 GPU batch 6: weight gradients on the side branch (HF_ADJ_SPLIT) A/B on three workloads; acc Hessian test.
+O=gpurun_out/r4g; mkdir -p $O
+run() { name=$1; shift; "$@" > $O/$name.log 2>&1; echo "$name rc=$?" >> $O/rc.log; }
+run tests python -m pytest tests/test_acc_session_gpu.py tests/test_engine_gpu.py -q -m gpu -k "hessian or resnet18_engine_product"
+HF_ADJ_SPLIT=1 python -m pytest tests/test_engine_gpu.py tests/test_session_gpu.py -q -m gpu -k "resnet18_engine_product or allcnnc_plain or session_steps_match or bottleneck_net_engine" > $O/tests_split.log 2>&1; echo "tests_split rc=$?" >> $O/rc.log
+: > $O/adj_split.jsonl
+for rep in 1 2; do
+  for sp in 0 1; do
+    for wl in resnet18 resnet50 allcnnc; do
+      echo "== HF_ADJ_SPLIT=$sp $wl rep $rep" >> $O/adj_split.jsonl
+      HF_ADJ_SPLIT=$sp python bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-step-timing --no-beyond-l3 >> $O/adj_split.jsonl 2>> $O/adj_split.err
+    done
+  done
+done
+cat $O/rc.log
