@@ -13,4 +13,11 @@ for rep in 1 2; do
     done
   done
 done
+export TMPDIR=/tmp
+for spec in "allcnnc hessian ach" "allcnnc ggn acg"; do
+  set -- $spec
+  rocprofv3 --kernel-trace --output-format csv -d $O/tr_$3 -- python3 scripts/engine_product_driver.py --workload $1 --curvature $2 --products 8 --out $O/launches_$3.json > $O/tr_$3.log 2>&1
+  find $O/tr_$3 -name "*kernel_trace.csv" -exec cp {} $O/$3_kernel_trace.csv \;
+  rm -rf $O/tr_$3
+done
 cat $O/rc.log
