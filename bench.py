@@ -341,6 +341,15 @@ def full_step_timing(args, device, n_steps=8, warmup=2):
             fn(model, lossf, x, t, "mean")
             torch.cuda.synchronize()
             precond_ms[name] = (time.perf_counter() - t0) * 1e3
+        if getattr(opt, "_session", None) is not None:
+            opt.get_preconditioner(model, lossf, x, t, "mean", use_backpack=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            opt.get_preconditioner(model, lossf, x, t, "mean", use_backpack=False)
+            torch.cuda.synchronize()
+            precond_ms["HessianFree.get_preconditioner with the session's engine (engine.diag_ef: one adjoint sweep + "
+                       "per-sample weight-gradient launches; what the timed steps use from the second step on)"] = (
+                (time.perf_counter() - t0) * 1e3)
     return {
         "precond_build_ms": precond_ms,
         "mean": sum(timed) / len(timed), "min": min(timed), "max": max(timed), "steps": n_steps,

@@ -424,7 +424,7 @@ def conv2d_nhwc_backward(dx, dw, dy, x, w_t, n, h, w, c, k, r, s, stride, paddin
     return dx, dw
 
 
-def pack_ex(dst, tensors, perms, splits, scale=1.0, live=None):
+def pack_ex(dst, tensors, perms, splits, scale=1.0, live=None, mode=0):
     """``pack`` for sources the caller describes itself: ``perms[i] = (I, H*W)`` marks tensor i as
     stored (O, H, W, I); ``splits[i] = (count, stride)`` makes it the sum of ``count`` split-K
     slabs ``stride`` elements apart (``hf_pack_ex``); ``live[i]`` = bit mask of the kernel taps
@@ -451,7 +451,7 @@ def pack_ex(dst, tensors, perms, splits, scale=1.0, live=None):
     if total != dst.numel():
         raise RuntimeError(f"pack_ex: {total} source elements for a vector of {dst.numel()}")
     check(
-        lib.hf_pack_ex(c_void_p(dst.data_ptr()), ptrs, numels, perm, spl, lv, n, float(scale), 0,
+        lib.hf_pack_ex(c_void_p(dst.data_ptr()), ptrs, numels, perm, spl, lv, n, float(scale), int(mode),
                        dtype_code(dst.dtype), current_stream_ptr(dst.device)),
         "hf_pack_ex")
     return dst

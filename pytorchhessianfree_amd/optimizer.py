@@ -756,11 +756,55 @@ class HessianFree(torch.optim.Optimizer):
     def get_preconditioner(self, model, loss_func, inputs, targets, reduction, exponent=None,
                            use_backpack=True):
         """Diagonal empirical-Fisher preconditioner at the CURRENT damping
-        (optimizer.py:928-952).  Unlike the reference, the result is returned."""
+        (optimizer.py:928-952).  Unlike the reference, the result is returned.  With a persistent engine
+        session for ``model`` (from the second ``step`` on) the diagonal comes from ONE adjoint sweep of the engine
+        plus per-sample weight-gradient launches (``engine.diag_ef``) instead of one backward pass per sample
+        (``use_backpack=False``) / a batched per-sample-gradient pass (``True``): the same quantity."""
+        diag = self._engine_diag_ef(model, loss_func, inputs, targets, reduction)
+        if diag is not None:
+            from .preconditioners import diag_to_preconditioner
+
+            damping = self._group["damping"]
+            return (diag_to_preconditioner(diag, damping) if exponent is None
+                    else diag_to_preconditioner(diag, damping, exponent))
         return diag_EF_preconditioner(model, loss_func, inputs, targets, reduction,
                                       damping=self._group["damping"], exponent=exponent,
                                       use_backpack=use_backpack)
 
+    def _engine_diag_ef(self, model, loss_func, inputs, targets, reduction):
+        """``sum_i g_i^2`` (/ N) on the session's engine, or ``None`` (no session for this model / shape / loss, train
+        mode, data parallelism, ``HF_ENGINE_DIAG_EF=0``): the caller then takes the autograd construction."""
+        import os
+
+        sess = self._session
+        if (sess is None or os.environ.get("HF_ENGINE_DIAG_EF", "1") == "0" or self.process_group is not None
+                or reduction not in ("mean", "sum")):
+            return None
+        eng = sess.engine
+        if (model is not eng.model_ref or eng.train_bn or eng.loss_spec is None
+                or not isinstance(inputs, torch.Tensor) or tuple(inputs.shape) != tuple(eng.x_in.shape)):
+            return None
+        from .engine import ce_loss_spec
+        from .modelprep import session_forward
+        from .session import _quadratic_signature
+
+        self._ensure_arena()
+        with session_forward(sess):  # (the forward pass is one replay of the session's graph)
+            out = model(inputs)
+        if out is not getattr(sess, "_override_out", None):
+            return None  # (the session did not answer this forward pass: another mode / shape)
+        loss = loss_func(out, targets)
+        spec = ce_loss_spec(loss, out, check_values=False)
+        if (spec is None or spec["reduction"] != reduction or spec["reduction"] != eng.loss_spec["reduction"]
+                or _quadratic_signature(spec) != _quadratic_signature(eng.loss_spec)
+                or tuple(spec["targets"].shape) != tuple(eng._targets.shape)):
+            return None
+        with torch.no_grad():
+            eng.set_targets(spec["targets"])
+            eng._loss_head()
+            if bool(eng.bad_targets):
+                return None
+            return eng.diag_ef(reduction)
 
 class _SessionTrials:
     """``tfunc`` of optimizer.py:288-294 on a persistent engine session: a trial point

@@ -406,6 +406,74 @@ def test_train_mode_folded_kernels_equal_the_separate_launches():
     restore()
 
 
+@pytest.mark.parametrize("case", ["allcnnc_l2", "allcnnc_hessian", "resnet18", "resnet18_sum"])
+def test_engine_diag_ef_matches_per_sample_autograd(case):
+    """The diagonal of the empirical Fisher ``(1/N) sum_i g_i^2`` (reference preconditioners.py:11-105: one backward
+    pass per sample, or BackPACK's ``SumGradSquared``) from ONE adjoint sweep of the engine + per-sample weight-gradient
+    launches + squaring gathers (``engine.diag_ef``) against the per-sample autograd loop on the same model
+    (``diag_EF_autograd``): 1e-5 max-norm relative -- All-CNN-C with the tagged L2 term (each per-sample loss carries it
+    whole: closed form), the Hessian engine (cotangents kept in ``g1`` / ``ga1``), ResNet-18 (BatchNorm parameters per
+    sample, linear head in closed form), reduction ``sum``."""
+    reduction = "sum" if case.endswith("_sum") else "mean"
+    if case.startswith("allcnnc"):
+        model, (x, t), lossf = tp.allcnnc_cifar100(batch_size=8, device=DEV, data_seed=3)
+        lossf = tp.l2_regularized(lossf, model, 5e-4)
+    else:
+        model, (x, t), _ = tp.resnet18_mnist(batch_size=8, device=DEV, data_seed=tp.RESNET18_B32_SEPARATED_SEEDS[0])
+        lossf = torch.nn.CrossEntropyLoss(reduction=reduction)
+    modelprep.prepare_model(model, channels_last=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    hessian = case == "allcnnc_hessian"
+    make = curvature.hessian_operator if hessian else curvature.ggn_operator
+    eng = make(lossf(out, t), out, params)
+    assert isinstance(eng, FusedGGNEngine) and eng.hessian == hessian
+    got = eng.diag_ef(reduction).clone()
+    want = hf.diag_EF_autograd(model, lossf, x, t, reduction)
+    assert float((got - want).abs().max() / want.abs().max()) < 1e-5
+    assert torch.equal(eng.diag_ef(reduction), got)  # repeatable
+    # the products of the same engine are untouched by the per-sample bookkeeping
+    v = torch.randn(eng.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    a = eng(v).clone()
+    eng.diag_ef(reduction)
+    assert torch.equal(eng(v), a)
+
+
+def test_get_preconditioner_uses_the_sessions_engine_from_the_second_step(monkeypatch):
+    """``HessianFree.get_preconditioner`` (optimizer.py:928-952) with a persistent session for the model: the diagonal
+    comes from the engine (no per-sample backward passes) and equals the autograd construction to 1e-5; before the
+    first step (no session yet) and for another input shape the autograd construction runs."""
+    from pytorchhessianfree_amd import optimizer as hfopt
+
+    model, (x, t), lossf0 = tp.allcnnc_cifar100(batch_size=8, device=DEV, data_seed=4)
+    lossf = tp.l2_regularized(lossf0, model, 5e-4)
+    modelprep.prepare_model(model, channels_last=True)
+    opt = hf.HessianFree(model.parameters(), curvature_opt="hessian", graph_matvec=True, cg_max_iter=5)
+    calls = []
+    real = hfopt.diag_EF_preconditioner
+    monkeypatch.setattr(hfopt, "diag_EF_preconditioner", lambda *a, **k: calls.append(1) or real(*a, **k))
+
+    def forward():
+        o = model(x)
+        return lossf(o, t), o
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        M0 = opt.get_preconditioner(model, lossf, x, t, "mean", use_backpack=False)   # no session yet
+        assert len(calls) == 1
+        opt.step(forward, M_func=M0)
+        assert opt._session is not None
+        M1 = opt.get_preconditioner(model, lossf, x, t, "mean", use_backpack=False)   # the engine's sweep
+        assert len(calls) == 1
+        want = hf.diag_EF_autograd(model, lossf, x, t, "mean")
+        assert float((M1.diag - want).abs().max() / want.abs().max()) < 1e-5
+        assert M1.damping == opt.param_groups[0]["damping"]
+        final = opt.step(forward, M_func=M1)
+        assert final <= opt.state["init_losses"][-1]
+        opt.get_preconditioner(model, lossf, x[:4], t[:4], "mean", use_backpack=False)  # another shape: autograd
+        assert len(calls) == 2
+
+
 def test_resnet18_engine_product_matches_cpu_oracle_at_batch_32():
     """The engine's product DIRECTLY against the CPU oracle (oracle/backpack_restated.py: BackPACK's
     ``ggn_vector_product_from_plist`` restated; reference call site optimizer.py:457-462) at
