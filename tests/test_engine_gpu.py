@@ -429,7 +429,16 @@ def test_engine_diag_ef_matches_per_sample_autograd(case):
     eng = make(lossf(out, t), out, params)
     assert isinstance(eng, FusedGGNEngine) and eng.hessian == hessian
     got = eng.diag_ef(reduction).clone()
-    want = hf.diag_EF_autograd(model, lossf, x, t, reduction)
+    # (the reference's loop, preconditioners.py:91-99, on batches of ONE sample: BatchNorm2d wants 4-D inputs)
+    want = torch.zeros_like(got)
+    for i in range(x.shape[0]):
+        g_i = torch.autograd.grad(lossf(model(x[i:i + 1]), t[i:i + 1]), params)
+        want += torch.cat([g.reshape(-1) for g in g_i]) ** 2
+    if reduction == "mean":
+        want /= x.shape[0]
+    if case.startswith("allcnnc"):
+        ref = hf.diag_EF_autograd(model, lossf, x, t, reduction)
+        assert float((ref - want).abs().max() / want.abs().max()) < 1e-6
     assert float((got - want).abs().max() / want.abs().max()) < 1e-5
     assert torch.equal(eng.diag_ef(reduction), got)  # repeatable
     # the products of the same engine are untouched by the per-sample bookkeeping
