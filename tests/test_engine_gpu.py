@@ -64,7 +64,10 @@ def test_resnet18_engine_product_matches_float64(batch):
     got = op(v).clone()
     for _ in range(3):
         assert torch.equal(op(v), got)  # the reference's _test_mvp_deterministic, bitwise
-    want = _float64_product(tp.resnet18_mnist, v, batch_size=batch)
+    # float64 autograd of the STOCK model on the engine's own ReLU decisions: no dependence on data seeds whose
+    # pre-activations happen to stay clear of zero (the plain float64 product is checked too where it applies)
+    masks = [(u.y > 0) for u in op.units if u.relu]
+    want = _float64_product(tp.resnet18_mnist, v, masks=masks, batch_size=batch)
     assert float((got.double() - want).abs().max() / want.abs().max()) < 5e-7
     # the stem's launch carries the v_W scatter (hf_conv2d_nhwc_slabs_unpack): same bits as the two launches
     assert op._carry_ok
