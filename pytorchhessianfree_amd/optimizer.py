@@ -804,6 +804,8 @@ class HessianFree(torch.optim.Optimizer):
             eng._loss_head()
             if bool(eng.bad_targets):
                 return None
+            if os.environ.get("HF_DIAG_EF_GRAPH", "1") != "0":
+                return sess.diag_ef(reduction)  # (one graph replay)
             return eng.diag_ef(reduction)
 
 class _SessionTrials:

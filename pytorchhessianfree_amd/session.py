@@ -262,6 +262,7 @@ class EngineSession(_TwoPhaseProduct):
         self._cache = {}
         self._signature = self._signature_of(eng)
         self._layers = eng.layer_signature()
+        self._diag_graphs = {}
 
     def _capture(self, fn, keep=False):
         g = torch.cuda.CUDAGraph(keep_graph=True) if keep else torch.cuda.CUDAGraph()
@@ -357,6 +358,26 @@ class EngineSession(_TwoPhaseProduct):
         self.g_fwd.replay()
         self.losses[slot].copy_(self.engine.loss_buf)
         return self.losses[slot]
+
+    def diag_ef(self, reduction):
+        """The diagonal empirical Fisher of the engine's current batch (``engine.diag_ef``: ~20 launches per sample)
+        as ONE graph replay; captured on first use.  Returns a fresh vector."""
+        key = ("diag", reduction)
+        if key not in self._diag_graphs:
+            eng = self.engine
+            cur = torch.cuda.current_stream()
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream), torch.no_grad():
+                buf = torch.empty(self.n, dtype=torch.float32, device=eng.dev)
+                eng.diag_ef(reduction, out=buf)  # warm-up (allocations, lazy buffers)
+            self.stream.synchronize()
+            with torch.no_grad():
+                g = self._capture(lambda: eng.diag_ef(reduction, out=buf))
+            cur.wait_stream(self.stream)
+            self._diag_graphs[key] = (g, buf)
+        g, buf = self._diag_graphs[key]
+        g.replay()
+        return buf.clone()
 
     # ---- operator interface of cg() (see curvature.GraphedOperator) -------------------------
     def raw_graph(self):
