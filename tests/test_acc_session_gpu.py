@@ -100,10 +100,10 @@ def test_acc_step_on_engine_matches_cpu_reference_path_with_ragged_chunks():
     SECOND step's final loss: it starts from parameters that differ like any two fp32 runs, and back-tracking /
     the line search pick between nearly tied candidates (measured: 2.22254 on the GPU -- the lower loss --
     against 2.22289): 5e-4."""
-    # (cg_max_iter = 10: the CPU side pays ~0.4 s per accumulated product)
-    acc, fa = _resnet_runs("acc", 2, sizes=(20, 12), cg_max_iter=10)
+    # (cg_max_iter = 6: the CPU side pays ~0.5 s per accumulated product)
+    acc, fa = _resnet_runs("acc", 2, sizes=(20, 12), cg_max_iter=6)
     assert acc._acc_session is not None and acc._acc_session.shapes[0][0] == 20
-    cpu, fc = _resnet_runs("cpu", 2, sizes=(20, 12), cg_max_iter=10)
+    cpu, fc = _resnet_runs("cpu", 2, sizes=(20, 12), cg_max_iter=6)
     assert abs(fa[0] - fc[0]) <= 1e-4 * abs(fc[0])
     _same_trace(acc, fa, cpu, fc, final_tol=5e-4)
 

@@ -105,8 +105,10 @@ def test_bottleneck_net_engine_product_matches_float64():
     assert torch.equal(op(v), got)
 
 
-def test_engine_declines_what_it_does_not_know():
-    """NCHW-prepared models, nets of other families and the Hessian keep the autograd path."""
+def test_engine_declines_what_it_does_not_know(monkeypatch):
+    """NCHW-prepared models, nets of other families and other losses keep the autograd path."""
+    # (no MIOpen find step for the NCHW shapes this test touches once: it cost 35 s of the suite)
+    monkeypatch.setattr(torch.backends.cudnn, "benchmark", False)
     model, (x, t), lossf = tp.resnet18_mnist(batch_size=4, device=DEV)
     modelprep.prepare_model(model)  # NCHW
     out = model(x)

@@ -253,7 +253,8 @@ def test_train_mode_batchnorm_session_equals_generic_path():
 # Sessions of the other engine families the bench reports: All-CNN-C GGN, All-CNN-C
 # Hessian + L2 + diagonal empirical-Fisher preconditioner (BASELINE configs[3]), the Bottleneck net
 # ---------------------------------------------------------------------------------------------------------
-def _run_family(make, device, steps, curv="ggn", l2=0.0, precond=False, seeds=(11, 12, 13), cg_max_iter=250, **mk):
+def _run_family(make, device, steps, curv="ggn", l2=0.0, precond=False, seeds=(11, 12, 13), cg_max_iter=250,
+                backtracking=True, **mk):
     """``steps`` default ``HessianFree.step()`` calls on fresh batches.  GPU: prepared NHWC model, persistent
     session.  CPU: stock model, torch autograd, host logic with the oracle PCG (reference order)."""
     from oracle import pcg as oracle
@@ -264,7 +265,7 @@ def _run_family(make, device, steps, curv="ggn", l2=0.0, precond=False, seeds=(1
     if device != "cpu":
         modelprep.prepare_model(model, channels_last=True)
     opt = hf.HessianFree(model.parameters(), curvature_opt=curv, graph_matvec=(device != "cpu"),
-                         cg_max_iter=cg_max_iter)
+                         cg_max_iter=cg_max_iter, use_cg_backtracking=backtracking)
     if device == "cpu":
         opt._cg = oracle.pcg
     finals = []
@@ -322,28 +323,24 @@ def test_allcnnc_hessian_l2_preconditioned_session_steps_match_reference_cpu_pat
     assert gpu._session is not None and gpu._session.steps == 3
     assert isinstance(gpu._session.engine, PlainStackEngine) and gpu._session.engine.hessian
     cpu, c_final = _run_family(tp.allcnnc_cifar100, "cpu", 3, **kw)
+    # (from its second step on the GPU side's preconditioner comes from the engine's own sweep, engine.diag_ef)
     _compare_family(gpu, g_final, cpu, c_final)
 
 
 def test_bottleneck_net_session_steps_match_reference_cpu_path():
-    """The Bottleneck (ResNet-50 topology, N = 25 557 032) net on 32x32 images, batch 4: two default steps through
-    the session; the FIRST against the CPU path (one CPU step of this 25 M-parameter net costs ~13 products of
-    ~1.5 s: the second step's CPU twin is left out for the suite's run time -- round 4 measured both: initial
-    losses 1e-5 / 1e-4, final losses 1e-3, identical schedules).  Stated tolerance for the first step: initial
-    loss 1e-5, learning rate / damping / reason identical, iteration count +-2, final loss 1e-4; the second step
-    is served by the same session and does not increase its batch's loss (on this net its line search ends at
-    lr = 0 -- on the CPU path too, round-4 measurement: the step is then rejected and the loss stays)."""
-    kw = dict(batch_size=4, image=32)
+    """The Bottleneck (ResNet-50 topology, N = 25 557 032) net on 32x32 images, batch 4: two steps through the session
+    against the CPU path.  The CPU side of this 25 M-parameter net costs ~2 s per product, so the solves are capped
+    at 5 PCG iterations and CG-backtracking is off (an unconverged iterate of this deep random-init net can overflow
+    the loss, which the line search -- but not the back-tracking walk of the reference, cg_backtracking.py:53-112 --
+    recovers from); LM damping and the line search run as usual.  Stated tolerance: initial losses 1e-5 / 1e-4 (the
+    second step starts from fp32-different parameters), learning rates / damping schedule / reasons / iteration counts
+    identical, final losses 1e-3."""
+    kw = dict(batch_size=4, image=32, cg_max_iter=5, backtracking=False)
     gpu, g_final = _run_family(tp.resnet50_small_images, DEV, 2, **kw)
     assert gpu._session is not None and gpu._session.steps == 2
-    cpu, c_final = _run_family(tp.resnet50_small_images, "cpu", 1, **kw)
-    first = {k: v[:1] for k, v in gpu.state.items() if isinstance(v, list)}
-
-    class _First:
-        state = first
-
-    _compare_family(_First, g_final[:1], cpu, c_final, loss_tol=1e-5, final_tol=1e-4, iters=2)
-    assert g_final[1] <= gpu.state["init_losses"][1]
+    cpu, c_final = _run_family(tp.resnet50_small_images, "cpu", 2, **kw)
+    assert abs(gpu.state["init_losses"][0] - cpu.state["init_losses"][0]) <= 1e-5 * abs(cpu.state["init_losses"][0])
+    _compare_family(gpu, g_final, cpu, c_final, loss_tol=1e-4, final_tol=1e-3, iters=0)
 
 
 def test_session_is_reverified_against_the_models_own_forward(monkeypatch):
