@@ -182,3 +182,20 @@ def test_ce_loss_spec_reads_the_loss_structure():
     # logits handed out as a leaf (what a persistent session's forward pass returns)
     leaf = out.detach().clone().requires_grad_(True)
     assert ce_loss_spec(ce(leaf, t), leaf) is not None
+
+
+def test_accumulated_session_plans_engines_by_chunk_identity():
+    """``acc_step`` on the engine keys one engine per DISTINCT chunk (identity of its tensors): lists that share
+    chunks -- the default, one list for loss, gradient and curvature (optimizer.py:519-606) -- share engines; distinct
+    lists get their own; a chunk listed twice in one list is one engine (its weight counts twice)."""
+    from pytorchhessianfree_amd.session import AccumulatedSession
+
+    a, b, c = [(torch.zeros(4, 3), torch.zeros(4)) for _ in range(3)]
+    one = [a, b]
+    slots, roles = AccumulatedSession._plan((one, one, one))
+    assert len(slots) == 2 and roles == [(0, 1), (0, 1), (0, 1)]
+    slots, roles = AccumulatedSession._plan(([a, b], [b, c], [c]))
+    assert [s is t for s, t in zip(slots, (a, b, c))] == [True, True, True]
+    assert roles == [(0, 1), (1, 2), (2,)]
+    slots, roles = AccumulatedSession._plan(([a, a], [a], [a]))
+    assert len(slots) == 1 and roles == [(0, 0), (0,), (0,)]
