@@ -195,7 +195,7 @@ def test_accumulated_session_plans_engines_by_chunk_identity():
     slots, roles = AccumulatedSession._plan((one, one, one))
     assert len(slots) == 2 and roles == [(0, 1), (0, 1), (0, 1)]
     slots, roles = AccumulatedSession._plan(([a, b], [b, c], [c]))
-    assert [s is t for s, t in zip(slots, (a, b, c))] == [True, True, True]
+    assert [s[0] is t[0] and s[1] is t[1] for s, t in zip(slots, (a, b, c))] == [True, True, True]
     assert roles == [(0, 1), (1, 2), (2,)]
     slots, roles = AccumulatedSession._plan(([a, a], [a], [a]))
     assert len(slots) == 1 and roles == [(0, 0), (0,), (0,)]
