@@ -1095,12 +1095,11 @@ class FusedGGNEngine(_Operator):
         if u.first:  # the network input needs no gradient
             self._conv_slabs(2, u.wbuf, u.x, ga, u.geo, u.sW)
             return
-        if self._wsplit:
-            # the weight gradient is not on the adjoint chain (only the gather reads it): its launch goes to the
-            # side branch, the chain's launch computes the data gradient alone
-            self._side_launch(lambda: self._conv_slabs(2, u.wbuf, u.x, ga, u.geo, u.sW))
-            self._conv_slabs(1, u.dbuf, ga, u.wT, u.geo, u.sD)
-            return
+        # (Measured and rejected, round 4: the weight gradient -- off the adjoint chain, only the gather reads it -- as
+        # its own launch on a side branch, the chain's launch computing the data gradient alone: one cross-branch
+        # dependency PER UNIT costs far more than the shorter chain saves -- ResNet-18 1 518 -> 1 037 matvecs/s,
+        # ResNet-50 topology 314 -> 253, All-CNN-C 753 -> 711.  A side branch pays when it forks ONCE: the Hessian
+        # products' extras below.)
         n_, h, w, c, k_, r, s, sd, pd = u.geo
         _lib.check(lib.hf_conv2d_nhwc_backward_slabs(
             _ptr(u.dbuf), _ptr(u.wbuf), _ptr(ga), _ptr(u.x), _ptr(u.wT), n_, h, w, c, k_, r, s, sd[0], sd[1],
@@ -1109,38 +1108,11 @@ class FusedGGNEngine(_Operator):
 
     # ---- side branch for launches that are off the adjoint sweep's dependency chain -------------------------
     # (inside a hipGraph capture: a parallel branch of the graph; eager: a second stream)
-    _wsplit = False
-
     def _side_setup(self):
         if getattr(self, "_xside", None) is None:
             self._xside = torch.cuda.Stream(device=self.dev)
-            self._xfork, self._xjoin = torch.cuda.Event(), torch.cuda.Event()
+            self._xfork = torch.cuda.Event()
             self._xev = {id(u): torch.cuda.Event() for u in self.units}
-            self._xpool = [torch.cuda.Event() for _ in range(4 * len(self.units) + 8)]
-        self._xpool_next = 0
-
-    def _side_launch(self, fn):
-        """``fn()`` on the side branch, ordered after everything enqueued on the chain so far."""
-        cur = torch.cuda.current_stream(self.dev)
-        ev = self._xpool[self._xpool_next % len(self._xpool)]
-        self._xpool_next += 1
-        ev.record(cur)
-        self._xside.wait_event(ev)
-        with torch.cuda.stream(self._xside):
-            fn()
-        self._side_used = True
-
-    def _side_join(self):
-        if getattr(self, "_side_used", False):
-            self._xjoin.record(self._xside)
-            torch.cuda.current_stream(self.dev).wait_event(self._xjoin)
-            self._side_used = False
-
-    def _wsplit_begin(self):
-        """Weight gradients on the side branch for this sweep?  (``HF_ADJ_SPLIT``; never inside another fork.)"""
-        self._wsplit = (os.environ.get("HF_ADJ_SPLIT", "0") != "0" and getattr(self, "_extras_allowed", True))
-        if self._wsplit:
-            self._side_setup()
 
     # ---- the product -------------------------------------------------------------------------
     def local(self, v, out=None):
@@ -1156,17 +1128,14 @@ class FusedGGNEngine(_Operator):
                 _lib.unpack_tangent(v, self._vt_slots, half=2)  # V as (I, H, W, O): the operand of conv_D(g, V)
             self._second, self._v = True, v
             self._extras_fork()
-        self._wsplit_begin()
         try:
             g_last, g_fw, g_fb = self._head(v)
             pool_srcs = self._adjoint_blocks(g_last)
             self._adjoint_stem(pool_srcs)
             if self.hessian:
                 self._extras_join()
-            self._side_join()
         finally:
             self._second, self._v = False, None
-            self._wsplit = False
         self._gather(out, g_fw, g_fb)
         if self.hessian and self._l2 is not None:  # the regulariser's Hessian: coef on its tensors' entries
             out.addcmul_(self._l2, v, value=self.weight)
@@ -1372,18 +1341,10 @@ class FusedGGNEngine(_Operator):
                     else:
                         self._bn_adjoint(u, incoming.pop(id(u)))
                         self._bn_adjoint(ds, [(last.g, 1, 0)])
-                    if self._wsplit:  # (both weight gradients: one grouped launch on the side branch)
-                        self._side_launch(lambda u=u, ds=ds: _lib.conv_group_slabs(
-                            [(2, u.wbuf, u.x, u.ga, u.geo, u.sW, 0, 0), (2, ds.wbuf, ds.x, ds.ga, ds.geo, ds.sW, 0, 0)],
-                            self.dev))
-                        _lib.conv_group_slabs(
-                            [(1, u.dbuf, u.ga, u.wT, u.geo, u.sD, 0, 0), (1, ds.dbuf, ds.ga, ds.wT, ds.geo, ds.sD, 0, 0)],
-                            self.dev)
-                    else:
-                        _lib.conv_group_slabs(
-                            [(1, u.dbuf, u.ga, u.wT, u.geo, u.sD, 0, 0), (2, u.wbuf, u.x, u.ga, u.geo, u.sW, 0, 0),
-                             (1, ds.dbuf, ds.ga, ds.wT, ds.geo, ds.sD, 0, 0),
-                             (2, ds.wbuf, ds.x, ds.ga, ds.geo, ds.sW, 0, 0)], self.dev)
+                    _lib.conv_group_slabs(
+                        [(1, u.dbuf, u.ga, u.wT, u.geo, u.sD, 0, 0), (2, u.wbuf, u.x, u.ga, u.geo, u.sW, 0, 0),
+                         (1, ds.dbuf, ds.ga, ds.wT, ds.geo, ds.sD, 0, 0), (2, ds.wbuf, ds.x, ds.ga, ds.geo, ds.sW, 0, 0)],
+                        self.dev)
                 else:
                     self._adjoint_unit(u, incoming.pop(id(u)))
                 if k > 0:
@@ -1861,15 +1822,12 @@ class PlainStackEngine(FusedGGNEngine):
             _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_pool_ce_head")
         if self.hessian:
             self._extras_fork()
-        self._wsplit_begin()
         try:
             self._adjoint_sweep(self._g_last)
             if self.hessian:
                 self._extras_join()
-            self._side_join()
         finally:
             self._second = False
-            self._wsplit = False
         self._gather(out, None, None)
         if self.hessian and self._l2 is not None:  # the regulariser's Hessian: coef on its tensors' entries
             out.addcmul_(self._l2, v, value=self.weight)
