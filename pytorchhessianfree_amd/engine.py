@@ -977,7 +977,12 @@ class FusedGGNEngine(_Operator):
         _lib.check(lib.hf_chan_affine_ex(
             _ptr(u.gah), _ptr(u.g1), None, None, _ptr(u.rstd), _ptr(v_gamma), None, None, _ptr(u.ga), None, 0, n, k,
             oh * ow, 1, 0, 0, 1, 0, _lib.HF_F32, st), "hf_chan_affine_ex")
-        self._conv_adjoint(u, u.gah)
+        if self._extras_mode == 2 and not u.im2col and not u.first:
+            # the chain's launch also computes conv_D(g_a, V) -- the one extra term the chain itself needs next
+            _lib.conv_group_slabs([(1, u.dbuf, u.gah, u.wT, u.geo, u.sD, 0, 0), (2, u.wbuf, u.x, u.gah, u.geo, u.sW, 0, 0),
+                                   (1, u.dbuf[u.sD:], u.ga1, u.vT, u.geo, u.sD, 0, 0)], self.dev)
+        else:
+            self._conv_adjoint(u, u.gah)
 
     def _hessian_extras(self, u):
         """The terms of a Hessian product that do NOT depend on the adjoint chain -- only on the tangent sweep's
@@ -992,21 +997,29 @@ class FusedGGNEngine(_Operator):
                 _lib.current_stream_ptr(self.dev)), "hf_chan_affine_bwd_ex")
         if not u.im2col and not u.first:
             c = u.x.shape[1]
-            _lib.conv_dw_slabs((1, u.dbuf[u.sD:], u.ga1, u.vT, u.geo, u.sD, 0, 0),
-                               (2, u.wbuf[u.sW:], u.xcat, u.ga1, u.geo, u.sW, 2 * c, 0), self.dev)
+            if self._extras_mode == 2:  # (conv_D(g_a, V) rides in the chain's launch: only the weight term here)
+                self._conv_slabs(2, u.wbuf[u.sW:], u.xcat, u.ga1, u.geo, u.sW, act_ld=2 * c)
+            else:
+                _lib.conv_dw_slabs((1, u.dbuf[u.sD:], u.ga1, u.vT, u.geo, u.sD, 0, 0),
+                                   (2, u.wbuf[u.sW:], u.xcat, u.ga1, u.geo, u.sW, 2 * c, 0), self.dev)
 
     # Those extras are half of a Hessian product's launches and none of them is on the adjoint sweep's dependency
     # chain: they are issued on a SECOND STREAM forked off after the tangent sweep (inside a hipGraph capture: a
     # parallel branch of the graph), in the adjoint's unit order; the chain waits per unit for the data-gradient
     # slabs it is about to sum (an event per unit) and once, before the gather, for the rest.
+    # HF_HESSIAN_PARALLEL: 0 = everything in sequence on the chain; 1 = all extras on the side branch, the chain waits
+    # per unit for the data-gradient slabs it needs (one cross-branch dependency per unit); 2 = conv_D(g, V) inside
+    # the chain's own grouped launch, ONLY results nobody on the chain reads on the side branch: one fork, one join.
     _extras_parallel = False
+    _extras_mode = 0
 
     def _extras_fork(self):
         # (``_extras_allowed = False``: the caller already runs this engine on one of several parallel branches --
         # session.AccumulatedSession -- and a fork inside a forked capture branch crashes hipStreamEndCapture
         # on this stack: segfault in capture_end, round-4 batch r4f)
-        self._extras_parallel = (os.environ.get("HF_HESSIAN_PARALLEL", "1") != "0"
-                                 and getattr(self, "_extras_allowed", True))
+        mode = int(os.environ.get("HF_HESSIAN_PARALLEL", "1"))
+        self._extras_parallel = mode != 0 and getattr(self, "_extras_allowed", True)
+        self._extras_mode = mode if self._extras_parallel else 0
         if not self._extras_parallel:
             return
         self._side_setup()
@@ -1017,7 +1030,7 @@ class FusedGGNEngine(_Operator):
         with torch.cuda.stream(self._xside):
             for u in reversed(self.units):
                 self._hessian_extras(u)
-                if getattr(u, "sD", 0) and not u.im2col and not u.first:
+                if self._extras_mode == 1 and getattr(u, "sD", 0) and not u.im2col and not u.first:
                     ev = self._xev[id(u)]
                     ev.record(self._xside)
                     self._xwait[u.dbuf.data_ptr()] = ev
@@ -1037,6 +1050,7 @@ class FusedGGNEngine(_Operator):
         if self._extras_parallel:
             torch.cuda.current_stream(self.dev).wait_event(self._xjoin2)
             self._extras_parallel = False
+        self._extras_mode = 0
 
     def _zeros(self, k):
         cache = self.__dict__.setdefault("_zeros_cache", {})
@@ -1798,8 +1812,12 @@ class PlainStackEngine(FusedGGNEngine):
                 # (two launches of two problems each; four in one grouped launch ran 3x slower -- with four
                 # by-value problem descriptions hipcc spills them to scratch memory.  The second one -- conv_D(g, V),
                 # conv_W(t_x, g): no dependence on this chain -- runs on the side branch, see _extras_fork)
-                _lib.conv_dw_slabs((1, u.dbuf, ga, u.wT, u.geo, u.sD, 0, 0), (2, u.wbuf, u.x, ga, u.geo, u.sW, 0, 0),
-                                   self.dev)
+                if self._extras_mode == 2:
+                    _lib.conv_group_slabs([(1, u.dbuf, ga, u.wT, u.geo, u.sD, 0, 0), (2, u.wbuf, u.x, ga, u.geo, u.sW, 0, 0),
+                                           (1, u.dbuf[u.sD:], u.ga1, u.vT, u.geo, u.sD, 0, 0)], self.dev)
+                else:
+                    _lib.conv_dw_slabs((1, u.dbuf, ga, u.wT, u.geo, u.sD, 0, 0),
+                                       (2, u.wbuf, u.x, ga, u.geo, u.sW, 0, 0), self.dev)
                 if not self._extras_parallel:
                     self._hessian_extras(u)
             else:
