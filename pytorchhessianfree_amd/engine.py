@@ -1012,12 +1012,15 @@ class FusedGGNEngine(_Operator):
     # the chain's own grouped launch, ONLY results nobody on the chain reads on the side branch: one fork, one join.
     _extras_parallel = False
     _extras_mode = 0
+    _extras_default = 2
 
     def _extras_fork(self):
         # (``_extras_allowed = False``: the caller already runs this engine on one of several parallel branches --
         # session.AccumulatedSession -- and a fork inside a forked capture branch crashes hipStreamEndCapture
         # on this stack: segfault in capture_end, round-4 batch r4f)
-        mode = int(os.environ.get("HF_HESSIAN_PARALLEL", "1"))
+        # (measured, profiles/r04_hessian_parallel_branch.jsonl: ResNet-18 form 1 922-930, form 2 947-959 matvecs/s;
+        # All-CNN-C form 1 521, form 2 283 -- its 128-wide tile configurations spill a three-problem argument block)
+        mode = int(os.environ.get("HF_HESSIAN_PARALLEL", str(self._extras_default)))
         self._extras_parallel = mode != 0 and getattr(self, "_extras_allowed", True)
         self._extras_mode = mode if self._extras_parallel else 0
         if not self._extras_parallel:
@@ -1684,6 +1687,7 @@ class PlainStackEngine(FusedGGNEngine):
     # (g: first-order cotangent of the step, g': its tangent; ReLU masks are piecewise constant), all four
     # in ONE grouped launch whose extra results are simply more split-K slabs for the consumers to sum.
     supports_hessian = True
+    _extras_default = 1
 
     def _layout(self, model):
         x_in = getattr(self.outputs, "_hf_input", None)
