@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 9
+#define HF_ABI_VERSION 10
 
 enum hf_dtype { HF_F32 = 0, HF_F64 = 1 };
 
@@ -376,6 +376,27 @@ int hf_bn_adjoint_rows_train(void* gx, void* gw, void* gb, void* gres, const voi
                              int64_t c, int64_t hw, int row_blocks, void* ticket, void* q_out, void* r_out,
                              const void* final_w, const void* vq, const void* vr, double count, int dtype,
                              void* stream);
+
+/*
+ * hf_bn_adjoint_rows_train AND the elementwise pass that consumes its per-channel vectors (hf_chan_affine_ex with
+ * q / r) in ONE launch -- the whole tangent resp. adjoint of a train-mode BatchNorm (+ residual add, + ReLU mask):
+ *   pass 1   g = mask_src > 0 ? sum of gy's (and gy2's) split-K slabs : 0  -> gres;  per-workgroup partial sums
+ *            of g and xhat*g -> gw / gb  ([row_blocks, c] each)
+ *   barrier  over the launch's workgroups (`barrier`: one zero-initialised uint64 per layer, counts arrivals, never
+ *            reset); row_blocks must not exceed the device's compute-unit count (HF_ERR_ARG) so that all are resident
+ *   pass 2   q = vq - final_w*rstd*S_x/count,  r = vr - final_w*rstd*S_1/count  (every workgroup, same order of
+ *            additions);  out[row*out_ld + ch] = out_mask > 0 ? t : 0,
+ *            t = g*(final_w*rstd) + xhat*q + r + add[row*add_ld + ch]      (out_ld / add_ld 0: dense)
+ * q_out / r_out (both or neither): the per-channel vectors, for inspection.  fp32 NHWC, c % 4 == 0, c <= 1024.
+ * Two launches less per train-mode BatchNorm layer and sweep than round 3 (optimizer.py:457-462 with
+ * examples/run_resnet18_mnist.py:19-35).
+ */
+int hf_bn_rows_train_apply(void* out, int64_t out_ld, void* gw, void* gb, void* gres, const void* gy, int gy_splits,
+                           int64_t gy_slab, const void* gy2, int gy2_splits, int64_t gy2_slab, const void* x,
+                           const void* mean, const void* rstd, const void* mask_src, int64_t n, int64_t c, int64_t hw,
+                           int row_blocks, void* barrier, void* q_out, void* r_out, const void* final_w,
+                           const void* vq, const void* vr, double count, const void* add, int64_t add_ld,
+                           const void* out_mask, int dtype, void* stream);
 
 /*
  * One-pass batch statistics of a train-mode BatchNorm in the engine's own forward pass (optimizer.py:216-229,

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HF_PCG_LIB") or os.path.join(_HERE, "csrc", "libhfpcg.so")
 
 HF_F32, HF_F64 = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 HF_ERR_ARG = -1  # hf_status of include/hf_pcg.h: null / negative / inconsistent argument
 HF_M_NONE, HF_M_DIAG, HF_M_EXTERNAL = 0, 1, 2
 REASONS = {
@@ -139,6 +139,9 @@ SIGNATURES = {
                               + [c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "hf_bn_adjoint_rows_train": (c_int, [c_void_p] * 5 + [c_int, c_int64, c_void_p, c_int, c_int64] + [c_void_p] * 5
                                  + [c_int64, c_int64, c_int64, c_int] + [c_void_p] * 6 + [c_double, c_int, c_void_p]),
+    "hf_bn_rows_train_apply": (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int, c_int64, c_void_p, c_int, c_int64]
+                               + [c_void_p] * 4 + [c_int64, c_int64, c_int64, c_int] + [c_void_p] * 6
+                               + [c_double, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
     "hf_bn_stats_rows": (c_int, [c_void_p, c_void_p, c_int, c_int64] + [c_void_p] * 6
                          + [c_double, c_double, c_double, c_int64, c_int64, c_int, c_int, c_void_p]),
     "hf_bn_adjoint_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64,

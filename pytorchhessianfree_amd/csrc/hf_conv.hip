@@ -835,9 +835,11 @@ int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_by
     if (best > steps / 2) best = steps / 2;
     // (one or two output tiles -- the stem's weight gradient: 6272 rows into a 64 x 52 matrix --
     // would leave most of the chip idle at 32 splits)
-    // (HF_CONV_FEW_TILES: up to how many output tiles the larger cap applies -- tuning knob)
+    // (HF_CONV_FEW_TILES: up to how many output tiles the larger cap applies.  Measured, round 4,
+    // profiles/r04_conv_few_tiles.jsonl: 2 / 4 / 8 tiles -> ResNet-50 topology 314 / 323 / 323 matvecs/s,
+    // ResNet-18 1507 / 1512 / 1507, All-CNN-C 742 / 751 / 755.)
     static int few_tiles = 0;
-    if (few_tiles == 0) { const char* e = getenv("HF_CONV_FEW_TILES"); few_tiles = e ? atoi(e) : 2; if (few_tiles < 1) few_tiles = 2; }
+    if (few_tiles == 0) { const char* e = getenv("HF_CONV_FEW_TILES"); few_tiles = e ? atoi(e) : 8; if (few_tiles < 1) few_tiles = 8; }
     const int64_t cap = tiles <= few_tiles ? hf_env_cap() : (big ? 128 : 32);
     if (best > cap) best = cap;
     if (best < 1) best = 1;

@@ -1592,6 +1592,131 @@ __global__ __launch_bounds__(BLOCK) void k_bn_adjoint_rows_train(
   }
 }
 
+// ---- train-mode BatchNorm: reduction, per-channel finalisation AND the elementwise pass in ONE launch ---------
+// A grid-wide barrier between the two passes (every workgroup is resident: the host refuses more row blocks than
+// the device has compute units).  `bar`: one zero-initialised 64-bit counter per layer, never reset -- the k-th
+// launch waits for k * gridDim.x arrivals (2^64 never wraps; a 32-bit word would after ~9 h of products).
+// Arrivals: this workgroup's partial rows were stored write-through and drained (as last_block_arrives); the rows
+// of the other workgroups are then read with agent-scope loads -- no acquire fence, which would drop every clean
+// line of this XCD's L2 forty times per product.
+__device__ __forceinline__ void grid_barrier(unsigned long long* bar) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long old = __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long target = (old / gridDim.x + 1ull) * gridDim.x;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+}
+
+// final_column_sums with agent-scope loads (the partial rows come from other workgroups of THIS launch).
+__device__ __forceinline__ void final_column_sums_agent(const float* rows, unsigned nrows, unsigned C,
+                                                        double* scratch, double* out) {
+  const unsigned quads = C / 4, G = BLOCK / quads;
+  const unsigned tx = threadIdx.x % quads, ty = threadIdx.x / quads;
+  if (ty < G) {
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (unsigned p0 = ty; p0 < nrows; p0 += 4 * G) {  // four partial rows (16 scalar loads) in flight
+      float v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned p = p0 + u * G < nrows ? p0 + u * G : p0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[u][k] = ld_agent(rows + (size_t)p * C + 4 * tx + k);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (p0 + u * G < nrows) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) a[k] += (double)v[u][k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) scratch[(k * G + ty) * quads + tx] = a[k];
+  }
+  __syncthreads();
+  for (unsigned idx = threadIdx.x; idx < 4 * quads; idx += BLOCK) {
+    const unsigned k = idx / quads, col = idx - k * quads;
+    double sum = 0.0;
+    for (unsigned t = 0; t < G; ++t) sum += scratch[(k * G + t) * quads + col];
+    out[col * 4 + k] = sum;
+  }
+  __syncthreads();
+}
+
+struct TrainApply {
+  unsigned long long* bar;
+  float* out;        // [rows, out_ld] (out_ld == 0: dense)
+  const float* add;  // nullable, [rows, add_ld]
+  const float* out_mask;  // nullable: out = out_mask > 0 ? t : 0
+  unsigned out_ld, add_ld;
+  float *q_out, *r_out;  // nullable: the per-channel vectors, written by workgroup 0 (tests)
+  const float *fw, *vq, *vr;
+  float inv_m;
+};
+
+// pass 1 = k_bn_adjoint_rows (g = mask * sum of slabs -> gres, partial sums of g and xhat*g per workgroup);
+// barrier; every workgroup adds the partial rows up (fixed order: the same sums in every workgroup) and forms
+//   q = vq - fw*rstd*S_x/m,  r = vr - fw*rstd*S_1/m;
+// pass 2 = hf_chan_affine_ex on the workgroup's OWN rows, each thread re-reading the g it wrote itself:
+//   out = mask(g*(fw*rstd) + xhat*q + r + add).
+__global__ __launch_bounds__(BLOCK) void k_bn_rows_train_apply(
+    float* gw, float* gb, float* gres, const float* __restrict__ gy, int s1, long long l1,
+    const float* __restrict__ gy2, int s2, long long l2, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ mask_src,
+    unsigned rows, unsigned C, unsigned rows_per_block, const TrainApply f) {
+  __shared__ double red[BLOCK * 8];
+  __shared__ double fin[2 * 4 * BLOCK];
+  __shared__ float qs[4 * BLOCK], rsh[4 * BLOCK];
+  bn_adjoint_rows_body(nullptr, gw, gb, gres, gy, s1, l1, gy2, s2, l2, x, mean, rstd, nullptr, mask_src, rows, C,
+                       rows_per_block, blockIdx.x, red, true);
+  grid_barrier(f.bar);
+  final_column_sums_agent(gw, gridDim.x, C, red, fin);
+  final_column_sums_agent(gb, gridDim.x, C, red, fin + 4 * BLOCK);
+  for (unsigned c = threadIdx.x; c < C; c += BLOCK) {
+    const float k = (f.fw ? f.fw[c] : 1.f) * rstd[c] * f.inv_m;
+    const float q = (f.vq ? f.vq[c] : 0.f) - k * (float)fin[c];
+    const float r = (f.vr ? f.vr[c] : 0.f) - k * (float)fin[4 * BLOCK + c];
+    qs[c] = q;
+    rsh[c] = r;
+    if (blockIdx.x == 0 && f.q_out) { f.q_out[c] = q; f.r_out[c] = r; }
+  }
+  __syncthreads();
+  const unsigned quads = C / 4, RP = BLOCK / quads;
+  const unsigned tx = threadIdx.x % quads, ty = threadIdx.x / quads;
+  if (ty >= RP) return;
+  const unsigned c0 = tx * 4;
+  const unsigned row_lo = blockIdx.x * rows_per_block;
+  const unsigned row_hi = row_lo + rows_per_block < rows ? row_lo + rows_per_block : rows;
+  float rs[4], mu[4], sc[4], q4[4], r4[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    rs[k] = rstd[c0 + k];
+    mu[k] = mean[c0 + k];
+    sc[k] = (f.fw ? f.fw[c0 + k] : 1.f) * rs[k];
+    q4[k] = qs[c0 + k];
+    r4[k] = rsh[c0 + k];
+  }
+  for (unsigned r = row_lo + ty; r < row_hi; r += RP) {
+    const unsigned idx = r * C + c0;
+    const F4 g = ld4(gres + idx), xv = ld4(x + idx);
+    F4 addv, mv, o;
+    if (f.add) addv = ld4(f.add + (f.add_ld ? r * f.add_ld + c0 : idx));
+    if (f.out_mask) mv = ld4(f.out_mask + idx);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float acc = g.e[k] * sc[k];
+      acc += ((xv.e[k] - mu[k]) * rs[k]) * q4[k];
+      acc += r4[k];
+      if (f.add) acc += addv.e[k];
+      if (f.out_mask) acc = mv.e[k] > 0.f ? acc : 0.f;
+      o.e[k] = acc;
+    }
+    *reinterpret_cast<F4*>(f.out + (f.out_ld ? r * f.out_ld + c0 : idx)) = o;
+  }
+}
+
 // One-pass batch statistics of a train-mode BatchNorm's forward: sums the convolution's split-K slabs into
 // a_out (row-major walk as k_bn_adjoint_rows), per-channel sum a and sum a^2 in fp64 per thread / block /
 // (last block) over the blocks; then mean, biased variance = E[a^2] - mean^2 (fp64: 1e-16 * mean^2/var relative,
@@ -3058,6 +3183,48 @@ int hf_bn_adjoint_rows_train(void* gx, void* gw, void* gb, void* gres, const voi
                      (long long)gy_slab, (const float*)gy2, gy2_splits, (long long)gy2_slab, (const float*)x,
                      (const float*)mean, (const float*)rstd, (const float*)w, (const float*)mask_src,
                      (unsigned)rows, (unsigned)c, rpb, f);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_bn_rows_train_apply(void* out, int64_t out_ld, void* gw, void* gb, void* gres, const void* gy, int gy_splits,
+                           int64_t gy_slab, const void* gy2, int gy2_splits, int64_t gy2_slab, const void* x,
+                           const void* mean, const void* rstd, const void* mask_src, int64_t n, int64_t c, int64_t hw,
+                           int row_blocks, void* barrier, void* q_out, void* r_out, const void* final_w,
+                           const void* vq, const void* vr, double count, const void* add, int64_t add_ld,
+                           const void* out_mask, int dtype, void* stream) {
+  if (!out || !gy || !gw || !gb || !gres || !x || !mean || !rstd || !barrier || n <= 0 || c <= 0 || hw <= 0 ||
+      gy_splits < 1 || gy2_splits < 1 || row_blocks < 1 || count <= 0.0 || dtype != HF_F32 || (!q_out != !r_out) ||
+      out_ld < 0 || add_ld < 0)
+    return HF_ERR_ARG;
+  if (!(c % 4 == 0 && c / 4 <= BLOCK)) return HF_ERR_ARG;
+  if ((gy_splits > 1 && gy_slab <= 0) || (gy2 && gy2_splits > 1 && gy2_slab <= 0)) return HF_ERR_ARG;
+  const int64_t rows = n * hw;
+  if (rows * (out_ld > c ? out_ld : c) > 0x7fffffffLL || rows * add_ld > 0x7fffffffLL) return HF_ERR_ARG;
+  if ((out_ld && out_ld < c) || (add_ld && add_ld < c) || (out_ld & 3) || (add_ld & 3) || (gy_slab & 3) ||
+      (gy2_slab & 3))
+    return HF_ERR_ARG;
+  // the launch waits inside itself for ALL its workgroups: they must all be resident at once
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    HF_HIP(hipGetDevice(&dev));
+    HF_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    if (v < 1) return HF_ERR_STATE;
+    cus = v;
+  }
+  if (row_blocks > cus) return HF_ERR_ARG;
+  const void* al[] = {out, gres, gy, gy2, x, mask_src, add, out_mask};
+  for (const void* p : al)
+    if (p && !aligned16(p)) return HF_ERR_ALIGN;
+  const unsigned rpb = (unsigned)((rows + row_blocks - 1) / row_blocks);
+  TrainApply f{(unsigned long long*)barrier, (float*)out, (const float*)add, (const float*)out_mask,
+               (unsigned)out_ld, (unsigned)add_ld, (float*)q_out, (float*)r_out, (const float*)final_w,
+               (const float*)vq, (const float*)vr, (float)(1.0 / count)};
+  hipLaunchKernelGGL(k_bn_rows_train_apply, dim3((unsigned)row_blocks), dim3(BLOCK), 0, (hipStream_t)stream,
+                     (float*)gw, (float*)gb, (float*)gres, (const float*)gy, gy_splits, (long long)gy_slab,
+                     (const float*)gy2, gy2_splits, (long long)gy2_slab, (const float*)x, (const float*)mean,
+                     (const float*)rstd, (const float*)mask_src, (unsigned)rows, (unsigned)c, rpb, f);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }

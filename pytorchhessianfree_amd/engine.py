@@ -58,6 +58,10 @@ def _cl(t):
     return t.contiguous(memory_format=torch.channels_last)
 
 
+def _cu_count(dev):
+    return torch.cuda.get_device_properties(dev).multi_processor_count
+
+
 class _Unit:
     """conv -> eval-BatchNorm (-> + residual) (-> ReLU), or conv + bias (-> ReLU) when ``bn`` is None."""
 
@@ -69,6 +73,7 @@ class _Unit:
         self.im2col = False       # tiny-Cin layer: runs as a 1x1 product over the im2col of the input
         self.train = False        # train-mode BatchNorm: batch statistics (recorded), tangent / adjoint carry
         self.mean_t = None        # the statistics' dependence on the layer input
+        self.fold = self.fuse = False  # train mode: how many launches its tangent / adjoint take (see _buffers)
         self.res_unit = None      # downsample unit whose output is added before the activation
         self.res_identity = False  # ... or the block input itself
         self.consumers = 0
@@ -786,7 +791,8 @@ class FusedGGNEngine(_Operator):
             # the BatchNorm adjoint shares the rows among `rb` workgroups per channel column; the
             # per-channel sums arrive as rb partial rows that hf_pack_ex adds up
             u.rb = 1
-            if k % 4 == 0 and k // 4 <= 256 and u.rows >= 64:
+            # (train mode: the one-launch tangent / adjoint wants row blocks for the late, small maps too)
+            if k % 4 == 0 and k // 4 <= 256 and (u.rows >= 64 or (u.train and u.rows >= 2 * (256 // (k // 4)))):
                 # row-major adjoint kernel: ~64 workgroups, each reading whole contiguous rows, one
                 # pass of the row loop where the map is small enough (measured on the ResNet-18
                 # bench: 32 workgroups x 2 passes 1124, 64 x 1 1150, 128 x 1 the same, 256 x 1 1138)
@@ -808,6 +814,11 @@ class FusedGGNEngine(_Operator):
                 u.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
                 u.stat_part = torch.empty((u.rb, 2, k), dtype=torch.float64, device=dev)
                 u.fold = u.rb > 1 and os.environ.get("HF_BN_FOLD", "1") != "0"
+                # ... and reduction + finalisation + elementwise pass in ONE launch around a grid barrier
+                # (hf_bn_rows_train_apply: all `rb` workgroups resident -- at most one per compute unit)
+                u.barrier = torch.zeros(1, dtype=torch.int64, device=dev)
+                u.fuse = (u.fold and u.g is not None and u.rb <= _cu_count(dev)
+                          and os.environ.get("HF_BN_FUSE", "1") != "0")
         # where each unit's output goes besides its own dense buffer: the [t_x | x] operand of its
         # consumer -- the tangent into the first half, the value (forward pass) into the second
         for u in self.units:
@@ -904,6 +915,16 @@ class FusedGGNEngine(_Operator):
         n, k, oh, ow = u.a.shape
         vg = v[self._offs[u.pg]: self._offs[u.pg] + k] if u.pg is not None else None
         vb = v[self._offs[u.pb]: self._offs[u.pb] + k] if u.pb is not None else None
+        if u.train and u.fuse:
+            # reduction, folding and the elementwise pass in ONE launch (grid barrier between the passes); u.g is
+            # free during the tangent sweep: the slabs' sum rests there between the passes
+            _lib.check(_lib.load().hf_bn_rows_train_apply(
+                _ptr(u.tout), u.tout_ld, _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(u.tbuf), u.sT, u.tbuf.shape[1],
+                None, 1, 0, _ptr(u.a), _ptr(u.mean), _ptr(u.rstd), None, n, k, oh * ow, u.rb, _ptr(u.barrier),
+                None, None, _ptr(u.scale), _ptr(vg), _ptr(vb), float(n * oh * ow), _ptr(add), add_ld,
+                _ptr(u.y) if u.relu else None, _lib.HF_F32, _lib.current_stream_ptr(self.dev)),
+                "hf_bn_rows_train_apply")
+            return
         if u.train and u.fold:
             # ... reduction and folding in ONE launch (the last workgroup finalises the per-channel vectors)
             _lib.check(_lib.load().hf_bn_adjoint_rows_train(
@@ -1078,6 +1099,13 @@ class FusedGGNEngine(_Operator):
             # pass 1: g = mask * (sum of the cotangents' slabs) and its per-channel sums (the parameter
             # gradients); pass 2: g_a = rstd*w * [g - mean(g) - xhat * mean(xhat*g)] (the batch statistics'
             # share), by the elementwise kernel with the corrections folded into its per-channel vectors
+            if u.fuse:  # (both passes in one launch)
+                _lib.check(lib.hf_bn_rows_train_apply(
+                    _ptr(ga), 0, _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a),
+                    _ptr(u.mean), _ptr(u.rstd), _ptr(u.y) if u.relu else None, n, k, oh * ow, u.rb, _ptr(u.barrier),
+                    None, None, _ptr(u.scale), None, None, float(n * oh * ow), None, 0, None, _lib.HF_F32, st),
+                    "hf_bn_rows_train_apply")
+                return
             if u.fold:  # (pass 1 finalises those vectors itself: its last workgroup)
                 _lib.check(lib.hf_bn_adjoint_rows_train(
                     None, _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a),

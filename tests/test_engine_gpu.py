@@ -376,13 +376,22 @@ def test_train_mode_folded_kernels_equal_the_separate_launches():
     assert isinstance(op, FusedGGNEngine) and op.train_bn and op.train_own
     folded = [u for u in op.units if u.train and u.fold]
     assert len(folded) >= 10
+    fused = [u for u in op.units if u.fuse]
+    assert len(fused) == len(op.units)  # (the one-launch form takes the late 1x1 / 2x2 maps too)
     v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(41))
-    got = op(v).clone()
+    one = op(v).clone()       # reduction + finalisation + elementwise pass in one launch (grid barrier)
+    for _ in range(20):       # (bitwise repeatable: fixed summation orders on both sides of the barrier)
+        assert torch.equal(op(v), one)
+    for u in fused:
+        u.fuse = False
+    got = op(v).clone()       # reduction + finalisation | elementwise pass
     assert torch.equal(op(v), got)
+    assert float((one - got).abs().max() / got.abs().max()) < 1e-6
     for u in folded:
         u.fold = False
-    sep = op(v).clone()
+    sep = op(v).clone()       # reduction | finalisation | elementwise pass
     assert float((sep - got).abs().max() / got.abs().max()) < 1e-6
+    assert float((sep - one).abs().max() / got.abs().max()) < 1e-6
     # forward pass: both variants from the same running statistics
     saved = [(u.bn.running_mean.clone(), u.bn.running_var.clone(), u.bn.num_batches_tracked.clone()) for u in op.units]
 
