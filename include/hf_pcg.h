@@ -399,6 +399,20 @@ int hf_bn_rows_train_apply(void* out, int64_t out_ld, void* gw, void* gb, void* 
                            const void* out_mask, int dtype, void* stream);
 
 /*
+ * hf_bn_train_coeffs folded into the PROLOGUE of hf_chan_affine_ex (fp32 NHWC, c % 4 == 0, c <= 1024, 16-byte
+ * aligned operands): every workgroup adds the `nparts` partial rows of S_x (`part_x`) and S_1 (`part_1`) -- what
+ * hf_chan_affine_bwd_ex wrote with gx = NULL -- up in the same fixed order, forms
+ *   q = vq - w*rstd*S_x/count,  r = vr - w*rstd*S_1/count   (vq / vr / w nullable),
+ * and applies  out = mask_src > 0 ? t : 0,  t = sum(a slabs)*(w*rstd) + xhat*q + r + add.
+ * One launch less per train-mode BatchNorm layer and sweep than hf_chan_affine_bwd_ex + hf_bn_train_coeffs +
+ * hf_chan_affine_ex, without the in-launch hand-over of hf_bn_adjoint_rows_train / hf_bn_rows_train_apply.
+ */
+int hf_chan_affine_train(void* out, const void* a, const void* x, const void* mean, const void* rstd, const void* w,
+                         const void* part_x, const void* part_1, int nparts, const void* vq, const void* vr,
+                         double count, const void* add, const void* mask_src, int64_t n, int64_t c, int64_t hw,
+                         int64_t out_ld, int64_t add_ld, int a_splits, int64_t a_slab, int dtype, void* stream);
+
+/*
  * One-pass batch statistics of a train-mode BatchNorm in the engine's own forward pass (optimizer.py:216-229,
  * :288-294 on a model in train mode): a_out (nullable) = sum of `splits` slabs of a (split order), per-channel
  * sum a and sum a^2 in fp64 (`part`: [row_blocks, 2, c] doubles, scratch), finalised by the last workgroup

@@ -142,6 +142,8 @@ SIGNATURES = {
     "hf_bn_rows_train_apply": (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int, c_int64, c_void_p, c_int, c_int64]
                                + [c_void_p] * 4 + [c_int64, c_int64, c_int64, c_int] + [c_void_p] * 6
                                + [c_double, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
+    "hf_chan_affine_train": (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p]
+                             + [c_int64] * 5 + [c_int, c_int64, c_int, c_void_p]),
     "hf_bn_stats_rows": (c_int, [c_void_p, c_void_p, c_int, c_int64] + [c_void_p] * 6
                          + [c_double, c_double, c_double, c_int64, c_int64, c_int, c_int, c_void_p]),
     "hf_bn_adjoint_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64,

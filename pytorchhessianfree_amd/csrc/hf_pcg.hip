@@ -1717,6 +1717,35 @@ __global__ __launch_bounds__(BLOCK) void k_bn_rows_train_apply(
   }
 }
 
+// ---- train-mode BatchNorm: the per-channel finalisation in the CONSUMER's prologue ---------------------------
+// k_chan_affine_v4 whose workgroups first add the reduction launch's partial rows up themselves (plain loads: the
+// rows come from the PREVIOUS launch; every workgroup the same fixed order, so the same q / r everywhere) --
+//   q = vq - w*rstd*S_x/m,  r = vr - w*rstd*S_1/m   (hf_bn_train_coeffs),  then  out = mask(a*(w*rstd) + xhat*q + r + add).
+// The redundant sums cost each workgroup one more round trip (nparts * C * 8 bytes out of L2); the finalisation as the
+// reduction launch's TAIL (k_bn_adjoint_rows_train) costs a ticket, a drain and a one-workgroup re-read, as its own
+// launch (k_bn_train_coeffs) a launch boundary more.
+__global__ __launch_bounds__(BLOCK) void k_chan_affine_v4_train(
+    float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ w,
+    const float* __restrict__ part_x, const float* __restrict__ part_1, unsigned nparts,
+    const float* __restrict__ vq, const float* __restrict__ vr, float inv_m, const float* __restrict__ add,
+    const float* __restrict__ mask_src, unsigned total, unsigned C, unsigned out_ld, unsigned add_ld, int a_splits,
+    long long a_slab) {
+  __shared__ double scratch[4 * BLOCK];
+  __shared__ double fin[2 * 4 * BLOCK];
+  __shared__ float qs[4 * BLOCK], rsh[4 * BLOCK];
+  final_column_sums(part_x, nparts, C, scratch, fin);
+  final_column_sums(part_1, nparts, C, scratch, fin + 4 * BLOCK);
+  for (unsigned c = threadIdx.x; c < C; c += BLOCK) {
+    const float k = (w ? w[c] : 1.f) * rstd[c] * inv_m;
+    qs[c] = (vq ? vq[c] : 0.f) - k * (float)fin[c];
+    rsh[c] = (vr ? vr[c] : 0.f) - k * (float)fin[4 * BLOCK + c];
+  }
+  __syncthreads();
+  chan_affine_v4_body(out, a, x, mean, rstd, w, qs, rsh, add, mask_src, 0, total, C, out_ld, add_ld, a_splits, a_slab,
+                      blockIdx.x, gridDim.x);
+}
+
 // One-pass batch statistics of a train-mode BatchNorm's forward: sums the convolution's split-K slabs into
 // a_out (row-major walk as k_bn_adjoint_rows), per-channel sum a and sum a^2 in fp64 per thread / block /
 // (last block) over the blocks; then mean, biased variance = E[a^2] - mean^2 (fp64: 1e-16 * mean^2/var relative,
@@ -3012,6 +3041,29 @@ int hf_chan_affine_ex(void* out, const void* a, const void* x, const void* mean,
                                channels_last, out_ld, add_ld, a_splits, a_slab);
   else
     return HF_ERR_ARG;
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_chan_affine_train(void* out, const void* a, const void* x, const void* mean, const void* rstd, const void* w,
+                         const void* part_x, const void* part_1, int nparts, const void* vq, const void* vr,
+                         double count, const void* add, const void* mask_src, int64_t n, int64_t c, int64_t hw,
+                         int64_t out_ld, int64_t add_ld, int a_splits, int64_t a_slab, int dtype, void* stream) {
+  if (!out || !a || !x || !mean || !rstd || !part_x || !part_1 || nparts < 1 || count <= 0.0 || n <= 0 || c <= 0 ||
+      hw <= 0 || a_splits < 1 || (a_splits > 1 && a_slab <= 0) || dtype != HF_F32)
+    return HF_ERR_ARG;
+  if (!(c % 4 == 0 && c / 4 <= BLOCK)) return HF_ERR_ARG;
+  if ((out_ld && out_ld < c) || (add_ld && (add_ld < c || !add)) || out_ld > 0x3fffffffLL || add_ld > 0x3fffffffLL)
+    return HF_ERR_ARG;
+  const long long total = (long long)n * c * hw;
+  if (!affine_vec4_ok(out, a, x, mean, rstd, w, nullptr, nullptr, add, mask_src, total, c, 1, out_ld, add_ld, a_slab) ||
+      !aligned16(part_x) || !aligned16(part_1))
+    return HF_ERR_ALIGN;
+  hipLaunchKernelGGL(k_chan_affine_v4_train, dim3(wide_grid(total / 4)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     (float*)out, (const float*)a, (const float*)x, (const float*)mean, (const float*)rstd,
+                     (const float*)w, (const float*)part_x, (const float*)part_1, (unsigned)nparts, (const float*)vq,
+                     (const float*)vr, (float)(1.0 / count), (const float*)add, (const float*)mask_src,
+                     (unsigned)total, (unsigned)c, (unsigned)out_ld, (unsigned)add_ld, a_splits, (long long)a_slab);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }

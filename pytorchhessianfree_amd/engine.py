@@ -73,7 +73,7 @@ class _Unit:
         self.im2col = False       # tiny-Cin layer: runs as a 1x1 product over the im2col of the input
         self.train = False        # train-mode BatchNorm: batch statistics (recorded), tangent / adjoint carry
         self.mean_t = None        # the statistics' dependence on the layer input
-        self.fold = self.fuse = False  # train mode: how many launches its tangent / adjoint take (see _buffers)
+        self.fold = self.fuse = self.pro = self.stats_fold = False  # train mode: how many launches its tangent / adjoint take (see _buffers)
         self.res_unit = None      # downsample unit whose output is added before the activation
         self.res_identity = False  # ... or the block input itself
         self.consumers = 0
@@ -434,7 +434,7 @@ class FusedGGNEngine(_Operator):
     def _bn_forward(self, u, splits, update_running=True):
         n, k, oh, ow = u.a.shape
         res = u.res
-        if u.train and u.fold:
+        if u.train and u.stats_fold:
             # ONE pass: the convolution's slabs summed into ``a``, per-channel sum a / sum a^2 in fp64, finalised by
             # the launch's last workgroup (mean, rstd, running statistics) -- 3 launches per unit instead of 6
             bn = u.bn
@@ -792,7 +792,8 @@ class FusedGGNEngine(_Operator):
             # per-channel sums arrive as rb partial rows that hf_pack_ex adds up
             u.rb = 1
             # (train mode: the one-launch tangent / adjoint wants row blocks for the late, small maps too)
-            if k % 4 == 0 and k // 4 <= 256 and (u.rows >= 64 or (u.train and u.rows >= 2 * (256 // (k // 4)))):
+            form = os.environ.get("HF_BN_TRAIN_FORM", "prologue") if u.train else ""
+            if k % 4 == 0 and k // 4 <= 256 and (u.rows >= 64 or (form == "barrier" and u.rows >= 2 * (256 // (k // 4)))):
                 # row-major adjoint kernel: ~64 workgroups, each reading whole contiguous rows, one
                 # pass of the row loop where the map is small enough (measured on the ResNet-18
                 # bench: 32 workgroups x 2 passes 1124, 64 x 1 1150, 128 x 1 the same, 256 x 1 1138)
@@ -813,12 +814,18 @@ class FusedGGNEngine(_Operator):
                 # self-resetting ticket word and the one-pass statistics' fp64 partial sums
                 u.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
                 u.stat_part = torch.empty((u.rb, 2, k), dtype=torch.float64, device=dev)
-                u.fold = u.rb > 1 and os.environ.get("HF_BN_FOLD", "1") != "0"
-                # ... and reduction + finalisation + elementwise pass in ONE launch around a grid barrier
-                # (hf_bn_rows_train_apply: all `rb` workgroups resident -- at most one per compute unit)
+                # Where the per-channel finalisation of a tangent / adjoint runs (HF_BN_TRAIN_FORM; measured,
+                # profiles/r04_train_bn_forms.jsonl):
+                #   "separate"  reduction | hf_bn_train_coeffs | elementwise pass          (3 launches, round 3)
+                #   "tail"      reduction + finalisation by its last workgroup | elementwise pass
+                #   "barrier"   all three in one launch around a grid barrier (hf_bn_rows_train_apply: all `rb`
+                #               workgroups resident -- at most one per compute unit)
+                #   "prologue"  reduction | elementwise pass whose workgroups add the partial rows up themselves
+                u.stats_fold = u.rb > 1 and os.environ.get("HF_BN_FOLD", "1") != "0"  # (the forward's statistics)
+                u.fold = u.stats_fold and form in ("tail", "barrier")
                 u.barrier = torch.zeros(1, dtype=torch.int64, device=dev)
-                u.fuse = (u.fold and u.g is not None and u.rb <= _cu_count(dev)
-                          and os.environ.get("HF_BN_FUSE", "1") != "0")
+                u.fuse = u.fold and form == "barrier" and u.g is not None and u.rb <= _cu_count(dev)
+                u.pro = form == "prologue" and k % 4 == 0 and k // 4 <= 256
         # where each unit's output goes besides its own dense buffer: the [t_x | x] operand of its
         # consumer -- the tangent into the first half, the value (forward pass) into the second
         for u in self.units:
@@ -924,6 +931,18 @@ class FusedGGNEngine(_Operator):
                 None, None, _ptr(u.scale), _ptr(vg), _ptr(vb), float(n * oh * ow), _ptr(add), add_ld,
                 _ptr(u.y) if u.relu else None, _lib.HF_F32, _lib.current_stream_ptr(self.dev)),
                 "hf_bn_rows_train_apply")
+            return
+        if u.train and u.pro:
+            # reduction (partial rows), then the elementwise pass adds them up in its own prologue
+            lib, st = _lib.load(), _lib.current_stream_ptr(self.dev)
+            _lib.check(lib.hf_chan_affine_bwd_ex(
+                None, _ptr(u.gw), _ptr(u.gb), None, _ptr(u.tbuf), u.sT, u.tbuf.shape[1], None, 1, 0, _ptr(u.a),
+                _ptr(u.mean), _ptr(u.rstd), None, None, n, k, oh * ow, 1, u.rb, _lib.HF_F32, st),
+                "hf_chan_affine_bwd_ex")
+            _lib.check(lib.hf_chan_affine_train(
+                _ptr(u.tout), _ptr(u.tbuf), _ptr(u.a), _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.gw),
+                _ptr(u.gb), u.rb, _ptr(vg), _ptr(vb), float(n * oh * ow), _ptr(add), _ptr(u.y) if u.relu else None,
+                n, k, oh * ow, u.tout_ld, add_ld, u.sT, u.tbuf.shape[1], _lib.HF_F32, st), "hf_chan_affine_train")
             return
         if u.train and u.fold:
             # ... reduction and folding in ONE launch (the last workgroup finalises the per-channel vectors)
@@ -1105,6 +1124,16 @@ class FusedGGNEngine(_Operator):
                     _ptr(u.mean), _ptr(u.rstd), _ptr(u.y) if u.relu else None, n, k, oh * ow, u.rb, _ptr(u.barrier),
                     None, None, _ptr(u.scale), None, None, float(n * oh * ow), None, 0, None, _lib.HF_F32, st),
                     "hf_bn_rows_train_apply")
+                return
+            if u.pro:  # (pass 2 adds the partial rows up in its prologue)
+                _lib.check(lib.hf_chan_affine_bwd_ex(
+                    None, _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a),
+                    _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.y) if u.relu else None, n, k, oh * ow, 1,
+                    u.rb, _lib.HF_F32, st), "hf_chan_affine_bwd_ex")
+                _lib.check(lib.hf_chan_affine_train(
+                    _ptr(ga), _ptr(u.g), _ptr(u.a), _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.gw),
+                    _ptr(u.gb), u.rb, None, None, float(n * oh * ow), None, None, n, k, oh * ow, 0, 0, 1, 0,
+                    _lib.HF_F32, st), "hf_chan_affine_train")
                 return
             if u.fold:  # (pass 1 finalises those vectors itself: its last workgroup)
                 _lib.check(lib.hf_bn_adjoint_rows_train(

@@ -359,40 +359,47 @@ def test_train_mode_batchnorm_engine_product_matches_cpu_oracle_and_float64():
     assert final < opt.state["init_losses"][0]
 
 
-def test_train_mode_folded_kernels_equal_the_separate_launches():
-    """Train-mode BatchNorm with the per-channel finalisation INSIDE the reduction's launch (last workgroup by
-    ticket: ``hf_bn_adjoint_rows_train``, ``hf_bn_stats_rows``) against the separate reduction + finalisation
-    launches (``HF_BN_FOLD=0`` path): the curvature product agrees to 1e-6 (the same partial sums, added in another
-    fixed order by the whole finalising workgroup) and is bitwise repeatable; the one-pass forward statistics
-    (E[a^2] - mean^2 in fp64 instead of a second pass over a - mean) reproduce the logits of this 20-layer net to
-    5e-6, batch means to 1e-6, rstd / running variances to 5e-6 (max-norm relative)."""
+def test_train_mode_folded_kernels_equal_the_separate_launches(monkeypatch):
+    """Train-mode BatchNorm inside the product -- WHERE the per-channel finalisation runs (``HF_BN_TRAIN_FORM``):
+    its own launch between reduction and elementwise pass ("separate": ``hf_bn_train_coeffs``), the reduction launch's
+    last workgroup by ticket ("tail": ``hf_bn_adjoint_rows_train``), everything in one launch around a grid barrier
+    ("barrier": ``hf_bn_rows_train_apply``), or the prologue of the elementwise pass ("prologue":
+    ``hf_chan_affine_train``).  The four products agree to 1e-6 (the same partial sums, added in other fixed orders) and
+    each is bitwise repeatable.  Forward pass: the one-pass statistics (E[a^2] - mean^2 in fp64, ``hf_bn_stats_rows``)
+    against the second pass over a - mean: logits of this 20-layer net to 5e-6, batch means to 1e-6, rstd / running
+    variances to 5e-6 (max-norm relative)."""
     seed = tp.RESNET18_B32_SEPARATED_SEEDS[2]
-    model, (x, t), lossf = tp.resnet18_mnist(batch_size=16, device=DEV, data_seed=seed)
-    model.train()
-    modelprep.prepare_model(model, channels_last=True)
-    params = [p for p in model.parameters() if p.requires_grad]
-    out = model(x)
-    op = curvature.ggn_operator(lossf(out, t), out, params)
-    assert isinstance(op, FusedGGNEngine) and op.train_bn and op.train_own
-    folded = [u for u in op.units if u.train and u.fold]
+    v = None
+    products = {}
+    for form in ("prologue", "barrier", "tail", "separate"):
+        monkeypatch.setenv("HF_BN_TRAIN_FORM", form)
+        model, (x, t), lossf = tp.resnet18_mnist(batch_size=16, device=DEV, data_seed=seed)
+        model.train()
+        modelprep.prepare_model(model, channels_last=True)
+        params = [p for p in model.parameters() if p.requires_grad]
+        out = model(x)
+        op = curvature.ggn_operator(lossf(out, t), out, params)
+        assert isinstance(op, FusedGGNEngine) and op.train_bn and op.train_own
+        if form == "prologue":
+            assert all(u.pro and not u.fold for u in op.units)
+        elif form == "barrier":
+            assert all(u.fuse for u in op.units)  # (the one-launch form takes the late 1x1 / 2x2 maps too)
+        elif form == "tail":
+            assert sum(u.fold and not u.fuse for u in op.units) >= 10
+        else:
+            assert not any(u.pro or u.fold or u.fuse for u in op.units)
+        if v is None:
+            v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(41))
+        got = op(v).clone()
+        for _ in range(10):  # (fixed summation orders, also on both sides of the grid barrier)
+            assert torch.equal(op(v), got)
+        products[form] = got
+    ref = products["separate"]
+    for form, got in products.items():
+        assert float((got - ref).abs().max() / ref.abs().max()) < 1e-6, form
+    # forward pass (the engine of the last form): both variants from the same running statistics
+    folded = [u for u in op.units if u.stats_fold]
     assert len(folded) >= 10
-    fused = [u for u in op.units if u.fuse]
-    assert len(fused) == len(op.units)  # (the one-launch form takes the late 1x1 / 2x2 maps too)
-    v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(41))
-    one = op(v).clone()       # reduction + finalisation + elementwise pass in one launch (grid barrier)
-    for _ in range(20):       # (bitwise repeatable: fixed summation orders on both sides of the barrier)
-        assert torch.equal(op(v), one)
-    for u in fused:
-        u.fuse = False
-    got = op(v).clone()       # reduction + finalisation | elementwise pass
-    assert torch.equal(op(v), got)
-    assert float((one - got).abs().max() / got.abs().max()) < 1e-6
-    for u in folded:
-        u.fold = False
-    sep = op(v).clone()       # reduction | finalisation | elementwise pass
-    assert float((sep - got).abs().max() / got.abs().max()) < 1e-6
-    assert float((sep - one).abs().max() / got.abs().max()) < 1e-6
-    # forward pass: both variants from the same running statistics
     saved = [(u.bn.running_mean.clone(), u.bn.running_var.clone(), u.bn.num_batches_tracked.clone()) for u in op.units]
 
     def restore():
@@ -404,12 +411,14 @@ def test_train_mode_folded_kernels_equal_the_separate_launches():
     def rel(a, b):
         return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
+    for u in folded:
+        u.stats_fold = False
     op.forward_own(update_running=True)
     ref = (op.logits.clone(), [(u.mean_t.clone(), u.rstd.clone(), u.bn.running_mean.clone(), u.bn.running_var.clone())
                                for u in op.units])
     restore()
     for u in folded:
-        u.fold = True
+        u.stats_fold = True
     op.forward_own(update_running=True)
     assert rel(op.logits, ref[0]) < 5e-6
     for u, (m, r, rm, rv) in zip(op.units, ref[1]):
