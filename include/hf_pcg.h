@@ -402,7 +402,7 @@ int hf_bn_rows_train_apply(void* out, int64_t out_ld, void* gw, void* gb, void* 
  * hf_bn_train_coeffs folded into the PROLOGUE of hf_chan_affine_ex (fp32 NHWC, c % 4 == 0, c <= 1024, 16-byte
  * aligned operands): every workgroup adds the `nparts` partial rows of S_x (`part_x`) and S_1 (`part_1`) -- what
  * hf_chan_affine_bwd_ex wrote with gx = NULL -- up in the same fixed order, forms
- *   q = vq - w*rstd*S_x/count,  r = vr - w*rstd*S_1/count   (vq / vr / w nullable),
+ *   q = vq - w*rstd*S_x/count,  r = vr - w*rstd*S_1/count   (vq / vr nullable),
  * and applies  out = mask_src > 0 ? t : 0,  t = sum(a slabs)*(w*rstd) + xhat*q + r + add.
  * One launch less per train-mode BatchNorm layer and sweep than hf_chan_affine_bwd_ex + hf_bn_train_coeffs +
  * hf_chan_affine_ex, without the in-launch hand-over of hf_bn_adjoint_rows_train / hf_bn_rows_train_apply.

@@ -1717,6 +1717,63 @@ __global__ __launch_bounds__(BLOCK) void k_bn_rows_train_apply(
   }
 }
 
+// Both column sums in one pass (all loads of both partial-row sets in flight together).  scratch: 8 * BLOCK doubles.
+// `between()` runs right after the first batch of partial-row loads is issued: the caller's own independent loads go
+// there, so that one round trip covers both.
+template <typename Between>
+__device__ __forceinline__ void final_column_sums2(const float* __restrict__ rows_a, const float* __restrict__ rows_b,
+                                                   unsigned nrows, unsigned C, double* scratch, double* out_a,
+                                                   double* out_b, Between&& between) {
+  const unsigned quads = C / 4, G = BLOCK / quads;
+  const unsigned tx = threadIdx.x % quads, ty = threadIdx.x / quads;
+  const bool live = ty < G;
+  double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  F4 va[4], vb[4];
+  auto issue = [&](unsigned p0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned p = p0 + u * G < nrows ? p0 + u * G : 0u;
+      va[u] = ld4(rows_a + (size_t)p * C + 4 * tx);
+      vb[u] = ld4(rows_b + (size_t)p * C + 4 * tx);
+    }
+  };
+  auto add = [&](unsigned p0) {  // four partial rows of each set, added in row order
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (p0 + u * G < nrows) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] += (double)va[u].e[k]; a[4 + k] += (double)vb[u].e[k]; }
+      }
+  };
+  const bool first = live && ty < nrows;
+  issue(ty);  // (unconditional, out-of-range rows read row 0: a branch here makes the compiler shuffle -- and wait for --
+              // the loaded registers at its join)
+  between();
+  if (first) {
+    // (pins the first use of the rows BEHIND the caller's loads: without it the compiler adds them up -- and waits
+    // for them -- before it issues those)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      asm volatile("" : "+v"(va[u].e[0]), "+v"(va[u].e[1]), "+v"(va[u].e[2]), "+v"(va[u].e[3]) : : "memory");
+      asm volatile("" : "+v"(vb[u].e[0]), "+v"(vb[u].e[1]), "+v"(vb[u].e[2]), "+v"(vb[u].e[3]) : : "memory");
+    }
+    add(ty);
+  }
+  if (live) {
+    for (unsigned p0 = ty + 4 * G; p0 < nrows; p0 += 4 * G) { issue(p0); add(p0); }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) scratch[(k * G + ty) * quads + tx] = a[k];
+  }
+  __syncthreads();
+  for (unsigned idx = threadIdx.x; idx < 8 * quads; idx += BLOCK) {
+    const unsigned k = idx / quads, col = idx - k * quads;
+    double sum = 0.0;
+    for (unsigned t = 0; t < G; ++t) sum += scratch[(k * G + t) * quads + col];
+    (k < 4 ? out_a : out_b)[col * 4 + (k & 3)] = sum;
+  }
+  __syncthreads();
+}
+
 // ---- train-mode BatchNorm: the per-channel finalisation in the CONSUMER's prologue ---------------------------
 // k_chan_affine_v4 whose workgroups first add the reduction launch's partial rows up themselves (plain loads: the
 // rows come from the PREVIOUS launch; every workgroup the same fixed order, so the same q / r everywhere) --
@@ -1724,6 +1781,7 @@ __global__ __launch_bounds__(BLOCK) void k_bn_rows_train_apply(
 // The redundant sums cost each workgroup one more round trip (nparts * C * 8 bytes out of L2); the finalisation as the
 // reduction launch's TAIL (k_bn_adjoint_rows_train) costs a ticket, a drain and a one-workgroup re-read, as its own
 // launch (k_bn_train_coeffs) a launch boundary more.
+template <bool SLABS, bool ADD, bool MASK>
 __global__ __launch_bounds__(BLOCK) void k_chan_affine_v4_train(
     float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ w,
@@ -1731,19 +1789,71 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_v4_train(
     const float* __restrict__ vq, const float* __restrict__ vr, float inv_m, const float* __restrict__ add,
     const float* __restrict__ mask_src, unsigned total, unsigned C, unsigned out_ld, unsigned add_ld, int a_splits,
     long long a_slab) {
-  __shared__ double scratch[4 * BLOCK];
+  __shared__ double scratch[8 * BLOCK];
   __shared__ double fin[2 * 4 * BLOCK];
   __shared__ float qs[4 * BLOCK], rsh[4 * BLOCK];
-  final_column_sums(part_x, nparts, C, scratch, fin);
-  final_column_sums(part_1, nparts, C, scratch, fin + 4 * BLOCK);
-  for (unsigned c = threadIdx.x; c < C; c += BLOCK) {
-    const float k = (w ? w[c] : 1.f) * rstd[c] * inv_m;
-    qs[c] = (vq ? vq[c] : 0.f) - k * (float)fin[c];
-    rsh[c] = (vr ? vr[c] : 0.f) - k * (float)fin[4 * BLOCK + c];
+  // this thread's element quad: every load of it issued right behind the first partial-row loads and BEFORE those are
+  // added up (none depends on the sums): one round trip for both
+  const unsigned quads_total = total >> 2;
+  const unsigned v = blockIdx.x * BLOCK + threadIdx.x;
+  const bool have = v < quads_total;
+  const unsigned i = v << 2;
+  const unsigned row = i / C, c = i - row * C;
+  F4 rs4, w4, mu4, xv, addv, mv, av, t[16];
+  final_column_sums2(part_x, part_1, nparts, C, scratch, fin, fin + 4 * BLOCK, [&]() {
+    // (no run-time branches around these loads -- optional operands are template flags, threads past the end read
+    // element 0: at a branch's join the compiler copies the loaded registers, which waits for them right here)
+    const unsigned ii = have ? i : 0u, cc = have ? c : 0u, rr = have ? row : 0u;
+    rs4 = ld4(rstd + cc);
+    mu4 = ld4(mean + cc);
+    xv = ld4(x + ii);
+    w4 = ld4(w + cc);
+    if (ADD) addv = ld4(add + (add_ld ? rr * add_ld + cc : ii));
+    if (MASK) mv = ld4(mask_src + ii);
+    av = ld4(a + ii);
+    if (SLABS) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = ld4(a + (long long)(1 + u < a_splits ? 1 + u : 0) * a_slab + ii);
+    }
+  });
+  for (unsigned ch = threadIdx.x; ch < C; ch += BLOCK) {
+    const float k = w[ch] * rstd[ch] * inv_m;
+    qs[ch] = (vq ? vq[ch] : 0.f) - k * (float)fin[ch];
+    rsh[ch] = (vr ? vr[ch] : 0.f) - k * (float)fin[4 * BLOCK + ch];
   }
   __syncthreads();
-  chan_affine_v4_body(out, a, x, mean, rstd, w, qs, rsh, add, mask_src, 0, total, C, out_ld, add_ld, a_splits, a_slab,
-                      blockIdx.x, gridDim.x);
+  if (have) {
+    if (SLABS) {  // (slabs in split order, as chan_affine_v4_body)
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) av.e[k] += 1 + u < a_splits ? t[u].e[k] : 0.f;
+      for (int sp = 17; sp < a_splits; sp += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = ld4(a + (long long)(sp + u < a_splits ? sp + u : 0) * a_slab + i);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) av.e[k] += sp + u < a_splits ? t[u].e[k] : 0.f;
+      }
+    }
+    F4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float rs = rs4.e[k];
+      float acc = av.e[k] * (w4.e[k] * rs);
+      acc += ((xv.e[k] - mu4.e[k]) * rs) * qs[c + k];
+      acc += rsh[c + k];
+      if (ADD) acc += addv.e[k];
+      if (MASK) acc = mv.e[k] > 0.f ? acc : 0.f;
+      o.e[k] = acc;
+    }
+    *reinterpret_cast<F4*>(out + (out_ld ? row * out_ld + c : i)) = o;
+  }
+  // (a grid capped below one quad per thread: the rest by the plain walk)
+  if (gridDim.x * BLOCK < quads_total)
+    chan_affine_v4_body(out, a, x, mean, rstd, w, qs, rsh, add, mask_src, 0, total, C, out_ld, add_ld, a_splits,
+                        a_slab, blockIdx.x + gridDim.x, gridDim.x);
 }
 
 // One-pass batch statistics of a train-mode BatchNorm's forward: sums the convolution's split-K slabs into
@@ -3049,7 +3159,7 @@ int hf_chan_affine_train(void* out, const void* a, const void* x, const void* me
                          const void* part_x, const void* part_1, int nparts, const void* vq, const void* vr,
                          double count, const void* add, const void* mask_src, int64_t n, int64_t c, int64_t hw,
                          int64_t out_ld, int64_t add_ld, int a_splits, int64_t a_slab, int dtype, void* stream) {
-  if (!out || !a || !x || !mean || !rstd || !part_x || !part_1 || nparts < 1 || count <= 0.0 || n <= 0 || c <= 0 ||
+  if (!out || !a || !x || !mean || !rstd || !w || !part_x || !part_1 || nparts < 1 || count <= 0.0 || n <= 0 || c <= 0 ||
       hw <= 0 || a_splits < 1 || (a_splits > 1 && a_slab <= 0) || dtype != HF_F32)
     return HF_ERR_ARG;
   if (!(c % 4 == 0 && c / 4 <= BLOCK)) return HF_ERR_ARG;
@@ -3059,8 +3169,16 @@ int hf_chan_affine_train(void* out, const void* a, const void* x, const void* me
   if (!affine_vec4_ok(out, a, x, mean, rstd, w, nullptr, nullptr, add, mask_src, total, c, 1, out_ld, add_ld, a_slab) ||
       !aligned16(part_x) || !aligned16(part_1))
     return HF_ERR_ALIGN;
-  hipLaunchKernelGGL(k_chan_affine_v4_train, dim3(wide_grid(total / 4)), dim3(BLOCK), 0, (hipStream_t)stream,
-                     (float*)out, (const float*)a, (const float*)x, (const float*)mean, (const float*)rstd,
+  typedef void (*Kern)(float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                       const float*, unsigned, const float*, const float*, float, const float*, const float*, unsigned,
+                       unsigned, unsigned, unsigned, int, long long);
+  static const Kern kerns[8] = {
+      k_chan_affine_v4_train<false, false, false>, k_chan_affine_v4_train<true, false, false>,
+      k_chan_affine_v4_train<false, true, false>,  k_chan_affine_v4_train<true, true, false>,
+      k_chan_affine_v4_train<false, false, true>,  k_chan_affine_v4_train<true, false, true>,
+      k_chan_affine_v4_train<false, true, true>,   k_chan_affine_v4_train<true, true, true>};
+  hipLaunchKernelGGL(kerns[(a_splits > 1 ? 1 : 0) | (add ? 2 : 0) | (mask_src ? 4 : 0)],
+                     dim3(wide_grid(total / 4)), dim3(BLOCK), 0, (hipStream_t)stream, (float*)out, (const float*)a, (const float*)x, (const float*)mean, (const float*)rstd,
                      (const float*)w, (const float*)part_x, (const float*)part_1, (unsigned)nparts, (const float*)vq,
                      (const float*)vr, (float)(1.0 / count), (const float*)add, (const float*)mask_src,
                      (unsigned)total, (unsigned)c, (unsigned)out_ld, (unsigned)add_ld, a_splits, (long long)a_slab);
