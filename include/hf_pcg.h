@@ -528,6 +528,20 @@ typedef struct hf_conv_problem {
   int64_t mat_ld;           /* see hf_conv2d_nhwc_slabs; 0 = dense */
 } hf_conv_problem;
 int hf_conv2d_nhwc_group_slabs(const hf_conv_problem* problems, int n_problems, int dtype, void* stream);
+/* Tangent convolutions in front of TRAIN-mode BatchNorm layers (optimizer.py:457-462 with a model in train mode,
+ * examples/run_resnet18_mnist.py:19-35): hf_conv2d_nhwc_group_slabs for direction-0 problems whose epilogue ALSO
+ * writes, per problem with part_1 != NULL, the per-channel partial sums of every (row tile, split)'s output tile,
+ *   part_1[(tile_m*splits + split)][ch] = sum_rows t,   part_x[...] = sum_rows t * (x - mean[ch]) * rstd[ch]
+ * (x: the layer's recorded convolution output [rows][k]; part_rows = ceil(rows / 64) * splits rows of k floats) --
+ * what the reduction launch between convolution and elementwise pass computed; hf_chan_affine_train adds the rows
+ * up.  64x64-tile problems only (HF_ERR_ARG otherwise: the caller falls back to the two launches). */
+typedef struct hf_conv_bnsum {
+  const void *x, *mean, *rstd;
+  void *part_x, *part_1;
+  int64_t part_rows;
+} hf_conv_bnsum;
+int hf_conv2d_nhwc_group_slabs_bnsum(const hf_conv_problem* problems, int n_problems, const hf_conv_bnsum* sums,
+                                     int dtype, void* stream);
 /* ONE forward / data-gradient problem (`d`, direction 0 or 1) and ONE weight-gradient problem (`w`, direction 2)
  * in one launch, each described like a grouped problem (so either may read an operand that is a channel slice
  * of a wider buffer: act_ld / mat_ld).  hf_conv2d_nhwc_backward_slabs is the special case "same layer, dense

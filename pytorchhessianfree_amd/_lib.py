@@ -144,6 +144,7 @@ SIGNATURES = {
                                + [c_double, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
     "hf_chan_affine_train": (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p]
                              + [c_int64] * 5 + [c_int, c_int64, c_int, c_void_p]),
+    "hf_conv2d_nhwc_group_slabs_bnsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "hf_bn_stats_rows": (c_int, [c_void_p, c_void_p, c_int, c_int64] + [c_void_p] * 6
                          + [c_double, c_double, c_double, c_int64, c_int64, c_int, c_int, c_void_p]),
     "hf_bn_adjoint_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64,
@@ -505,6 +506,34 @@ def conv_group_slabs(problems, device):
         q.slab_stride = out.shape[1] if out.dim() == 2 else 0
     check(load().hf_conv2d_nhwc_group_slabs(ctypes.cast(arr, c_void_p), len(problems), HF_F32,
                                             current_stream_ptr(device)), "hf_conv2d_nhwc_group_slabs")
+
+
+class ConvBnSum(ctypes.Structure):
+    """``hf_conv_bnsum`` (include/hf_pcg.h)."""
+
+    _fields_ = [("x", c_void_p), ("mean", c_void_p), ("rstd", c_void_p), ("part_x", c_void_p), ("part_1", c_void_p),
+                ("part_rows", c_int64)]
+
+
+def conv_group_slabs_bnsum(problems, sums, device):
+    """``conv_group_slabs`` for tangent convolutions whose epilogue also writes the per-channel partial sums of a
+    train-mode BatchNorm behind them; ``sums``: per problem ``None`` or ``(x, mean, rstd, part_x, part_1)`` with
+    ``part_*`` of shape [ceil(rows / 64) * splits, k].  Returns False when the library refuses the geometry (the caller
+    issues the plain launch + the reduction launch)."""
+    arr = (ConvProblem * len(problems))()
+    bn = (ConvBnSum * len(problems))()
+    for q, b, prob, sm in zip(arr, bn, problems, sums):
+        _fill_problem(q, prob)
+        if sm is not None:
+            x, mean, rstd, part_x, part_1 = sm
+            b.x, b.mean, b.rstd = x.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+            b.part_x, b.part_1, b.part_rows = part_x.data_ptr(), part_1.data_ptr(), part_1.shape[0]
+    rc = load().hf_conv2d_nhwc_group_slabs_bnsum(ctypes.cast(arr, c_void_p), len(problems), ctypes.cast(bn, c_void_p),
+                                                 HF_F32, current_stream_ptr(device))
+    if rc == HF_ERR_ARG:
+        return False
+    check(rc, "hf_conv2d_nhwc_group_slabs_bnsum")
+    return True
 
 
 def _fill_problem(q, prob):

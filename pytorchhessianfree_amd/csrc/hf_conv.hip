@@ -131,6 +131,12 @@ struct ConvArgs {
   int cls_h[4], cls_w[4], cls_py[4], cls_px[4];  // pixels of the class: y = y'*stride_h + py, y' < cls_h
   // launch constants as divisors (filled by seal() right before the launch)
   FastDiv fd_tiles_n, fd_tiles_m, fd_splits, fd_rw, fd_rh, fd_csteps, fd_cblocks;
+  // BNSUM instantiations (tangent convolution in front of a TRAIN-mode BatchNorm): per-channel partial sums of this
+  // workgroup's tile, sum(t) and sum(t * xhat), xhat = (bn_x - bn_mean) * bn_rstd, to row (tile_m * splits + split)
+  // of bn_part_1 / bn_part_x ([tiles_m * splits][nout]) -- what the reduction launch between the convolution and the
+  // elementwise pass computed (hf_chan_affine_bwd_ex with gx = NULL); the elementwise pass adds the rows up
+  const float *bn_x, *bn_mean, *bn_rstd;
+  float *bn_part_x, *bn_part_1;
 };
 
 // One scalar load per 64-byte line of the argument block, all in flight together, before anything else: the
@@ -195,13 +201,50 @@ __device__ __forceinline__ float4 ldg4s(const float* p, int valid) {
 
 // Last-arriver reduction of the split-K partials of one block tile (fixed order).  The wave at
 // (wm, wn) holds TM x TN MFMA tiles: tile (im, in) covers rows wm*32*TM + im*32 .., cols likewise.
-template <typename C, bool CLS = false>
+template <typename C, bool CLS = false, bool BNSUM = false>
 __device__ __forceinline__ void finish_tile(const ConvArgs& a, const f32x16 (&acc)[C::TM][C::TN], int tile, int split,
                                             int wm, int wn, int lane, float* out_tile_base,
                                             int row0, int col0, int row_lim, int col_lim, int ldc,
-                                            int* flag_lds, int cls = -1) {
+                                            int* flag_lds, int cls = -1, float* lds = nullptr) {
   constexpr int BM = C::BM, BN = C::BN;
   const int i = lane & 31, h = lane >> 5;
+  if constexpr (BNSUM) {
+    static_assert(C::TM == 1 && C::TN == 1 && !CLS, "per-tile column sums: 64x64 tiles, plain row enumeration");
+    // column `col` of this tile: 2 waves (wm) x 2 lane halves (h) x 16 accumulator rows each.  Every load first
+    // (the tile's xhat operand), fp64 sums per lane, the four shares combined through LDS in a fixed order.
+    const int col = wn * 32 + i, gcol = col0 + col;
+    const bool cok = gcol < col_lim;
+    const float mu = cok ? a.bn_mean[gcol] : 0.f, rs = cok ? a.bn_rstd[gcol] : 0.f;
+    float xv[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int orow = row0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      xv[reg] = (cok && orow < row_lim) ? a.bn_x[(size_t)orow * ldc + gcol] : mu;
+    }
+    double s1 = 0.0, sx = 0.0;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int orow = row0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (cok && orow < row_lim) {
+        const float v = acc[0][0][reg];
+        s1 += (double)v;
+        sx += (double)v * (double)(float)((xv[reg] - mu) * rs);
+      }
+    }
+    double* red = reinterpret_cast<double*>(lds);  // [2][4][BN]; the caller synchronised after its last LDS read
+    red[(0 * 4 + wm * 2 + h) * BN + col] = s1;
+    red[(1 * 4 + wm * 2 + h) * BN + col] = sx;
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < 2 * BN) {
+      const int kind = t / BN, c = t - kind * BN;
+      const double sum = ((red[(kind * 4 + 0) * BN + c] + red[(kind * 4 + 1) * BN + c]) +
+                          red[(kind * 4 + 2) * BN + c]) + red[(kind * 4 + 3) * BN + c];
+      const int tile_m = (int)fdiv((unsigned)tile, a.fd_tiles_n);
+      if (col0 + c < col_lim)
+        (kind ? a.bn_part_x : a.bn_part_1)[(size_t)(tile_m * a.splits + split) * a.nout + col0 + c] = (float)sum;
+    }
+  }
   if (a.splits == 1 || a.slabs) {
     float* dst = out_tile_base + (a.slabs ? (size_t)split * (size_t)a.slab_stride : 0);
 #pragma unroll
@@ -287,7 +330,7 @@ __device__ __forceinline__ void finish_tile(const ConvArgs& a, const f32x16 (&ac
 // ---------------------------------------------------------------------------------
 // CLS: the instantiation that understands the residue-class enumeration of strided data gradients (ConvArgs::ncls);
 // the plain one keeps the prologue of the latency-bound small-map launches short (+1 us per launch otherwise).
-template <bool SCALAR, typename C, bool CLS = false>
+template <bool SCALAR, typename C, bool CLS = false, bool BNSUM = false>
 __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int bid) {
   constexpr int BM = C::BM, BN = C::BN, BK = C::BK, KQ = C::KQ, RPT = C::RPT, HK = C::HK, LDK = C::LDK;
   constexpr int NU = 2;
@@ -502,8 +545,8 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
     }
   }
   __syncthreads();  // the LDS array is reused below (last-arriver flag)
-  finish_tile<C, CLS>(a, acc, tile, split, wm, wn, lane, a.out, row_base, tile_n * BN, rows_c, a.nout, a.ldc,
-                      &flag, cls);
+  finish_tile<C, CLS, BNSUM>(a, acc, tile, split, wm, wn, lane, a.out, row_base, tile_n * BN, rows_c, a.nout, a.ldc,
+                             &flag, cls, lds);
 }
 
 // ---------------------------------------------------------------------------------
@@ -688,10 +731,10 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
                  a.R * a.S * a.out_c, &flag);
 }
 
-template <bool SCALAR, typename C, bool CLS = false>
+template <bool SCALAR, typename C, bool CLS = false, bool BNSUM = false>
 __global__ __launch_bounds__(CT) void k_conv_nt(const ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
-  conv_nt_body<SCALAR, C, CLS>(a, lds, blockIdx.x);
+  conv_nt_body<SCALAR, C, CLS, BNSUM>(a, lds, blockIdx.x);
 }
 
 // A forward / tangent convolution whose launch CARRIES the tangent sweep's weight scatter (hf_unpack_weights) as
@@ -753,8 +796,13 @@ struct GroupMeta {
   int n;
 };
 
-template <bool ANYBIG, bool CLS>
+template <bool ANYBIG, bool CLS, bool BNSUM = false>
 __device__ __forceinline__ void group_run(const ConvArgs& a, int tn, float* lds, int local) {
+  if constexpr (BNSUM) {  // (tangent convolutions on 64x64 tiles only: checked on the host)
+    if (a.bn_part_1) conv_nt_body<false, Small, false, true>(a, lds, local);
+    else conv_nt_body<false, Small, false, false>(a, lds, local);
+    return;
+  }
   if (tn) {
     if (ANYBIG && a.big == 1) conv_tn_body<false, Big>(a, lds, local);
     else if (ANYBIG && a.big == 2) conv_tn_body<false, Big96>(a, lds, local);
@@ -766,17 +814,17 @@ __device__ __forceinline__ void group_run(const ConvArgs& a, int tn, float* lds,
   }
 }
 
-template <bool ANYBIG, bool CLS = false>
+template <bool ANYBIG, bool CLS = false, bool BNSUM = false>
 __global__ __launch_bounds__(CT) void k_conv_group(const ConvArgs a0, const ConvArgs a1, const ConvArgs a2,
                                                    const ConvArgs a3, const GroupMeta m) {
   constexpr int LDSB = Big::LDS_FLOATS > Big96::LDS_FLOATS ? Big::LDS_FLOATS : Big96::LDS_FLOATS;
   constexpr int LDSF = ANYBIG ? (LDSB > Small::LDS_FLOATS ? LDSB : Small::LDS_FLOATS) : Small::LDS_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[LDSF];
   const int b = (int)blockIdx.x;
-  if (b < m.start[1]) group_run<ANYBIG, CLS>(a0, m.tn[0], lds, b);
-  else if (b < m.start[2]) group_run<ANYBIG, CLS>(a1, m.tn[1], lds, b - m.start[1]);
-  else if (b < m.start[3]) group_run<ANYBIG, CLS>(a2, m.tn[2], lds, b - m.start[2]);
-  else group_run<ANYBIG, CLS>(a3, m.tn[3], lds, b - m.start[3]);
+  if (b < m.start[1]) group_run<ANYBIG, CLS, BNSUM>(a0, m.tn[0], lds, b);
+  else if (b < m.start[2]) group_run<ANYBIG, CLS, BNSUM>(a1, m.tn[1], lds, b - m.start[1]);
+  else if (b < m.start[3]) group_run<ANYBIG, CLS, BNSUM>(a2, m.tn[2], lds, b - m.start[2]);
+  else group_run<ANYBIG, CLS, BNSUM>(a3, m.tn[3], lds, b - m.start[3]);
 }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -1279,6 +1327,56 @@ int hf_conv2d_nhwc_dw_slabs(const hf_conv_problem* d, const hf_conv_problem* w, 
   const dim3 grid((unsigned)(blocks[0] + blocks[1]));
   (void)grid;
   launch_dw(a[0], a[1], blocks[0], blocks[1], (hipStream_t)stream);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+// Tangent convolutions (direction 0, slab mode, 64x64 tiles) whose epilogue also writes the per-channel partial sums
+// a TRAIN-mode BatchNorm behind them needs (ConvArgs::bn_*): one launch for up to GROUP_MAX problems, each with or
+// without sums.  HF_ERR_ARG for anything the BNSUM instantiations do not cover -- the caller then issues the plain
+// launch and the reduction launch.
+int hf_conv2d_nhwc_group_slabs_bnsum(const hf_conv_problem* problems, int n_problems, const hf_conv_bnsum* sums,
+                                     int dtype, void* stream) {
+  if (!problems || !sums || n_problems < 1 || n_problems > GROUP_MAX) return HF_ERR_ARG;
+  GroupArgs q;
+  memset(&q, 0, sizeof(q));
+  int64_t total = 0;
+  alignas(16) float dummy_ws[4];
+  for (int i = 0; i < n_problems; ++i) {
+    const hf_conv_problem& pr = problems[i];
+    if (pr.direction != 0 || pr.splits < 1 || pr.slab_stride < 0 || pr.mat_ld < 0 || pr.out_c) return HF_ERR_ARG;
+    const int rc = check_common(pr.out, pr.act, pr.mat, dummy_ws, dummy_ws, dtype, pr.n, pr.h, pr.w, pr.c, pr.k,
+                                pr.r, pr.s, pr.stride_h, pr.stride_w, pr.pad_h, pr.pad_w);
+    if (rc) return rc;
+    ConvArgs& a = q.a[i];
+    const int64_t blocks = setup(a, 0, pr.out, pr.act, pr.mat, pr.n, pr.h, pr.w, pr.c, pr.k, pr.r, pr.s,
+                                 pr.stride_h, pr.stride_w, pr.pad_h, pr.pad_w, pr.act_ld, nullptr, 0, nullptr, 0, 0,
+                                 pr.splits, pr.slab_stride, pr.mat_ld);
+    if (blocks <= 0) return (int)blocks;
+    if (a.splits != pr.splits || a.scalar || a.big || a.ncls > 0 || !a.slabs) return HF_ERR_ARG;
+    const hf_conv_bnsum& b = sums[i];
+    if (b.part_1) {
+      if (!b.part_x || !b.x || !b.mean || !b.rstd) return HF_ERR_ARG;
+      if (b.part_rows != (int64_t)a.tiles_m * a.splits) return HF_ERR_ARG;  // (= ceil(rows / 64) * splits)
+      a.bn_x = (const float*)b.x; a.bn_mean = (const float*)b.mean; a.bn_rstd = (const float*)b.rstd;
+      a.bn_part_x = (float*)b.part_x; a.bn_part_1 = (float*)b.part_1;
+    }
+    q.start[i] = (int)total;
+    total += blocks;
+    if (total > 0x7fffffffLL) return HF_ERR_ARG;
+  }
+  GroupMeta m;
+  memset(&m, 0, sizeof(m));
+  for (int i = 0; i < GROUP_MAX; ++i) m.start[i] = i < n_problems ? q.start[i] : (int)total;
+  m.start[GROUP_MAX] = (int)total;
+  m.n = n_problems;
+  for (int i = 0; i < n_problems; ++i) seal(q.a[i], 0);
+  const dim3 grid((unsigned)total), block(CT);
+  hipStream_t st = (hipStream_t)stream;
+  if (n_problems == 1 && q.a[0].bn_part_1)
+    hipLaunchKernelGGL((k_conv_nt<false, Small, false, true>), grid, block, 0, st, q.a[0]);
+  else
+    hipLaunchKernelGGL((k_conv_group<false, false, true>), grid, block, 0, st, q.a[0], q.a[1], q.a[2], q.a[3], m);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }

@@ -73,7 +73,7 @@ class _Unit:
         self.im2col = False       # tiny-Cin layer: runs as a 1x1 product over the im2col of the input
         self.train = False        # train-mode BatchNorm: batch statistics (recorded), tangent / adjoint carry
         self.mean_t = None        # the statistics' dependence on the layer input
-        self.fold = self.fuse = self.pro = self.stats_fold = False  # train mode: how many launches its tangent / adjoint take (see _buffers)
+        self.fold = self.fuse = self.pro = self.stats_fold = self.epi = self.tsum = False  # train mode: how many launches its tangent / adjoint take (see _buffers)
         self.res_unit = None      # downsample unit whose output is added before the activation
         self.res_identity = False  # ... or the block input itself
         self.consumers = 0
@@ -826,6 +826,16 @@ class FusedGGNEngine(_Operator):
                 u.barrier = torch.zeros(1, dtype=torch.int64, device=dev)
                 u.fuse = u.fold and form == "barrier" and u.g is not None and u.rb <= _cu_count(dev)
                 u.pro = form == "prologue" and k % 4 == 0 and k // 4 <= 256
+                # ... and the tangent's partial sums by the convolution's own epilogue (64x64-tile launches; one row per
+                # (row tile, split): beyond HF_BN_EPILOGUE_ROWS rows the separate reduction's `rb` rows are cheaper
+                # for the elementwise pass to add up)
+                tp_rows = -(-u.rows // 64) * u.sT
+                u.epi = (u.pro and not u.im2col and not u.first and hasattr(u, "xcat")
+                         and tp_rows <= int(os.environ.get("HF_BN_EPILOGUE_ROWS", "256"))
+                         and os.environ.get("HF_BN_EPILOGUE", "1") != "0")
+                if u.epi:
+                    u.tp1 = torch.empty((tp_rows, k), dtype=f32, device=dev)
+                    u.tpx = torch.empty((tp_rows, k), dtype=f32, device=dev)
         # where each unit's output goes besides its own dense buffer: the [t_x | x] operand of its
         # consumer -- the tangent into the first half, the value (forward pass) into the second
         for u in self.units:
@@ -933,15 +943,20 @@ class FusedGGNEngine(_Operator):
                 "hf_bn_rows_train_apply")
             return
         if u.train and u.pro:
-            # reduction (partial rows), then the elementwise pass adds them up in its own prologue
+            # reduction (partial rows: by the convolution's epilogue, else by its own launch), then the elementwise
+            # pass adds them up in its prologue
             lib, st = _lib.load(), _lib.current_stream_ptr(self.dev)
-            _lib.check(lib.hf_chan_affine_bwd_ex(
-                None, _ptr(u.gw), _ptr(u.gb), None, _ptr(u.tbuf), u.sT, u.tbuf.shape[1], None, 1, 0, _ptr(u.a),
-                _ptr(u.mean), _ptr(u.rstd), None, None, n, k, oh * ow, 1, u.rb, _lib.HF_F32, st),
-                "hf_chan_affine_bwd_ex")
+            px, p1, nparts = u.gw, u.gb, u.rb
+            if u.tsum:
+                px, p1, nparts = u.tpx, u.tp1, u.tp1.shape[0]
+            else:
+                _lib.check(lib.hf_chan_affine_bwd_ex(
+                    None, _ptr(u.gw), _ptr(u.gb), None, _ptr(u.tbuf), u.sT, u.tbuf.shape[1], None, 1, 0, _ptr(u.a),
+                    _ptr(u.mean), _ptr(u.rstd), None, None, n, k, oh * ow, 1, u.rb, _lib.HF_F32, st),
+                    "hf_chan_affine_bwd_ex")
             _lib.check(lib.hf_chan_affine_train(
-                _ptr(u.tout), _ptr(u.tbuf), _ptr(u.a), _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.gw),
-                _ptr(u.gb), u.rb, _ptr(vg), _ptr(vb), float(n * oh * ow), _ptr(add), _ptr(u.y) if u.relu else None,
+                _ptr(u.tout), _ptr(u.tbuf), _ptr(u.a), _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(px),
+                _ptr(p1), nparts, _ptr(vg), _ptr(vb), float(n * oh * ow), _ptr(add), _ptr(u.y) if u.relu else None,
                 n, k, oh * ow, u.tout_ld, add_ld, u.sT, u.tbuf.shape[1], _lib.HF_F32, st), "hf_chan_affine_train")
             return
         if u.train and u.fold:
@@ -1311,6 +1326,28 @@ class FusedGGNEngine(_Operator):
             _ptr(self.pool_t), _ptr(s.tout), _ptr(self.pool_idx32), pn, ph, pw, poh, pow_, c0, 2 * c0,
             _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_maxpool_tangent_nhwc")
 
+    def _tangent_convs(self, units):
+        """The tangent convolutions ``conv([t_x | x], [W | v_W])`` of one or two units in ONE launch.  In front of a
+        train-mode BatchNorm the launch's epilogue also writes the per-channel partial sums of its output tiles
+        (``hf_conv2d_nhwc_group_slabs_bnsum``): the reduction launch between convolution and elementwise pass is gone
+        (``u.tsum``: ``_bn_tangent`` then adds ``u.tp1 / u.tpx`` up instead of ``u.gb / u.gw``)."""
+        probs = [(0, u.tbuf, u.xcat, u.wcat, self._tgeo(u), u.sT, 0, 0) for u in units]
+        if any(u.epi for u in units):
+            sums = [(u.a, u.mean, u.rstd, u.tpx, u.tp1) if u.epi else None for u in units]
+            if _lib.conv_group_slabs_bnsum(probs, sums, self.dev):
+                for u in units:
+                    u.tsum = u.epi
+                return
+            for u in units:  # (a geometry the 64x64-tile instantiations do not cover: not tried again)
+                u.epi = False
+        for u in units:
+            u.tsum = False
+        if len(units) == 1:
+            u = units[0]
+            self._conv_slabs(0, u.tbuf, u.xcat, u.wcat, self._tgeo(u), u.sT)
+        else:
+            _lib.conv_group_slabs(probs, self.dev)
+
     def _tangent_blocks(self, v):
         group = self._grouping()
         for chain, ds, _x in self.blocks:
@@ -1319,9 +1356,7 @@ class FusedGGNEngine(_Operator):
             if ds is not None and group:
                 # the downsample branch and the block's first convolution read the same operand:
                 # both tangent convolutions in ONE launch
-                _lib.conv_group_slabs([(0, ds.tbuf, ds.xcat, ds.wcat, self._tgeo(ds), ds.sT, 0, 0),
-                                       (0, head.tbuf, head.xcat, head.wcat, self._tgeo(head), head.sT, 0, 0)],
-                                      self.dev)
+                self._tangent_convs([ds, head])
                 paired = (head.res_unit is None and not head.res_identity and len(chain) > 1
                           and not head.train and not ds.train)
                 if paired:  # ... and both BatchNorm tangents in one
@@ -1329,13 +1364,13 @@ class FusedGGNEngine(_Operator):
                 else:
                     self._bn_tangent(ds, v, None, 0)
             elif ds is not None:
-                self._conv_slabs(0, ds.tbuf, ds.xcat, ds.wcat, self._tgeo(ds), ds.sT)
+                self._tangent_convs([ds])
                 self._bn_tangent(ds, v, None, 0)
             for u in chain:
                 if u is head and paired:
                     continue
                 if not (u is head and ds is not None and group):
-                    self._conv_slabs(0, u.tbuf, u.xcat, u.wcat, self._tgeo(u), u.sT)
+                    self._tangent_convs([u])
                 add, add_ld = None, 0
                 if u.res_unit is not None:
                     add, add_ld = u.res_unit.tout, u.res_unit.tout_ld

@@ -371,8 +371,9 @@ def test_train_mode_folded_kernels_equal_the_separate_launches(monkeypatch):
     seed = tp.RESNET18_B32_SEPARATED_SEEDS[2]
     v = None
     products = {}
-    for form in ("prologue", "barrier", "tail", "separate"):
-        monkeypatch.setenv("HF_BN_TRAIN_FORM", form)
+    for form in ("prologue", "prologue-no-epilogue", "barrier", "tail", "separate"):
+        monkeypatch.setenv("HF_BN_TRAIN_FORM", form.split("-")[0])
+        monkeypatch.setenv("HF_BN_EPILOGUE", "0" if form.endswith("no-epilogue") else "1")
         model, (x, t), lossf = tp.resnet18_mnist(batch_size=16, device=DEV, data_seed=seed)
         model.train()
         modelprep.prepare_model(model, channels_last=True)
@@ -380,8 +381,11 @@ def test_train_mode_folded_kernels_equal_the_separate_launches(monkeypatch):
         out = model(x)
         op = curvature.ggn_operator(lossf(out, t), out, params)
         assert isinstance(op, FusedGGNEngine) and op.train_bn and op.train_own
-        if form == "prologue":
+        if form.startswith("prologue"):
             assert all(u.pro and not u.fold for u in op.units)
+            # the tangent's partial sums by the convolution's own epilogue (hf_conv2d_nhwc_group_slabs_bnsum): every
+            # unit but the im2col'd stem, unless switched off
+            assert sum(u.epi for u in op.units) == (0 if form.endswith("no-epilogue") else len(op.units) - 1)
         elif form == "barrier":
             assert all(u.fuse for u in op.units)  # (the one-launch form takes the late 1x1 / 2x2 maps too)
         elif form == "tail":
@@ -393,6 +397,8 @@ def test_train_mode_folded_kernels_equal_the_separate_launches(monkeypatch):
         got = op(v).clone()
         for _ in range(10):  # (fixed summation orders, also on both sides of the grid barrier)
             assert torch.equal(op(v), got)
+        if form == "prologue":
+            assert all(u.tsum == u.epi for u in op.units) and sum(u.tsum for u in op.units) == len(op.units) - 1
         products[form] = got
     ref = products["separate"]
     for form, got in products.items():
