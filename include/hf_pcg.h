@@ -424,6 +424,18 @@ int hf_bn_stats_rows(void* a_out, const void* a, int splits, int64_t slab_stride
                      void* mean, void* rstd, void* running_mean, void* running_var, double count, double eps,
                      double momentum, int64_t rows, int64_t c, int row_blocks, int dtype, void* stream);
 
+/*
+ * The forward of a train-mode BatchNorm (+ residual, + ReLU) with the statistics' finalisation in its PROLOGUE:
+ * hf_bn_stats_rows with ticket = NULL leaves only its partial rows (`part`: [nparts][2][c] doubles); every workgroup
+ * of this launch adds them up (fixed order), forms mean / biased variance / rstd as hf_bn_stats_rows' last workgroup
+ * would, applies  y = act(((a - mean)*rstd)*w + b + res)  to its share (`a`: the summed convolution output), and
+ * workgroup 0 writes mean / rstd and moves the running statistics (momentum < 0: not).  fp32 NHWC, c % 4 == 0.
+ */
+int hf_bn_forward_train(void* y, void* y2, int64_t y2_ld, const void* a, const void* part, int nparts, void* mean,
+                        void* rstd, void* running_mean, void* running_var, double count, double eps, double momentum,
+                        const void* w, const void* b, const void* res, int64_t res_ld, int relu, int64_t rows,
+                        int64_t c, int dtype, void* stream);
+
 /* Elementwise adjoint pre-pass of a fused BatchNorm(+add+ReLU) layer, NHWC [rows, c]:
  *   g = (sum of gy_a's slabs + sum of gy_b's slabs) * [mask_src > 0];  g_out = g (nullable);
  *   ga_out = g * w[c]*rstd[c] (nullable): the cotangent of the convolution output that

@@ -145,6 +145,8 @@ SIGNATURES = {
     "hf_chan_affine_train": (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p]
                              + [c_int64] * 5 + [c_int, c_int64, c_int, c_void_p]),
     "hf_conv2d_nhwc_group_slabs_bnsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "hf_bn_forward_train": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int] + [c_void_p] * 4
+                            + [c_double] * 3 + [c_void_p] * 3 + [c_int64, c_int, c_int64, c_int64, c_int, c_void_p]),
     "hf_bn_stats_rows": (c_int, [c_void_p, c_void_p, c_int, c_int64] + [c_void_p] * 6
                          + [c_double, c_double, c_double, c_int64, c_int64, c_int, c_int, c_void_p]),
     "hf_bn_adjoint_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64,

@@ -1912,6 +1912,7 @@ __global__ __launch_bounds__(BLOCK) void k_bn_stats_rows(
     __hip_atomic_store(part + ((size_t)blockIdx.x * 2 + (k & 1)) * C + col * 4 + (k >> 1), sum, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);  // (write-through: see last_block_arrives)
   }
+  if (!ticket) return;  // (partial sums only: hf_bn_forward_train adds them up in its prologue)
   if (!last_block_arrives(ticket, &s_last)) return;
   for (unsigned c = threadIdx.x; c < C; c += BLOCK) {
     double s = 0.0, sq = 0.0;
@@ -2018,6 +2019,93 @@ __global__ __launch_bounds__(BLOCK) void k_bn_forward(
   if (y) y[i] = t;
   if (y2) y2[(size_t)row * y2_ld + c] = t;
   }
+}
+
+// Forward of a TRAIN-mode BatchNorm (+ residual, + ReLU) whose workgroups first add the one-pass statistics' partial
+// rows up themselves (k_bn_stats_rows without its tail: part [nparts][2][C] doubles = sum a, sum a^2 per row block) --
+// mean, biased variance = E[a^2] - mean^2, rstd exactly as that tail computes them; workgroup 0 also writes mean /
+// rstd (the sweeps read them) and moves the running statistics.  fp32 NHWC, C % 4 == 0, `a` already summed.
+__global__ __launch_bounds__(BLOCK) void k_bn_forward_train(
+    float* __restrict__ y, float* __restrict__ y2, unsigned y2_ld, const float* __restrict__ a,
+    const double* __restrict__ part, unsigned nparts, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+    float* __restrict__ run_mean, float* __restrict__ run_var, double count, float eps, float momentum,
+    const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ res, unsigned res_ld,
+    int relu, unsigned total, unsigned C) {
+  struct alignas(16) D2 { double e[2]; };
+  __shared__ D2 scratch[2 * BLOCK];  // [row group][column pair], C <= 2 * BLOCK column pairs
+  __shared__ double fin[8 * BLOCK];   // sum a | sum a^2, C <= 4 * BLOCK each
+  __shared__ float mus[4 * BLOCK], rss[4 * BLOCK];
+  // this thread's element quad first (independent of the statistics)
+  const unsigned quads_total = total >> 2;
+  const unsigned v = blockIdx.x * BLOCK + threadIdx.x;
+  const bool have = v < quads_total;
+  const unsigned i = have ? v << 2 : 0u;
+  const unsigned row = i / C, c = i - row * C;
+  const F4 av = ld4(a + i);
+  const F4 w4 = ld4(w + c);
+  F4 b4, r4;
+  if (b) b4 = ld4(b + c);
+  if (res) r4 = ld4(res + (res_ld ? row * res_ld + c : i));
+  // column sums of the [nparts][2C] matrix of doubles, as pairs: thread (tx, ty) adds rows ty, ty + G, ... of column
+  // pair tx (+ lanes, ...), four rows in flight, fixed order; the row groups are combined through LDS
+  const unsigned CP = C;  // pairs of doubles per row
+  const unsigned lanes = CP < BLOCK ? CP : BLOCK, G = BLOCK / lanes;
+  const unsigned tx = threadIdx.x % lanes, ty = threadIdx.x / lanes;
+  const D2* rows2 = reinterpret_cast<const D2*>(part);
+  for (unsigned col = tx; col < CP; col += lanes) {
+    D2 acc = {{0.0, 0.0}};
+    if (ty < G) {
+      for (unsigned p0 = ty; p0 < nparts; p0 += 4 * G) {
+        D2 t4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t4[u] = rows2[(size_t)(p0 + u * G < nparts ? p0 + u * G : p0) * CP + col];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (p0 + u * G < nparts) { acc.e[0] += t4[u].e[0]; acc.e[1] += t4[u].e[1]; }
+      }
+      if (G > 1) scratch[ty * lanes + col] = acc;
+      else { fin[2 * col] = acc.e[0]; fin[2 * col + 1] = acc.e[1]; }
+    }
+  }
+  __syncthreads();
+  if (G > 1) {
+    for (unsigned j = threadIdx.x; j < 2 * C; j += BLOCK) {
+      double sum = 0.0;
+      for (unsigned t = 0; t < G; ++t) sum += scratch[t * lanes + (j >> 1)].e[j & 1];
+      fin[j] = sum;
+    }
+    __syncthreads();
+  }
+  for (unsigned ch = threadIdx.x; ch < C; ch += BLOCK) {
+    const double m = fin[ch] / count;
+    double var = fin[C + ch] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
+    mus[ch] = mf;
+    rss[ch] = rf;
+    if (blockIdx.x == 0) {
+      mean_out[ch] = mf;
+      rstd_out[ch] = rf;
+      if (momentum >= 0.f && run_mean && run_var) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        run_mean[ch] = (float)((1.0 - (double)momentum) * (double)run_mean[ch] + (double)momentum * (double)mf);
+        run_var[ch] = (float)((1.0 - (double)momentum) * (double)run_var[ch] + (double)momentum * unbiased);
+      }
+    }
+  }
+  __syncthreads();
+  if (!have) return;
+  F4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float t = ((av.e[k] - mus[c + k]) * rss[c + k]) * w4.e[k];
+    if (b) t += b4.e[k];
+    if (res) t += r4.e[k];
+    if (relu) t = t > 0.f ? t : 0.f;
+    o.e[k] = t;
+  }
+  if (y) *reinterpret_cast<F4*>(y + i) = o;
+  if (y2) *reinterpret_cast<F4*>(y2 + (size_t)row * y2_ld + c) = o;
 }
 
 // Train-mode BatchNorm inside the curvature product: the batch statistics depend on the layer input, so
@@ -3064,6 +3152,33 @@ int hf_bn_forward(void* y, void* y2, int64_t y2_ld, void* a_out, const void* a, 
   return HF_OK;
 }
 
+int hf_bn_forward_train(void* y, void* y2, int64_t y2_ld, const void* a, const void* part, int nparts, void* mean,
+                        void* rstd, void* running_mean, void* running_var, double count, double eps, double momentum,
+                        const void* w, const void* b, const void* res, int64_t res_ld, int relu, int64_t rows,
+                        int64_t c, int dtype, void* stream) {
+  if (dtype != HF_F32 || !a || (!y && !y2) || !part || nparts < 1 || !mean || !rstd || !w || count <= 0.0 ||
+      rows <= 0 || c <= 0)
+    return HF_ERR_ARG;
+  if (!(c % 4 == 0 && c / 4 <= BLOCK)) return HF_ERR_ARG;
+  if ((y2 && (y2_ld < c || (y2_ld & 3))) || (res && res_ld && (res_ld < c || (res_ld & 3)))) return HF_ERR_ARG;
+  const long long total = (long long)rows * c;
+  const long long widest = (long long)rows * (y2_ld > res_ld ? (y2_ld > c ? y2_ld : c) : (res_ld > c ? res_ld : c));
+  if (total > 0x7fffffffLL || widest > 0x7fffffffLL) return HF_ERR_ARG;
+  const void* al[] = {y, y2, a, part, w, b, res};
+  for (const void* p : al)
+    if (p && !aligned16(p)) return HF_ERR_ALIGN;
+  // (the grid covers every quad: one per thread, as the prologue's sums are per workgroup anyway)
+  const long long wgs = (total / 4 + BLOCK - 1) / BLOCK;
+  if (wgs > 0x7fffffLL) return HF_ERR_ARG;
+  hipLaunchKernelGGL(k_bn_forward_train, dim3((unsigned)wgs), dim3(BLOCK), 0, (hipStream_t)stream, (float*)y,
+                     (float*)y2, (unsigned)y2_ld, (const float*)a, (const double*)part, (unsigned)nparts, (float*)mean,
+                     (float*)rstd, (float*)running_mean, (float*)running_var, count, (float)eps, (float)momentum,
+                     (const float*)w, (const float*)b, (const float*)res, (unsigned)res_ld, relu, (unsigned)total,
+                     (unsigned)c);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
 int hf_softmax_ce_hvp(void* out, const void* p, const void* v, double scale, int64_t rows,
                       int64_t cols, int dtype, void* stream) {
   if (!out || !p || !v || rows <= 0 || cols <= 0 || cols > 0x7fffffffLL || rows > 0x7fffffffLL)
@@ -3402,7 +3517,7 @@ int hf_bn_rows_train_apply(void* out, int64_t out_ld, void* gw, void* gb, void* 
 int hf_bn_stats_rows(void* a_out, const void* a, int splits, int64_t slab_stride, void* part, void* ticket,
                      void* mean, void* rstd, void* running_mean, void* running_var, double count, double eps,
                      double momentum, int64_t rows, int64_t c, int row_blocks, int dtype, void* stream) {
-  if (!a || !part || !ticket || !mean || !rstd || splits < 1 || (splits > 1 && slab_stride <= 0) || rows <= 0 ||
+  if (!a || !part || (ticket && (!mean || !rstd)) || splits < 1 || (splits > 1 && slab_stride <= 0) || rows <= 0 ||
       c <= 0 || row_blocks < 1 || count <= 0.0 || dtype != HF_F32)
     return HF_ERR_ARG;
   if (!(c % 4 == 0 && c / 4 <= BLOCK) || rows * c > 0x7fffffffLL) return HF_ERR_ARG;

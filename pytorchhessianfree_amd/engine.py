@@ -73,7 +73,7 @@ class _Unit:
         self.im2col = False       # tiny-Cin layer: runs as a 1x1 product over the im2col of the input
         self.train = False        # train-mode BatchNorm: batch statistics (recorded), tangent / adjoint carry
         self.mean_t = None        # the statistics' dependence on the layer input
-        self.fold = self.fuse = self.pro = self.stats_fold = self.epi = self.tsum = False  # train mode: how many launches its tangent / adjoint take (see _buffers)
+        self.fold = self.fuse = self.pro = self.stats_fold = self.fwd_pro = self.epi = self.tsum = False  # train mode: how many launches its tangent / adjoint take (see _buffers)
         self.res_unit = None      # downsample unit whose output is added before the activation
         self.res_identity = False  # ... or the block input itself
         self.consumers = 0
@@ -434,6 +434,24 @@ class FusedGGNEngine(_Operator):
     def _bn_forward(self, u, splits, update_running=True):
         n, k, oh, ow = u.a.shape
         res = u.res
+        if u.train and u.stats_fold and u.fwd_pro:
+            # ONE pass for the partial sums (the convolution's slabs summed into ``a``, per-channel sum a / sum a^2 in
+            # fp64 per row block); the normalising launch adds them up in its prologue -- 2 launches per unit
+            bn, st = u.bn, _lib.current_stream_ptr(self.dev)
+            move = update_running and bn.track_running_stats
+            count = float(n * oh * ow)
+            _lib.check(_lib.load().hf_bn_stats_rows(
+                _ptr(u.a), _ptr(u.tbuf), splits, u.tbuf.shape[1], _ptr(u.stat_part), None, None, None, None, None,
+                count, float(bn.eps), -1.0, n * oh * ow, k, u.rb, _lib.HF_F32, st), "hf_bn_stats_rows")
+            _lib.check(_lib.load().hf_bn_forward_train(
+                _ptr(u.y), _ptr(u.yout2), 2 * k if u.yout2 is not None else 0, _ptr(u.a), _ptr(u.stat_part), u.rb,
+                _ptr(u.mean_t), _ptr(u.rstd), _ptr(bn.running_mean) if move else None,
+                _ptr(bn.running_var) if move else None, count, float(bn.eps), float(bn.momentum) if move else -1.0,
+                _ptr(u.scale), _ptr(u.shift), _ptr(res), 0, 1 if u.relu else 0, n * oh * ow, k, _lib.HF_F32, st),
+                "hf_bn_forward_train")
+            if move:
+                bn.num_batches_tracked.add_(1)
+            return
         if u.train and u.stats_fold:
             # ONE pass: the convolution's slabs summed into ``a``, per-channel sum a / sum a^2 in fp64, finalised by
             # the launch's last workgroup (mean, rstd, running statistics) -- 3 launches per unit instead of 6
@@ -822,6 +840,7 @@ class FusedGGNEngine(_Operator):
                 #               workgroups resident -- at most one per compute unit)
                 #   "prologue"  reduction | elementwise pass whose workgroups add the partial rows up themselves
                 u.stats_fold = u.rb > 1 and os.environ.get("HF_BN_FOLD", "1") != "0"  # (the forward's statistics)
+                u.fwd_pro = u.stats_fold and os.environ.get("HF_BN_FWD_PROLOGUE", "1") != "0"  # (see _bn_forward)
                 u.fold = u.stats_fold and form in ("tail", "barrier")
                 u.barrier = torch.zeros(1, dtype=torch.int64, device=dev)
                 u.fuse = u.fold and form == "barrier" and u.g is not None and u.rb <= _cu_count(dev)

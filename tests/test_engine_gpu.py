@@ -424,16 +424,24 @@ def test_train_mode_folded_kernels_equal_the_separate_launches(monkeypatch):
     op.forward_own(update_running=True)
     ref = (op.logits.clone(), [(u.mean_t.clone(), u.rstd.clone(), u.bn.running_mean.clone(), u.bn.running_var.clone())
                                for u in op.units])
-    restore()
-    for u in folded:
-        u.stats_fold = True
-    op.forward_own(update_running=True)
-    assert rel(op.logits, ref[0]) < 5e-6
-    for u, (m, r, rm, rv) in zip(op.units, ref[1]):
-        # (the two-pass variance subtracts the fp32-ROUNDED mean: it is the less exact of the two, 1.5e-6 measured)
-        assert rel(u.mean_t, m) < 1e-6 and rel(u.rstd, r) < 5e-6
-        assert rel(u.bn.running_mean, rm) < 1e-6 and rel(u.bn.running_var, rv) < 5e-6
-    assert int(op.units[0].bn.num_batches_tracked) == int(saved[0][2]) + 1
+    # one-pass statistics, finalised by the reduction launch's last workgroup (fwd_pro False) resp. in the prologue of
+    # the normalising launch (``hf_bn_forward_train``, the default)
+    assert all(u.fwd_pro for u in folded)
+    for pro in (False, True):
+        restore()
+        for u in folded:
+            u.stats_fold, u.fwd_pro = True, pro
+        op.forward_own(update_running=True)
+        assert rel(op.logits, ref[0]) < 5e-6
+        for u, (m, r, rm, rv) in zip(op.units, ref[1]):
+            # (the two-pass variance subtracts the fp32-ROUNDED mean: it is the less exact of the two, 1.5e-6 measured)
+            assert rel(u.mean_t, m) < 1e-6 and rel(u.rstd, r) < 5e-6
+            assert rel(u.bn.running_mean, rm) < 1e-6 and rel(u.bn.running_var, rv) < 5e-6
+        assert int(op.units[0].bn.num_batches_tracked) == int(saved[0][2]) + 1
+        logits = op.logits.clone()
+        restore()
+        op.forward_own(update_running=True)
+        assert torch.equal(op.logits, logits)  # (bitwise repeatable)
     restore()
 
 
