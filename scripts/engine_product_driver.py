@@ -128,6 +128,36 @@ class Recorder:
         return [("k_bn_adjoint_rows_train", rd, wr, 8.0 * n * c * hw)]
 
     @staticmethod
+    def _cost_hf_chan_affine_train(out, a, x, mean, rstd, w, px, p1, nparts, vq, vr, count, add, mask, n, c, hw, old,
+                                   ald, splits, slab, dtype, stream):
+        tot = 4 * n * c * hw
+        rd = tot * (splits + 1 + (1 if add else 0) + (1 if mask else 0)) + 4 * 2 * nparts * c
+        return [("k_chan_affine_v4_train", rd, tot, 8.0 * n * c * hw)]
+
+    @staticmethod
+    def _cost_hf_conv2d_nhwc_group_slabs_bnsum(problems, count, sums, dtype, stream):
+        arr = _lib.ctypes.cast(problems, _lib.ctypes.POINTER(_lib.ConvProblem * count)).contents
+        bn = _lib.ctypes.cast(sums, _lib.ctypes.POINTER(_lib.ConvBnSum * count)).contents
+        rd = wr = fl = 0
+        for q, b in zip(arr, bn):
+            a, b_, c_ = conv_cost(q.direction, q.n, q.h, q.w, q.c, q.k, q.r, q.s, q.stride_h, q.stride_w, q.pad_h,
+                                  q.pad_w, q.splits, q.out_c)
+            rd, wr, fl = rd + a, wr + b_, fl + c_
+            if b.part_1:  # the tile's xhat operand once per split; two partial rows per (row tile, split)
+                oh = (q.h + 2 * q.pad_h - q.r) // q.stride_h + 1
+                ow = (q.w + 2 * q.pad_w - q.s) // q.stride_w + 1
+                rd += 4 * q.n * oh * ow * q.k * q.splits
+                wr += 4 * 2 * b.part_rows * q.k
+        return [("k_conv_group" if count > 1 else "k_conv_nt<false", rd, wr, fl)]
+
+    @staticmethod
+    def _cost_hf_bn_rows_train_apply(out, old, gw, gb, gres, gy, s1, l1, gy2, s2, l2, x, mean, rstd, mask, n, c, hw, rb,
+                                     bar, q_out, r_out, fw, vq, vr, count, add, ald, omask, dtype, stream):
+        tot = 4 * n * c * hw
+        rd = tot * (s1 + (s2 if gy2 else 0) + 2 + (1 if mask else 0) + (1 if add else 0) + (1 if omask else 0))
+        return [("k_bn_rows_train_apply", rd, 2 * tot, 16.0 * n * c * hw)]
+
+    @staticmethod
     def _cost_hf_bn_train_coeffs(q_out, r_out, px, p1, nparts, w, rstd, vq, vr, count, c, dtype, stream):
         return [("k_bn_train_coeffs", 4 * 2 * nparts * c, 4 * 2 * c, 0.0)]
 

@@ -12,3 +12,6 @@ if grep -q "tests rc=0" $O/rc.log; then
   done
 fi
 cat $O/rc.log
+rocprofv3 --kernel-trace --output-format csv -d $O/tr_train -- python3 scripts/engine_product_driver.py --workload resnet18 --products 6 --out $O/launches_train.json --bn train > $O/tr_train.log 2>&1
+python3 scripts/product_trace_table.py $O/launches_train.json $O/tr_train > $O/resnet18_train_one_product_trace.txt 2>> $O/tr_train.log
+rm -rf $O/tr_train
