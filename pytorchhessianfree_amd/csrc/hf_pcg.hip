@@ -1106,64 +1106,6 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_v4(
                       a_slab, blockIdx.x, gridDim.x);
 }
 
-// k_chan_affine_v4 as straight-line code, one quad per thread: which operands exist is a template flag, the first
-// sixteen slabs are loaded without a loop around them, and an empty asm pins the first addition behind the last
-// load.  (In the generic walk the compiler starts adding the slabs -- and waiting -- after eight loads, the other
-// eight then start a second round trip; a branch or loop around the loads makes it copy, i.e. wait for, the loaded
-// registers at the join.)  Same expressions in the same order: bitwise the generic walk's results.
-template <bool SLABS, bool Q, bool ADD, bool MASK>
-__global__ __launch_bounds__(BLOCK) void k_chan_affine_v4s(
-    float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ x,
-    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ w,
-    const float* __restrict__ q, const float* __restrict__ r, const float* __restrict__ add,
-    const float* __restrict__ mask_src, unsigned total, unsigned C, unsigned out_ld, unsigned add_ld, int a_splits,
-    long long a_slab) {
-  const unsigned v = blockIdx.x * BLOCK + threadIdx.x;
-  if (v >= (total >> 2)) return;
-  const unsigned i = v << 2;
-  const unsigned row = i / C, c = i - row * C;
-  F4 rs4, w4, q4, r4, mu4, xv, addv, mv, av, t[16];
-  rs4 = ld4(rstd + c);
-  w4 = ld4(w + c);
-  r4 = ld4(r + c);
-  if (Q) { q4 = ld4(q + c); mu4 = ld4(mean + c); xv = ld4(x + i); }
-  if (ADD) addv = ld4(add + (add_ld ? row * add_ld + c : i));
-  if (MASK) mv = ld4(mask_src + i);
-  av = ld4(a + i);
-  if (SLABS) {
-#pragma unroll
-    for (int u = 0; u < 16; ++u) t[u] = ld4(a + (long long)(1 + u < a_splits ? 1 + u : 0) * a_slab + i);
-    HF_PIN4(rs4); HF_PIN4(w4); HF_PIN4(r4); HF_PIN4(av);  // (every early load: none is used before the last is issued)
-    if (Q) { HF_PIN4(q4); HF_PIN4(mu4); HF_PIN4(xv); }
-    if (ADD) HF_PIN4(addv);
-    if (MASK) HF_PIN4(mv);
-#pragma unroll
-    for (int u = 0; u < 16; ++u)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) av.e[k] += 1 + u < a_splits ? t[u].e[k] : 0.f;
-    for (int sp = 17; sp < a_splits; sp += 16) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) t[u] = ld4(a + (long long)(sp + u < a_splits ? sp + u : 0) * a_slab + i);
-#pragma unroll
-      for (int u = 0; u < 16; ++u)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) av.e[k] += sp + u < a_splits ? t[u].e[k] : 0.f;
-    }
-  }
-  F4 o;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float rs = rs4.e[k];
-    float acc = av.e[k] * (w4.e[k] * rs);
-    if (Q) acc += ((xv.e[k] - mu4.e[k]) * rs) * q4.e[k];
-    acc += r4.e[k];
-    if (ADD) acc += addv.e[k];
-    if (MASK) acc = mv.e[k] > 0.f ? acc : 0.f;
-    o.e[k] = acc;
-  }
-  *reinterpret_cast<F4*>(out + (out_ld ? row * out_ld + c : i)) = o;
-}
-
 template <typename T, typename I>
 __global__ __launch_bounds__(BLOCK) void k_chan_affine(
     T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ x,
@@ -3321,30 +3263,8 @@ static void launch_chan_affine(hipStream_t s, void* out, const void* a, const vo
                                int relu_self, long long total, long long c, long long hw,
                                int nhwc, long long out_ld, long long add_ld, int a_splits = 1,
                                long long a_slab = 0) {
-  const bool vec4 = sizeof(T) == 4 && affine_vec4_ok(out, a, x, mean, rstd, w, q, r, add, mask_src, total, c,
-                                                    nhwc || hw == 1, out_ld, add_ld, a_slab);
-  // the BatchNorm tangent of the curvature engine (every per-channel operand present, no ReLU of its own, one quad
-  // per thread): the straight-line instantiations
-  static const bool straight = getenv("HF_AFFINE_STRAIGHT") == nullptr || atoi(getenv("HF_AFFINE_STRAIGHT")) != 0;
-  if (vec4 && straight && a && rstd && w && r && !relu_self && (!q || (x && mean)) && total / 4 <= 16384LL * BLOCK) {
-    typedef void (*Kern)(float*, const float*, const float*, const float*, const float*, const float*, const float*,
-                         const float*, const float*, const float*, unsigned, unsigned, unsigned, unsigned, int,
-                         long long);
-#define HF_V4S(S, Q_, A_, M_) k_chan_affine_v4s<S, Q_, A_, M_>
-    static const Kern kerns[16] = {
-        HF_V4S(false, false, false, false), HF_V4S(true, false, false, false), HF_V4S(false, true, false, false),
-        HF_V4S(true, true, false, false),   HF_V4S(false, false, true, false), HF_V4S(true, false, true, false),
-        HF_V4S(false, true, true, false),   HF_V4S(true, true, true, false),   HF_V4S(false, false, false, true),
-        HF_V4S(true, false, false, true),   HF_V4S(false, true, false, true),  HF_V4S(true, true, false, true),
-        HF_V4S(false, false, true, true),   HF_V4S(true, false, true, true),   HF_V4S(false, true, true, true),
-        HF_V4S(true, true, true, true)};
-#undef HF_V4S
-    hipLaunchKernelGGL(kerns[(a_splits > 1 ? 1 : 0) | (q ? 2 : 0) | (add ? 4 : 0) | (mask_src ? 8 : 0)],
-                       dim3(wide_grid(total / 4)), dim3(BLOCK), 0, s, (float*)out, (const float*)a, (const float*)x,
-                       (const float*)mean, (const float*)rstd, (const float*)w, (const float*)q, (const float*)r,
-                       (const float*)add, (const float*)mask_src, (unsigned)total, (unsigned)c, (unsigned)out_ld,
-                       (unsigned)add_ld, a_splits, a_slab);
-  } else if (vec4)
+  if (sizeof(T) == 4 && affine_vec4_ok(out, a, x, mean, rstd, w, q, r, add, mask_src, total, c, nhwc || hw == 1,
+                                       out_ld, add_ld, a_slab))
     hipLaunchKernelGGL(k_chan_affine_v4, dim3(wide_grid(total / 4)), dim3(BLOCK), 0, s, (float*)out,
                        (const float*)a, (const float*)x, (const float*)mean, (const float*)rstd, (const float*)w,
                        (const float*)q, (const float*)r, (const float*)add, (const float*)mask_src, relu_self,
