@@ -1045,9 +1045,7 @@ __device__ __forceinline__ void chan_affine_body(
 // eight, one for w[c], one for x / q / r, one for add, one for the mask.  Same expressions, same order of
 // additions: bitwise the scalar walk's results.
 struct alignas(16) F4 { float e[4]; };
-// An empty asm that "rewrites" a loaded quad: whatever uses the quad comes after it, and (memory clobber) every load
-// written before it is issued before it -- pins the first use of a batch of loads behind the batch's last load.
-#define HF_PIN4(v) asm volatile("" : "+v"(v.e[0]), "+v"(v.e[1]), "+v"(v.e[2]), "+v"(v.e[3]) : : "memory")
+
 __device__ __forceinline__ F4 ld4(const float* p) { return *reinterpret_cast<const F4*>(p); }
 
 __device__ __forceinline__ void chan_affine_v4_body(
@@ -1382,9 +1380,6 @@ __global__ __launch_bounds__(BS) void k_chan_affine_bwd_nhwc(
 // line per lane).  Per-channel sums: per thread over its rows, then over ty through LDS in a
 // fixed order; every block writes its partial sums to gw / gb + blockIdx.x*C (hf_pack_ex adds
 // the row shares up).  Cotangents may arrive as split-K slabs.
-__device__ const float hf_ones4[4] = {1.f, 1.f, 1.f, 1.f};
-__device__ const float hf_zeros4[4] = {0.f, 0.f, 0.f, 0.f};
-
 __device__ __forceinline__ void bn_adjoint_rows_body(
     float* __restrict__ gx, float* __restrict__ gw, float* __restrict__ gb, float* __restrict__ gres,
     const float* __restrict__ gy, int s1, long long l1, const float* __restrict__ gy2, int s2, long long l2,
@@ -1396,19 +1391,18 @@ __device__ __forceinline__ void bn_adjoint_rows_body(
   const unsigned tx = threadIdx.x % quads, ty = threadIdx.x / quads;
   const unsigned c0 = tx * 4;
   const bool live = ty < RP;
-  // per-channel vectors: 16-byte loads, absent ones from constant rows (no branch around a load: the loaded registers
-  // of a branch are copied -- waited for -- at its join); first USED behind the row loads below (HF_PIN4)
-  Col rs4 = *reinterpret_cast<const Col*>(rstd ? rstd + c0 : hf_ones4);
-  Col mu4 = *reinterpret_cast<const Col*>(mean ? mean + c0 : hf_zeros4);
-  Col w4 = *reinterpret_cast<const Col*>(w ? w + c0 : hf_ones4);
   float rs[4], mu[4], sc[4];
-  bool coeffs = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    rs[k] = rstd ? rstd[c0 + k] : 1.f;
+    mu[k] = mean ? mean[c0 + k] : 0.f;
+    sc[k] = (w ? w[c0 + k] : 1.f) * rs[k];
+  }
   double acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.0;
   const unsigned row_lo = bid * rows_per_block;
   const unsigned row_hi = row_lo + rows_per_block < rows ? row_lo + rows_per_block : rows;
-  const int smax = (gy2 && s2 > s1) ? s2 : s1;
   if (live) {
     // two rows per pass: their first loads and their slab batches are all in flight together
     for (unsigned r = row_lo + ty; r < row_hi; r += 2 * RP) {
@@ -1422,47 +1416,14 @@ __device__ __forceinline__ void bn_adjoint_rows_body(
         m0 = *reinterpret_cast<const Col*>(mask_src + idx0);
         m1 = *reinterpret_cast<const Col*>(mask_src + idx1);
       }
-      // split-K slabs of both rows and both cotangents: 8 slabs x up to 4 columns in flight per batch (each column
-      // still adds its slabs in split order: bitwise the one-column-at-a-time sums, which cost a round trip per
-      // column and batch).  The FIRST batch is straight-line code behind the row loads, its first addition pinned
-      // behind its last load: as a loop the compiler waits for the row loads at the loop's header (the sums are
-      // loop-carried) before it issues any slab load -- one more round trip per launch.
-      // (sixteen slabs x two columns per batch was measured slower: 272 VGPRs)
-      if (smax > 1) {
-        Col vg0[8], vg1[8], vh0[8], vh1[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const long long o1 = (long long)(1 + u < s1 ? 1 + u : 0) * l1;
-          vg0[u] = *reinterpret_cast<const Col*>(gy + o1 + idx0);
-          vg1[u] = *reinterpret_cast<const Col*>(gy + o1 + idx1);
-        }
-        if (gy2 && s2 > 1) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const long long o2 = (long long)(1 + u < s2 ? 1 + u : 0) * l2;
-            vh0[u] = *reinterpret_cast<const Col*>(gy2 + o2 + idx0);
-            vh1[u] = *reinterpret_cast<const Col*>(gy2 + o2 + idx1);
-          }
-        }
-        HF_PIN4(g0); HF_PIN4(g1);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (1 + u < s1) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { g0.e[k] += vg0[u].e[k]; g1.e[k] += vg1[u].e[k]; }
-          }
-        }
-        if (gy2 && s2 > 1) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            if (1 + u < s2) {
-#pragma unroll
-              for (int k = 0; k < 4; ++k) { h0.e[k] += vh0[u].e[k]; h1.e[k] += vh1[u].e[k]; }
-            }
-          }
-        }
-      }
-      for (int sp = 9; sp < smax; sp += 8) {
+      // split-K slabs of both rows and both cotangents: one loop, 8 slabs x up to 4 columns in flight per
+      // pass (each column still adds its slabs in split order: bitwise the one-column-at-a-time sums, which
+      // cost a round trip per column and batch)
+      // (sixteen slabs x two columns per pass was measured slower: 272 VGPRs; the first batch as straight-line code
+      // behind the row loads with its first addition pinned behind its last load -- 43 loads before the first wait, 256
+      // VGPRs -- measured +0.5 % on ResNet-18, -1.5 % on All-CNN-C's large maps: profiles/r04_rows_straight_rejected.jsonl)
+      const int smax = (gy2 && s2 > s1) ? s2 : s1;
+      for (int sp = 1; sp < smax; sp += 8) {
         Col vg0[8], vg1[8], vh0[8], vh1[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -1494,12 +1455,6 @@ __device__ __forceinline__ void bn_adjoint_rows_body(
             }
           }
         }
-      }
-      if (!coeffs) {  // (first pass: the per-channel vectors have long arrived)
-        HF_PIN4(rs4); HF_PIN4(mu4); HF_PIN4(w4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { rs[k] = rs4.e[k]; mu[k] = mu4.e[k]; sc[k] = w4.e[k] * rs4.e[k]; }
-        coeffs = true;
       }
       Col o0, o1;
 #pragma unroll
