@@ -6,7 +6,8 @@ set -u
 OUT=${1:-gpurun_out/pmc}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-DRV="python3 scripts/engine_product_driver.py --products 20"
+# DRV_ARGS: extra driver arguments (e.g. "--workload resnet50", "--bn train")
+DRV="python3 scripts/engine_product_driver.py --products ${DRV_PRODUCTS:-20} ${DRV_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $DRV --out "$OUT/launches.json" > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $DRV > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $DRV > "$OUT/write.log" 2>&1
