@@ -84,6 +84,16 @@ class Recorder:
         return [("k_conv_dw", r1 + r2 - 4 * n * oh * ow * k, w1 + w2, f1 + f2)]  # dY counted once
 
     @staticmethod
+    def _cost_hf_conv2d_nhwc_dw_slabs(d, w, dtype, stream):
+        rd = wr = fl = 0
+        for ptr in (d, w):
+            q = _lib.ctypes.cast(ptr, _lib.ctypes.POINTER(_lib.ConvProblem)).contents
+            a, b, c_ = conv_cost(q.direction, q.n, q.h, q.w, q.c, q.k, q.r, q.s, q.stride_h, q.stride_w, q.pad_h,
+                                 q.pad_w, q.splits, q.out_c)
+            rd, wr, fl = rd + a, wr + b, fl + c_
+        return [("k_conv_dw", rd, wr, fl)]
+
+    @staticmethod
     def _cost_hf_conv2d_nhwc_group_slabs(problems, count, dtype, stream):
         arr = _lib.ctypes.cast(problems, _lib.ctypes.POINTER(_lib.ConvProblem * count)).contents
         rd = wr = fl = 0

@@ -51,12 +51,16 @@ def main():
     meta = json.load(open(sys.argv[1]))
     trace_dir, fetch_dir, write_dir, sq_dir = sys.argv[2:6]
     L, P, launches = meta["launches_per_product"], meta["products"], meta["launches"]
-    trace = dispatches(trace_dir, "*kernel_trace.csv")
+    # (only the library's own kernels -- anonymous namespace, k_* -- are in the driver's log; a classifier head the
+    # engine does not fuse adds rocBLAS / ATen launches to a product, which are skipped here)
+    ours = "(anonymous namespace)::k_"
+    trace = [r for r in dispatches(trace_dir, "*kernel_trace.csv") if ours in r["Kernel_Name"]]
     trace.sort(key=lambda r: int(r["Start_Timestamp"]))
     trace = tail_products(trace, L, P)
     passes = {}
     for key, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir), ("SQ", sq_dir)):
-        passes[key] = tail_products(by_dispatch(dispatches(d, "*counter_collection.csv")), L, P)
+        rows = [r for r in dispatches(d, "*counter_collection.csv") if ours in r["Kernel_Name"]]
+        passes[key] = tail_products(by_dispatch(rows), L, P)
     table = {}
     for i in range(L * P):
         want = launches[i % L]
