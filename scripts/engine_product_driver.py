@@ -217,6 +217,10 @@ class Recorder:
         return [("k_pool_ce_head", tot + 4 * n * k, tot, 0.0)]
 
     @staticmethod
+    def _cost_hf_softmax_ce_hvp(out, p, v, scale, rows, cols, dtype, stream):
+        return [("k_softmax_ce_hvp", 2 * 4 * rows * cols, 4 * rows * cols, 0.0)]
+
+    @staticmethod
     def _cost_hf_linear_ce_head(gf, gw, gb, tf, f, w, vw, vb, p, scale, rows, feat, classes, dtype, stream):
         groups = (rows + 3) // 4
         rd = 4 * (2 * rows * feat + 2 * classes * feat * groups + rows * classes)
