@@ -47,6 +47,33 @@ def tail_products(seq, launches, products):
     return seq[len(seq) - need:]
 
 
+def base(kernel):
+    return kernel.split("<")[0].split("(")[0]
+
+
+def align(seq, logged, products, name_of):
+    """The rows of ``seq`` (dispatch order) that are the logged launches of the LAST ``products`` products: every
+    product starts at the anchor kernel (its first logged launch); inside a product the logged launches are matched
+    in order by kernel name, rows in between that match nothing (launches the driver has no cost model for) are
+    skipped and counted."""
+    anchor = base(logged[0]["kernel"])
+    starts = [i for i, r in enumerate(seq) if anchor in name_of(r)]
+    if len(starts) < products:
+        raise SystemExit(f"only {len(starts)} products in the trace, need {products}")
+    starts = starts[-products:] + [len(seq)]
+    out, skipped = [], 0
+    for p in range(products):
+        i = starts[p]
+        for want in logged:
+            while i < starts[p + 1] and base(want["kernel"]) not in name_of(seq[i]):
+                i, skipped = i + 1, skipped + 1
+            if i >= starts[p + 1]:
+                raise SystemExit(f"product {p}: logged launch {want['kernel']} not found in the trace")
+            out.append(seq[i])
+            i += 1
+    return out, skipped
+
+
 def main():
     meta = json.load(open(sys.argv[1]))
     trace_dir, fetch_dir, write_dir, sq_dir = sys.argv[2:6]
@@ -56,11 +83,11 @@ def main():
     ours = "(anonymous namespace)::k_"
     trace = [r for r in dispatches(trace_dir, "*kernel_trace.csv") if ours in r["Kernel_Name"]]
     trace.sort(key=lambda r: int(r["Start_Timestamp"]))
-    trace = tail_products(trace, L, P)
+    trace, skipped = align(trace, launches, P, lambda r: r["Kernel_Name"])
     passes = {}
     for key, d in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir), ("SQ", sq_dir)):
         rows = [r for r in dispatches(d, "*counter_collection.csv") if ours in r["Kernel_Name"]]
-        passes[key] = tail_products(by_dispatch(rows), L, P)
+        passes[key], _ = align(by_dispatch(rows), launches, P, lambda r: r["name"])
     table = {}
     for i in range(L * P):
         want = launches[i % L]
@@ -110,7 +137,7 @@ def main():
         out[name] = e
     total = sum(v["avg_us"] * v["launches_per_product"] for v in out.values())
     print(json.dumps({"per_kernel": out, "sum_us_per_product": round(total, 1), "products": P,
-                      "launches_per_product": L}, indent=1))
+                      "launches_per_product": L, "own_launches_without_cost_model_per_product": skipped / P}, indent=1))
 
 
 if __name__ == "__main__":
