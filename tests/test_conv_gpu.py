@@ -222,3 +222,52 @@ def test_convolution_launch_carrying_the_weight_scatter_equals_the_two_launches(
         P(out.data_ptr()), P(x.data_ptr()), P(w.data_ptr()), n, h, h, c, k, 3, 3, 1, 1, 1, 1, 0, 0, sp, out.shape[1],
         P(v.data_ptr()), *_lib.unpack_table(v, slots), _lib.HF_F32, _lib.current_stream_ptr(v.device))
     assert rc == _lib.HF_ERR_ARG
+
+
+@pytest.mark.parametrize("geom", [
+    (32, 7, 7, 64, 64, 3, 3, (1, 1), (1, 1)),     # 1568 rows: ragged last row tile
+    (32, 7, 7, 64, 128, 3, 3, (2, 2), (1, 1)),    # strided, two column tiles
+    (8, 5, 5, 32, 96, 1, 1, (1, 1), (0, 0)),      # 96 outputs: second column tile half full; 200 rows
+    (4, 3, 3, 128, 256, 3, 3, (1, 1), (1, 1)),    # 36 rows: one ragged row tile, four column tiles
+], ids=lambda g: str(g[:7]))
+def test_tangent_convolution_with_batchnorm_partial_sums_in_its_epilogue(geom):
+    """``hf_conv2d_nhwc_group_slabs_bnsum``: the slabs are bitwise those of the plain slab launch; the partial rows,
+    added up, are the per-channel sums of the convolution output and of output * xhat (float64 reference; tolerance:
+    the slab sums' fp32 rounding, 2e-6 of the column's sum of magnitudes); a second launch writes the same bits; one
+    launch for two problems, one with sums and one without, equals the single launches."""
+    n, h, w_, c, k, r, s, stride, padding = geom
+    gen = torch.Generator(device=DEV).manual_seed(7 + c + k)
+    x = _cl(torch.randn(n, c, h, w_, device=DEV, generator=gen))
+    wt = _cl(torch.randn(k, c, r, s, device=DEV, generator=gen) / (c * r * s) ** 0.5)
+    geo = (n, h, w_, c, k, r, s, stride, padding)
+    splits = _lib.conv_plan(0, n, h, w_, c, k, r, s, stride, padding)
+    oh, ow = (h + 2 * padding[0] - r) // stride[0] + 1, (w_ + 2 * padding[1] - s) // stride[1] + 1
+    rows = n * oh * ow
+    plain = torch.empty((splits, rows * k), device=DEV)
+    _lib.conv2d_nhwc_slabs(0, plain, x, wt, n, h, w_, c, k, r, s, stride, padding, splits)
+    a = torch.randn(rows, k, device=DEV, generator=gen)          # the layer's recorded convolution output
+    mean = a.mean(0).contiguous()
+    rstd = (1.0 / (a.var(0, unbiased=False) + 1e-5).sqrt()).contiguous()
+    nparts = -(-rows // 64) * splits
+    out = torch.empty_like(plain)
+    p1, px = (torch.full((nparts, k), float("nan"), device=DEV) for _ in range(2))
+    probs = [(0, out, x, wt, geo, splits, 0, 0)]
+    assert _lib.conv_group_slabs_bnsum(probs, [(a, mean, rstd, px, p1)], DEV)
+    assert torch.equal(out, plain)
+    t64 = plain.double().sum(0).view(rows, k)
+    xhat = ((a - mean) * rstd).double()
+    for got, ref, mag in ((p1, t64.sum(0), t64.abs().sum(0)), (px, (t64 * xhat).sum(0), (t64 * xhat).abs().sum(0))):
+        assert torch.isfinite(got).all()
+        assert float(((got.double().sum(0) - ref).abs() / mag.clamp_min(1e-30)).max()) < 2e-6
+    p1b, pxb = torch.empty_like(p1), torch.empty_like(px)
+    assert _lib.conv_group_slabs_bnsum(probs, [(a, mean, rstd, pxb, p1b)], DEV)
+    assert torch.equal(p1b, p1) and torch.equal(pxb, px)
+    # two problems in one launch: the first without sums
+    out2, out3 = torch.empty_like(plain), torch.empty_like(plain)
+    p1c, pxc = torch.empty_like(p1), torch.empty_like(px)
+    assert _lib.conv_group_slabs_bnsum([(0, out2, x, wt, geo, splits, 0, 0), (0, out3, x, wt, geo, splits, 0, 0)],
+                                       [None, (a, mean, rstd, pxc, p1c)], DEV)
+    assert torch.equal(out2, plain) and torch.equal(out3, plain)
+    assert torch.equal(p1c, p1) and torch.equal(pxc, px)
+    # a wrong number of partial rows is refused (the caller then takes the two-launch path)
+    assert not _lib.conv_group_slabs_bnsum(probs, [(a, mean, rstd, px[:-1], p1[:-1])], DEV)

@@ -823,3 +823,86 @@ def test_grouped_launches_equal_the_single_ones_bitwise():
     for o1, o2 in want_a:
         for a, b in zip(o1, o2):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("rows,ch,splits,rb", [(1568, 64, 5, 63), (512, 128, 9, 64), (128, 256, 17, 32), (32, 512, 3, 1),
+                                               (200, 96, 1, 7)])
+def test_train_mode_batchnorm_launches_against_float64_formulas(rows, ch, splits, rb):
+    """The launches of a train-mode BatchNorm unit, each against the float64 formula it implements (C ABI, no engine):
+    ``hf_chan_affine_bwd_ex`` (partial rows) + ``hf_chan_affine_train`` (adds them up in its prologue) =
+    ``mask * (w*rstd * [t - mean(t) - xhat*mean(xhat*t)] + xhat*vq + vr + add)`` with ``t`` the sum of the slabs;
+    ``hf_bn_rows_train_apply`` (the same in one launch around a grid barrier) agrees with it to 1e-6;
+    ``hf_bn_stats_rows`` (no ticket) + ``hf_bn_forward_train`` = ``F.batch_norm(training=True)`` + residual + ReLU,
+    batch statistics and moved running statistics included.  Tolerances: 2e-6 of the output's max-norm."""
+    gen = torch.Generator(device=DEV).manual_seed(rows + ch)
+
+    def r_(*shape):
+        return torch.randn(*shape, device=DEV, generator=gen)
+
+    lib, st, P = _lib.load(), _lib.current_stream_ptr(torch.device(DEV)), _lib.c_void_p
+
+    def p(t):
+        return P(t.data_ptr()) if t is not None else None
+
+    slabs = r_(splits, rows * ch)
+    a, y, add = r_(rows, ch) * 2 + 0.5, r_(rows, ch), r_(rows, 2 * ch)      # conv output, ReLU mask source, residual
+    w, vq, vr = r_(ch), r_(ch), r_(ch)
+    mean = a.mean(0).contiguous()
+    rstd = (1.0 / (a.var(0, unbiased=False) + 1e-5).sqrt()).contiguous()
+    t64 = slabs.double().sum(0).view(rows, ch)
+    xhat = (a.double() - mean.double()) * rstd.double()
+    core = w.double() * rstd.double() * (t64 - t64.mean(0) - xhat * (xhat * t64).mean(0))
+    want = core + xhat * vq.double() + vr.double() + add[:, :ch].double()
+    want = torch.where(y > 0, want, torch.zeros_like(want))
+    tol = 2e-6 * float(want.abs().max())
+    # reduction launch + elementwise pass with the prologue
+    gw, gb = torch.empty(rb, ch, device=DEV), torch.empty(rb, ch, device=DEV)
+    _lib.check(lib.hf_chan_affine_bwd_ex(None, p(gw), p(gb), None, p(slabs), splits, rows * ch, None, 1, 0, p(a), p(mean),
+                                         p(rstd), None, None, rows, ch, 1, 1, rb, _lib.HF_F32, st), "reduction")
+    out = torch.full((rows, 2 * ch), float("nan"), device=DEV)
+    _lib.check(lib.hf_chan_affine_train(p(out), p(slabs), p(a), p(mean), p(rstd), p(w), p(gw), p(gb), rb, p(vq), p(vr),
+                                        float(rows), p(add), p(y), rows, ch, 1, 2 * ch, 2 * ch, splits, rows * ch,
+                                        _lib.HF_F32, st), "hf_chan_affine_train")
+    assert float((out[:, :ch].double() - want).abs().max()) < tol
+    assert torch.isnan(out[:, ch:]).all()  # (the other half of the wider buffer is not touched)
+    again = torch.empty_like(out)
+    _lib.check(lib.hf_chan_affine_train(p(again), p(slabs), p(a), p(mean), p(rstd), p(w), p(gw), p(gb), rb, p(vq), p(vr),
+                                        float(rows), p(add), p(y), rows, ch, 1, 2 * ch, 2 * ch, splits, rows * ch,
+                                        _lib.HF_F32, st), "hf_chan_affine_train")
+    assert torch.equal(again[:, :ch], out[:, :ch])
+    # the same in one launch around a grid barrier
+    if rb > 1:
+        gw2, gb2, g = torch.empty_like(gw), torch.empty_like(gb), torch.empty(rows, ch, device=DEV)
+        bar = torch.zeros(1, dtype=torch.int64, device=DEV)
+        one = torch.empty(rows, 2 * ch, device=DEV)
+        for _ in range(3):  # (the arrival counter is never reset: the k-th launch waits for k * rb arrivals)
+            _lib.check(lib.hf_bn_rows_train_apply(p(one), 2 * ch, p(gw2), p(gb2), p(g), p(slabs), splits, rows * ch, None,
+                                                  1, 0, p(a), p(mean), p(rstd), None, rows, ch, 1, rb, p(bar), None, None,
+                                                  p(w), p(vq), p(vr), float(rows), p(add), 2 * ch, p(y), _lib.HF_F32, st),
+                       "hf_bn_rows_train_apply")
+        assert int(bar) == 3 * rb
+        assert float((one[:, :ch] - out[:, :ch]).abs().max()) < 1e-6 * float(want.abs().max())
+    # forward: one-pass statistics' partial rows + the normalising launch that finalises them
+    part = torch.empty(rb, 2, ch, dtype=torch.float64, device=DEV)
+    asum = torch.empty(rows, ch, device=DEV)
+    bn_w, bn_b, res = r_(ch), r_(ch), r_(rows, ch)
+    rm, rv = r_(ch), r_(ch).abs() + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    _lib.check(lib.hf_bn_stats_rows(p(asum), p(slabs), splits, rows * ch, p(part), None, None, None, None, None,
+                                    float(rows), 1e-5, -1.0, rows, ch, rb, _lib.HF_F32, st), "hf_bn_stats_rows")
+    assert torch.equal(asum.view(-1), slabs.sum(0)) or float((asum.view(-1) - slabs.sum(0)).abs().max()) < 1e-5
+    m_out, r_out = torch.empty(ch, device=DEV), torch.empty(ch, device=DEV)
+    yy, y2 = torch.empty(rows, ch, device=DEV), torch.full((rows, 2 * ch), float("nan"), device=DEV)
+    _lib.check(lib.hf_bn_forward_train(p(yy), p(y2[:, ch:]), 2 * ch, p(asum), p(part), rb, p(m_out), p(r_out), p(rm),
+                                       p(rv), float(rows), 1e-5, 0.1, p(bn_w), p(bn_b), p(res), 0, 1, rows, ch,
+                                       _lib.HF_F32, st), "hf_bn_forward_train")
+    a64 = asum.double()
+    ref = torch.nn.functional.batch_norm(a64.t().reshape(1, ch, rows), rm0.double().clone(), rv0.double().clone(),
+                                         bn_w.double(), bn_b.double(), True, 0.1, 1e-5).reshape(ch, rows).t()
+    ref = torch.relu(ref + res.double())
+    assert float((yy.double() - ref).abs().max()) < 2e-6 * float(ref.abs().max())
+    assert torch.equal(y2[:, ch:], yy) and torch.isnan(y2[:, :ch]).all()
+    assert float((m_out.double() - a64.mean(0)).abs().max()) < 1e-6 * float(a64.mean(0).abs().max())
+    assert float((r_out.double() * (a64.var(0, unbiased=False) + 1e-5).sqrt() - 1).abs().max()) < 2e-6
+    assert float((rm.double() - (0.9 * rm0.double() + 0.1 * a64.mean(0))).abs().max()) < 1e-6
+    assert float((rv.double() - (0.9 * rv0.double() + 0.1 * a64.var(0, unbiased=True))).abs().max()) < 2e-6 * float(rv.abs().max())
