@@ -834,6 +834,8 @@ def test_train_mode_batchnorm_launches_against_float64_formulas(rows, ch, splits
     ``hf_bn_rows_train_apply`` (the same in one launch around a grid barrier) agrees with it to 1e-6;
     ``hf_bn_stats_rows`` (no ticket) + ``hf_bn_forward_train`` = ``F.batch_norm(training=True)`` + residual + ReLU,
     batch statistics and moved running statistics included.  Tolerances: 2e-6 of the output's max-norm."""
+    from pytorchhessianfree_amd import _lib
+
     gen = torch.Generator(device=DEV).manual_seed(rows + ch)
 
     def r_(*shape):
