@@ -388,6 +388,9 @@ int hf_bn_adjoint_rows_train(void* gx, void* gw, void* gb, void* gres, const voi
  *            additions);  out[row*out_ld + ch] = out_mask > 0 ? t : 0,
  *            t = g*(final_w*rstd) + xhat*q + r + add[row*add_ld + ch]      (out_ld / add_ld 0: dense)
  * q_out / r_out (both or neither): the per-channel vectors, for inspection.  fp32 NHWC, c % 4 == 0, c <= 1024.
+ * The launch waits inside itself: do not run several of them concurrently on different streams unless all their
+ * workgroups together fit the device.  (Measured slower than hf_chan_affine_bwd_ex + hf_chan_affine_train; kept as a
+ * selectable form, HF_BN_TRAIN_FORM=barrier.)
  * Two launches less per train-mode BatchNorm layer and sweep than round 3 (optimizer.py:457-462 with
  * examples/run_resnet18_mnist.py:19-35).
  */
@@ -418,7 +421,8 @@ int hf_chan_affine_train(void* out, const void* a, const void* x, const void* me
  * sum a and sum a^2 in fp64 (`part`: [row_blocks, 2, c] doubles, scratch), finalised by the last workgroup
  * (`ticket`: zero-initialised uint32, resets itself): mean, rstd = 1/sqrt(E[a^2] - mean^2 + eps), and -- momentum >= 0,
  * running_mean / running_var not NULL -- the running statistics as torch.nn.BatchNorm2d's forward moves them.
- * Replaces two reduction launches + two hf_bn_batch_stats launches per layer.
+ * Replaces two reduction launches + two hf_bn_batch_stats launches per layer.  ticket == NULL: the partial rows only
+ * (mean / rstd / running_* ignored, may be NULL) -- hf_bn_forward_train finalises them.
  */
 int hf_bn_stats_rows(void* a_out, const void* a, int splits, int64_t slab_stride, void* part, void* ticket,
                      void* mean, void* rstd, void* running_mean, void* running_var, double count, double eps,
