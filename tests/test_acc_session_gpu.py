@@ -170,3 +170,56 @@ def test_acc_step_falls_back_for_models_the_engine_does_not_cover():
         opt.acc_step(model, lossf, _chunks(x, t, (16, 16)), reduction="mean")
         opt.acc_step(model, lossf, _chunks(x, t, (16, 16)), reduction="mean")
     assert opt._acc_session is None
+
+
+def test_acc_step_train_mode_batchnorm_session_equals_generic_accumulation(monkeypatch):
+    """TRAIN-mode BatchNorm through ``acc_step`` (the reference accumulates over chunks with the model as it is,
+    optimizer.py:600-700: every chunk is normalised with ITS batch statistics): the accumulated session -- one
+    train-mode engine per chunk, the chunks' sweeps in sequence (they move the same running statistics), loss /
+    gradient / trial losses as replays -- against this package's generic accumulation (``HF_ACC_SESSION=0``: autograd
+    operators per chunk) on the same model, chunks [16, 16], two calls on fresh batches.  Tolerances as for the
+    train-mode session of ``step`` (tests/test_session_gpu.py): initial losses 1e-5 / 1e-3, first final loss 5e-4,
+    the damping schedule identical, iteration counts +-2, every call reduces its batch's loss; the accumulated
+    product against the generic accumulated product at the same point 2e-3 (two fp32 train-mode forward passes of
+    this 20-layer net: DESIGN.md section 5), bitwise repeatable."""
+    def run(session):
+        monkeypatch.setenv("HF_ACC_SESSION", "1" if session else "0")
+        model, _, lossf = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=SEEDS[0])
+        model.train()
+        modelprep.prepare_model(model, channels_last=True)
+        opt = hf.HessianFree(model.parameters(), graph_matvec=True)
+        finals = []
+        for i in range(2):
+            _, (x, t), _ = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=SEEDS[i])
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                finals.append(opt.acc_step(model, lossf, _chunks(x, t, (16, 16)), reduction="mean"))
+        return opt, finals, model, lossf
+
+    a, fa, model, lossf = run(True)
+    sess = a._acc_session
+    assert sess is not None and sess.train_bn and len(sess.engines) == 2 and sess.steps == 2
+    assert all(e.train_bn and all(u.pro for u in e.units) for e in sess.engines)
+    b, fb, _, _ = run(False)
+    assert b._acc_session is None
+    ia, ib = a.state["init_losses"], b.state["init_losses"]
+    assert abs(ia[0] - ib[0]) <= 1e-5 * abs(ib[0]) and abs(ia[1] - ib[1]) <= 1e-3 * abs(ib[1])
+    assert abs(fa[0] - fb[0]) <= 5e-4 * abs(fb[0])
+    assert a.state["dampings"] == b.state["dampings"]
+    for x, y in zip(a.state["num_cg_iters"], b.state["num_cg_iters"]):
+        assert abs(x - y) <= 2
+    for f, i0 in zip(fa, ia):
+        assert f < i0
+    # the accumulated product of the session against the generic accumulation at the session's current point
+    monkeypatch.setenv("HF_ACC_SESSION", "1")
+    _, (x, t), _ = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=SEEDS[2])
+    chunks = _chunks(x, t, (16, 16))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, _, _, s2 = a.acc_linearise(model, lossf, chunks, chunks, chunks, "mean")
+    assert s2 is sess
+    v = torch.randn(sess.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    got = sess(v).clone()
+    assert torch.equal(sess(v), got)
+    want = a._acc_mvp(model, lossf, chunks, "ggn", "mean", v)
+    assert float((got - want).abs().max() / want.abs().max()) < 2e-3
