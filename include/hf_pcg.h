@@ -414,6 +414,20 @@ int hf_chan_affine_train(void* out, const void* a, const void* x, const void* me
                          const void* part_x, const void* part_1, int nparts, const void* vq, const void* vr,
                          double count, const void* add, const void* mask_src, int64_t n, int64_t c, int64_t hw,
                          int64_t out_ld, int64_t add_ld, int a_splits, int64_t a_slab, int dtype, void* stream);
+/* Two independent layers (a residual block's first BatchNorm and its downsample branch's; no residual operand) in ONE
+ * launch: each problem is what hf_chan_affine_train takes. */
+typedef struct hf_affine_train_problem {
+  void* out;
+  const void *a, *x, *mean, *rstd, *w, *part_x, *part_1;
+  int nparts;
+  const void *vq, *vr;
+  double count;
+  const void *add, *mask_src; /* add must be NULL */
+  int64_t n, c, hw, out_ld;
+  int a_splits;
+  int64_t a_slab;
+} hf_affine_train_problem;
+int hf_chan_affine_train_pair(const hf_affine_train_problem* problems /* [2] */, int dtype, void* stream);
 
 /*
  * One-pass batch statistics of a train-mode BatchNorm in the engine's own forward pass (optimizer.py:216-229,

@@ -147,6 +147,7 @@ SIGNATURES = {
     "hf_conv2d_nhwc_group_slabs_bnsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "hf_bn_forward_train": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int] + [c_void_p] * 4
                             + [c_double] * 3 + [c_void_p] * 3 + [c_int64, c_int, c_int64, c_int64, c_int, c_void_p]),
+    "hf_chan_affine_train_pair": (c_int, [c_void_p, c_int, c_void_p]),
     "hf_bn_stats_rows": (c_int, [c_void_p, c_void_p, c_int, c_int64] + [c_void_p] * 6
                          + [c_double, c_double, c_double, c_int64, c_int64, c_int, c_int, c_void_p]),
     "hf_bn_adjoint_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64,
@@ -482,6 +483,15 @@ class BnAdjointProblem(ctypes.Structure):
                                                                                  ("gy2_slab", c_int64)]
                 + [(nm, c_void_p) for nm in ("x", "mean", "rstd", "w", "mask_src")]
                 + [(nm, c_int64) for nm in ("n", "c", "hw")] + [("row_blocks", c_int)])
+
+
+class AffineTrainProblem(ctypes.Structure):
+    """``hf_affine_train_problem`` of include/hf_pcg.h."""
+
+    _fields_ = ([("out", c_void_p)] + [(nm, c_void_p) for nm in ("a", "x", "mean", "rstd", "w", "part_x", "part_1")]
+                + [("nparts", c_int), ("vq", c_void_p), ("vr", c_void_p), ("count", ctypes.c_double),
+                   ("add", c_void_p), ("mask_src", c_void_p)]
+                + [(nm, c_int64) for nm in ("n", "c", "hw", "out_ld")] + [("a_splits", c_int), ("a_slab", c_int64)])
 
 
 class ConvProblem(ctypes.Structure):

@@ -1784,26 +1784,41 @@ __device__ __forceinline__ void final_column_sums2(const float* __restrict__ row
 // The redundant sums cost each workgroup one more round trip (nparts * C * 8 bytes out of L2); the finalisation as the
 // reduction launch's TAIL (k_bn_adjoint_rows_train) costs a ticket, a drain and a one-workgroup re-read, as its own
 // launch (k_bn_train_coeffs) a launch boundary more.
+struct AffTrainArgs {
+  float* out;
+  const float *a, *x, *mean, *rstd, *w, *part_x, *part_1;
+  unsigned nparts;
+  const float *vq, *vr;
+  float inv_m;
+  const float *add, *mask_src;
+  unsigned total, C, out_ld, add_ld;
+  int a_splits;
+  long long a_slab;
+};
+
 template <bool SLABS, bool ADD, bool MASK>
-__global__ __launch_bounds__(BLOCK) void k_chan_affine_v4_train(
-    float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ x,
-    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ w,
-    const float* __restrict__ part_x, const float* __restrict__ part_1, unsigned nparts,
-    const float* __restrict__ vq, const float* __restrict__ vr, float inv_m, const float* __restrict__ add,
-    const float* __restrict__ mask_src, unsigned total, unsigned C, unsigned out_ld, unsigned add_ld, int a_splits,
-    long long a_slab) {
-  __shared__ double scratch[8 * BLOCK];
-  __shared__ double fin[2 * 4 * BLOCK];
-  __shared__ float qs[4 * BLOCK], rsh[4 * BLOCK];
+__device__ __forceinline__ void affine_train_body(const AffTrainArgs& p, unsigned bid, unsigned nblocks,
+                                                  double* scratch, double* fin, float* qs, float* rsh) {
+  const float* __restrict__ a = p.a;
+  const float* __restrict__ x = p.x;
+  const float* __restrict__ mean = p.mean;
+  const float* __restrict__ rstd = p.rstd;
+  const float* __restrict__ w = p.w;
+  const float* __restrict__ add = p.add;
+  const float* __restrict__ mask_src = p.mask_src;
+  float* __restrict__ out = p.out;
+  const unsigned total = p.total, C = p.C, out_ld = p.out_ld, add_ld = p.add_ld;
+  const int a_splits = p.a_splits;
+  const long long a_slab = p.a_slab;
   // this thread's element quad: every load of it issued right behind the first partial-row loads and BEFORE those are
   // added up (none depends on the sums): one round trip for both
   const unsigned quads_total = total >> 2;
-  const unsigned v = blockIdx.x * BLOCK + threadIdx.x;
+  const unsigned v = bid * BLOCK + threadIdx.x;
   const bool have = v < quads_total;
   const unsigned i = v << 2;
   const unsigned row = i / C, c = i - row * C;
   F4 rs4, w4, mu4, xv, addv, mv, av, t[16];
-  final_column_sums2(part_x, part_1, nparts, C, scratch, fin, fin + 4 * BLOCK, [&]() {
+  final_column_sums2(p.part_x, p.part_1, p.nparts, C, scratch, fin, fin + 4 * BLOCK, [&]() {
     // (no run-time branches around these loads -- optional operands are template flags, threads past the end read
     // element 0: at a branch's join the compiler copies the loaded registers, which waits for them right here)
     const unsigned ii = have ? i : 0u, cc = have ? c : 0u, rr = have ? row : 0u;
@@ -1820,9 +1835,9 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_v4_train(
     }
   });
   for (unsigned ch = threadIdx.x; ch < C; ch += BLOCK) {
-    const float k = w[ch] * rstd[ch] * inv_m;
-    qs[ch] = (vq ? vq[ch] : 0.f) - k * (float)fin[ch];
-    rsh[ch] = (vr ? vr[ch] : 0.f) - k * (float)fin[4 * BLOCK + ch];
+    const float k = w[ch] * rstd[ch] * p.inv_m;
+    qs[ch] = (p.vq ? p.vq[ch] : 0.f) - k * (float)fin[ch];
+    rsh[ch] = (p.vr ? p.vr[ch] : 0.f) - k * (float)fin[4 * BLOCK + ch];
   }
   __syncthreads();
   if (have) {
@@ -1854,9 +1869,29 @@ __global__ __launch_bounds__(BLOCK) void k_chan_affine_v4_train(
     *reinterpret_cast<F4*>(out + (out_ld ? row * out_ld + c : i)) = o;
   }
   // (a grid capped below one quad per thread: the rest by the plain walk)
-  if (gridDim.x * BLOCK < quads_total)
+  if (nblocks * BLOCK < quads_total)
     chan_affine_v4_body(out, a, x, mean, rstd, w, qs, rsh, add, mask_src, 0, total, C, out_ld, add_ld, a_splits,
-                        a_slab, blockIdx.x + gridDim.x, gridDim.x);
+                        a_slab, bid + nblocks, nblocks);
+}
+
+template <bool SLABS, bool ADD, bool MASK>
+__global__ __launch_bounds__(BLOCK) void k_chan_affine_v4_train(const AffTrainArgs p) {
+  __shared__ double scratch[8 * BLOCK];
+  __shared__ double fin[2 * 4 * BLOCK];
+  __shared__ float qs[4 * BLOCK], rsh[4 * BLOCK];
+  affine_train_body<SLABS, ADD, MASK>(p, blockIdx.x, gridDim.x, scratch, fin, qs, rsh);
+}
+
+// Two independent train-mode layers (a residual block's first BatchNorm and its downsample branch's) in ONE launch:
+// the first `blocks_a` workgroups run problem A.  No residual operand in either (template flags: slabs / mask of A, B).
+template <bool SA, bool MA, bool SB, bool MB>
+__global__ __launch_bounds__(BLOCK) void k_chan_affine_v4_train_pair(const AffTrainArgs A, const AffTrainArgs B,
+                                                                     unsigned blocks_a) {
+  __shared__ double scratch[8 * BLOCK];
+  __shared__ double fin[2 * 4 * BLOCK];
+  __shared__ float qs[4 * BLOCK], rsh[4 * BLOCK];
+  if (blockIdx.x < blocks_a) affine_train_body<SA, false, MA>(A, blockIdx.x, blocks_a, scratch, fin, qs, rsh);
+  else affine_train_body<SB, false, MB>(B, blockIdx.x - blocks_a, gridDim.x - blocks_a, scratch, fin, qs, rsh);
 }
 
 // One-pass batch statistics of a train-mode BatchNorm's forward: sums the convolution's split-K slabs into
@@ -3273,10 +3308,10 @@ int hf_chan_affine_ex(void* out, const void* a, const void* x, const void* mean,
   return HF_OK;
 }
 
-int hf_chan_affine_train(void* out, const void* a, const void* x, const void* mean, const void* rstd, const void* w,
-                         const void* part_x, const void* part_1, int nparts, const void* vq, const void* vr,
-                         double count, const void* add, const void* mask_src, int64_t n, int64_t c, int64_t hw,
-                         int64_t out_ld, int64_t add_ld, int a_splits, int64_t a_slab, int dtype, void* stream) {
+static int fill_aff_train(AffTrainArgs& q, void* out, const void* a, const void* x, const void* mean, const void* rstd,
+                          const void* w, const void* part_x, const void* part_1, int nparts, const void* vq,
+                          const void* vr, double count, const void* add, const void* mask_src, int64_t n, int64_t c,
+                          int64_t hw, int64_t out_ld, int64_t add_ld, int a_splits, int64_t a_slab, int dtype) {
   if (!out || !a || !x || !mean || !rstd || !w || !part_x || !part_1 || nparts < 1 || count <= 0.0 || n <= 0 || c <= 0 ||
       hw <= 0 || a_splits < 1 || (a_splits > 1 && a_slab <= 0) || dtype != HF_F32)
     return HF_ERR_ARG;
@@ -3287,19 +3322,58 @@ int hf_chan_affine_train(void* out, const void* a, const void* x, const void* me
   if (!affine_vec4_ok(out, a, x, mean, rstd, w, nullptr, nullptr, add, mask_src, total, c, 1, out_ld, add_ld, a_slab) ||
       !aligned16(part_x) || !aligned16(part_1))
     return HF_ERR_ALIGN;
-  typedef void (*Kern)(float*, const float*, const float*, const float*, const float*, const float*, const float*,
-                       const float*, unsigned, const float*, const float*, float, const float*, const float*, unsigned,
-                       unsigned, unsigned, unsigned, int, long long);
+  q = AffTrainArgs{(float*)out, (const float*)a, (const float*)x, (const float*)mean, (const float*)rstd,
+                   (const float*)w, (const float*)part_x, (const float*)part_1, (unsigned)nparts, (const float*)vq,
+                   (const float*)vr, (float)(1.0 / count), (const float*)add, (const float*)mask_src, (unsigned)total,
+                   (unsigned)c, (unsigned)out_ld, (unsigned)add_ld, a_splits, (long long)a_slab};
+  return HF_OK;
+}
+
+int hf_chan_affine_train(void* out, const void* a, const void* x, const void* mean, const void* rstd, const void* w,
+                         const void* part_x, const void* part_1, int nparts, const void* vq, const void* vr,
+                         double count, const void* add, const void* mask_src, int64_t n, int64_t c, int64_t hw,
+                         int64_t out_ld, int64_t add_ld, int a_splits, int64_t a_slab, int dtype, void* stream) {
+  AffTrainArgs q;
+  const int rc = fill_aff_train(q, out, a, x, mean, rstd, w, part_x, part_1, nparts, vq, vr, count, add, mask_src, n, c,
+                                hw, out_ld, add_ld, a_splits, a_slab, dtype);
+  if (rc) return rc;
+  typedef void (*Kern)(AffTrainArgs);
   static const Kern kerns[8] = {
       k_chan_affine_v4_train<false, false, false>, k_chan_affine_v4_train<true, false, false>,
       k_chan_affine_v4_train<false, true, false>,  k_chan_affine_v4_train<true, true, false>,
       k_chan_affine_v4_train<false, false, true>,  k_chan_affine_v4_train<true, false, true>,
       k_chan_affine_v4_train<false, true, true>,   k_chan_affine_v4_train<true, true, true>};
   hipLaunchKernelGGL(kerns[(a_splits > 1 ? 1 : 0) | (add ? 2 : 0) | (mask_src ? 4 : 0)],
-                     dim3(wide_grid(total / 4)), dim3(BLOCK), 0, (hipStream_t)stream, (float*)out, (const float*)a, (const float*)x, (const float*)mean, (const float*)rstd,
-                     (const float*)w, (const float*)part_x, (const float*)part_1, (unsigned)nparts, (const float*)vq,
-                     (const float*)vr, (float)(1.0 / count), (const float*)add, (const float*)mask_src,
-                     (unsigned)total, (unsigned)c, (unsigned)out_ld, (unsigned)add_ld, a_splits, (long long)a_slab);
+                     dim3(wide_grid(q.total / 4)), dim3(BLOCK), 0, (hipStream_t)stream, q);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_chan_affine_train_pair(const hf_affine_train_problem* problems, int dtype, void* stream) {
+  if (!problems) return HF_ERR_ARG;
+  AffTrainArgs q[2];
+  for (int i = 0; i < 2; ++i) {
+    const hf_affine_train_problem& p = problems[i];
+    if (p.add) return HF_ERR_ARG;  // (no residual operand in the paired form)
+    const int rc = fill_aff_train(q[i], p.out, p.a, p.x, p.mean, p.rstd, p.w, p.part_x, p.part_1, p.nparts, p.vq, p.vr,
+                                  p.count, nullptr, p.mask_src, p.n, p.c, p.hw, p.out_ld, 0, p.a_splits, p.a_slab,
+                                  dtype);
+    if (rc) return rc;
+  }
+  typedef void (*Kern)(AffTrainArgs, AffTrainArgs, unsigned);
+#define HF_ATP(SA, MA, SB, MB) k_chan_affine_v4_train_pair<SA, MA, SB, MB>
+  static const Kern kerns[16] = {
+      HF_ATP(false, false, false, false), HF_ATP(true, false, false, false), HF_ATP(false, true, false, false),
+      HF_ATP(true, true, false, false),   HF_ATP(false, false, true, false), HF_ATP(true, false, true, false),
+      HF_ATP(false, true, true, false),   HF_ATP(true, true, true, false),   HF_ATP(false, false, false, true),
+      HF_ATP(true, false, false, true),   HF_ATP(false, true, false, true),  HF_ATP(true, true, false, true),
+      HF_ATP(false, false, true, true),   HF_ATP(true, false, true, true),   HF_ATP(false, true, true, true),
+      HF_ATP(true, true, true, true)};
+#undef HF_ATP
+  const unsigned ba = (unsigned)wide_grid(q[0].total / 4), bb = (unsigned)wide_grid(q[1].total / 4);
+  const int idx = (q[0].a_splits > 1 ? 1 : 0) | (q[0].mask_src ? 2 : 0) | (q[1].a_splits > 1 ? 4 : 0) |
+                  (q[1].mask_src ? 8 : 0);
+  hipLaunchKernelGGL(kerns[idx], dim3(ba + bb), dim3(BLOCK), 0, (hipStream_t)stream, q[0], q[1], ba);
   HF_HIP(hipGetLastError());
   return HF_OK;
 }

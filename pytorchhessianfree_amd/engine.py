@@ -1001,6 +1001,42 @@ class FusedGGNEngine(_Operator):
             _ptr(vg), _ptr(vb), _ptr(add), _ptr(u.y) if u.relu else None, 0, n, k, oh * ow, 1, u.tout_ld, add_ld,
             u.sT, u.tbuf.shape[1], _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_chan_affine_ex")
 
+    def _train_pair_ok(self, u1, u2):
+        return (u1.train and u2.train and u1.pro and u2.pro
+                and os.environ.get("HF_BN_TRAIN_PAIR", "1") != "0")
+
+    def _affine_train_problem(self, q, u, out, out_ld, a, a_splits, a_slab, px, p1, nparts, vq, vr, mask):
+        n, k, oh, ow = u.a.shape
+        q.out, q.a, q.x = out.data_ptr(), a.data_ptr(), u.a.data_ptr()
+        q.mean, q.rstd, q.w = u.mean.data_ptr(), u.rstd.data_ptr(), u.scale.data_ptr()
+        q.part_x, q.part_1, q.nparts = px.data_ptr(), p1.data_ptr(), nparts
+        q.vq = vq.data_ptr() if vq is not None else None
+        q.vr = vr.data_ptr() if vr is not None else None
+        q.count, q.add, q.mask_src = float(n * oh * ow), None, (mask.data_ptr() if mask is not None else None)
+        q.n, q.c, q.hw, q.out_ld, q.a_splits, q.a_slab = n, k, oh * ow, out_ld, a_splits, a_slab
+
+    def _bn_tangent_pair_train(self, u1, u2, v):
+        """Train mode, prologue form: the elementwise passes of two units without residual input in ONE launch (their
+        partial sums came from the convolutions' epilogue)."""
+        arr = (_lib.AffineTrainProblem * 2)()
+        for q, u in zip(arr, (u1, u2)):
+            k = u.a.shape[1]
+            vg = v[self._offs[u.pg]: self._offs[u.pg] + k] if u.pg is not None else None
+            vb = v[self._offs[u.pb]: self._offs[u.pb] + k] if u.pb is not None else None
+            self._affine_train_problem(q, u, u.tout, u.tout_ld, u.tbuf, u.sT, u.tbuf.shape[1], u.tpx, u.tp1,
+                                       u.tp1.shape[0], vg, vb, u.y if u.relu else None)
+        _lib.check(_lib.load().hf_chan_affine_train_pair(_lib.ctypes.cast(arr, _lib.c_void_p), _lib.HF_F32,
+                                                         _lib.current_stream_ptr(self.dev)), "hf_chan_affine_train_pair")
+
+    def _bn_adjoint_pair_train(self, u1, srcs1, u2, srcs2):
+        """Train mode, prologue form: both units' reduction passes in one launch, both elementwise passes in one."""
+        self._bn_adjoint_pair(u1, srcs1, u2, srcs2, train=True)
+        arr = (_lib.AffineTrainProblem * 2)()
+        for q, u in zip(arr, (u1, u2)):
+            self._affine_train_problem(q, u, u.ga, 0, u.g, 1, 0, u.gw, u.gb, u.rb, None, None, None)
+        _lib.check(_lib.load().hf_chan_affine_train_pair(_lib.ctypes.cast(arr, _lib.c_void_p), _lib.HF_F32,
+                                                         _lib.current_stream_ptr(self.dev)), "hf_chan_affine_train_pair")
+
     def _bn_tangent_pair(self, u1, u2, v):
         """The BatchNorm tangents of two units without residual input in ONE launch."""
         arr = (_lib.AffineProblem * 2)()
@@ -1016,8 +1052,9 @@ class FusedGGNEngine(_Operator):
         _lib.check(_lib.load().hf_chan_affine_pair(_lib.ctypes.cast(arr, _lib.c_void_p), _lib.HF_F32,
                                                    _lib.current_stream_ptr(self.dev)), "hf_chan_affine_pair")
 
-    def _bn_adjoint_pair(self, u1, srcs1, u2, srcs2):
-        """The BatchNorm adjoints of two units (row-major kernel) in ONE launch."""
+    def _bn_adjoint_pair(self, u1, srcs1, u2, srcs2, train=False):
+        """The BatchNorm adjoints of two units (row-major kernel) in ONE launch.  ``train``: the reduction pass of the
+        train-mode adjoint (masked cotangent and partial sums only)."""
         arr = (_lib.BnAdjointProblem * 2)()
         for q, u, srcs in zip(arr, (u1, u2), (srcs1, srcs2)):
             if not 1 <= len(srcs) <= 2:
@@ -1025,10 +1062,10 @@ class FusedGGNEngine(_Operator):
             (a, sa, la) = srcs[0]
             (b, sb, lb) = srcs[1] if len(srcs) == 2 else (None, 1, 0)
             n, k, oh, ow = u.a.shape
-            q.gx, q.gw, q.gb, q.gres = u.ga.data_ptr(), u.gw.data_ptr(), u.gb.data_ptr(), u.g.data_ptr()
+            q.gx, q.gw, q.gb, q.gres = (None if train else u.ga.data_ptr()), u.gw.data_ptr(), u.gb.data_ptr(), u.g.data_ptr()
             q.gy, q.gy_splits, q.gy_slab = a.data_ptr(), sa, la
             q.gy2, q.gy2_splits, q.gy2_slab = (None if b is None else b.data_ptr()), sb, lb
-            q.x, q.mean, q.rstd, q.w = u.a.data_ptr(), u.bn.running_mean.data_ptr(), u.rstd.data_ptr(), u.bn.weight.data_ptr()
+            q.x, q.mean, q.rstd, q.w = u.a.data_ptr(), u.mean.data_ptr(), u.rstd.data_ptr(), u.bn.weight.data_ptr()
             q.mask_src = u.y.data_ptr() if u.relu else None
             q.n, q.c, q.hw, q.row_blocks = n, k, oh * ow, u.rb
         _lib.check(_lib.load().hf_chan_affine_bwd_pair(_lib.ctypes.cast(arr, _lib.c_void_p), _lib.HF_F32,
@@ -1376,10 +1413,13 @@ class FusedGGNEngine(_Operator):
                 # the downsample branch and the block's first convolution read the same operand:
                 # both tangent convolutions in ONE launch
                 self._tangent_convs([ds, head])
-                paired = (head.res_unit is None and not head.res_identity and len(chain) > 1
-                          and not head.train and not ds.train)
+                alone = head.res_unit is None and not head.res_identity and len(chain) > 1
+                paired = alone and not head.train and not ds.train
                 if paired:  # ... and both BatchNorm tangents in one
                     self._bn_tangent_pair(ds, head, v)
+                elif alone and self._train_pair_ok(ds, head) and ds.tsum and head.tsum:
+                    self._bn_tangent_pair_train(ds, head, v)  # (train mode: the same, prologue form)
+                    paired = True
                 else:
                     self._bn_tangent(ds, v, None, 0)
             elif ds is not None:
@@ -1466,6 +1506,8 @@ class FusedGGNEngine(_Operator):
                     # convolution AND of its downsample branch in ONE launch (four problems)
                     if u.rb > 1 and ds.rb > 1 and not u.train and not ds.train:
                         self._bn_adjoint_pair(u, incoming.pop(id(u)), ds, [(last.g, 1, 0)])
+                    elif u.rb > 1 and ds.rb > 1 and self._train_pair_ok(u, ds):
+                        self._bn_adjoint_pair_train(u, incoming.pop(id(u)), ds, [(last.g, 1, 0)])
                     else:
                         self._bn_adjoint(u, incoming.pop(id(u)))
                         self._bn_adjoint(ds, [(last.g, 1, 0)])

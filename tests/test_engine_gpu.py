@@ -371,9 +371,10 @@ def test_train_mode_folded_kernels_equal_the_separate_launches(monkeypatch):
     seed = tp.RESNET18_B32_SEPARATED_SEEDS[2]
     v = None
     products = {}
-    for form in ("prologue", "prologue-no-epilogue", "barrier", "tail", "separate"):
+    for form in ("prologue", "prologue-no-pair", "prologue-no-epilogue", "barrier", "tail", "separate"):
         monkeypatch.setenv("HF_BN_TRAIN_FORM", form.split("-")[0])
         monkeypatch.setenv("HF_BN_EPILOGUE", "0" if form.endswith("no-epilogue") else "1")
+        monkeypatch.setenv("HF_BN_TRAIN_PAIR", "0" if form.endswith("no-pair") else "1")
         model, (x, t), lossf = tp.resnet18_mnist(batch_size=16, device=DEV, data_seed=seed)
         model.train()
         modelprep.prepare_model(model, channels_last=True)
@@ -400,11 +401,14 @@ def test_train_mode_folded_kernels_equal_the_separate_launches(monkeypatch):
         if form == "prologue":
             assert all(u.tsum == u.epi for u in op.units) and sum(u.tsum for u in op.units) == len(op.units) - 1
         products[form] = got
+    # (the downsample blocks' two units in one launch each -- hf_chan_affine_train_pair, hf_chan_affine_bwd_pair --
+    # or in launches of their own: the same workgroup code, the same bits)
+    assert torch.equal(products["prologue"], products["prologue-no-pair"])
     ref = products["separate"]
     for form, got in products.items():
         # (the convolution's epilogue multiplies every SPLIT's partial tile by xhat and adds the products up in fp64;
         # the reduction launch multiplies the fp32 sum of the slabs: 1.0e-6 measured between the two)
-        assert float((got - ref).abs().max() / ref.abs().max()) < (3e-6 if form == "prologue" else 1e-6), form
+        assert float((got - ref).abs().max() / ref.abs().max()) < (3e-6 if form in ("prologue", "prologue-no-pair") else 1e-6), form
     # forward pass (the engine of the last form): both variants from the same running statistics
     folded = [u for u in op.units if u.stats_fold]
     assert len(folded) >= 10
