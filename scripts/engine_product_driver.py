@@ -145,6 +145,16 @@ class Recorder:
         return [("k_chan_affine_v4_train", rd, tot, 8.0 * n * c * hw)]
 
     @staticmethod
+    def _cost_hf_chan_affine_train_pair(problems, dtype, stream):
+        arr = _lib.ctypes.cast(problems, _lib.ctypes.POINTER(_lib.AffineTrainProblem * 2)).contents
+        rd = wr = 0
+        for q in arr:
+            tot = 4 * q.n * q.c * q.hw
+            rd += tot * (q.a_splits + 1 + (1 if q.mask_src else 0)) + 4 * 2 * q.nparts * q.c
+            wr += tot
+        return [("k_chan_affine_v4_train_pair", rd, wr, 0.0)]
+
+    @staticmethod
     def _cost_hf_conv2d_nhwc_group_slabs_bnsum(problems, count, sums, dtype, stream):
         arr = _lib.ctypes.cast(problems, _lib.ctypes.POINTER(_lib.ConvProblem * count)).contents
         bn = _lib.ctypes.cast(sums, _lib.ctypes.POINTER(_lib.ConvBnSum * count)).contents
