@@ -20,6 +20,12 @@ def pytest_configure(config):
     import pytorchhessianfree_amd
 
     pytorchhessianfree_amd.configure()
+    # The CPU references of the GPU tests (stock models, autograd, the oracle PCG) run on the box's host cores; with
+    # one thread per core of a 256-core host these small convolutions spend their time synchronising (bench.py's
+    # cpu_baseline probes the thread count and lands on 16).  HF_TEST_CPU_THREADS=0: torch's default.
+    cap = int(os.environ.get("HF_TEST_CPU_THREADS", "16"))
+    if cap > 0 and torch.get_num_threads() > cap:
+        torch.set_num_threads(cap)
 
 
 def pytest_collection_modifyitems(config, items):
