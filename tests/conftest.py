@@ -20,10 +20,12 @@ def pytest_configure(config):
     import pytorchhessianfree_amd
 
     pytorchhessianfree_amd.configure()
-    # The CPU references of the GPU tests (stock models, autograd, the oracle PCG) run on the box's host cores; with
-    # one thread per core of a 256-core host these small convolutions spend their time synchronising (bench.py's
-    # cpu_baseline probes the thread count and lands on 16).  HF_TEST_CPU_THREADS=0: torch's default.
-    cap = int(os.environ.get("HF_TEST_CPU_THREADS", "16"))
+    # The CPU references of the GPU tests (stock models, autograd, the oracle PCG) run on the box's host cores with
+    # torch's default thread count.  HF_TEST_CPU_THREADS=16 makes them ~3.5x faster on a 256-core host (bench.py's
+    # cpu_baseline probe lands on 16 threads too) but moves the fp32 CPU results by their own rounding (other reduction
+    # partitions): the tightest comparisons are calibrated to the default (m_1 of the ResNet-18 solve: 1.04e-5 against
+    # its 1e-5 bound with 16 threads) -- an option for local runs, not the default.
+    cap = int(os.environ.get("HF_TEST_CPU_THREADS", "0"))
     if cap > 0 and torch.get_num_threads() > cap:
         torch.set_num_threads(cap)
 
