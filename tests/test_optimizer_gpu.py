@@ -666,20 +666,26 @@ def test_config2_full_step_matches_reference_cpu_path(deterministic):
     iteration count +-2 with the deterministic kernels (+-12 with MIOpen's atomics, see
     test_resnet18_newton_solve_matches_reference_cpu_path), back-tracked iterate equal or the
     adjacent snapshot, cosine of the two parameter updates > 0.999."""
-    from oracle import pcg as oracle
     from pytorchhessianfree_amd import modelprep
 
+    from helpers import cpu_resnet18_default_steps
+
     runs = {}
-    for device in ("cpu", DEV):
+    # CPU path: the first step of the shared single-process CPU run (tests/helpers.py: stock model, default
+    # HessianFree, oracle PCG, the batch of RESNET18_B32_SEPARATED_SEEDS[0]) -- computed once per pytest process;
+    # its second step's recorded damping is the damping after the first step's update
+    sc2, c_finals, _ = cpu_resnet18_default_steps(2)
+    _, _, c_params = cpu_resnet18_default_steps(1)
+    c_model, _, _ = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=tp.RESNET18_B32_SEPARATED_SEEDS[0])
+    runs["cpu"] = dict(state={k: v[:1] for k, v in sc2.items()}, final=c_finals[0], damping=sc2["dampings"][1],
+                       update=(torch.from_numpy(c_params) - trainable_vec(c_model)).double())
+    for device in (DEV,):
         # (a batch without a ReLU input within fp32 rounding of zero: testproblems.relu_margin)
         model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device=device,
                                                  data_seed=tp.RESNET18_B32_SEPARATED_SEEDS[0])
-        if device != "cpu":
-            modelprep.prepare_model(model, channels_last=deterministic, deterministic=deterministic)
+        modelprep.prepare_model(model, channels_last=deterministic, deterministic=deterministic)
         before = trainable_vec(model).clone()
-        opt = hf.HessianFree(model.parameters(), graph_matvec=(device != "cpu"))
-        if device == "cpu":
-            opt._cg = oracle.pcg
+        opt = hf.HessianFree(model.parameters(), graph_matvec=True)
 
         def forward():
             out = model(x)
