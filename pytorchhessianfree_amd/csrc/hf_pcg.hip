@@ -1608,7 +1608,11 @@ __device__ __forceinline__ void grid_barrier(unsigned long long* bar) {
   if (threadIdx.x == 0) {
     const unsigned long long old = __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long target = (old / gridDim.x + 1ull) * gridDim.x;
-    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    // (bounded: ~2^26 polls of >= 64 clocks are seconds -- a launch whose workgroups cannot all become resident ends
+    // with wrong sums instead of hanging the device; the host refuses such launches up front)
+    for (unsigned spins = 0; spins < (1u << 26) &&
+                             __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins)
+      __builtin_amdgcn_s_sleep(1);
   }
   __syncthreads();
 }
