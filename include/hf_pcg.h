@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 10
+#define HF_ABI_VERSION 11
 
 enum hf_dtype { HF_F32 = 0, HF_F64 = 1 };
 
@@ -322,17 +322,6 @@ typedef struct hf_bn_adjoint_problem {
 } hf_bn_adjoint_problem;
 int hf_chan_affine_bwd_pair(const hf_bn_adjoint_problem* problems /* [2] */, int dtype, void* stream);
 
-/* Batch statistics of a train-mode BatchNorm layer for the engine's OWN forward pass (the forward pass of
- * /root/reference/hessianfree/optimizer.py:216-229 and of every tfunc call, :288-294, on a model that was not put in
- * eval mode -- examples/run_resnet18_mnist.py:19-35): from `nparts` partial per-channel sums c elements apart (what
- * hf_chan_affine_bwd_ex leaves in gb / gw), added in order in fp64.
- *   stage 0: mean = sum(part) / count                      (part: sums of a)
- *   stage 1: var = sum(part) / count, rstd = 1/sqrt(var + eps)   (part: sums of a*(a - mean), mean as written by
- *            stage 0); momentum >= 0: running_mean / running_var (nullable) move as torch.nn.BatchNorm2d's forward
- *            moves them: r <- (1 - momentum) r + momentum * {mean, var * count/(count - 1)}. */
-int hf_bn_batch_stats(void* mean, void* rstd, void* running_mean, void* running_var, const void* part, int nparts,
-                      double count, double eps, double momentum, int stage, int64_t c, int dtype, void* stream);
-
 /*
  * Forward pass of conv -> (eval-BatchNorm | bias) (+ residual) (+ ReLU) from the convolution's split-K
  * slabs, NHWC fp32 [rows = n*hw, c] -- what the reference evaluates by `forward()` for the loss
@@ -355,60 +344,13 @@ int hf_bn_forward(void* y, void* y2, int64_t y2_ld, void* a_out, const void* a, 
  *     xhat' = rstd * [a' - mean(a') - xhat * mean(xhat * a')],
  * whose two per-channel corrections fold into the per-channel vectors of hf_chan_affine_ex
  * (t = a*(w*rstd) + xhat*q + r):   q = vq - w*rstd*S_x/count,   r = vr - w*rstd*S_1/count,
- * S_x = sum(xhat*a'), S_1 = sum(a') over the batch -- given as `nparts` partial sums c elements apart (what
- * hf_chan_affine_bwd_ex writes to gw / gb with gx = NULL), added here in order.  vq / vr nullable (the adjoint
- * has none), w nullable (1).
- */
-int hf_bn_train_coeffs(void* q_out, void* r_out, const void* part_x, const void* part_1, int nparts, const void* w,
-                       const void* rstd, const void* vq, const void* vr, double count, int64_t c, int dtype,
-                       void* stream);
-
-/*
- * hf_chan_affine_bwd_ex (row-major NHWC fp32 kernel, row_blocks >= 2) and hf_bn_train_coeffs in ONE launch: the
- * last workgroup to publish its partial sums (ticket word `ticket`: one zero-initialised uint32 per layer, resets
- * itself) adds all partial rows up in order and writes  q = vq - final_w*rstd*S_x/count,
- * r = vr - final_w*rstd*S_1/count  (final_w, vq, vr nullable).  One launch less per train-mode BatchNorm layer and
- * sweep of every curvature product (examples/run_resnet18_mnist.py:19-35 with optimizer.py:457-462).
- */
-int hf_bn_adjoint_rows_train(void* gx, void* gw, void* gb, void* gres, const void* gy, int gy_splits,
-                             int64_t gy_slab, const void* gy2, int gy2_splits, int64_t gy2_slab, const void* x,
-                             const void* mean, const void* rstd, const void* w, const void* mask_src, int64_t n,
-                             int64_t c, int64_t hw, int row_blocks, void* ticket, void* q_out, void* r_out,
-                             const void* final_w, const void* vq, const void* vr, double count, int dtype,
-                             void* stream);
-
-/*
- * hf_bn_adjoint_rows_train AND the elementwise pass that consumes its per-channel vectors (hf_chan_affine_ex with
- * q / r) in ONE launch -- the whole tangent resp. adjoint of a train-mode BatchNorm (+ residual add, + ReLU mask):
- *   pass 1   g = mask_src > 0 ? sum of gy's (and gy2's) split-K slabs : 0  -> gres;  per-workgroup partial sums
- *            of g and xhat*g -> gw / gb  ([row_blocks, c] each)
- *   barrier  over the launch's workgroups (`barrier`: one zero-initialised uint64 per layer, counts arrivals, never
- *            reset); row_blocks must not exceed the device's compute-unit count (HF_ERR_ARG) so that all are resident
- *   pass 2   q = vq - final_w*rstd*S_x/count,  r = vr - final_w*rstd*S_1/count  (every workgroup, same order of
- *            additions);  out[row*out_ld + ch] = out_mask > 0 ? t : 0,
- *            t = g*(final_w*rstd) + xhat*q + r + add[row*add_ld + ch]      (out_ld / add_ld 0: dense)
- * q_out / r_out (both or neither): the per-channel vectors, for inspection.  fp32 NHWC, c % 4 == 0, c <= 1024.
- * The launch waits inside itself: do not run several of them concurrently on different streams unless all their
- * workgroups together fit the device.  (Measured slower than hf_chan_affine_bwd_ex + hf_chan_affine_train; kept as a
- * selectable form, HF_BN_TRAIN_FORM=barrier.)
- * Two launches less per train-mode BatchNorm layer and sweep than round 3 (optimizer.py:457-462 with
- * examples/run_resnet18_mnist.py:19-35).
- */
-int hf_bn_rows_train_apply(void* out, int64_t out_ld, void* gw, void* gb, void* gres, const void* gy, int gy_splits,
-                           int64_t gy_slab, const void* gy2, int gy2_splits, int64_t gy2_slab, const void* x,
-                           const void* mean, const void* rstd, const void* mask_src, int64_t n, int64_t c, int64_t hw,
-                           int row_blocks, void* barrier, void* q_out, void* r_out, const void* final_w,
-                           const void* vq, const void* vr, double count, const void* add, int64_t add_ld,
-                           const void* out_mask, int dtype, void* stream);
-
-/*
- * hf_bn_train_coeffs folded into the PROLOGUE of hf_chan_affine_ex (fp32 NHWC, c % 4 == 0, c <= 1024, 16-byte
- * aligned operands): every workgroup adds the `nparts` partial rows of S_x (`part_x`) and S_1 (`part_1`) -- what
- * hf_chan_affine_bwd_ex wrote with gx = NULL -- up in the same fixed order, forms
- *   q = vq - w*rstd*S_x/count,  r = vr - w*rstd*S_1/count   (vq / vr nullable),
- * and applies  out = mask_src > 0 ? t : 0,  t = sum(a slabs)*(w*rstd) + xhat*q + r + add.
- * One launch less per train-mode BatchNorm layer and sweep than hf_chan_affine_bwd_ex + hf_bn_train_coeffs +
- * hf_chan_affine_ex, without the in-launch hand-over of hf_bn_adjoint_rows_train / hf_bn_rows_train_apply.
+ * S_x = sum(xhat*a'), S_1 = sum(a') over the batch.  The finalisation runs in the PROLOGUE of the elementwise launch
+ * (fp32 NHWC, c % 4 == 0, c <= 1024, 16-byte aligned operands): every workgroup adds the `nparts` partial rows of
+ * S_x (`part_x`) and S_1 (`part_1`) -- what hf_chan_affine_bwd_ex wrote with gx = NULL, or the tangent convolution's
+ * own epilogue (hf_conv2d_nhwc_group_slabs_bnsum) -- up in the same fixed order, forms q and r (vq / vr nullable: the
+ * adjoint has none) and applies  out = mask_src > 0 ? t : 0,  t = sum(a slabs)*(w*rstd) + xhat*q + r + add.
+ * (Round 4 also shipped the finalisation as a launch of its own, as the reduction launch's last workgroup and as one
+ * launch around a grid barrier; measured slower -- profiles/r04_train_bn_forms.jsonl -- and removed in ABI v11.)
  */
 int hf_chan_affine_train(void* out, const void* a, const void* x, const void* mean, const void* rstd, const void* w,
                          const void* part_x, const void* part_1, int nparts, const void* vq, const void* vr,
@@ -432,22 +374,17 @@ int hf_chan_affine_train_pair(const hf_affine_train_problem* problems /* [2] */,
 /*
  * One-pass batch statistics of a train-mode BatchNorm in the engine's own forward pass (optimizer.py:216-229,
  * :288-294 on a model in train mode): a_out (nullable) = sum of `splits` slabs of a (split order), per-channel
- * sum a and sum a^2 in fp64 (`part`: [row_blocks, 2, c] doubles, scratch), finalised by the last workgroup
- * (`ticket`: zero-initialised uint32, resets itself): mean, rstd = 1/sqrt(E[a^2] - mean^2 + eps), and -- momentum >= 0,
- * running_mean / running_var not NULL -- the running statistics as torch.nn.BatchNorm2d's forward moves them.
- * Replaces two reduction launches + two hf_bn_batch_stats launches per layer.  ticket == NULL: the partial rows only
- * (mean / rstd / running_* ignored, may be NULL) -- hf_bn_forward_train finalises them.
+ * sum a and sum a^2 in fp64 per row block -> `part`: [row_blocks, 2, c] doubles.  hf_bn_forward_train finalises them.
  */
-int hf_bn_stats_rows(void* a_out, const void* a, int splits, int64_t slab_stride, void* part, void* ticket,
-                     void* mean, void* rstd, void* running_mean, void* running_var, double count, double eps,
-                     double momentum, int64_t rows, int64_t c, int row_blocks, int dtype, void* stream);
+int hf_bn_stats_rows(void* a_out, const void* a, int splits, int64_t slab_stride, void* part, int64_t rows, int64_t c,
+                     int row_blocks, int dtype, void* stream);
 
 /*
  * The forward of a train-mode BatchNorm (+ residual, + ReLU) with the statistics' finalisation in its PROLOGUE:
- * hf_bn_stats_rows with ticket = NULL leaves only its partial rows (`part`: [nparts][2][c] doubles); every workgroup
- * of this launch adds them up (fixed order), forms mean / biased variance / rstd as hf_bn_stats_rows' last workgroup
- * would, applies  y = act(((a - mean)*rstd)*w + b + res)  to its share (`a`: the summed convolution output), and
- * workgroup 0 writes mean / rstd and moves the running statistics (momentum < 0: not).  fp32 NHWC, c % 4 == 0.
+ * hf_bn_stats_rows leaves its partial rows (`part`: [nparts][2][c] doubles); every workgroup of this launch adds them
+ * up (fixed order), forms mean, biased variance = E[a^2] - mean^2 (fp64) and rstd = 1/sqrt(var + eps), applies  y = act(((a - mean)*rstd)*w + b + res)  to its share (`a`: the summed convolution output), and
+ * workgroup 0 writes mean / rstd and moves the running statistics as torch.nn.BatchNorm2d's
+ * forward does (momentum < 0: not): r <- (1 - momentum) r + momentum * {mean, var * count/(count - 1)}.  fp32 NHWC, c % 4 == 0.
  */
 int hf_bn_forward_train(void* y, void* y2, int64_t y2_ld, const void* a, const void* part, int nparts, void* mean,
                         void* rstd, void* running_mean, void* running_var, double count, double eps, double momentum,

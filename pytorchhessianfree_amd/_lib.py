@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HF_PCG_LIB") or os.path.join(_HERE, "csrc", "libhfpcg.so")
 
 HF_F32, HF_F64 = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 HF_ERR_ARG = -1  # hf_status of include/hf_pcg.h: null / negative / inconsistent argument
 HF_M_NONE, HF_M_DIAG, HF_M_EXTERNAL = 0, 1, 2
 REASONS = {
@@ -104,8 +104,6 @@ SIGNATURES = {
         c_int,
         [c_void_p, ctypes.POINTER(c_void_p)] + [ctypes.POINTER(c_int64)] * 6 + [c_int, c_int, c_void_p],
     ),
-    "hf_bn_train_coeffs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 4
-                           + [c_double, c_int64, c_int, c_void_p]),
     "hf_bn_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64] + [c_void_p] * 5
                       + [c_int64, c_int, c_int64, c_int64, c_int, c_void_p]),
     "hf_maxpool_forward_nhwc": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p] + [c_int64] * 12
@@ -126,7 +124,6 @@ SIGNATURES = {
     "hf_conv2d_nhwc_slabs_unpack": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int64] * 13 + [c_int, c_int64, c_void_p,
                                             ctypes.POINTER(c_void_p)] + [ctypes.POINTER(c_int64)] * 6
                                     + [c_int, c_int, c_void_p]),
-    "hf_bn_batch_stats": (c_int, [c_void_p] * 5 + [c_int, c_double, c_double, c_double, c_int, c_int64, c_int, c_void_p]),
     "hf_conv2d_nhwc_group_slabs": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "hf_conv2d_nhwc_dw_slabs": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "hf_chan_affine_pair": (c_int, [c_void_p, c_int, c_void_p]),
@@ -137,19 +134,13 @@ SIGNATURES = {
                                                      c_int, c_int64, c_int, c_void_p]),
     "hf_chan_affine_bwd_ex": (c_int, [c_void_p] * 5 + [c_int, c_int64, c_void_p, c_int, c_int64] + [c_void_p] * 5
                               + [c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
-    "hf_bn_adjoint_rows_train": (c_int, [c_void_p] * 5 + [c_int, c_int64, c_void_p, c_int, c_int64] + [c_void_p] * 5
-                                 + [c_int64, c_int64, c_int64, c_int] + [c_void_p] * 6 + [c_double, c_int, c_void_p]),
-    "hf_bn_rows_train_apply": (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int, c_int64, c_void_p, c_int, c_int64]
-                               + [c_void_p] * 4 + [c_int64, c_int64, c_int64, c_int] + [c_void_p] * 6
-                               + [c_double, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
     "hf_chan_affine_train": (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p]
                              + [c_int64] * 5 + [c_int, c_int64, c_int, c_void_p]),
     "hf_conv2d_nhwc_group_slabs_bnsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "hf_bn_forward_train": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int] + [c_void_p] * 4
                             + [c_double] * 3 + [c_void_p] * 3 + [c_int64, c_int, c_int64, c_int64, c_int, c_void_p]),
     "hf_chan_affine_train_pair": (c_int, [c_void_p, c_int, c_void_p]),
-    "hf_bn_stats_rows": (c_int, [c_void_p, c_void_p, c_int, c_int64] + [c_void_p] * 6
-                         + [c_double, c_double, c_double, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "hf_bn_stats_rows": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "hf_bn_adjoint_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64,
                                   c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "hf_pack_ex": (

@@ -10,12 +10,12 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SRC = os.path.join(HERE, "hf_pcg.hip")
-SRC_CONV = os.path.join(HERE, "hf_conv.hip")
-SRC_HEAD = os.path.join(HERE, "hf_head.hip")
-SOURCES = [SRC, SRC_CONV, SRC_HEAD]
+# one translation unit per kernel family: PCG solver | gather / scatter | BatchNorm / bias maps | convolutions |
+# pooling + classifier heads | the RCCL shim
+SOURCES = [os.path.join(HERE, f) for f in ("hf_pcg.hip", "hf_pack.hip", "hf_bn.hip", "hf_conv.hip", "hf_head.hip",
+                                           "hf_rccl.hip")]
 HDR = os.path.join(ROOT, "include", "hf_pcg.h")
-HDR_SHARED = os.path.join(HERE, "hf_unpack.h")  # shared by hf_pcg.hip and hf_conv.hip
+HDRS_SHARED = [os.path.join(HERE, f) for f in ("hf_common.h", "hf_unpack.h")]
 OUT = os.path.join(HERE, "libhfpcg.so")
 
 FLAGS = [
@@ -23,7 +23,6 @@ FLAGS = [
     "-O3",
     "-std=c++17",
     "-fPIC",
-    "-shared",
     # elementwise arithmetic mirrors the reference's separate roundings
     "-ffp-contract=off",
     "-fno-fast-math",
@@ -36,7 +35,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in (*SOURCES, HDR, HDR_SHARED, __file__))
+    return any(os.path.getmtime(f) > t for f in (*SOURCES, HDR, *HDRS_SHARED, __file__))
 
 
 def build(force=False, verbose=True, out=None, extra_flags=()):
@@ -46,10 +45,25 @@ def build(force=False, verbose=True, out=None, extra_flags=()):
     if out == OUT and not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *FLAGS, *extra_flags, "-I", os.path.join(ROOT, "include"), *SOURCES, "-o", out, "-ldl"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+
+    with tempfile.TemporaryDirectory(prefix="hfpcg_build_") as tmp:
+        objs = [os.path.join(tmp, os.path.basename(src)[:-4] + ".o") for src in SOURCES]
+
+        def compile_one(pair):
+            src, obj = pair
+            cmd = [hipcc, *FLAGS, *extra_flags, "-I", os.path.join(ROOT, "include"), "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+            list(pool.map(compile_one, zip(SOURCES, objs)))
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out, "-ldl"]
+        if verbose:
+            print(" ".join(link), flush=True)
+        subprocess.run(link, check=True)
     return out
 
 

@@ -73,7 +73,7 @@ class _Unit:
         self.im2col = False       # tiny-Cin layer: runs as a 1x1 product over the im2col of the input
         self.train = False        # train-mode BatchNorm: batch statistics (recorded), tangent / adjoint carry
         self.mean_t = None        # the statistics' dependence on the layer input
-        self.fold = self.fuse = self.pro = self.stats_fold = self.fwd_pro = self.epi = self.tsum = False  # train mode: how many launches its tangent / adjoint take (see _buffers)
+        self.epi = self.tsum = False  # train mode: the tangent's partial sums come from the convolution's epilogue
         self.res_unit = None      # downsample unit whose output is added before the activation
         self.res_identity = False  # ... or the block input itself
         self.consumers = 0
@@ -99,8 +99,6 @@ class FusedGGNEngine(_Operator):
     mode = ("fused curvature engine: own deterministic convolutions (split-K slabs summed by the consumer "
             "kernel), BatchNorm tangents/adjoints fused, 4 launches per conv-BN unit, downsample branches grouped "
             "with their block's first convolution")
-
-    _verified = set()
 
     # ------------------------------------------------------------------------------------
     @classmethod
@@ -182,8 +180,18 @@ class FusedGGNEngine(_Operator):
                 raise _Unsupported(f"the engine's forward pass differs from the model's output by {err:.2e}")
         self._loss_setup(loss, outputs)
         self._verify(loss)
+        # ONE linearisation point after construction, whether or not the first-use check ran (it is skipped for a
+        # model signature that has passed before): the engine's OWN forward pass where it has one, else -- a
+        # train-mode model whose layers the own pass does not reproduce -- everything the model recorded, batch
+        # statistics included.  (Round 4 left a train-mode engine whose check was skipped at the recorded
+        # activations with its own statistics: 3.65e-6 / one ReLU decision away from the checked one, GPUTEST_r04.)
+        if self._at != "own" and (not self.train_bn or self.train_own):
+            self.forward_own(update_running=False)  # (eval mode: nothing to move)
+            if self.hessian:
+                self.gradient()  # the first-order cotangents the Hessian products read, at the same point
         for u in self.units:  # the model's own activations were only needed up to here
             u.rx = u.ry = u.ra = None
+            u.rec_stats = None
         self._rec_pool = None
         if self.loss_spec is not None:
             self.outputs = None  # nothing of the step's autograd graph stays alive in the engine
@@ -240,6 +248,7 @@ class FusedGGNEngine(_Operator):
                                        "parallelism: batch statistics couple the samples of a shard)")
                 bx, bres, by, brelu, rstd, mean_t = rec
                 # (engine-owned static buffers: the own forward pass of a session rewrites them per batch)
+                u.rec_stats = (mean_t, rstd)
                 rstd, u.mean_t = rstd.clone(), mean_t.clone()
                 u.train = True
             else:
@@ -425,24 +434,18 @@ class FusedGGNEngine(_Operator):
                     if not u.im2col and not u.first:
                         u.wT.copy_(self.params[u.pw].detach().permute(1, 2, 3, 0))
 
-    def _ones(self, k):
-        cache = self.__dict__.setdefault("_ones_cache", {})
-        if k not in cache:
-            cache[k] = torch.ones(k, dtype=torch.float32, device=self.dev)
-        return cache[k]
-
     def _bn_forward(self, u, splits, update_running=True):
         n, k, oh, ow = u.a.shape
         res = u.res
-        if u.train and u.stats_fold and u.fwd_pro:
+        if u.train:
             # ONE pass for the partial sums (the convolution's slabs summed into ``a``, per-channel sum a / sum a^2 in
             # fp64 per row block); the normalising launch adds them up in its prologue -- 2 launches per unit
             bn, st = u.bn, _lib.current_stream_ptr(self.dev)
             move = update_running and bn.track_running_stats
             count = float(n * oh * ow)
             _lib.check(_lib.load().hf_bn_stats_rows(
-                _ptr(u.a), _ptr(u.tbuf), splits, u.tbuf.shape[1], _ptr(u.stat_part), None, None, None, None, None,
-                count, float(bn.eps), -1.0, n * oh * ow, k, u.rb, _lib.HF_F32, st), "hf_bn_stats_rows")
+                _ptr(u.a), _ptr(u.tbuf), splits, u.tbuf.shape[1], _ptr(u.stat_part), n * oh * ow, k, u.rb,
+                _lib.HF_F32, st), "hf_bn_stats_rows")
             _lib.check(_lib.load().hf_bn_forward_train(
                 _ptr(u.y), _ptr(u.yout2), 2 * k if u.yout2 is not None else 0, _ptr(u.a), _ptr(u.stat_part), u.rb,
                 _ptr(u.mean_t), _ptr(u.rstd), _ptr(bn.running_mean) if move else None,
@@ -452,44 +455,8 @@ class FusedGGNEngine(_Operator):
             if move:
                 bn.num_batches_tracked.add_(1)
             return
-        if u.train and u.stats_fold:
-            # ONE pass: the convolution's slabs summed into ``a``, per-channel sum a / sum a^2 in fp64, finalised by
-            # the launch's last workgroup (mean, rstd, running statistics) -- 3 launches per unit instead of 6
-            bn = u.bn
-            move = update_running and bn.track_running_stats
-            _lib.check(_lib.load().hf_bn_stats_rows(
-                _ptr(u.a), _ptr(u.tbuf), splits, u.tbuf.shape[1], _ptr(u.stat_part), _ptr(u.ticket), _ptr(u.mean_t),
-                _ptr(u.rstd), _ptr(bn.running_mean) if move else None, _ptr(bn.running_var) if move else None,
-                float(n * oh * ow), float(bn.eps), float(bn.momentum) if move else -1.0, n * oh * ow, k, u.rb,
-                _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_bn_stats_rows")
-            if move:
-                bn.num_batches_tracked.add_(1)
-            splits = 1  # (``a`` is summed)
-        elif u.train:
-            # batch statistics by two passes of the adjoint's reduction kernel over the convolution's output
-            # (sum a -> mean; sum a*(a - mean) -> biased variance), each followed by a per-channel finalisation;
-            # the first pass also sums the convolution's slabs into ``a``
-            lib, st, bn = _lib.load(), _lib.current_stream_ptr(self.dev), u.bn
-            count = float(n * oh * ow)
-            _lib.check(lib.hf_chan_affine_bwd_ex(
-                None, None, _ptr(u.gb), _ptr(u.a), _ptr(u.tbuf), splits, u.tbuf.shape[1], None, 1, 0, None, None,
-                None, None, None, n, k, oh * ow, 1, u.rb, _lib.HF_F32, st), "hf_chan_affine_bwd_ex")
-            _lib.check(lib.hf_bn_batch_stats(_ptr(u.mean_t), None, None, None, _ptr(u.gb), u.rb, count, 0.0, -1.0, 0,
-                                             k, _lib.HF_F32, st), "hf_bn_batch_stats")
-            _lib.check(lib.hf_chan_affine_bwd_ex(
-                None, _ptr(u.gw), _ptr(u.gb), None, _ptr(u.a), 1, 0, None, 1, 0, _ptr(u.a), _ptr(u.mean_t),
-                _ptr(self._ones(k)), None, None, n, k, oh * ow, 1, u.rb, _lib.HF_F32, st), "hf_chan_affine_bwd_ex")
-            move = update_running and bn.track_running_stats
-            _lib.check(lib.hf_bn_batch_stats(
-                _ptr(u.mean_t), _ptr(u.rstd), _ptr(bn.running_mean) if move else None,
-                _ptr(bn.running_var) if move else None, _ptr(u.gw), u.rb, count, float(bn.eps),
-                float(bn.momentum) if move else -1.0, 1, k, _lib.HF_F32, st), "hf_bn_batch_stats")
-            if move:
-                bn.num_batches_tracked.add_(1)
-            splits = 1  # (``a`` is summed)
         _lib.check(_lib.load().hf_bn_forward(
-            _ptr(u.y), _ptr(u.yout2), 2 * k if u.yout2 is not None else 0, _ptr(u.a),
-            _ptr(u.a if u.train else u.tbuf), splits,
+            _ptr(u.y), _ptr(u.yout2), 2 * k if u.yout2 is not None else 0, _ptr(u.a), _ptr(u.tbuf), splits,
             u.tbuf.shape[1], _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.shift),
             _ptr(res), 0, 1 if u.relu else 0, n * oh * ow, k, _lib.HF_F32, _lib.current_stream_ptr(self.dev)),
             "hf_bn_forward")
@@ -541,6 +508,7 @@ class FusedGGNEngine(_Operator):
             torch.mm(self.feat, fw.t(), out=self.logits)
         if getattr(self, "loss_spec", None) is not None:
             self._loss_head()
+        self._at = "own"
         return self.logits
 
     def _loss_head(self):
@@ -729,9 +697,7 @@ class FusedGGNEngine(_Operator):
         for u in self.units:
             u.a, u.y = nhwc(u.a.shape), nhwc(u.y.shape)
             if u.train:
-                u.rstd_version = None  # (u.rstd: the batch statistics recorded by the model's forward pass)
-                u.cq = torch.empty(u.a.shape[1], dtype=f32, device=dev)  # per-channel vectors of the corrected
-                u.cr = torch.empty(u.a.shape[1], dtype=f32, device=dev)  # elementwise pass (hf_bn_train_coeffs)
+                u.rstd_version = None  # (u.rstd: batch statistics -- recorded by the model's pass or the own one's)
             elif u.bn is not None:
                 u.rstd = torch.rsqrt(u.bn.running_var + u.bn.eps)
                 u.rstd_version = u.bn.running_var._version
@@ -809,9 +775,7 @@ class FusedGGNEngine(_Operator):
             # the BatchNorm adjoint shares the rows among `rb` workgroups per channel column; the
             # per-channel sums arrive as rb partial rows that hf_pack_ex adds up
             u.rb = 1
-            # (train mode: the one-launch tangent / adjoint wants row blocks for the late, small maps too)
-            form = os.environ.get("HF_BN_TRAIN_FORM", "prologue") if u.train else ""
-            if k % 4 == 0 and k // 4 <= 256 and (u.rows >= 64 or (form == "barrier" and u.rows >= 2 * (256 // (k // 4)))):
+            if k % 4 == 0 and k // 4 <= 256 and u.rows >= 64:
                 # row-major adjoint kernel: ~64 workgroups, each reading whole contiguous rows, one
                 # pass of the row loop where the map is small enough (measured on the ResNet-18
                 # bench: 32 workgroups x 2 passes 1124, 64 x 1 1150, 128 x 1 the same, 256 x 1 1138)
@@ -828,28 +792,19 @@ class FusedGGNEngine(_Operator):
             u.gw = torch.empty((u.gw_rows, k), dtype=f32, device=dev)
             u.gb = torch.empty((u.rb, k), dtype=f32, device=dev)
             if u.train:
-                # in-launch finalisation of the per-channel sums (hf_bn_adjoint_rows_train / hf_bn_stats_rows): a
-                # self-resetting ticket word and the one-pass statistics' fp64 partial sums
-                u.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
-                u.stat_part = torch.empty((u.rb, 2, k), dtype=torch.float64, device=dev)
-                # Where the per-channel finalisation of a tangent / adjoint runs (HF_BN_TRAIN_FORM; measured,
-                # profiles/r04_train_bn_forms.jsonl):
-                #   "separate"  reduction | hf_bn_train_coeffs | elementwise pass          (3 launches, round 3)
-                #   "tail"      reduction + finalisation by its last workgroup | elementwise pass
-                #   "barrier"   all three in one launch around a grid barrier (hf_bn_rows_train_apply: all `rb`
-                #               workgroups resident -- at most one per compute unit)
-                #   "prologue"  reduction | elementwise pass whose workgroups add the partial rows up themselves
-                u.stats_fold = u.rb > 1 and os.environ.get("HF_BN_FOLD", "1") != "0"  # (the forward's statistics)
-                u.fwd_pro = u.stats_fold and os.environ.get("HF_BN_FWD_PROLOGUE", "1") != "0"  # (see _bn_forward)
-                u.fold = u.stats_fold and form in ("tail", "barrier")
-                u.barrier = torch.zeros(1, dtype=torch.int64, device=dev)
-                u.fuse = u.fold and form == "barrier" and u.g is not None and u.rb <= _cu_count(dev)
-                u.pro = form == "prologue" and k % 4 == 0 and k // 4 <= 256
+                # The per-channel finalisation of a train-mode tangent / adjoint runs in the PROLOGUE of the elementwise
+                # pass: its workgroups add the reduction's partial rows up themselves (hf_chan_affine_train).  The
+                # forms of round 4 that handed over inside a launch or took a launch of their own were measured slower
+                # (profiles/r04_train_bn_forms.jsonl) and are gone.
+                if not (k % 4 == 0 and k // 4 <= 256):
+                    raise _Unsupported(f"{u.name}: train-mode BatchNorm over {k} channels (the prologue form takes "
+                                       "multiples of 4 up to 1024)")
+                u.stat_part = torch.empty((u.rb, 2, k), dtype=torch.float64, device=dev)  # one-pass statistics
                 # ... and the tangent's partial sums by the convolution's own epilogue (64x64-tile launches; one row per
                 # (row tile, split): beyond HF_BN_EPILOGUE_ROWS rows the separate reduction's `rb` rows are cheaper
                 # for the elementwise pass to add up)
                 tp_rows = -(-u.rows // 64) * u.sT
-                u.epi = (u.pro and not u.im2col and not u.first and hasattr(u, "xcat")
+                u.epi = (not u.im2col and not u.first and hasattr(u, "xcat")
                          and tp_rows <= int(os.environ.get("HF_BN_EPILOGUE_ROWS", "256"))
                          and os.environ.get("HF_BN_EPILOGUE", "1") != "0")
                 if u.epi:
@@ -938,30 +893,12 @@ class FusedGGNEngine(_Operator):
         _lib.check(rc, "hf_conv2d_nhwc_slabs_unpack")
         return True
 
-    def _train_coeffs(self, u, vq, vr):
-        """Per-channel vectors of the elementwise pass of a train-mode BatchNorm from the partial sums in
-        ``u.gw`` / ``u.gb`` (sum xhat*a', sum a' over the batch): see ``hf_bn_train_coeffs``."""
-        n, k, oh, ow = u.a.shape
-        _lib.check(_lib.load().hf_bn_train_coeffs(
-            _ptr(u.cq), _ptr(u.cr), _ptr(u.gw), _ptr(u.gb), u.rb, _ptr(u.scale), _ptr(u.rstd), _ptr(vq), _ptr(vr),
-            float(n * oh * ow), k, _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_bn_train_coeffs")
-
     def _bn_tangent(self, u, v, add, add_ld):
         """t_y = mask * (sum(T slabs) * w*rstd + xhat * v_w + v_b + add), into the consumer's operand."""
         n, k, oh, ow = u.a.shape
         vg = v[self._offs[u.pg]: self._offs[u.pg] + k] if u.pg is not None else None
         vb = v[self._offs[u.pb]: self._offs[u.pb] + k] if u.pb is not None else None
-        if u.train and u.fuse:
-            # reduction, folding and the elementwise pass in ONE launch (grid barrier between the passes); u.g is
-            # free during the tangent sweep: the slabs' sum rests there between the passes
-            _lib.check(_lib.load().hf_bn_rows_train_apply(
-                _ptr(u.tout), u.tout_ld, _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(u.tbuf), u.sT, u.tbuf.shape[1],
-                None, 1, 0, _ptr(u.a), _ptr(u.mean), _ptr(u.rstd), None, n, k, oh * ow, u.rb, _ptr(u.barrier),
-                None, None, _ptr(u.scale), _ptr(vg), _ptr(vb), float(n * oh * ow), _ptr(add), add_ld,
-                _ptr(u.y) if u.relu else None, _lib.HF_F32, _lib.current_stream_ptr(self.dev)),
-                "hf_bn_rows_train_apply")
-            return
-        if u.train and u.pro:
+        if u.train:
             # reduction (partial rows: by the convolution's epilogue, else by its own launch), then the elementwise
             # pass adds them up in its prologue
             lib, st = _lib.load(), _lib.current_stream_ptr(self.dev)
@@ -978,32 +915,13 @@ class FusedGGNEngine(_Operator):
                 _ptr(p1), nparts, _ptr(vg), _ptr(vb), float(n * oh * ow), _ptr(add), _ptr(u.y) if u.relu else None,
                 n, k, oh * ow, u.tout_ld, add_ld, u.sT, u.tbuf.shape[1], _lib.HF_F32, st), "hf_chan_affine_train")
             return
-        if u.train and u.fold:
-            # ... reduction and folding in ONE launch (the last workgroup finalises the per-channel vectors)
-            _lib.check(_lib.load().hf_bn_adjoint_rows_train(
-                None, _ptr(u.gw), _ptr(u.gb), None, _ptr(u.tbuf), u.sT, u.tbuf.shape[1], None, 1, 0, _ptr(u.a),
-                _ptr(u.mean), _ptr(u.rstd), None, None, n, k, oh * ow, u.rb, _ptr(u.ticket), _ptr(u.cq), _ptr(u.cr),
-                _ptr(u.scale), _ptr(vg), _ptr(vb), float(n * oh * ow), _lib.HF_F32,
-                _lib.current_stream_ptr(self.dev)), "hf_bn_adjoint_rows_train")
-            vg, vb = u.cq, u.cr
-        elif u.train:
-            # batch statistics move with the input: sums of a' and xhat*a' over the batch (the adjoint's
-            # reduction kernel on the tangent slabs), folded into the per-channel vectors of the same pass
-            lib, st = _lib.load(), _lib.current_stream_ptr(self.dev)
-            _lib.check(lib.hf_chan_affine_bwd_ex(
-                None, _ptr(u.gw), _ptr(u.gb), None, _ptr(u.tbuf), u.sT, u.tbuf.shape[1], None, 1, 0, _ptr(u.a),
-                _ptr(u.mean), _ptr(u.rstd), None, None, n, k, oh * ow, 1, u.rb, _lib.HF_F32, st),
-                "hf_chan_affine_bwd_ex")
-            self._train_coeffs(u, vg, vb)
-            vg, vb = u.cq, u.cr
         _lib.check(_lib.load().hf_chan_affine_ex(
             _ptr(u.tout), _ptr(u.tbuf), _ptr(u.a), _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale),
             _ptr(vg), _ptr(vb), _ptr(add), _ptr(u.y) if u.relu else None, 0, n, k, oh * ow, 1, u.tout_ld, add_ld,
             u.sT, u.tbuf.shape[1], _lib.HF_F32, _lib.current_stream_ptr(self.dev)), "hf_chan_affine_ex")
 
     def _train_pair_ok(self, u1, u2):
-        return (u1.train and u2.train and u1.pro and u2.pro
-                and os.environ.get("HF_BN_TRAIN_PAIR", "1") != "0")
+        return u1.train and u2.train and os.environ.get("HF_BN_TRAIN_PAIR", "1") != "0"
 
     def _affine_train_problem(self, q, u, out, out_ld, a, a_splits, a_slab, px, p1, nparts, vq, vr, mask):
         n, k, oh, ow = u.a.shape
@@ -1189,38 +1107,15 @@ class FusedGGNEngine(_Operator):
             # pass 1: g = mask * (sum of the cotangents' slabs) and its per-channel sums (the parameter
             # gradients); pass 2: g_a = rstd*w * [g - mean(g) - xhat * mean(xhat*g)] (the batch statistics'
             # share), by the elementwise kernel with the corrections folded into its per-channel vectors
-            if u.fuse:  # (both passes in one launch)
-                _lib.check(lib.hf_bn_rows_train_apply(
-                    _ptr(ga), 0, _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a),
-                    _ptr(u.mean), _ptr(u.rstd), _ptr(u.y) if u.relu else None, n, k, oh * ow, u.rb, _ptr(u.barrier),
-                    None, None, _ptr(u.scale), None, None, float(n * oh * ow), None, 0, None, _lib.HF_F32, st),
-                    "hf_bn_rows_train_apply")
-                return
-            if u.pro:  # (pass 2 adds the partial rows up in its prologue)
-                _lib.check(lib.hf_chan_affine_bwd_ex(
-                    None, _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a),
-                    _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.y) if u.relu else None, n, k, oh * ow, 1,
-                    u.rb, _lib.HF_F32, st), "hf_chan_affine_bwd_ex")
-                _lib.check(lib.hf_chan_affine_train(
-                    _ptr(ga), _ptr(u.g), _ptr(u.a), _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.gw),
-                    _ptr(u.gb), u.rb, None, None, float(n * oh * ow), None, None, n, k, oh * ow, 0, 0, 1, 0,
-                    _lib.HF_F32, st), "hf_chan_affine_train")
-                return
-            if u.fold:  # (pass 1 finalises those vectors itself: its last workgroup)
-                _lib.check(lib.hf_bn_adjoint_rows_train(
-                    None, _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a),
-                    _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.y) if u.relu else None, n, k, oh * ow, u.rb,
-                    _ptr(u.ticket), _ptr(u.cq), _ptr(u.cr), _ptr(u.scale), None, None, float(n * oh * ow),
-                    _lib.HF_F32, st), "hf_bn_adjoint_rows_train")
-            else:
-                _lib.check(lib.hf_chan_affine_bwd_ex(
-                    None, _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a),
-                    _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.y) if u.relu else None, n, k, oh * ow, 1,
-                    u.rb, _lib.HF_F32, st), "hf_chan_affine_bwd_ex")
-                self._train_coeffs(u, None, None)
-            _lib.check(lib.hf_chan_affine_ex(
-                _ptr(ga), _ptr(u.g), _ptr(u.a), _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.cq), _ptr(u.cr),
-                None, None, 0, n, k, oh * ow, 1, 0, 0, 1, 0, _lib.HF_F32, st), "hf_chan_affine_ex")
+            # (pass 2 adds the partial rows up in its prologue)
+            _lib.check(lib.hf_chan_affine_bwd_ex(
+                None, _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a),
+                _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.y) if u.relu else None, n, k, oh * ow, 1,
+                u.rb, _lib.HF_F32, st), "hf_chan_affine_bwd_ex")
+            _lib.check(lib.hf_chan_affine_train(
+                _ptr(ga), _ptr(u.g), _ptr(u.a), _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.gw),
+                _ptr(u.gb), u.rb, None, None, float(n * oh * ow), None, None, n, k, oh * ow, 0, 0, 1, 0,
+                _lib.HF_F32, st), "hf_chan_affine_train")
             return
         # g = mask * (sum of both cotangents' slabs) -> u.g; g * w*rstd -> u.ga; per-channel sums
         bn = u.bn is not None
@@ -1770,6 +1665,9 @@ class FusedGGNEngine(_Operator):
             u.y.copy_(u.ry)
             if u.yout2 is not None:
                 u.yout2.copy_(u.ry)
+            if u.train:  # (the own forward pass writes its batch statistics into the same buffers)
+                u.mean_t.copy_(u.rec_stats[0])
+                u.rstd.copy_(u.rec_stats[1])
         if self.pool_args is not None:
             ks, st_, pd, dl, cm = self.pool_args
             _, idx = torch.nn.functional.max_pool2d(self.stem.ry, ks, st_, pd, dl, cm, return_indices=True)
@@ -1782,16 +1680,20 @@ class FusedGGNEngine(_Operator):
         self.logits.copy_(outputs.detach())
         if getattr(self, "loss_spec", None) is not None:
             self._loss_head()
+        self._at = "recorded"
 
     def _verify(self, loss):
         """First product of every (model, shape) signature against the autograd operator, both on the
         activations the model's own forward pass recorded (``_load_recorded``)."""
         policy = os.environ.get("HF_ENGINE_VERIFY", "first")
-        key = ("hessian" if self.hessian else "ggn", id(self.model_ref),
+        key = ("hessian" if self.hessian else "ggn", self.train_bn,
                tuple(type(m).__name__ for m in self.model_ref.modules()), self.n,
                tuple(tuple(p.shape) for p in self.params), tuple(self.logits.shape), tuple(self.x_in.shape),
                str(self.dev))
-        if policy == "never" or (policy != "always" and key in FusedGGNEngine._verified):
+        # (kept ON the model: a registry keyed by id(model) outlives the model, and CPython hands the address of a
+        # collected model to the next one)
+        verified = self.model_ref.__dict__.setdefault("_hf_engine_verified", set())
+        if policy == "never" or (policy != "always" and key in verified):
             return
         gen = torch.Generator(device=self.dev).manual_seed(4321)
         v = torch.randn(self.n, device=self.dev, generator=gen)
@@ -1802,13 +1704,7 @@ class FusedGGNEngine(_Operator):
                 self.gradient()  # first-order cotangents at the recorded activations
             got = self.local(v).clone()
         finally:
-            self.weight = weight
-            if not self.train_bn:
-                self.forward_own()  # back to the engine's own activations
-            elif self.train_own:
-                self.forward_own(update_running=False)
-            if self.hessian:
-                self.gradient()
+            self.weight = weight  # (the constructor moves the engine to its final linearisation point afterwards)
         if self.hessian:
             from .curvature import HessianOperator
 
@@ -1821,7 +1717,7 @@ class FusedGGNEngine(_Operator):
                                f"(tolerance {FusedGGNEngine.verify_tol:.1e}); using the autograd operator")
             exc.loud = True
             raise exc
-        FusedGGNEngine._verified.add(key)
+        verified.add(key)
 
 
 class PlainStackEngine(FusedGGNEngine):
@@ -1936,6 +1832,7 @@ class PlainStackEngine(FusedGGNEngine):
         torch.mean(self.tail.y, dim=(2, 3), out=self.logits)
         if getattr(self, "loss_spec", None) is not None:
             self._loss_head()
+        self._at = "own"
         return self.logits
 
     # ---- product ------------------------------------------------------------------------------

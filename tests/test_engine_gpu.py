@@ -359,22 +359,26 @@ def test_train_mode_batchnorm_engine_product_matches_cpu_oracle_and_float64():
     assert final < opt.state["init_losses"][0]
 
 
-def test_train_mode_folded_kernels_equal_the_separate_launches(monkeypatch):
-    """Train-mode BatchNorm inside the product -- WHERE the per-channel finalisation runs (``HF_BN_TRAIN_FORM``):
-    its own launch between reduction and elementwise pass ("separate": ``hf_bn_train_coeffs``), the reduction launch's
-    last workgroup by ticket ("tail": ``hf_bn_adjoint_rows_train``), everything in one launch around a grid barrier
-    ("barrier": ``hf_bn_rows_train_apply``), or the prologue of the elementwise pass ("prologue":
-    ``hf_chan_affine_train``).  The four products agree to 1e-6 (the same partial sums, added in other fixed orders) and
-    each is bitwise repeatable.  Forward pass: the one-pass statistics (E[a^2] - mean^2 in fp64, ``hf_bn_stats_rows``)
-    against the second pass over a - mean: logits of this 20-layer net to 5e-6, batch means to 1e-6, rstd / running
-    variances to 5e-6 (max-norm relative)."""
+def test_train_mode_prologue_form_variants_agree_and_state_is_independent_of_the_first_use_check(monkeypatch):
+    """Train-mode BatchNorm inside the product: the per-channel finalisation runs in the prologue of the elementwise
+    pass (``hf_chan_affine_train``); the tangent's partial sums come from the convolution's own epilogue
+    (``hf_conv2d_nhwc_group_slabs_bnsum``) or -- ``HF_BN_EPILOGUE=0`` -- from the reduction launch; the downsample
+    blocks' two units share launches (``hf_chan_affine_train_pair``) or not (``HF_BN_TRAIN_PAIR=0``).  Same workgroup
+    code with and without the pair launches: the same bits.  Epilogue vs reduction launch: the epilogue multiplies
+    every SPLIT's partial tile by xhat and adds the products up in fp64, the reduction launch multiplies the fp32 sum
+    of the slabs -- 0.8e-6 ... 1.1e-6 of the product's max-norm measured over ten data seeds on two leases
+    (gpurun_out/r5a/diag2.jsonl): bound 5e-6.  Each form is bitwise repeatable.
+
+    GPUTEST_r04's red test, root cause: the engine's linearisation point after construction
+    depended on whether its first-use check ran -- skipped, a train-mode engine stayed at the model's recorded
+    activations with its OWN batch statistics -- and the check's registry was keyed by ``id(model)``, an address CPython
+    reuses.  So: an engine built with ``HF_ENGINE_VERIFY=never`` and one built with ``always`` must hold bitwise the
+    same activations, statistics and masks, and give bitwise the same product."""
     seed = tp.RESNET18_B32_SEPARATED_SEEDS[2]
     v = None
-    products = {}
-    for form in ("prologue", "prologue-no-pair", "prologue-no-epilogue", "barrier", "tail", "separate"):
-        monkeypatch.setenv("HF_BN_TRAIN_FORM", form.split("-")[0])
-        monkeypatch.setenv("HF_BN_EPILOGUE", "0" if form.endswith("no-epilogue") else "1")
-        monkeypatch.setenv("HF_BN_TRAIN_PAIR", "0" if form.endswith("no-pair") else "1")
+    products, states = {}, {}
+
+    def build():
         model, (x, t), lossf = tp.resnet18_mnist(batch_size=16, device=DEV, data_seed=seed)
         model.train()
         modelprep.prepare_model(model, channels_last=True)
@@ -382,71 +386,54 @@ def test_train_mode_folded_kernels_equal_the_separate_launches(monkeypatch):
         out = model(x)
         op = curvature.ggn_operator(lossf(out, t), out, params)
         assert isinstance(op, FusedGGNEngine) and op.train_bn and op.train_own
-        if form.startswith("prologue"):
-            assert all(u.pro and not u.fold for u in op.units)
-            # the tangent's partial sums by the convolution's own epilogue (hf_conv2d_nhwc_group_slabs_bnsum): every
-            # unit but the im2col'd stem, unless switched off
-            assert sum(u.epi for u in op.units) == (0 if form.endswith("no-epilogue") else len(op.units) - 1)
-        elif form == "barrier":
-            assert all(u.fuse for u in op.units)  # (the one-launch form takes the late 1x1 / 2x2 maps too)
-        elif form == "tail":
-            assert sum(u.fold and not u.fuse for u in op.units) >= 10
-        else:
-            assert not any(u.pro or u.fold or u.fuse for u in op.units)
+        return op
+
+    for form in ("default", "no-pair", "no-epilogue", "verify-never", "verify-always"):
+        monkeypatch.setenv("HF_BN_EPILOGUE", "0" if form == "no-epilogue" else "1")
+        monkeypatch.setenv("HF_BN_TRAIN_PAIR", "0" if form == "no-pair" else "1")
+        monkeypatch.setenv("HF_ENGINE_VERIFY", form.split("-")[1] if form.startswith("verify") else "first")
+        op = build()
+        # the tangent's partial sums by the convolution's own epilogue: every unit but the im2col'd stem, unless off
+        assert sum(u.epi for u in op.units) == (0 if form == "no-epilogue" else len(op.units) - 1)
         if v is None:
             v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(41))
         got = op(v).clone()
-        for _ in range(10):  # (fixed summation orders, also on both sides of the grid barrier)
+        for _ in range(10):
             assert torch.equal(op(v), got)
-        if form == "prologue":
-            assert all(u.tsum == u.epi for u in op.units) and sum(u.tsum for u in op.units) == len(op.units) - 1
+        assert all(u.tsum == u.epi for u in op.units)
         products[form] = got
-    # (the downsample blocks' two units in one launch each -- hf_chan_affine_train_pair, hf_chan_affine_bwd_pair --
-    # or in launches of their own: the same workgroup code, the same bits)
-    assert torch.equal(products["prologue"], products["prologue-no-pair"])
-    ref = products["separate"]
-    for form, got in products.items():
-        # (the convolution's epilogue multiplies every SPLIT's partial tile by xhat and adds the products up in fp64;
-        # the reduction launch multiplies the fp32 sum of the slabs: 1.0e-6 measured between the two)
-        assert float((got - ref).abs().max() / ref.abs().max()) < (3e-6 if form in ("prologue", "prologue-no-pair") else 1e-6), form
-    # forward pass (the engine of the last form): both variants from the same running statistics
-    folded = [u for u in op.units if u.stats_fold]
-    assert len(folded) >= 10
+        states[form] = [t.clone() for u in op.units for t in (u.a, u.y, u.mean_t, u.rstd)]
+    assert torch.equal(products["default"], products["no-pair"])
+    ref = products["no-epilogue"]
+    assert float((products["default"] - ref).abs().max() / ref.abs().max()) < 5e-6
+    for form in ("verify-never", "verify-always"):
+        assert torch.equal(products[form], products["default"]), form
+        assert all(torch.equal(a, b) for a, b in zip(states[form], states["default"])), form
+    # forward pass: the one-pass statistics (E[a^2] - mean^2 in fp64) against torch's batch_norm on the same summed
+    # convolution output, per unit: batch means 1e-6, rstd 5e-6 (max-norm relative); running statistics moved once
     saved = [(u.bn.running_mean.clone(), u.bn.running_var.clone(), u.bn.num_batches_tracked.clone()) for u in op.units]
-
-    def restore():
-        for u, (m, var, nb) in zip(op.units, saved):
-            u.bn.running_mean.copy_(m)
-            u.bn.running_var.copy_(var)
-            u.bn.num_batches_tracked.copy_(nb)
 
     def rel(a, b):
         return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
-    for u in folded:
-        u.stats_fold = False
     op.forward_own(update_running=True)
-    ref = (op.logits.clone(), [(u.mean_t.clone(), u.rstd.clone(), u.bn.running_mean.clone(), u.bn.running_var.clone())
-                               for u in op.units])
-    # one-pass statistics, finalised by the reduction launch's last workgroup (fwd_pro False) resp. in the prologue of
-    # the normalising launch (``hf_bn_forward_train``, the default)
-    assert all(u.fwd_pro for u in folded)
-    for pro in (False, True):
-        restore()
-        for u in folded:
-            u.stats_fold, u.fwd_pro = True, pro
-        op.forward_own(update_running=True)
-        assert rel(op.logits, ref[0]) < 5e-6
-        for u, (m, r, rm, rv) in zip(op.units, ref[1]):
-            # (the two-pass variance subtracts the fp32-ROUNDED mean: it is the less exact of the two, 1.5e-6 measured)
-            assert rel(u.mean_t, m) < 1e-6 and rel(u.rstd, r) < 5e-6
-            assert rel(u.bn.running_mean, rm) < 1e-6 and rel(u.bn.running_var, rv) < 5e-6
-        assert int(op.units[0].bn.num_batches_tracked) == int(saved[0][2]) + 1
-        logits = op.logits.clone()
-        restore()
-        op.forward_own(update_running=True)
-        assert torch.equal(op.logits, logits)  # (bitwise repeatable)
-    restore()
+    logits = op.logits.clone()
+    for u, (rm, rv, nb) in zip(op.units, saved):
+        a64 = u.a.double()
+        mean = a64.mean(dim=(0, 2, 3))
+        var = a64.var(dim=(0, 2, 3), unbiased=False)
+        cnt = a64.numel() / a64.shape[1]
+        assert rel(u.mean_t.double(), mean) < 1e-6 and rel(u.rstd.double(), (var + u.bn.eps).rsqrt()) < 5e-6
+        mom = u.bn.momentum
+        assert rel(u.bn.running_mean.double(), (1 - mom) * rm.double() + mom * mean) < 1e-6
+        assert rel(u.bn.running_var.double(), (1 - mom) * rv.double() + mom * var * cnt / (cnt - 1)) < 5e-6
+        assert int(u.bn.num_batches_tracked) == int(nb) + 1
+    for u, (rm, rv, nb) in zip(op.units, saved):
+        u.bn.running_mean.copy_(rm)
+        u.bn.running_var.copy_(rv)
+        u.bn.num_batches_tracked.copy_(nb)
+    op.forward_own(update_running=True)
+    assert torch.equal(op.logits, logits)  # (bitwise repeatable)
 
 
 @pytest.mark.parametrize("case", ["allcnnc_l2", "allcnnc_hessian", "resnet18", "resnet18_sum"])
@@ -835,8 +822,7 @@ def test_train_mode_batchnorm_launches_against_float64_formulas(rows, ch, splits
     """The launches of a train-mode BatchNorm unit, each against the float64 formula it implements (C ABI, no engine):
     ``hf_chan_affine_bwd_ex`` (partial rows) + ``hf_chan_affine_train`` (adds them up in its prologue) =
     ``mask * (w*rstd * [t - mean(t) - xhat*mean(xhat*t)] + xhat*vq + vr + add)`` with ``t`` the sum of the slabs;
-    ``hf_bn_rows_train_apply`` (the same in one launch around a grid barrier) agrees with it to 1e-6;
-    ``hf_bn_stats_rows`` (no ticket) + ``hf_bn_forward_train`` = ``F.batch_norm(training=True)`` + residual + ReLU,
+    ``hf_bn_stats_rows`` + ``hf_bn_forward_train`` = ``F.batch_norm(training=True)`` + residual + ReLU,
     batch statistics and moved running statistics included.  Tolerances: 2e-6 of the output's max-norm."""
     from pytorchhessianfree_amd import _lib
 
@@ -876,26 +862,14 @@ def test_train_mode_batchnorm_launches_against_float64_formulas(rows, ch, splits
                                         float(rows), p(add), p(y), rows, ch, 1, 2 * ch, 2 * ch, splits, rows * ch,
                                         _lib.HF_F32, st), "hf_chan_affine_train")
     assert torch.equal(again[:, :ch], out[:, :ch])
-    # the same in one launch around a grid barrier
-    if rb > 1:
-        gw2, gb2, g = torch.empty_like(gw), torch.empty_like(gb), torch.empty(rows, ch, device=DEV)
-        bar = torch.zeros(1, dtype=torch.int64, device=DEV)
-        one = torch.empty(rows, 2 * ch, device=DEV)
-        for _ in range(3):  # (the arrival counter is never reset: the k-th launch waits for k * rb arrivals)
-            _lib.check(lib.hf_bn_rows_train_apply(p(one), 2 * ch, p(gw2), p(gb2), p(g), p(slabs), splits, rows * ch, None,
-                                                  1, 0, p(a), p(mean), p(rstd), None, rows, ch, 1, rb, p(bar), None, None,
-                                                  p(w), p(vq), p(vr), float(rows), p(add), 2 * ch, p(y), _lib.HF_F32, st),
-                       "hf_bn_rows_train_apply")
-        assert int(bar) == 3 * rb
-        assert float((one[:, :ch] - out[:, :ch]).abs().max()) < 1e-6 * float(want.abs().max())
     # forward: one-pass statistics' partial rows + the normalising launch that finalises them
     part = torch.empty(rb, 2, ch, dtype=torch.float64, device=DEV)
     asum = torch.empty(rows, ch, device=DEV)
     bn_w, bn_b, res = r_(ch), r_(ch), r_(rows, ch)
     rm, rv = r_(ch), r_(ch).abs() + 0.5
     rm0, rv0 = rm.clone(), rv.clone()
-    _lib.check(lib.hf_bn_stats_rows(p(asum), p(slabs), splits, rows * ch, p(part), None, None, None, None, None,
-                                    float(rows), 1e-5, -1.0, rows, ch, rb, _lib.HF_F32, st), "hf_bn_stats_rows")
+    _lib.check(lib.hf_bn_stats_rows(p(asum), p(slabs), splits, rows * ch, p(part), rows, ch, rb, _lib.HF_F32, st),
+               "hf_bn_stats_rows")
     assert torch.equal(asum.view(-1), slabs.sum(0)) or float((asum.view(-1) - slabs.sum(0)).abs().max()) < 1e-5
     m_out, r_out = torch.empty(ch, device=DEV), torch.empty(ch, device=DEV)
     yy, y2 = torch.empty(rows, ch, device=DEV), torch.full((rows, 2 * ch), float("nan"), device=DEV)
