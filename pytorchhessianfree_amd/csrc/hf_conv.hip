@@ -1264,7 +1264,7 @@ int hf_conv2d_nhwc_slabs_unpack(void* out, const void* act, const void* mat, int
   hf_shared::UnpackArgs u;
   int ublocks = 0;
   const int next = hf_shared::fill_unpack_args<float>(u, &ublocks, 0, udsts, usrc_offs, unumels, uslabs, uinners,
-                                                      ulive, uhalves, n_tensors);
+                                                      ulive, uhalves, n_tensors, /*allow_transposed=*/false);
   if (next < 0) return next;
   if (next != n_tensors || ublocks < 1) return HF_ERR_ARG;  // more tensors than one argument block holds
   seal(a, 0);

@@ -473,7 +473,7 @@ static int unpack_impl(const void* src, void* const* dsts, const int64_t* src_of
   while (t < nt) {
     UnpackArgs a;
     int blocks = 0;
-    t = hf_shared::fill_unpack_args<T>(a, &blocks, t, dsts, src_offs, numels, slabs, inners, live, halves, nt);
+    t = hf_shared::fill_unpack_args<T>(a, &blocks, t, dsts, src_offs, numels, slabs, inners, live, halves, nt, true);
     if (t < 0) return t;
     if (blocks == 0) continue;
     hipLaunchKernelGGL((k_unpack_tangent<T>), dim3(blocks), dim3(BLOCK), 0, s, (const T*)src, a);

@@ -107,6 +107,7 @@ __device__ __forceinline__ void unpack_block(const T* __restrict__ src_base, con
 // stores O floats apart: 157 us for the 44.7 MB of a ResNet-18 vector, once per Hessian product).
 // Returns false when workgroup `bid` belongs to a tensor of another kind.  lds: TT * (TT + 1) elements.
 constexpr int TT = 64;
+static_assert(BLOCK % TT == 0 && BLOCK >= TT, "unpack_transposed_block walks BLOCK / TT rows of a TT x TT tile per pass");
 template <typename T>
 __device__ __forceinline__ bool unpack_transposed_block(const T* __restrict__ src_base, const UnpackArgs& a,
                                                         unsigned bid, T* lds) {
@@ -143,7 +144,10 @@ __device__ __forceinline__ bool unpack_transposed_block(const T* __restrict__ sr
 template <typename T>
 inline int fill_unpack_args(UnpackArgs& a, int* blocks_out, int t, void* const* dsts, const int64_t* src_offs,
                             const int64_t* numels, const int64_t* slabs, const int64_t* inners, const int64_t* live,
-                            const int64_t* halves, int nt) {
+                            const int64_t* halves, int nt, bool allow_transposed) {
+  // allow_transposed: the caller's kernel runs unpack_transposed_block for half == 2 tensors (k_unpack_tangent does;
+  // a launch that only runs unpack_block -- the convolution carrying the scatter -- must refuse them: unpack_block
+  // returns without writing anything for such a tensor)
   memset(&a, 0, sizeof(a));
   int k = 0, blocks = 0;
   while (t < nt && k < PACK_MAXT) {
@@ -161,7 +165,7 @@ inline int fill_unpack_args(UnpackArgs& a, int* blocks_out, int t, void* const* 
       if (live && live[t] > 0 && I > 0 && slab / I <= 16)
         a.live[k] = (unsigned short)(live[t] & ((1 << (slab / I)) - 1));
       a.half[k] = (unsigned char)(!halves ? 1 : halves[t] == 0 ? 0 : halves[t] == 2 ? 2 : 1);
-      if (a.half[k] == 2 && I <= 0) return HF_ERR_ARG;
+      if (a.half[k] == 2 && (I <= 0 || !allow_transposed)) return HF_ERR_ARG;
       // (LDS-staged NHWC variants measured slower twice: round 1 30.9 vs 24.5 us; round 3 -- contiguous 16-byte
       // reads into LDS, lane = channel on the way out -- 21.2 vs 14.3 us, scripts/experiments/unpack_time.py)
       a.chunk[k] = PACK_CHUNK;

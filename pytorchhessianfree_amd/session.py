@@ -110,8 +110,11 @@ class _TwoPhaseProduct:
         self.g_a.instantiate()
         self.g_b.instantiate()
         self._chain, self.use_chain = None, False
-        mode = os.environ.get("HF_CHUNK_ONEGRAPH", "auto")
-        if mode != "0":
+        # (opt-in: the chained launch -- an event-record node inside the graph, a host hipStreamWaitEvent right after
+        # the launch -- has only ever run on a 1-rank RCCL group, where the all-reduce is the identity; until a
+        # multi-rank RCCL run shows it bitwise equal to the two-launch form it is not a candidate of the measured choice)
+        mode = os.environ.get("HF_CHUNK_ONEGRAPH", "0")
+        if mode == "1":
             handle = _lib.c_void_p()
             rc = _lib.load().hf_graph_chain_create(_lib.ctypes.byref(handle), _lib.c_void_p(self.g_a.raw_cuda_graph()),
                                                    _lib.c_void_p(self.g_b.raw_cuda_graph()))
@@ -417,6 +420,10 @@ class EngineSession(_TwoPhaseProduct):
         sync = torch.zeros(2, dtype=torch.float64, device=self.engine.dev)
         # candidates: single graph; two launches; (direct RCCL only) the two graphs chained into ONE launch
         chain_ok = self._chain is not None and hfdist.side_comm(self.output_buffer, self.group) is not None
+        # (one candidate list for all ranks: a rank whose chain could not be built must not time a shorter list)
+        flag = torch.tensor([1.0 if chain_ok else 0.0], dtype=torch.float64, device=self.engine.dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        chain_ok = bool(flag.item() > 0.5)
         cands = [("single_graph", None, False), ("two_phase", self._split_plan, False)]
         if chain_ok:
             cands.append(("two_phase_one_launch", self._split_plan, True))
@@ -647,6 +654,12 @@ class AccumulatedSession:
                 engines.append(eng)
                 del out, loss
             self.engines = engines
+            self._layers = [e.layer_signature() for e in engines]
+            # (the compact all-reduce layout -- which kernel taps can meet data -- is engine[0]'s: it depends on the
+            # chunks' spatial shape, so all chunks must share everything but the batch size)
+            if any(tuple(sh[1:]) != tuple(self.shapes[0][1:]) for sh in self.shapes):
+                cur.wait_stream(self.stream)
+                raise _NoEngine()
             e0 = engines[0]
             self.engine = e0
             self.n, self.dev = e0.n, e0.dev
@@ -795,7 +808,12 @@ class AccumulatedSession:
         slots, roles = self._plan(lists)
         if (model is not self.model or loss_func is not self.loss_func or reduction != self.reduction
                 or bool(hessian) != self.hessian or group is not self.group or roles != self.roles
-                or tuple(float(c) for c in counts) != self.counts or model.training != self.train_bn):
+                or tuple(float(c) for c in counts) != self.counts):
+            return None
+        # (what the captured graphs bake in about the layers -- module identities, every BatchNorm's mode / eps /
+        # momentum, the model's mode where it matters -- as EngineSession compares it; not model.training itself: an
+        # eval() model with one train-mode BatchNorm is a train_bn session)
+        if any(eng.layer_signature() != sig for eng, sig in zip(self.engines, self._layers)):
             return None
         if [tuple(x.shape) for x, _ in slots] != self.shapes:
             return None

@@ -4,6 +4,8 @@ arrays stored in tests/golden (no RNG agreement with the generator needed)."""
 import numpy as np
 import torch
 
+from tol import within
+
 
 def T(a, device="cpu", dtype=None):
     t = torch.from_numpy(np.asarray(a).copy())
@@ -59,40 +61,112 @@ def lowrank_operator(g, key, device, dtype=torch.float32):
     return A, B, damping
 
 
-_CPU_STEPS = {}
+# ---------------------------------------------------------------------------------------------------------
+# Conv-net reference traces (tests/golden/convnet_*.npz, written by tests/golden/make_golden_convnets.py from the REAL
+# reference in the build container): the GPU tests take their reference side from these files instead of re-running
+# a CPU path on the GPU box's host cores.
+# ---------------------------------------------------------------------------------------------------------
+_GOLDEN_CACHE = {}
 
 
-def cpu_resnet18_default_steps(n_steps):
-    """``n_steps`` default ``HessianFree.step()`` calls of the single-process CPU path on the 32-sample ResNet-18
-    batches of ``RESNET18_B32_SEPARATED_SEEDS`` -- stock model, torch autograd, host logic with the oracle PCG (the
-    reference's algorithm, pinned bit for bit by tests/golden/make_golden.py).  Returns ``(state, finals, params)``
-    truncated to ``n_steps``; computed once per pytest process (the longest run so far serves the shorter ones:
-    the steps are sequential)."""
-    import warnings
+def convnet_golden(family):
+    import os
 
-    import pytorchhessianfree_amd as hf
-    from oracle import pcg as oracle
-    from pytorchhessianfree_amd import testproblems as tp
+    if family not in _GOLDEN_CACHE:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"convnet_{family}.npz")
+        _GOLDEN_CACHE[family] = np.load(path, allow_pickle=False)
+    return _GOLDEN_CACHE[family]
 
-    run = _CPU_STEPS.get("run")
-    if run is None:
-        seeds = tp.RESNET18_B32_SEPARATED_SEEDS
-        model, _, lossf = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=seeds[0])
-        opt = hf.HessianFree(model.parameters())
-        opt._cg = oracle.pcg
-        run = _CPU_STEPS["run"] = dict(model=model, lossf=lossf, opt=opt, finals=[], params=[])
-    model, lossf, opt = run["model"], run["lossf"], run["opt"]
-    while len(run["finals"]) < n_steps:  # (continue the same run: the steps are sequential)
-        i = len(run["finals"])
-        _, (x, t), _ = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=tp.RESNET18_B32_SEPARATED_SEEDS[i])
 
-        def forward():
-            o = model(x)
-            return lossf(o, t), o
+def sha1_of(t):
+    import hashlib
 
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            run["finals"].append(opt.step(forward))
-        run["params"].append(torch.cat([p.detach().reshape(-1) for p in opt._params_list]).numpy().copy())
-    state = {k: list(v[:n_steps]) for k, v in opt.state.items() if isinstance(v, list)}
-    return state, run["finals"][:n_steps], run["params"][n_steps - 1]
+    return hashlib.sha1(t.detach().contiguous().cpu().numpy().tobytes()).hexdigest()
+
+
+class RefTrace:
+    """One run of the reference stored under ``key`` of a conv-net fixture: ``state`` (the optimizer's lists),
+    ``finals``, index sample + norms of the vectors the generator kept."""
+
+    def __init__(self, family, key):
+        self.g, self.key = convnet_golden(family), key
+        g = self.g
+        self.index = torch.from_numpy(g[f"index_{int(g[key + '/n'])}"])
+        names = ("init_losses", "dampings", "cg_reasons", "num_cg_iters", "best_cg_iters", "learning_rates")
+        if f"{key}/state/init_losses" in g.files:
+            self.state = {k: g[f"{key}/state/{k}"].tolist() for k in names}
+            self.finals = g[key + "/final_losses"].tolist()
+
+    def _path(self, name):
+        return self.key if not name else f"{self.key}/{name}"
+
+    def has(self, name):
+        return self._path(name) in self.g.files
+
+    def scalar(self, name):
+        return self.g[self._path(name)].item()
+
+    def array(self, name):
+        return self.g[self._path(name)]
+
+    def check_inputs(self, params=None, x=None, step=None):
+        """The problem the GPU test built IS the generator's: digests of the initial flat parameter vector and of the
+        input batch (both made on the CPU from seeds, before any ``.to(device)``)."""
+        if params is not None:
+            flat = torch.cat([p.detach().reshape(-1).cpu() for p in params])
+            assert sha1_of(flat) == str(self.array("init_sha1")), "initial parameters differ from the generator's"
+        if x is not None:
+            name = "inputs_sha1" if step is None else f"inputs_sha1/{step}"
+            assert sha1_of(x) == str(self.array(name)), "input batch differs from the generator's"
+
+    def probe(self):
+        """The CPU-seeded vector a stored product was taken of (``put_product``): regenerated, digest checked."""
+        n = int(self.scalar("n"))
+        v = torch.randn(n, generator=torch.Generator().manual_seed(int(self.scalar("v_seed"))))
+        assert sha1_of(v) == str(self.array("v_sha1")), "probe vector differs from the generator's"
+        return v
+
+    # a stored vector ``name`` ("" = the key itself): index sample, l2 norm and max-norm of the full vector
+    def sample(self, name=""):
+        return torch.from_numpy(self.array((name + "/" if name else "") + "sample").astype(np.float64))
+
+    def _got(self, v):
+        return v.detach().reshape(-1)[self.index.to(v.device)].double().cpu()
+
+    def vec_err(self, name, v):
+        """max |v[idx] - ref[idx]| / max |ref| over the stored index sample (``v``: the full vector, any device)."""
+        absmax = self.scalar((name + "/" if name else "") + "absmax")
+        return float((self._got(v) - self.sample(name)).abs().max() / max(absmax, 1e-300))
+
+    def vec_rel_l2(self, name, v):
+        """||v[idx] - ref[idx]|| / ||ref[idx]|| over the stored index sample."""
+        ref = self.sample(name)
+        return float((self._got(v) - ref).norm() / ref.norm().clamp_min(1e-300))
+
+    def vec_cos(self, name, v):
+        ref, got = self.sample(name), self._got(v)
+        return float(got @ ref / (got.norm() * ref.norm()).clamp_min(1e-300))
+
+    def norm_err(self, name, v):
+        want = self.scalar((name + "/" if name else "") + "norm")
+        return abs(float(v.detach().double().norm()) - want) / max(want, 1e-300)
+
+
+def compare_trace(got_state, got_finals, ref, steps=None, loss_tol=1e-5, final_tol=1e-4, iters=2, best=None):
+    """The discrete entries of a ``step`` / ``acc_step`` trace identical to the reference's (termination reasons,
+    learning rates, damping schedule), initial / final losses within the stated fp32 tolerances, iteration counts
+    within ``iters``."""
+    sc = ref.state
+    n = len(got_state["init_losses"]) if steps is None else steps
+    for a, b in zip(got_state["init_losses"][:n], sc["init_losses"][:n]):
+        within(abs(a - b), loss_tol * abs(b), strict=False, note=(got_state["init_losses"], sc["init_losses"]))
+    assert list(got_state["cg_reasons"][:n]) == list(sc["cg_reasons"][:n]), (got_state["cg_reasons"], sc["cg_reasons"])
+    assert list(got_state["learning_rates"][:n]) == list(sc["learning_rates"][:n])
+    assert list(got_state["dampings"][:n]) == list(sc["dampings"][:n])
+    for a, b in zip(got_state["num_cg_iters"][:n], sc["num_cg_iters"][:n]):
+        assert abs(a - b) <= iters, (got_state["num_cg_iters"], sc["num_cg_iters"])
+    for a, b in zip(got_finals[:n], ref.finals[:n]):
+        within(abs(a - b), final_tol * abs(b), strict=False, note=(got_finals, ref.finals))
+    if best is not None:
+        for a, b in zip(got_state["best_cg_iters"][:n], sc["best_cg_iters"][:n]):
+            assert abs(int(a) - int(b)) <= best, (got_state["best_cg_iters"], sc["best_cg_iters"])

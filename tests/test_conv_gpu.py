@@ -10,6 +10,7 @@ atomic accumulation do not give)."""
 
 import pytest
 import torch
+from tol import within
 
 from pytorchhessianfree_amd import _lib
 
@@ -70,16 +71,16 @@ def test_three_directions_match_float64(geom):
     for _ in range(2):  # the second round runs on recycled tickets / workspace
         y = _cl(torch.empty(n, k, oh, ow, device=DEV))
         _lib.conv2d_nhwc(0, y, x, w, n, h, w_, c, k, r, s, stride, padding)
-        assert rel(y, y64) < 2e-5
+        within(rel(y, y64), 2e-5)
 
         wT = w.permute(1, 2, 3, 0).contiguous()  # (I, H, W, O)
         gx = _cl(torch.empty(n, c, h, w_, device=DEV))
         _lib.conv2d_nhwc(1, gx, gy, wT, n, h, w_, c, k, r, s, stride, padding)
-        assert rel(gx, gx64) < 2e-5
+        within(rel(gx, gx64), 2e-5)
 
         gw = torch.zeros_like(w)
         _lib.conv2d_nhwc(2, gw, x, gy, n, h, w_, c, k, r, s, stride, padding)
-        assert rel(gw, gw64) < 2e-5
+        within(rel(gw, gw64), 2e-5)
 
         # data + weight gradient in ONE launch: the same numbers as the two separate launches
         if c % 4 == 0 and k % 4 == 0:  # (the merged launch has the 16-byte gather variant only)
@@ -96,7 +97,7 @@ def test_three_directions_match_float64(geom):
                 slabs = torch.zeros((sp, numel), device=DEV)  # (zeros: direction 2 skips dead taps)
                 _lib.conv2d_nhwc_slabs(d, slabs, act, mat, n, h, w_, c, k, r, s, stride, padding, sp)
                 got = slabs.sum(0).view(shape).permute(0, 3, 1, 2)
-                assert rel(got, ref) < 2e-5, (d, sp)
+                within(rel(got, ref), 2e-5, note=(d, sp))
 
         # bitwise repeatable
         y2, gx2, gw2 = torch.empty_like(y), torch.empty_like(gx), torch.zeros_like(w)
@@ -116,7 +117,7 @@ def test_channel_slice_of_a_wider_buffer():
     y = _cl(torch.empty(n, k, h, w_, device=DEV))
     _lib.conv2d_nhwc(0, y, x, w, n, h, w_, c, k, 3, 3, (1, 1), (1, 1), act_ld=2 * c)
     want = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
-    assert float((y.double() - want).abs().max() / want.abs().max()) < 2e-5
+    within(float((y.double() - want).abs().max() / want.abs().max()), 2e-5)
 
 
 def test_bad_geometry_is_refused():
@@ -146,7 +147,7 @@ def test_weight_slice_of_a_wider_buffer():
     _lib.conv2d_nhwc_slabs(0, out, x, wcat, n, h, w_, c, k, 3, 3, (1, 1), (1, 1), sp, mat_ld=2 * c)
     y = out.sum(0).view(n, h, w_, k).permute(0, 3, 1, 2)
     want = torch.nn.functional.conv2d(x.double(), wcat[:, :c].double(), None, 1, 1)
-    assert float((y.double() - want).abs().max() / want.abs().max()) < 2e-5
+    within(float((y.double() - want).abs().max() / want.abs().max()), 2e-5)
 
 
 def test_more_output_tiles_than_tickets_runs_unsplit():
@@ -160,7 +161,7 @@ def test_more_output_tiles_than_tickets_runs_unsplit():
     y = _cl(torch.empty(n, k, h, w_, device=DEV))
     _lib.conv2d_nhwc(0, y, x, w, n, h, w_, c, k, 3, 3, (1, 1), (1, 1))
     want = torch.nn.functional.conv2d(x, w, None, 1, 1)
-    assert float((y - want).abs().max() / want.abs().max()) < 2e-5
+    within(float((y - want).abs().max() / want.abs().max()), 2e-5)
     from pytorchhessianfree_amd import modelprep
 
     conv = torch.nn.Conv2d(c, k, 3, 1, 1, bias=False).to(DEV)
@@ -168,7 +169,7 @@ def test_more_output_tiles_than_tickets_runs_unsplit():
     modelprep.fuse_conv_tangent(net, channels_last=True)
     got = net(x)
     ref = torch.nn.functional.conv2d(x.double(), conv.weight.detach().double(), None, 1, 1)
-    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    within(float((got.double() - ref).abs().max() / ref.abs().max()), 2e-5)
     (g,) = torch.autograd.grad(got.sum(), conv.weight)
     assert torch.isfinite(g).all()
 
@@ -209,7 +210,7 @@ def test_convolution_launch_carrying_the_weight_scatter_equals_the_two_launches(
             assert torch.equal(ba, bb)
         got = out_b.sum(0).view(rows, k).double()
         want = cols.double() @ vw.view(k, c).double().t()
-        assert float((got - want).abs().max() / want.abs().max()) < 2e-5
+        within(float((got - want).abs().max() / want.abs().max()), 2e-5)
         assert not torch.equal(slots_b[0][1], torch.full_like(slots_b[0][1], 7.0))  # (the scatter really ran)
     # a large-map geometry runs the 128-wide configuration: the merged launch declines it
     n, h, c, k = 32, 32, 96, 96
@@ -258,7 +259,7 @@ def test_tangent_convolution_with_batchnorm_partial_sums_in_its_epilogue(geom):
     xhat = ((a - mean) * rstd).double()
     for got, ref, mag in ((p1, t64.sum(0), t64.abs().sum(0)), (px, (t64 * xhat).sum(0), (t64 * xhat).abs().sum(0))):
         assert torch.isfinite(got).all()
-        assert float(((got.double().sum(0) - ref).abs() / mag.clamp_min(1e-30)).max()) < 2e-6
+        within(float(((got.double().sum(0) - ref).abs() / mag.clamp_min(1e-30)).max()), 2e-6)
     p1b, pxb = torch.empty_like(p1), torch.empty_like(px)
     assert _lib.conv_group_slabs_bnsum(probs, [(a, mean, rstd, pxb, p1b)], DEV)
     assert torch.equal(p1b, p1) and torch.equal(pxb, px)

@@ -3,14 +3,15 @@ engine and its hipGraphs kept across ``HessianFree.step()`` calls, the forward p
 trial losses of LM damping, CG-backtracking and the line search as graph replays on static buffers
 (reference ``/root/reference/hessianfree/optimizer.py:216-234, :288-350``).
 
-Oracle: the CPU path -- stock model, torch autograd, and the host logic with ``oracle.pcg`` (the
-reference's PCG restated, pinned bit for bit by tests/golden/make_golden.py) plugged in.  Stated fp32
-tolerances are written at the assertions."""
+Reference side: traces of the REAL reference (``hessianfree.optimizer.HessianFree`` on the stock CPU models, run in
+the build container by tests/golden/make_golden_convnets.py) committed under tests/golden/convnet_*.npz -- nothing is
+recomputed on the GPU box's host cores.  Stated fp32 tolerances are written at the assertions."""
 
 import warnings
 
 import pytest
 import torch
+from tol import within
 
 import pytorchhessianfree_amd as hf
 from pytorchhessianfree_amd import curvature, modelprep
@@ -28,30 +29,26 @@ def _prepared(batch=32, seed=SEEDS[0]):
     return model, x, t, lossf
 
 
-def _cpu_reference(batch=32, seed=SEEDS[0]):
-    model, (x, t), lossf = tp.resnet18_mnist(batch_size=batch, device="cpu", data_seed=seed)
-    params = [p for p in model.parameters() if p.requires_grad]
-    out = model(x)
-    loss = lossf(out, t)
-    grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, params)])
-    return out.detach(), float(loss), grad
+def test_engine_forward_loss_and_gradient_match_reference():
+    """The engine's own forward pass (own kernels on static buffers), its loss value and its one-sweep gradient
+    against the reference's CPU run (golden ``solve_martens``: stock model, ``torch.autograd.grad``): logits 5e-6
+    (max-norm relative), loss 2e-6, gradient 5e-6 on the stored index sample, its l2 norm 1e-5."""
+    from helpers import RefTrace
 
-
-def test_engine_forward_loss_and_gradient_match_cpu_reference():
-    """The engine's own forward pass (own kernels on static buffers), its loss value and its
-    one-sweep gradient against stock torch autograd on the CPU: logits 2e-6 (max-norm relative),
-    loss 1e-6, gradient 2e-6."""
+    ref = RefTrace("resnet18", "solve_martens")
+    cm, (cx, _), _ = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=SEEDS[0])
+    ref.check_inputs([p for p in cm.parameters() if p.requires_grad], cx)
     model, x, t, lossf = _prepared()
     params = [p for p in model.parameters() if p.requires_grad]
     out = model(x)
     sess = EngineSession.try_create(lossf(out, t), out, params)
     assert sess is not None
-    want_out, want_loss, want_grad = _cpu_reference()
     eng = sess.engine
-    assert float((eng.logits.cpu() - want_out).abs().max() / want_out.abs().max()) < 2e-6
-    assert abs(float(eng.loss_buf) - want_loss) <= 1e-6 * abs(want_loss)
-    got = sess.gradient().cpu()
-    assert float((got - want_grad).abs().max() / want_grad.abs().max()) < 2e-6
+    want_out = torch.from_numpy(ref.array("logits"))
+    within(float((eng.logits.cpu() - want_out).abs().max() / want_out.abs().max()), 5e-6)
+    within(abs(float(eng.loss_buf) - ref.scalar("loss")), 2e-6 * abs(ref.scalar("loss")), strict=False)
+    got = sess.gradient()
+    assert ref.vec_err("grad", got) < 5e-6 and ref.norm_err("grad", got) < 1e-5
     # a second replay of everything is bitwise the same
     first = sess.gradient().clone()
     sess.g_fwd.replay()
@@ -80,28 +77,29 @@ def test_session_refreshes_for_new_batch_and_new_parameters():
     spec = sess.accepts(loss2, out2, params, 1.0, None)
     assert spec is not None
     own = sess.begin_step(out2, spec)
-    assert abs(float(own) - float(loss2)) <= 5e-6 * abs(float(loss2))
+    within(abs(float(own) - float(loss2)), 5e-6 * abs(float(loss2)), strict=False)
     want_grad = curvature.flatten_into(torch.autograd.grad(loss2, params, retain_graph=True), params)
-    assert float((sess.gradient() - want_grad).abs().max() / want_grad.abs().max()) < 2e-6
+    within(float((sess.gradient() - want_grad).abs().max() / want_grad.abs().max()), 2e-6)
     v = torch.randn(sess.n, device=DEV, generator=gen)
     want = curvature.GGNOperator(loss2, out2, params)(v)
-    assert float((sess(v) - want).abs().max() / want.abs().max()) < 2e-6
+    within(float((sess(v) - want).abs().max() / want.abs().max()), 2e-6)
 
 
-def _run_steps(device, steps, session=True):
-    from oracle import pcg as oracle
-
-    model, _, lossf = tp.resnet18_mnist(batch_size=32, device=device, data_seed=SEEDS[0])
-    if device != "cpu":
-        modelprep.prepare_model(model, channels_last=True)
-    opt = hf.HessianFree(model.parameters(), graph_matvec=(device != "cpu"))
-    if device == "cpu":
-        opt._cg = oracle.pcg
+def _run_steps(device, steps, session=True, ref=None):
+    model, _, lossf = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=SEEDS[0])
+    if ref is not None:
+        ref.check_inputs([p for p in model.parameters() if p.requires_grad])
+    model = model.to(device)
+    modelprep.prepare_model(model, channels_last=True)
+    opt = hf.HessianFree(model.parameters(), graph_matvec=True)
     if not session:
         opt._session_off = True
     finals = []
     for i in range(steps):
-        _, (x, t), _ = tp.resnet18_mnist(batch_size=32, device=device, data_seed=SEEDS[i])
+        _, (x, t), _ = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=SEEDS[i])
+        if ref is not None:
+            ref.check_inputs(x=x, step=i)
+        x, t = x.to(device), t.to(device)
 
         def forward():
             out = model(x)
@@ -113,27 +111,18 @@ def _run_steps(device, steps, session=True):
     return opt, finals
 
 
-def test_session_steps_match_reference_cpu_path():
-    """THREE consecutive default ``HessianFree.step()`` calls on fresh batches (config 2 of
-    BASELINE.json, N = 11 175 370) with the persistent session against the CPU path (stock model,
-    reference-order PCG): the session must serve steps 2 and 3 without being rebuilt.  Stated
-    tolerance: initial losses 1e-5 (steps 2+ start from fp32-different parameters), learning rates,
-    damping schedule and termination reasons identical, iteration counts +-2, final losses 1e-4."""
-    from helpers import cpu_resnet18_default_steps
+def test_session_steps_match_reference_trace():
+    """THREE consecutive default ``HessianFree.step()`` calls on fresh batches (config 2 of BASELINE.json,
+    N = 11 175 370) with the persistent session against the reference's own run (golden ``steps``): the session must
+    serve steps 2 and 3 without being rebuilt.  Stated tolerance: initial losses 1e-5 (steps 2+ start from
+    fp32-different parameters), learning rates, damping schedule and termination reasons identical, iteration counts
+    +-2, final losses 1e-4."""
+    from helpers import RefTrace, compare_trace
 
-    gpu, g_final = _run_steps(DEV, 3)
+    ref = RefTrace("resnet18", "steps")
+    gpu, g_final = _run_steps(DEV, 3, ref=ref)
     assert gpu._session is not None and gpu._session.steps == 3
-    sc, c_final, _ = cpu_resnet18_default_steps(3)  # (computed once per pytest process, shared with the 2-/8-rank tests)
-    sg = gpu.state
-    for a, b in zip(sg["init_losses"], sc["init_losses"]):
-        assert abs(a - b) <= 1e-5 * abs(b)
-    assert sg["cg_reasons"] == sc["cg_reasons"]
-    assert sg["learning_rates"] == sc["learning_rates"]
-    assert sg["dampings"] == sc["dampings"]
-    for a, b in zip(sg["num_cg_iters"], sc["num_cg_iters"]):
-        assert abs(a - b) <= 2
-    for a, b in zip(g_final, c_final):
-        assert abs(a - b) <= 1e-4 * abs(b)
+    compare_trace(gpu.state, g_final, ref)
 
 
 def test_session_equals_generic_path_and_is_faster_to_restart():
@@ -147,13 +136,13 @@ def test_session_equals_generic_path_and_is_faster_to_restart():
     # (Martens' criterion is a threshold on fp32 quantities: the generic path's eager forward passes are not
     # bitwise repeatable, one run in three stops a solve one iteration earlier or later)
     for x, y in zip(a.state["num_cg_iters"], b.state["num_cg_iters"]):
-        assert abs(x - y) <= 1
+        within(abs(x - y), 1, strict=False)
     assert a.state["learning_rates"] == b.state["learning_rates"]
     assert a.state["dampings"] == b.state["dampings"]
-    assert abs(a.state["init_losses"][0] - b.state["init_losses"][0]) <= 1e-6 * abs(b.state["init_losses"][0])
-    assert abs(fa[0] - fb[0]) <= 1e-5 * abs(fb[0])
+    within(abs(a.state["init_losses"][0] - b.state["init_losses"][0]), 1e-6 * abs(b.state["init_losses"][0]), strict=False)
+    within(abs(fa[0] - fb[0]), 1e-5 * abs(fb[0]), strict=False)
     for x, y in zip(a.state["init_losses"] + fa, b.state["init_losses"] + fb):
-        assert abs(x - y) <= 1e-3 * abs(y)
+        within(abs(x - y), 1e-3 * abs(y), strict=False)
 
 
 def test_session_is_refused_for_other_losses_and_models():
@@ -230,13 +219,13 @@ def test_train_mode_batchnorm_session_equals_generic_path():
     assert a._session is not None and a._session.steps == 3 and a._session.engine.train_own
     b, fb, mb = _run_train_mode_steps(3, session=False)
     assert b._session is None
-    assert abs(a.state["init_losses"][0] - b.state["init_losses"][0]) <= 1e-5 * abs(b.state["init_losses"][0])
+    within(abs(a.state["init_losses"][0] - b.state["init_losses"][0]), 1e-5 * abs(b.state["init_losses"][0]), strict=False)
     # (the session's one-pass batch statistics -- E[a^2] - mean^2 in fp64 -- and torch's two-pass ones agree to
     # ~1e-7 per layer; the train-mode solve amplifies that: measured 2.1e-4 on the first step's final loss)
-    assert abs(fa[0] - fb[0]) <= 5e-4 * abs(fb[0])
+    within(abs(fa[0] - fb[0]), 5e-4 * abs(fb[0]), strict=False)
     assert a.state["dampings"] == b.state["dampings"]
     for x, y in zip(a.state["num_cg_iters"], b.state["num_cg_iters"]):
-        assert abs(x - y) <= 2
+        within(abs(x - y), 2, strict=False)
     ia, ib = a.state["init_losses"], b.state["init_losses"]
     assert abs(ia[1] - ib[1]) <= 1e-3 * abs(ib[1]) and abs(fa[1] - fb[1]) <= 1e-3 * abs(fb[1])
     assert abs(ia[2] - ib[2]) <= 2e-3 * abs(ib[2]) and abs(fa[2] - fb[2]) <= 5e-2 * abs(fb[2])
@@ -244,33 +233,32 @@ def test_train_mode_batchnorm_session_equals_generic_path():
         assert x < y  # every step reduced its batch's loss
     ra, rb = ma.bn1.running_mean, mb.bn1.running_mean
     assert float(ra.abs().max()) > 0 and int(ma.bn1.num_batches_tracked) > 3
-    assert float((ra - rb).abs().max()) <= 0.25 * float(rb.abs().max())
+    within(float((ra - rb).abs().max()), 0.25 * float(rb.abs().max()), strict=False)
     va, vb = ma.layers[4].bn1.running_var, mb.layers[4].bn1.running_var
-    assert float((va - vb).abs().max()) <= 0.25 * float(vb.abs().max())
+    within(float((va - vb).abs().max()), 0.25 * float(vb.abs().max()), strict=False)
 
 
 # ---------------------------------------------------------------------------------------------------------
 # Sessions of the other engine families the bench reports: All-CNN-C GGN, All-CNN-C
 # Hessian + L2 + diagonal empirical-Fisher preconditioner (BASELINE configs[3]), the Bottleneck net
 # ---------------------------------------------------------------------------------------------------------
-def _run_family(make, device, steps, curv="ggn", l2=0.0, precond=False, seeds=(11, 12, 13), cg_max_iter=250,
+def _run_family(make, steps, ref, curv="ggn", l2=0.0, precond=False, seeds=(11, 12, 13), cg_max_iter=250,
                 backtracking=True, **mk):
-    """``steps`` default ``HessianFree.step()`` calls on fresh batches.  GPU: prepared NHWC model, persistent
-    session.  CPU: stock model, torch autograd, host logic with the oracle PCG (reference order)."""
-    from oracle import pcg as oracle
-
-    model, _, lossf = make(device=device, data_seed=seeds[0], **mk)
+    """``steps`` default ``HessianFree.step()`` calls on fresh batches: prepared NHWC model, persistent session.  Model
+    and batches are built on the CPU from the generator's seeds (digests checked against the fixture)."""
+    model, _, lossf = make(device="cpu", data_seed=seeds[0], **mk)
+    ref.check_inputs([p for p in model.parameters() if p.requires_grad])
+    model = model.to(DEV)
     if l2:
         lossf = tp.l2_regularized(lossf, model, l2)
-    if device != "cpu":
-        modelprep.prepare_model(model, channels_last=True)
-    opt = hf.HessianFree(model.parameters(), curvature_opt=curv, graph_matvec=(device != "cpu"),
-                         cg_max_iter=cg_max_iter, use_cg_backtracking=backtracking)
-    if device == "cpu":
-        opt._cg = oracle.pcg
+    modelprep.prepare_model(model, channels_last=True)
+    opt = hf.HessianFree(model.parameters(), curvature_opt=curv, graph_matvec=True, cg_max_iter=cg_max_iter,
+                         use_cg_backtracking=backtracking)
     finals = []
     for i in range(steps):
-        _, (x, t), _ = make(device=device, data_seed=seeds[i], **mk)
+        _, (x, t), _ = make(device="cpu", data_seed=seeds[i], **mk)
+        ref.check_inputs(x=x, step=i)
+        x, t = x.to(DEV), t.to(DEV)
 
         def forward():
             out = model(x)
@@ -283,67 +271,57 @@ def _run_family(make, device, steps, curv="ggn", l2=0.0, precond=False, seeds=(1
     return opt, finals
 
 
-def _compare_family(gpu, g_final, cpu, c_final, loss_tol=1e-5, final_tol=1e-4, iters=2):
-    sg, sc = gpu.state, cpu.state
-    for a, b in zip(sg["init_losses"], sc["init_losses"]):
-        assert abs(a - b) <= loss_tol * abs(b), (sg["init_losses"], sc["init_losses"])
-    assert sg["cg_reasons"] == sc["cg_reasons"]
-    assert sg["learning_rates"] == sc["learning_rates"]
-    assert sg["dampings"] == sc["dampings"]
-    for a, b in zip(sg["num_cg_iters"], sc["num_cg_iters"]):
-        assert abs(a - b) <= iters, (sg["num_cg_iters"], sc["num_cg_iters"])
-    for a, b in zip(g_final, c_final):
-        assert abs(a - b) <= final_tol * abs(b), (g_final, c_final)
-
-
-def test_allcnnc_ggn_session_steps_match_reference_cpu_path():
+def test_allcnnc_ggn_session_steps_match_reference_trace():
     """All-CNN-C / CIFAR-100 shapes (N = 1 387 108), GGN: three default steps on fresh batches through the
-    plain-stack engine's persistent session against the CPU path.  Stated tolerance: initial losses 1e-5,
-    learning rates / damping schedule / reasons identical, iteration counts +-2, final losses 1e-4."""
+    plain-stack engine's persistent session against the reference's run (golden ``ggn_steps``).  Stated tolerance:
+    initial losses 1e-5, learning rates / damping schedule / reasons identical, iteration counts +-2, final losses
+    1e-4."""
+    from helpers import RefTrace, compare_trace
     from pytorchhessianfree_amd.engine import PlainStackEngine
 
-    gpu, g_final = _run_family(tp.allcnnc_cifar100, DEV, 3, batch_size=32)
+    ref = RefTrace("allcnnc", "ggn_steps")
+    gpu, g_final = _run_family(tp.allcnnc_cifar100, 3, ref, batch_size=32)
     assert gpu._session is not None and gpu._session.steps == 3
     assert isinstance(gpu._session.engine, PlainStackEngine) and not gpu._session.engine.hessian
-    cpu, c_final = _run_family(tp.allcnnc_cifar100, "cpu", 3, batch_size=32)
-    _compare_family(gpu, g_final, cpu, c_final)
+    compare_trace(gpu.state, g_final, ref)
 
 
-def test_allcnnc_hessian_l2_preconditioned_session_steps_match_reference_cpu_path():
+def test_allcnnc_hessian_l2_preconditioned_session_steps_match_reference_trace():
     """BASELINE configs[3] as stated -- All-CNN-C, ``curvature_opt="hessian"``, the L2 term of
     examples/example_utils.py:77-81, diagonal empirical-Fisher preconditioner (exponent 0.75, per-sample autograd
-    path, rebuilt per step at the current damping) -- two default steps (the CPU side's double backward costs ~8 s per
-    step) through the Hessian engine's session
+    path, rebuilt per step at the current damping) -- two default steps through the Hessian engine's session
     (``PlainStackEngine(hessian=True)``, ``HF_M_DIAG`` kernels inside the one-launch iteration graph) against the
-    CPU path (double backward of the stock model, ``M_func`` re-evaluated per call, oracle PCG).  Same
+    reference's run (golden ``config4_steps``: ``diag_EF_preconditioner`` + ``step(forward, M_func=...)``).  Same
     tolerances; iteration counts +-2."""
+    from helpers import RefTrace, compare_trace
     from pytorchhessianfree_amd.engine import PlainStackEngine
 
-    kw = dict(curv="hessian", l2=5e-4, precond=True, batch_size=32)
-    gpu, g_final = _run_family(tp.allcnnc_cifar100, DEV, 2, **kw)
+    ref = RefTrace("allcnnc", "config4_steps")
+    gpu, g_final = _run_family(tp.allcnnc_cifar100, 2, ref, curv="hessian", l2=5e-4, precond=True, batch_size=32)
     assert gpu._session is not None and gpu._session.steps == 2
     assert isinstance(gpu._session.engine, PlainStackEngine) and gpu._session.engine.hessian
-    cpu, c_final = _run_family(tp.allcnnc_cifar100, "cpu", 2, **kw)
     # (from its second step on the GPU side's preconditioner comes from the engine's own sweep, engine.diag_ef)
-    _compare_family(gpu, g_final, cpu, c_final)
+    compare_trace(gpu.state, g_final, ref)
 
 
-def test_bottleneck_net_session_steps_match_reference_cpu_path():
+def test_bottleneck_net_session_steps_match_reference_trace():
     """The Bottleneck (ResNet-50 topology, N = 25 557 032) net on 32x32 images, batch 4: two steps through the session
-    against the CPU path.  The CPU side of this 25 M-parameter net costs ~2 s per product, so the solves are capped
-    at 5 PCG iterations and CG-backtracking is off (an unconverged iterate of this deep random-init net can overflow
-    the loss, which the line search -- but not the back-tracking walk of the reference, cg_backtracking.py:53-112 --
-    recovers from); LM damping and the line search run as usual.  Stated tolerance: initial losses 1e-5 / 1e-4 (the
-    second step starts from fp32-different parameters), learning rates / damping schedule / reasons / iteration counts
-    identical, final loss of the first step 1e-4; of the second 1e-2 (a 5-iteration step of this net is far from
-    converged and amplifies the 1e-4 difference of its starting point: measured 5.4e-3)."""
-    kw = dict(batch_size=4, image=32, cg_max_iter=5, backtracking=False)
-    gpu, g_final = _run_family(tp.resnet50_small_images, DEV, 2, **kw)
+    against the reference's run (golden ``convnet_bottleneck.npz``).  The solves are capped at 5 PCG iterations and
+    CG-backtracking is off (an unconverged iterate of this deep random-init net can overflow the loss, which the line
+    search -- but not the back-tracking walk of the reference, cg_backtracking.py:53-112 -- recovers from); LM damping
+    and the line search run as usual.  Stated tolerance: initial losses 1e-5 / 1e-4 (the second step starts from
+    fp32-different parameters), learning rates / damping schedule / reasons / iteration counts identical, final loss
+    of the first step 1e-4; of the second 1e-2 (a 5-iteration step of this net is far from converged and amplifies
+    the 1e-4 difference of its starting point: measured 5.4e-3)."""
+    from helpers import RefTrace, compare_trace
+
+    ref = RefTrace("bottleneck", "steps")
+    gpu, g_final = _run_family(tp.resnet50_small_images, 2, ref, seeds=(11, 12), batch_size=4, image=32,
+                               cg_max_iter=5, backtracking=False)
     assert gpu._session is not None and gpu._session.steps == 2
-    cpu, c_final = _run_family(tp.resnet50_small_images, "cpu", 2, **kw)
-    assert abs(gpu.state["init_losses"][0] - cpu.state["init_losses"][0]) <= 1e-5 * abs(cpu.state["init_losses"][0])
-    assert abs(g_final[0] - c_final[0]) <= 1e-4 * abs(c_final[0])
-    _compare_family(gpu, g_final, cpu, c_final, loss_tol=1e-4, final_tol=1e-2, iters=0)
+    within(abs(gpu.state["init_losses"][0] - ref.state["init_losses"][0]), 1e-5 * abs(ref.state["init_losses"][0]), strict=False)
+    within(abs(g_final[0] - ref.finals[0]), 1e-4 * abs(ref.finals[0]), strict=False)
+    compare_trace(gpu.state, g_final, ref, loss_tol=1e-4, final_tol=1e-2, iters=0)
 
 
 def test_session_is_reverified_against_the_models_own_forward(monkeypatch):
