@@ -85,6 +85,9 @@ def parse():
                     help="1: the fused curvature engine (own deterministic convolutions, BatchNorm fused, "
                          "split-K slabs summed by the consumer kernel) where the model family is supported; "
                          "0: the autograd product")
+    ap.add_argument("--no-train-bn", action="store_true",
+                    help="skip the `train_bn` leg (the same workload with TRAIN-mode BatchNorm -- what the reference's "
+                         "examples/run_resnet18_mnist.py runs -- measured by a child run of this script)")
     ap.add_argument("--bn", default="eval", choices=["eval", "train"],
                     help="BatchNorm mode: eval (running statistics; what batch sharding needs) or train (batch "
                          "statistics, what examples/run_resnet18_mnist.py runs; single GPU)")
@@ -367,6 +370,34 @@ def full_step_timing(args, device, n_steps=8, warmup=2):
                     + ("; diag empirical-Fisher preconditioner rebuilt per step (per-sample autograd, timed)"
                        if args.precond else ""),
     }
+
+
+def train_bn_leg(args):
+    """The headline workload with TRAIN-mode BatchNorm (the reference's examples/run_resnet18_mnist.py:19-35 never
+    calls ``model.eval()``: batch statistics, the GGN couples the samples), measured by a CHILD run of this script
+    (a fresh process: its own engine, graphs and MIOpen state; started, never exec'ed) so that the driver's bench run
+    times it too.  Same metric, same PCG iteration count; single GPU only (batch statistics do not shard)."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--bn", "train", "--steps", "4", "--warmup", "2",
+           "--iters", str(args.iters), "--batch", str(args.batch), "--no-cpu-baseline", "--no-beyond-l3",
+           "--no-train-bn"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"error": f"child run failed (rc {p.returncode}): {p.stderr[-400:]}"}
+        rec = json.loads(lines[-1])
+        step = rec.get("step_ms") or {}
+        return {
+            "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"], "steps": rec["steps"],
+            "pcg_iterations_per_step": args.iters, "step_ms": step.get("mean"), "step_ms_cg_iters": step.get("cg_iters"),
+            "matvec": rec["config"]["matvec"], "iteration": rec["config"]["iteration"],
+            "note": "python bench.py --bn train (child process of this run)",
+        }
+    except Exception as exc:  # noqa: BLE001  (the headline number must not depend on this leg)
+        return {"error": repr(exc)}
 
 
 def main():
@@ -739,6 +770,11 @@ def main():
         achieved = k2_bytes / k2_s / 1e9 if k2_s > 0 else 0.0
         all3 = (timing["k1_ms"] + timing["k2_ms"] + timing["k3_ms"]) * 1e-3
         fused = bool(getattr(op, "_iteration_graphs", None))
+        # K1 (p.(Bp + damping p): 8 N bytes re-read) is gone where the product's own gather leaves its partial sums
+        # (hf_pack_ex_curv): the solver's kernels are then K2 + K3, 40 N (48 N) bytes per iteration
+        k1_fused = fused and any(key[-1] for key in getattr(op, "_iteration_graphs", {}))
+        if k1_fused:
+            it_bytes -= 8.0 * n
         line = {
             "metric": "GGN-matvecs/sec (damped operator calls inside the PCG loop)",
             "value": world * matvecs / dt,
@@ -780,7 +816,9 @@ def main():
                           + "; convolutions: " + (os.environ.get("HF_CONV") or "auto") + "; " + layout
                           + ("; deterministic (two products bitwise equal)" if check.get("deterministic")
                              else "; NOT bitwise repeatable (library kernels with atomics)"),
-                "iteration": ("one hipGraph launch per PCG iteration (product -> K1 -> K2 -> K3)" if fused and group is None
+                "iteration": ("one hipGraph launch per PCG iteration (product, whose gather also leaves K1's partial "
+                              "sums of p.(Bp + damping p) -> K2 -> K3; no K1 launch)" if fused and group is None and k1_fused
+                              else "one hipGraph launch per PCG iteration (product -> K1 -> K2 -> K3)" if fused and group is None
                               else "product graph A -> [all-reduce of the late layers' share on a second communicator] "
                                    "|| product graph B -> all-reduce of the rest -> scatter -> K1-K3 graph"
                               if fused and getattr(op, "split", None) is not None
@@ -829,6 +867,8 @@ def main():
                 "all_pcg_kernels": {
                     "k1_ms": timing["k1_ms"], "k2_ms": timing["k2_ms"], "k3_ms": timing["k3_ms"],
                     "alg_bytes_per_iter": it_bytes,
+                    "k1": ("no launch: the product's gather emits the partial sums (hf_pack_ex_curv), 8 N bytes "
+                           "per iteration saved" if k1_fused else "k_curvature, 8 N bytes"),
                     "achieved_GBs": it_bytes / all3 / 1e9 if all3 > 0 else 0.0,
                 },
             },
@@ -862,6 +902,9 @@ def main():
                 line["step_ms"] = full_step_timing(args, device)
             except Exception as exc:  # noqa: BLE001  (the headline number must not depend on this leg)
                 line["step_ms"] = {"error": repr(exc)}
+        if (world == 1 and not dist_on and not args.no_train_bn and args.bn == "eval" and args.workload == "resnet18"
+                and args.curvature == "ggn" and not args.acc):
+            line["train_bn"] = train_bn_leg(args)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line), flush=True)

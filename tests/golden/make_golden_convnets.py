@@ -132,8 +132,20 @@ def run_steps(store, key, make, seeds, steps, curv="ggn", l2=0.0, precond=False,
           f"reasons {opt.state['cg_reasons']}  finals {finals}", flush=True)
 
 
-def run_solve(store, key, model, lossf, x, t, curv, lam, cg_kw, diag_precond=False, sample_iters=None):
-    """One damped PCG solve by the reference's ``cg`` on the reference's curvature product."""
+def double_twin(model, loss_of, x):
+    """The same problem in float64 (the reference's code is dtype-agnostic): what its fp32 results are rounded from."""
+    import copy
+
+    m64 = copy.deepcopy(model).double()
+    return m64, loss_of(m64), x.double()
+
+
+def run_solve(store, key, model, loss_of, x, t, curv, lam, cg_kw, diag_precond=False, sample_iters=None):
+    """One damped PCG solve by the reference's ``cg`` on the reference's curvature product.  ``loss_of(model)``: the
+    loss function (a regulariser is bound to its model's weights).  Gradient / diagonal / products are stored twice:
+    as the reference computes them (fp32) and from the same code in float64 (``.../f64``) -- the distance between the
+    two is the reference's OWN fp32 error, which bounds how closely any fp32 implementation can be asked to match it."""
+    lossf = loss_of(model)
     params = [p for p in model.parameters() if p.requires_grad]
     idx = put_index(store, key, params)
     store[key + "/init_sha1"] = np.array(sha(flat(params)))
@@ -142,6 +154,12 @@ def run_solve(store, key, model, lossf, x, t, curv, lam, cg_kw, diag_precond=Fal
     loss = lossf(out, t)
     grad = parameters_to_vector(torch.autograd.grad(loss, params, retain_graph=True)).detach()
     put_vec(store, key + "/grad", grad, idx)
+    m64, lossf64, x64 = double_twin(model, loss_of, x)
+    p64 = [p for p in m64.parameters() if p.requires_grad]
+    out64 = m64(x64)
+    loss64 = lossf64(out64, t)
+    put_vec(store, key + "/grad/f64", parameters_to_vector(torch.autograd.grad(loss64, p64, retain_graph=True)), idx)
+    store[key + "/loss_f64"] = np.array(float(loss64.detach()))
     store[key + "/loss"] = np.array(float(loss.detach()))
     store[key + "/logits"] = npy(out)
 
@@ -156,6 +174,7 @@ def run_solve(store, key, model, lossf, x, t, curv, lam, cg_kw, diag_precond=Fal
 
         diag = diag_EF_autograd(model, lossf, x, t, "mean")
         put_vec(store, key + "/diag", diag, idx)
+        put_vec(store, key + "/diag/f64", diag_EF_autograd(m64, lossf64, x64, t, "mean"), idx)
         M = diag_to_preconditioner(diag, lam, 0.75)
     t0 = time.time()
     with warnings.catch_warnings(record=True) as rec:
@@ -183,7 +202,13 @@ def run_solve(store, key, model, lossf, x, t, curv, lam, cg_kw, diag_precond=Fal
             vals.append(float(0.5 * torch.dot(xi.double(), Ax.double()) - torch.dot(b.double(), xi.double())))
         store[key + "/m_at_stored"] = np.array(vals, dtype=np.float64)
     print(f"  {key}: {time.time() - t0:.1f} s  {reason}  n_iters {len(x_iters) - 1}  nonpos {nonpos[:8]}", flush=True)
-    return B, grad, idx
+
+    def B64(v):
+        if curv == "ggn":
+            return RefHF._Gv(loss64, out64, p64, v).detach()
+        return RefHF._Hv(loss64, p64, v).detach()
+
+    return B, grad, idx, B64
 
 
 def quiet_keep_warnings(fn, *a, **k):
@@ -197,12 +222,14 @@ def quiet_keep_warnings(fn, *a, **k):
         sys.stdout = old
 
 
-def put_product(store, key, B, n, idx, seed):
+def put_product(store, key, B, n, idx, seed, B64=None):
     v = torch.randn(n, generator=torch.Generator().manual_seed(seed))
     store[key + "/n"] = np.array(n)
     store[key + "/v_seed"] = np.array(seed)
     store[key + "/v_sha1"] = np.array(sha(v))
     put_vec(store, key, B(v), idx)
+    if B64 is not None:
+        put_vec(store, key + "/f64", B64(v.double()), idx)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -219,23 +246,27 @@ def make_resnet18():
     run_steps(store, "hessian_step", tp.resnet18_mnist, SEEDS, 1, curv="hessian", mk=dict(batch_size=32))
     # the damped GGN solve of the bench's problem: to Martens' criterion, and 250 forced iterations
     model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=SEEDS[0])
-    B, grad, idx = run_solve(store, "solve_martens", model, lossf, x, t, "ggn", 1e-3,
-                             dict(max_iter=80, martens_conv_crit=True, store_x_at_iters=list(range(81))),
-                             sample_iters=set(range(0, 12)))
-    put_product(store, "ggn_product", B, grad.numel(), idx, seed=41)
+    B, grad, idx, B64 = run_solve(store, "solve_martens", model, lambda m: lossf, x, t, "ggn", 1e-3,
+                                  dict(max_iter=80, martens_conv_crit=True, store_x_at_iters=list(range(81))),
+                                  sample_iters=set(range(0, 12)))
+    put_product(store, "ggn_product", B, grad.numel(), idx, seed=41, B64=B64)
     grid = [0, 1, 2, 3, 4, 6, 8, 10, 13, 17, 23, 30, 39, 51, 66, 86, 112, 146, 190, 247]
-    run_solve(store, "solve_250", model, lossf, x, t, "ggn", 1e-3,
+    run_solve(store, "solve_250", model, lambda m: lossf, x, t, "ggn", 1e-3,
               dict(max_iter=250, tol=0.0, martens_conv_crit=False, store_x_at_iters=grid))
     params = [p for p in model.parameters() if p.requires_grad]
     out = model(x)
     loss = lossf(out, t)
-    put_product(store, "hessian_product", lambda v: RefHF._Hv(loss, params, v).detach(), grad.numel(), idx, seed=43)
+    m64, l64, x64 = double_twin(model, lambda m: lossf, x)
+    p64 = [p for p in m64.parameters() if p.requires_grad]
+    loss64 = l64(m64(x64), t)
+    put_product(store, "hessian_product", lambda v: RefHF._Hv(loss, params, v).detach(), grad.numel(), idx, seed=43,
+                B64=lambda v: RefHF._Hv(loss64, p64, v).detach())
     # train-mode BatchNorm (what examples/run_resnet18_mnist.py runs), batch 16: product, short solve
     model, (x, t), lossf = tp.resnet18_mnist(batch_size=16, device="cpu", data_seed=5)
     model.train()
-    B, grad, idx = run_solve(store, "train_solve", model, lossf, x, t, "ggn", 1.0,
-                             dict(max_iter=8, martens_conv_crit=True, store_x_at_iters=list(range(9))))
-    put_product(store, "train_product", B, grad.numel(), idx, seed=2)
+    B, grad, idx, B64 = run_solve(store, "train_solve", model, lambda m: lossf, x, t, "ggn", 1.0,
+                                  dict(max_iter=8, martens_conv_crit=True, store_x_at_iters=list(range(9))))
+    put_product(store, "train_product", B, grad.numel(), idx, seed=2, B64=B64)
     mg.save("convnet_resnet18.npz", store)
 
 
@@ -249,24 +280,31 @@ def make_allcnnc():
               mk=dict(batch_size=32))
     for lam in (1.0, 0.01):
         model, (x, t), lossf0 = tp.allcnnc_cifar100(batch_size=32, device="cpu")
-        lossf = tp.l2_regularized(lossf0, model, 5e-4)
-        B, grad, idx = run_solve(store, f"config4_solve_lam{lam}", model, lossf, x, t, "hessian", lam,
-                                 dict(max_iter=40, martens_conv_crit=True, store_x_at_iters=list(range(41))),
-                                 diag_precond=True, sample_iters=set(range(0, 12)))
+        B, grad, idx, B64 = run_solve(store, f"config4_solve_lam{lam}", model,
+                                      lambda m: tp.l2_regularized(lossf0, m, 5e-4), x, t, "hessian", lam,
+                                      dict(max_iter=40, martens_conv_crit=True, store_x_at_iters=list(range(41))),
+                                      diag_precond=True, sample_iters=set(range(0, 12)))
         if lam == 1.0:
-            put_product(store, "hessian_l2_product", B, grad.numel(), idx, seed=47)
+            put_product(store, "hessian_l2_product", B, grad.numel(), idx, seed=47, B64=B64)
     model, (x, t), lossf = tp.allcnnc_cifar100(batch_size=32, device="cpu")
     params = [p for p in model.parameters() if p.requires_grad]
     idx = put_index(store, "products", params)
     out = model(x)
     loss = lossf(out, t)
+    m64, l64, x64 = double_twin(model, lambda m: lossf, x)
+    p64 = [p for p in m64.parameters() if p.requires_grad]
+    out64 = m64(x64)
+    loss64 = l64(out64, t)
     store["products/init_sha1"] = np.array(sha(flat(params)))
     store["products/inputs_sha1"] = np.array(sha(x))
     store["products/logits"] = npy(out)
     put_vec(store, "products/grad", parameters_to_vector(torch.autograd.grad(loss, params, retain_graph=True)), idx)
+    put_vec(store, "products/grad/f64", parameters_to_vector(torch.autograd.grad(loss64, p64, retain_graph=True)), idx)
     n = sum(p.numel() for p in params)
-    put_product(store, "products/ggn", lambda v: RefHF._Gv(loss, out, params, v).detach(), n, idx, seed=44)
-    put_product(store, "products/hessian", lambda v: RefHF._Hv(loss, params, v).detach(), n, idx, seed=45)
+    put_product(store, "products/ggn", lambda v: RefHF._Gv(loss, out, params, v).detach(), n, idx, seed=44,
+                B64=lambda v: RefHF._Gv(loss64, out64, p64, v).detach())
+    put_product(store, "products/hessian", lambda v: RefHF._Hv(loss, params, v).detach(), n, idx, seed=45,
+                B64=lambda v: RefHF._Hv(loss64, p64, v).detach())
     mg.save("convnet_allcnnc.npz", store)
 
 

@@ -147,26 +147,48 @@ class RefTrace:
         ref, got = self.sample(name), self._got(v)
         return float(got @ ref / (got.norm() * ref.norm()).clamp_min(1e-300))
 
+    # ``name + "/f64"``: the same quantity from the reference's code run in float64 (the generator stores both)
+    def own_err(self, name):
+        """The REFERENCE's own fp32 error: max |ref32[idx] - ref64[idx]| / max |ref64| on the index sample."""
+        f64 = (name + "/" if name else "") + "f64"
+        return float((self.sample(name) - self.sample(f64)).abs().max() / max(self.scalar(f64 + "/absmax"), 1e-300))
+
+    def vec_err64(self, name, v):
+        """max |v[idx] - ref64[idx]| / max |ref64|: distance to the float64 value the reference's result is rounded from."""
+        return self.vec_err((name + "/" if name else "") + "f64", v)
+
+    def envelope(self, name, tight):
+        """Bound for the distance of an fp32 result to the reference's fp32 result: ``tight`` (what is asked of the
+        distance to float64) + twice the reference's own fp32 distance to float64."""
+        return tight + 2.0 * self.own_err(name)
+
     def norm_err(self, name, v):
         want = self.scalar((name + "/" if name else "") + "norm")
         return abs(float(v.detach().double().norm()) - want) / max(want, 1e-300)
 
 
-def compare_trace(got_state, got_finals, ref, steps=None, loss_tol=1e-5, final_tol=1e-4, iters=2, best=None):
+def compare_trace(got_state, got_finals, ref, steps=None, loss_tol=(1e-5, 3e-5), final_tol=(1e-4, 5e-4), iters=2,
+                  best=None):
     """The discrete entries of a ``step`` / ``acc_step`` trace identical to the reference's (termination reasons,
-    learning rates, damping schedule), initial / final losses within the stated fp32 tolerances, iteration counts
-    within ``iters``."""
+    learning rates, damping schedule), initial / final losses within the stated fp32 tolerances -- ``(first step, later
+    steps)``: a later step starts from parameters that differ like any two fp32 runs, and back-tracking / the line
+    search pick between nearly tied candidates (measured over the round-5 leases: initial losses <= 3.7e-6 / final
+    losses <= 5.8e-5 relative on the later steps of the ResNet-18 and All-CNN-C runs) --, iteration counts within
+    ``iters``."""
+    def pair(t):
+        return t if isinstance(t, tuple) else (t, t)
+
     sc = ref.state
     n = len(got_state["init_losses"]) if steps is None else steps
-    for a, b in zip(got_state["init_losses"][:n], sc["init_losses"][:n]):
-        within(abs(a - b), loss_tol * abs(b), strict=False, note=(got_state["init_losses"], sc["init_losses"]))
+    for i, (a, b) in enumerate(zip(got_state["init_losses"][:n], sc["init_losses"][:n])):
+        within(abs(a - b), pair(loss_tol)[min(i, 1)] * abs(b), strict=False, note=(got_state["init_losses"], sc["init_losses"]))
     assert list(got_state["cg_reasons"][:n]) == list(sc["cg_reasons"][:n]), (got_state["cg_reasons"], sc["cg_reasons"])
     assert list(got_state["learning_rates"][:n]) == list(sc["learning_rates"][:n])
     assert list(got_state["dampings"][:n]) == list(sc["dampings"][:n])
     for a, b in zip(got_state["num_cg_iters"][:n], sc["num_cg_iters"][:n]):
         assert abs(a - b) <= iters, (got_state["num_cg_iters"], sc["num_cg_iters"])
-    for a, b in zip(got_finals[:n], ref.finals[:n]):
-        within(abs(a - b), final_tol * abs(b), strict=False, note=(got_finals, ref.finals))
+    for i, (a, b) in enumerate(zip(got_finals[:n], ref.finals[:n])):
+        within(abs(a - b), pair(final_tol)[min(i, 1)] * abs(b), strict=False, note=(got_finals, ref.finals))
     if best is not None:
         for a, b in zip(got_state["best_cg_iters"][:n], sc["best_cg_iters"][:n]):
             assert abs(int(a) - int(b)) <= best, (got_state["best_cg_iters"], sc["best_cg_iters"])
