@@ -154,7 +154,7 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
         self._rec_pool = None
         if self.loss_spec is not None:
             self.outputs = None  # nothing of the step's autograd graph stays alive in the engine
-            from .modelprep import release_records
+            from ..modelprep import release_records
 
             release_records(model)  # (the layers' records pinned this pass's activations until the next one)
 
@@ -299,7 +299,7 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
         finally:
             self.weight = weight  # (the constructor moves the engine to its final linearisation point afterwards)
         if self.hessian:
-            from .curvature import HessianOperator
+            from ..curvature import HessianOperator
 
             want = HessianOperator(loss, self.params).local(v)
         else:

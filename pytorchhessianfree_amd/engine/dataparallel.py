@@ -133,7 +133,7 @@ class _DataParallel:
         if (self._live_segments() is None or t.dtype != torch.float32 or t.numel() != self.n
                 or not t.is_contiguous() or not t.is_cuda):
             return _all_reduce_sum(t, group)
-        from .distributed import all_reduce_sum_multi
+        from ..distributed import all_reduce_sum_multi
 
         self._live_copy(t, False)
         all_reduce_sum_multi(self._reduce_pieces(t), group)  # (direct RCCL: one grouped launch)

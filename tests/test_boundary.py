@@ -76,3 +76,24 @@ def test_missing_library_is_an_error(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libhfpcg.so")
     with pytest.raises(RuntimeError, match="REQUIRED"):
         _lib.load()
+
+
+def test_every_relative_import_of_the_package_resolves():
+    """Function-level ``from .x import y`` lines are only executed on a GPU box: a module moved into a sub-package
+    (``engine/``) must not leave a stale relative import behind for the GPU run to find."""
+    import ast
+    import glob
+    import importlib
+    import importlib.util
+
+    root = os.path.join(ROOT, "pytorchhessianfree_amd")
+    for path in glob.glob(os.path.join(root, "**", "*.py"), recursive=True):
+        rel = os.path.relpath(path, ROOT)[:-3].split(os.sep)
+        pkg = rel[:-1] if rel[-1] != "__init__" else rel[:-1]
+        for node in ast.walk(ast.parse(open(path).read())):
+            if isinstance(node, ast.ImportFrom) and node.level > 0:
+                base = pkg[: len(pkg) - (node.level - 1)]
+                mod = ".".join(base + ([node.module] if node.module else []))
+                m = importlib.import_module(mod)
+                for a in node.names:
+                    assert hasattr(m, a.name) or importlib.util.find_spec(mod + "." + a.name) is not None, (path, mod, a.name)

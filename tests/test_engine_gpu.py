@@ -37,20 +37,33 @@ def _float64_product(make, v, masks=None, **kw):
     return curvature.GGNOperator(lossf(out, t), out, params)(v.double())
 
 
-def _replay_relu_decisions(model, masks):
-    """Make every ``nn.ReLU`` call of ``model`` take the sign decisions ``masks`` (in call order)."""
+def _replay_relu_decisions(model, masks, max_flips=200, margin=1e-5):
+    """Make every ``nn.ReLU`` call of ``model`` take the sign decisions ``masks`` (in call order) -- and BOUND what is
+    being replayed: a decision may differ from the model's own (``input > 0``) only where the model's own input lies
+    within ``margin`` x the layer's max-norm of zero (an fp32 forward pass is good to ~1e-6 of that), and in at most
+    ``max_flips`` entries over the whole network.  A wrong mask -- a kernel bug -- would flip decisions of inputs far
+    from zero, or many of them, and is not inherited by the reference product."""
     import types
 
-    cursor = [0]
+    cursor, flips = [0], [0]
 
     def relu_forward(self, inp):
-        m = masks[cursor[0]]
+        m = masks[cursor[0]].to(device=inp.device)
         cursor[0] += 1
-        return inp * m.to(device=inp.device, dtype=inp.dtype)
+        own = inp > 0
+        diff = own != (m > 0)
+        n = int(diff.sum())
+        if n:
+            flips[0] += n
+            worst = float(inp[diff].abs().max() / inp.abs().max())
+            within(worst, margin, note=("replayed ReLU decision far from zero", cursor[0] - 1, n))
+            within(flips[0], max_flips, strict=False, note="replayed ReLU decisions that differ from the model's own")
+        return inp * m.to(dtype=inp.dtype)
 
     for mod in model.modules():
         if isinstance(mod, torch.nn.ReLU):
             mod.forward = types.MethodType(relu_forward, mod)
+    return flips
 
 
 @pytest.mark.parametrize("batch", [32, 5])
