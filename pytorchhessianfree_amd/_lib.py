@@ -395,7 +395,7 @@ def conv_scratch(device):
     key = device.index if device.index is not None else torch.cuda.current_device()
     sc = _conv_scratch.get(key)
     if sc is None:
-        ws = torch.empty(int(os.environ.get("HF_CONV_WS_MB", "64")) << 18, dtype=torch.float32, device=device)
+        ws = torch.empty(64 << 18, dtype=torch.float32, device=device)
         tickets = torch.zeros(8192, dtype=torch.int32, device=device)
         sc = _conv_scratch[key] = (ws, tickets)
     return sc
@@ -411,7 +411,7 @@ def conv2d_nhwc(direction, out, act, mat, n, h, w, c, k, r, s, stride, padding, 
             int(direction), c_void_p(out.data_ptr()), c_void_p(act.data_ptr()), c_void_p(mat.data_ptr()),
             n, h, w, c, k, r, s, stride[0], stride[1], padding[0], padding[1], act_ld,
             c_void_p(ws.data_ptr()), ws.numel() * 4, c_void_p(tickets.data_ptr()), tickets.numel(),
-            int(os.environ.get("HF_CONV_BLOCKS", "0")), HF_F32, current_stream_ptr(out.device)),
+            0, HF_F32, current_stream_ptr(out.device)),
         "hf_conv2d_nhwc")
     return out
 
@@ -426,7 +426,7 @@ def conv2d_nhwc_backward(dx, dw, dy, x, w_t, n, h, w, c, k, r, s, stride, paddin
             c_void_p(dx.data_ptr()), c_void_p(dw.data_ptr()), c_void_p(dy.data_ptr()), c_void_p(x.data_ptr()),
             c_void_p(w_t.data_ptr()), n, h, w, c, k, r, s, stride[0], stride[1], padding[0], padding[1],
             c_void_p(ws.data_ptr()), ws.numel() * 4, c_void_p(tickets.data_ptr()), tickets.numel(),
-            int(os.environ.get("HF_CONV_BLOCKS", "0")), HF_F32, current_stream_ptr(dx.device)),
+            0, HF_F32, current_stream_ptr(dx.device)),
         "hf_conv2d_nhwc_backward")
     return dx, dw
 
@@ -581,7 +581,7 @@ def conv_dw_slabs(d_problem, w_problem, device):
 def conv_plan(direction, n, h, w, c, k, r, s, stride, padding):
     """Number of K-splits a slab-mode launch of this geometry uses (``hf_conv2d_nhwc_plan``)."""
     sp = load().hf_conv2d_nhwc_plan(int(direction), n, h, w, c, k, r, s, stride[0], stride[1], padding[0],
-                                    padding[1], int(os.environ.get("HF_CONV_BLOCKS", "0")))
+                                    padding[1], 0)
     if sp < 1:
         check(sp, "hf_conv2d_nhwc_plan")
     return sp

@@ -40,7 +40,7 @@ _LAG = 2  # how many iterations the host may run ahead of the device
 # ... and when one iteration is a single graph launch of a whole curvature product (>= 0.1 ms): every
 # iteration enqueued beyond the terminating one is a wasted product -- one in flight keeps the device busy
 # (measured: headline unchanged, a default step() of config 2 0.6 ms shorter)
-_LAG_FUSED = int(os.environ.get("HF_CG_LAG", "1"))
+_LAG_FUSED = 1
 
 
 class DampedCurvature:

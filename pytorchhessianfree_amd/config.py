@@ -106,3 +106,59 @@ def configure(winograd=None, wrw_xdlops=None, suggest_nhwc=True, find=True, db=N
 
 def configured():
     return _state["done"]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Every environment switch the package reads, once.  ``tests/test_boundary.py`` checks that no other ``HF_*`` name is
+# read anywhere in the package and that each of these is exercised with a non-default value by the test named here.
+# Round 5 removed the switches whose non-default value was a measured-and-rejected variant (their numbers stay in
+# DESIGN.md / profiles/): HF_BN_TRAIN_FORM, HF_BN_FOLD, HF_BN_FWD_PROLOGUE, HF_BN_ROW_BLOCKS / _ROW_PASSES /
+# _EPILOGUE_ROWS, HF_HESSIAN_PARALLEL, HF_ACC_PARALLEL, HF_CONV_BLOCKS / _BIG_BLOCKS / _FEW_TILES(_CAP) / _DCLASS /
+# _AUTO / _WS_MB, HF_OWN_CONV, HF_AFFINE_SCALAR, HF_CARRY_SCATTER, HF_ENGINE_LIVE / _HEAD / _GROUP / _DIAG_EF,
+# HF_DIAG_EF_GRAPH, HF_INPLACE_PREFIX, HF_COMPACT_ALLREDUCE, HF_CHUNK_TAIL, HF_RCCL_GROUPED, HF_CG_LAG,
+# HF_TRAIN_SESSION.
+# ----------------------------------------------------------------------------------------------------------------
+SWITCHES = {
+    # name: (default, what the non-default value does, test that exercises it)
+    "HF_ENGINE": ("1", "0: curvature products by the autograd operators (no fused engine)",
+                  "tests/test_engine_gpu.py::test_engine_declines_what_it_does_not_know"),
+    "HF_ENGINE_VERIFY": ("first", "always / never: the engine's first-use check against the autograd product",
+                         "tests/test_engine_gpu.py::test_train_mode_prologue_form_variants_agree_and_state_is_independent_of_the_first_use_check"),
+    "HF_ENGINE_DEBUG": ("", "1: say why a model was not taken by the engine",
+                        "tests/test_engine_gpu.py::test_engine_declines_what_it_does_not_know"),
+    "HF_CONV": ("auto", "own / miopen: which convolution implementation the autograd path of a prepared model uses",
+                "tests/test_optimizer_gpu.py::test_deterministic_mode_products_are_bitwise_repeatable"),
+    "HF_NHWC_FIND": ("", "1: keep MIOpen's find step for NHWC problems (used once to produce the shipped records)",
+                     "tests/test_host_logic_cpu.py::test_configure_is_explicit_and_idempotent"),
+    "HF_SESSION": ("1", "0: no persistent engine session (engine + graphs rebuilt per step)",
+                   "tests/test_session_gpu.py::test_session_equals_generic_path_and_is_faster_to_restart"),
+    "HF_SESSION_VERIFY": ("", "1: re-verify the session against the model's own forward pass every step",
+                          "tests/test_session_gpu.py::test_session_is_reverified_against_the_models_own_forward"),
+    "HF_SESSION_VERIFY_EVERY": ("16", "every how many steps the session is re-verified",
+                                "tests/test_session_gpu.py::test_session_is_reverified_against_the_models_own_forward"),
+    "HF_ACC_SESSION": ("1", "0: acc_step on the generic accumulation",
+                       "tests/test_acc_session_gpu.py::test_acc_step_train_mode_batchnorm_session_equals_generic_accumulation"),
+    "HF_GRAPH_VERIFY": ("first", "always / never: replay check of a freshly captured product graph",
+                        "tests/test_optimizer_gpu.py::test_graphed_operator_refuses_a_replay_that_differs_from_the_eager_product"),
+    "HF_FUSE_ITERATION": ("1", "0: product, K1, K2, K3 as separate launches (no iteration graph)",
+                          "tests/test_engine_gpu.py::test_solve_with_the_curvature_scalar_from_the_gather_equals_the_k1_launch"),
+    "HF_FUSE_CURVATURE": ("1", "0: the gather does not emit K1's partial sums (K1 stays a launch)",
+                          "tests/test_engine_gpu.py::test_solve_with_the_curvature_scalar_from_the_gather_equals_the_k1_launch"),
+    "HF_BN_EPILOGUE": ("1", "0: train-mode tangent partial sums by the reduction launch, not the convolution's epilogue",
+                       "tests/test_engine_gpu.py::test_train_mode_prologue_form_variants_agree_and_state_is_independent_of_the_first_use_check"),
+    "HF_BN_TRAIN_PAIR": ("1", "0: a downsample block's two train-mode units in launches of their own",
+                         "tests/test_engine_gpu.py::test_train_mode_prologue_form_variants_agree_and_state_is_independent_of_the_first_use_check"),
+    "HF_CHUNKED_ALLREDUCE": ("auto", "0 / 1: force the single-graph resp. the two-phase data-parallel product",
+                             "tests/test_distributed_gpu.py::test_step_two_ranks_engine_session_equals_cpu_whole_batch"),
+    "HF_CHUNK_ONEGRAPH": ("0", "1: the two phase graphs chained into one launch (opt-in, 1-rank RCCL only so far)",
+                          "tests/test_distributed_gpu.py::test_step_one_rank_rccl_two_phase_product_as_one_launch"),
+    "HF_PCG_BLOCKS": ("0", "workgroups of the PCG vector kernels (0: 2 per CU); must agree on all ranks",
+                      "tests/test_cg_gpu.py::test_kernel_grid_override_gives_the_same_solve"),
+    "HF_PCG_LIB": ("", "path of another build of libhfpcg.so (tuning variants)",
+                   "tests/test_boundary.py::test_alternate_library_path"),
+    "HF_ALLOW_WINOGRAD": ("0", "1: keep MIOpen's fp32 Winograd solvers", "tests/test_host_logic_cpu.py::test_configure_is_explicit_and_idempotent"),
+    "HF_ALLOW_WRW_XDLOPS": ("0", "1: keep MIOpen's CK split-K weight gradient",
+                            "tests/test_host_logic_cpu.py::test_configure_is_explicit_and_idempotent"),
+    "HF_MIOPEN_DB": ("user", "<dir> / off: where the writable copy of the shipped MIOpen records lives",
+                     "tests/test_host_logic_cpu.py::test_configure_is_explicit_and_idempotent"),
+}

@@ -1036,9 +1036,7 @@ static bool affine_vec4_ok(const void* out, const void* a, const void* x, const 
   const void* ptrs[] = {out, a, x, mean, rstd, w, q, r, add, mask_src};
   for (const void* p : ptrs)
     if (p && !aligned16(p)) return false;
-  static const bool scalar_only = getenv("HF_AFFINE_SCALAR") != nullptr;  // (A/B switch for measurements)
-  return nhwc && c % 4 == 0 && out_ld % 4 == 0 && add_ld % 4 == 0 && a_slab % 4 == 0 && 2 * total < 0x7fffffffLL &&
-         !scalar_only;
+  return nhwc && c % 4 == 0 && out_ld % 4 == 0 && add_ld % 4 == 0 && a_slab % 4 == 0 && 2 * total < 0x7fffffffLL;
 }
 
 template <typename T>

@@ -845,25 +845,9 @@ namespace {
 // hides (~1.0 us at BK = 32, ~1.5 us at BK = 64; the fp32 MFMA work itself is 0.43 / 0.86 us),
 // a split run pays ~3 us to publish and collect tickets plus ~0.15 us per slab the last
 // arriver sums; workgroups beyond two per CU queue.
-inline int64_t hf_env_big_blocks() {
-  static int64_t v = 0;
-  if (v == 0) {
-    const char* e = getenv("HF_CONV_BIG_BLOCKS");
-    v = e ? atoll(e) : 768;
-    if (v < 1) v = 768;
-  }
-  return v;
-}
-
-inline int64_t hf_env_cap() {  // tuning knob, default measured on the ResNet-18 bench
-  static int64_t cap = 0;
-  if (cap == 0) {
-    const char* e = getenv("HF_CONV_FEW_TILES_CAP");
-    cap = e ? atoll(e) : 96;
-    if (cap < 1) cap = 32;
-  }
-  return cap;
-}
+constexpr int64_t BIG_TARGET_BLOCKS = 768;  // workgroups a 128-wide launch is split towards (measured: below)
+constexpr int64_t FEW_TILES = 8;            // up to this many output tiles ...
+constexpr int64_t FEW_TILES_CAP = 96;       // ... a weight gradient may be split this deep (default measured on ResNet-18)
 
 int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_bytes, bool slabs = false,
                   int bk = Small::BK, int64_t tile_elems = Small::BM * Small::BN) {
@@ -878,17 +862,15 @@ int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_by
     // the All-CNN-C shapes, scripts/conv_kernel_bench.py --big 1: 256 / 512 / 768 workgroups ->
     // tangent 76 / 93 / 99, data gradient 68 / 83 / 87, weight gradient 39 / 52 / 65 TFLOP/s)
     const bool big = bk != Small::BK;
-    best = ((big ? hf_env_big_blocks() : 256) + tiles - 1) / tiles;
+    best = ((big ? BIG_TARGET_BLOCKS : 256) + tiles - 1) / tiles;
     if (big && best > steps / 8) best = steps / 8;  // (>= 8 steps per workgroup)
     if (best > steps / 2) best = steps / 2;
     // (one or two output tiles -- the stem's weight gradient: 6272 rows into a 64 x 52 matrix --
     // would leave most of the chip idle at 32 splits)
-    // (HF_CONV_FEW_TILES: up to how many output tiles the larger cap applies.  Measured, round 4,
+    // (FEW_TILES: up to how many output tiles the larger cap applies.  Measured, round 4,
     // profiles/r04_conv_few_tiles.jsonl: 2 / 4 / 8 tiles -> ResNet-50 topology 314 / 323 / 323 matvecs/s,
     // ResNet-18 1507 / 1512 / 1507, All-CNN-C 742 / 751 / 755.)
-    static int few_tiles = 0;
-    if (few_tiles == 0) { const char* e = getenv("HF_CONV_FEW_TILES"); few_tiles = e ? atoi(e) : 8; if (few_tiles < 1) few_tiles = 8; }
-    const int64_t cap = tiles <= few_tiles ? hf_env_cap() : (big ? 128 : 32);
+    const int64_t cap = tiles <= FEW_TILES ? FEW_TILES_CAP : (big ? 128 : 32);
     if (best > cap) best = cap;
     if (best < 1) best = 1;
     while (best > 1 && ((steps + best - 1) / best) * (best - 1) >= steps) --best;
@@ -974,18 +956,10 @@ void launch_dw(const ConvArgs& d_in, const ConvArgs& w_in, int64_t bd, int64_t b
 
 // Which tile configuration a problem runs in: a pure function of its geometry (hf_conv2d_nhwc_plan and
 // every launch path must agree).  Big (128x128) needs both output dimensions to fill most of a tile
-// and enough GEMM rows that the 64x64 kernel would be issue-bound; HF_CONV_BIG=0/1 forces it (tuning).
-inline int hf_env_dclass() {  // HF_CONV_DCLASS=0: plain enumeration for strided data gradients (tuning / bisecting)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("HF_CONV_DCLASS"); v = e ? (atoi(e) != 0) : 1; }
-  return v;
-}
+// and enough GEMM rows that the 64x64 kernel would be issue-bound.
+inline int hf_env_dclass() { return 1; }  // (strided data gradients are enumerated by residue class: 1 268 -> 1 292, round 3)
 
-inline int hf_env_big() {
-  static int v = -2;
-  if (v == -2) { const char* e = getenv("HF_CONV_BIG"); v = e ? atoi(e) : -1; }
-  return v;
-}
+inline int hf_env_big() { return -1; }  // (-1: by geometry; 0 / 1 force a configuration when bisecting)
 
 int want_big(int direction, int64_t rows, int64_t dim_m, int64_t dim_n, int64_t red, int64_t mult, bool scalar) {
   // dim_m x dim_n: the output matrix (NT: rows x nout; TN: kout x cs per tap, `mult` = live taps of them);
@@ -1007,7 +981,7 @@ int want_big(int direction, int64_t rows, int64_t dim_m, int64_t dim_n, int64_t 
   // they fit; All-CNN-C's 8192-row layers, 9 steps per workgroup: 128x96 tiles 37 us, 64x64 tiles 64 us)
   const int64_t tiles = ((dim_m + 127) / 128) * ((dim_n + (kind == 2 ? 95 : 127)) / (kind == 2 ? 96 : 128)) * mult;
   const int64_t steps = (red + Big::BK - 1) / Big::BK;
-  return (fits && rows >= 2048 && tiles * steps >= hf_env_big_blocks() * 8) ? kind : 0;
+  return (fits && rows >= 2048 && tiles * steps >= BIG_TARGET_BLOCKS * 8) ? kind : 0;
 }
 
 int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void* mat, int64_t n, int64_t h,

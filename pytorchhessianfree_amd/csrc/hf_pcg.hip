@@ -201,7 +201,7 @@ __global__ __launch_bounds__(BLOCK) void k_init_finalize(DevState* __restrict__ 
 // (All-CNN-C: 5.5 MB vectors, one tile per block) that prologue used to sit in front of
 // the first load and cost more than the streaming itself.
 // Non-temporal access to the solver's streams (template flag NT of K1 / K2, chosen per handle at run time: vectors
-// of >= HF_PCG_NT_MIN elements, default 16 M = six fp32 vectors of 1.5 x the 256 MiB Infinity Cache).  Beyond the
+// of >= 16 M elements = six fp32 vectors of 1.5 x the 256 MiB Infinity Cache).  Beyond the
 // cache nothing these kernels read survives until its next use, and non-temporal loads / stores stream faster
 // (profiles/r04_pcg_nt_variants.jsonl, N = 100 M: K1 151.8 -> 137.2, K2 466.9 -> 440.0 us; all three kernels 0.70 ->
 // 0.77 of 8 TB/s; N = 25.6 M: 0.71 -> 0.79).  At the ResNet-18 size (six vectors = 256 MiB, the cache's edge) the
@@ -612,9 +612,7 @@ int grid_for(const hf_pcg* h, int unroll) {
 
 // non-temporal streams for vectors that cannot stay cached between their uses (see HF_LD)
 bool nt_streams(const hf_pcg* h) {
-  static long long min_n = -1;
-  if (min_n < 0) { const char* e = getenv("HF_PCG_NT_MIN"); min_n = e ? atoll(e) : 16000000LL; }
-  return h->n >= min_n;
+  return h->n >= 16000000LL;  // (six fp32 vectors of 1.5 x the 256 MiB Infinity Cache)
 }
 }  // namespace
 

@@ -10,7 +10,7 @@ Two ways to issue the collective:
   hand-off to the process group's side stream and back (two stream hops per product
   with ``torch.distributed.all_reduce``; measured ~0.2 ms per collective on a 1-rank
   group).  The communicator is bootstrapped through the existing process group (rank
-  0's unique id is broadcast).  ``HF_RCCL_DIRECT=0`` switches it off; if creating the
+  0's unique id is broadcast).  If creating the
   communicator fails, a warning is issued and the process-group path is used.
 * ``torch.distributed.all_reduce`` -- gloo in the CPU / shared-GPU tests, and the
   fall-back for RCCL.
@@ -82,7 +82,7 @@ class _DirectComm:
 
 
 def _wants_direct(t, group):
-    if os.environ.get("HF_RCCL_DIRECT", "1") == "0" or not (t.is_cuda and t.is_contiguous()):
+    if not (t.is_cuda and t.is_contiguous()):
         return False
     if t.dtype not in (torch.float32, torch.float64):
         return False
@@ -147,7 +147,7 @@ def all_reduce_sum_multi(pieces, group):
     if group is None or not pieces:
         return pieces
     if (len(pieces) <= 16 and all(_wants_direct(t, group) for t in pieces)
-            and len({t.dtype for t in pieces}) == 1 and os.environ.get("HF_RCCL_GROUPED", "1") != "0"):
+            and len({t.dtype for t in pieces}) == 1):
         comm = _direct_comm(group)
         if comm is not None:
             return comm.all_reduce_sum_multi(pieces)

@@ -20,7 +20,7 @@ class _Buffers:
         cin = 2 * c if (direction == 0 and not forward) else c
         sp = _lib.load().hf_conv2d_nhwc_plan(direction, n, h, w, cin, k, r, s, u.conv.stride[0], u.conv.stride[1],
                                              u.conv.padding[0], u.conv.padding[1],
-                                             int(os.environ.get("HF_CONV_BLOCKS", "0")))
+                                             0)
         if sp < 1:
             raise _Unsupported(f"{u.name}: convolution geometry refused ({sp})")
         return sp
@@ -127,8 +127,8 @@ class _Buffers:
                 rp = 256 // (k // 4)
                 # (64 workgroups suit the <= 1.6 MB maps of ResNet-18; a 12.6 MB map of All-CNN-C needs the
                 # whole chip: one workgroup per 32 KB of the map, 64 ... 1024)
-                tgt = int(os.environ.get("HF_BN_ROW_BLOCKS", "0")) or min(1024, max(64, u.a.numel() * 4 // 32768))
-                per = max(int(os.environ.get("HF_BN_ROW_PASSES", "1")) * rp, -(-u.rows // tgt))
+                tgt = min(1024, max(64, u.a.numel() * 4 // 32768))
+                per = max(rp, -(-u.rows // tgt))
                 u.rb = -(-u.rows // per)
                 if u.rb < 2:
                     u.rb = 1
@@ -146,11 +146,11 @@ class _Buffers:
                                        "multiples of 4 up to 1024)")
                 u.stat_part = torch.empty((u.rb, 2, k), dtype=torch.float64, device=dev)  # one-pass statistics
                 # ... and the tangent's partial sums by the convolution's own epilogue (64x64-tile launches; one row per
-                # (row tile, split): beyond HF_BN_EPILOGUE_ROWS rows the separate reduction's `rb` rows are cheaper
+                # (row tile, split): beyond 256 rows the separate reduction's `rb` rows are cheaper
                 # for the elementwise pass to add up)
                 tp_rows = -(-u.rows // 64) * u.sT
                 u.epi = (not u.im2col and not u.first and hasattr(u, "xcat")
-                         and tp_rows <= int(os.environ.get("HF_BN_EPILOGUE_ROWS", "256"))
+                         and tp_rows <= 256
                          and os.environ.get("HF_BN_EPILOGUE", "1") != "0")
                 if u.epi:
                     u.tp1 = torch.empty((tp_rows, k), dtype=f32, device=dev)
@@ -166,7 +166,7 @@ class _Buffers:
                 u.tout, u.tout_ld, u.yout2 = torch.empty_like(u.y), 0, None
         self._xcats = xcats
         self._slot_list = list(self._tangent_slots.values())
-        self._carry_ok = os.environ.get("HF_CARRY_SCATTER", "1") != "0"  # (the stem's launch carries the v_W scatter)
+        self._carry_ok = True  # (the stem's launch carries the v_W scatter; False once the library refused it)
         # (I, H, W, O) copies: the weights (once per step) and, for Hessian products, V (per product)
         self._wt_slots = [(self._offs[u.pw], u.wT, u.x.shape[1]) for u in self.units if not u.im2col and not u.first]
         self._vt_slots = [(self._offs[u.pw], u.vT, u.x.shape[1]) for u in self.units
@@ -206,7 +206,7 @@ class _Buffers:
     def _plan_stem(self, direction, geo):
         n, h, w, c, k, r, s, st, pd = geo
         sp = _lib.load().hf_conv2d_nhwc_plan(direction, n, h, w, c, k, r, s, 1, 1, 0, 0,
-                                             int(os.environ.get("HF_CONV_BLOCKS", "0")))
+                                             0)
         if sp < 1:
             raise _Unsupported(f"stem geometry refused ({sp})")
         return sp

@@ -123,8 +123,7 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
             # forward pass recorded.  Its own forward pass (batch statistics by own kernels, running statistics
             # moved as the layers' forward moves them) lets a persistent session serve such a model too -- if it
             # reproduces the model's output here (with the running statistics left alone)
-            if (os.environ.get("HF_TRAIN_SESSION", "1") != "0"
-                    and all(u.bn.momentum is not None and u.bn.track_running_stats for u in self.units if u.train)):
+            if (all(u.bn.momentum is not None and u.bn.track_running_stats for u in self.units if u.train)):
                 self.forward_own(update_running=False)
                 want = outputs.detach()
                 err = float((self.logits - want).abs().max() / want.abs().max().clamp_min(1e-30))
@@ -273,7 +272,7 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
     # products of the shipped workloads agree to ~1e-6.  Deep, badly conditioned nets (the random-init
     # ResNet-50) scatter more for EVERY fp32 implementation: callers that have measured what stock
     # fp32 autograd achieves against float64 (bench.py) raise it to max(1e-5, 5 x that error)
-    verify_tol = float(os.environ.get("HF_ENGINE_VERIFY_TOL", "1e-5"))
+    verify_tol = 1e-5
 
     def _verify(self, loss):
         """First product of every (model, shape) signature against the autograd operator, both on the

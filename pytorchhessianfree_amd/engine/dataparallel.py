@@ -69,13 +69,12 @@ class _DataParallel:
             # the in-place prefix: leading dense segments (at most two: a chunk break may cut the run), each
             # worth a collective of its own (>= 1 MB) and 16-byte aligned
             n_pre, prefix = 0, 0
-            if os.environ.get("HF_INPLACE_PREFIX", "1") != "0":
-                while (n_pre < min(2, len(segs) - 1) and segs[n_pre][2] == 0 and segs[n_pre][1] >= (1 << 18)
-                       and (segs[n_pre][0] + segs[n_pre][1]) % 4 == 0):
-                    prefix = segs[n_pre][0] + segs[n_pre][1]
-                    n_pre += 1
-            if (masked and dead >= 0.2 * self.n and len(segs) - n_pre <= 24
-                    and os.environ.get("HF_COMPACT_ALLREDUCE", "1") != "0"):
+            # (reduced in place: +59 -> +27 us per iteration on a 1-rank RCCL group, round 3)
+            while (n_pre < min(2, len(segs) - 1) and segs[n_pre][2] == 0 and segs[n_pre][1] >= (1 << 18)
+                   and (segs[n_pre][0] + segs[n_pre][1]) % 4 == 0):
+                prefix = segs[n_pre][0] + segs[n_pre][1]
+                n_pre += 1
+            if masked and dead >= 0.2 * self.n and len(segs) - n_pre <= 24:
                 self._prefix_runs = [(sg[0], sg[0] + sg[1]) for sg in segs[:n_pre]]
                 if self._seg_cut is not None:
                     k, coff = self._seg_cut

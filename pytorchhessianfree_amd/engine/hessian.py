@@ -35,9 +35,12 @@ class _HessianExtras:
     # chain: they are issued on a SECOND STREAM forked off after the tangent sweep (inside a hipGraph capture: a
     # parallel branch of the graph), in the adjoint's unit order; the chain waits per unit for the data-gradient
     # slabs it is about to sum (an event per unit) and once, before the gather, for the rest.
-    # HF_HESSIAN_PARALLEL: 0 = everything in sequence on the chain; 1 = all extras on the side branch, the chain waits
-    # per unit for the data-gradient slabs it needs (one cross-branch dependency per unit); 2 = conv_D(g, V) inside
-    # the chain's own grouped launch, ONLY results nobody on the chain reads on the side branch: one fork, one join.
+    # Forms: 1 = all extras on the side branch, the chain waits per unit for the data-gradient slabs it needs (one
+    # cross-branch dependency per unit); 2 = conv_D(g, V) inside the chain's own grouped launch, ONLY results nobody on
+    # the chain reads on the side branch: one fork, one join.  One form per engine family (``_extras_default``), by
+    # measurement (profiles/r04_hessian_parallel_branch.jsonl: ResNet-18 sequential 852 / form 1 922-930 / form 2
+    # 947-959 matvecs/s; All-CNN-C 493 / 521 / 283 -- its 128-wide tiles spill a three-problem argument block); in
+    # sequence only where the caller already runs this engine on one of several parallel branches.
     _extras_parallel = False
     _extras_mode = 0
     _extras_default = 2
@@ -48,8 +51,8 @@ class _HessianExtras:
         # on this stack: segfault in capture_end, round-4 batch r4f)
         # (measured, profiles/r04_hessian_parallel_branch.jsonl: ResNet-18 form 1 922-930, form 2 947-959 matvecs/s;
         # All-CNN-C form 1 521, form 2 283 -- its 128-wide tile configurations spill a three-problem argument block)
-        mode = int(os.environ.get("HF_HESSIAN_PARALLEL", str(self._extras_default)))
-        self._extras_parallel = mode != 0 and getattr(self, "_extras_allowed", True)
+        mode = self._extras_default
+        self._extras_parallel = getattr(self, "_extras_allowed", True)
         self._extras_mode = mode if self._extras_parallel else 0
         if not self._extras_parallel:
             return

@@ -207,7 +207,7 @@ class _TangentSweep:
             fw = self.fc.weight
             k, f = fw.shape
             ok = (
-                os.environ.get("HF_ENGINE_HEAD", "1") != "0" and self._ce is not None and hw == 1
+                self._ce is not None and hw == 1
                 and fw.is_contiguous() and fw.dtype == torch.float32 and k <= 64 and f <= 512 and f % 4 == 0
                 and self.feat.is_contiguous() and tuple(self.feat.shape) == (self.logits.shape[0], f)
                 and self.logits.shape[0] <= 4096 and ((2 * k + 4) * f + 4 * k) * 4 <= 64 * 1024
@@ -224,4 +224,4 @@ class _TangentSweep:
 
     def _grouping(self):
         # (Hessian products carry extra terms per unit: the plain one-unit launches)
-        return os.environ.get("HF_ENGINE_GROUP", "1") != "0" and not self.hessian
+        return not self.hessian

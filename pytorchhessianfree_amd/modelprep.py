@@ -595,10 +595,9 @@ def _bias_grad(gy):
 def _own_conv_ok(x, w, cl, dilation, channels):
     """The package's implicit-GEMM kernels (``hf_conv2d_nhwc``: one launch, deterministic
     split-K, dead taps skipped) apply: NHWC fp32 on the GPU, unit dilation, both channel
-    counts multiples of 4.  ``HF_OWN_CONV=0`` keeps MIOpen everywhere."""
+    counts multiples of 4 (``HF_CONV=miopen`` keeps MIOpen everywhere)."""
     if not (cl and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and list(dilation) == [1, 1]
-            and channels % 4 == 0 and w.shape[0] % 4 == 0 and w.shape[2] * w.shape[3] <= 64
-            and os.environ.get("HF_OWN_CONV", "1") != "0"):
+            and channels % 4 == 0 and w.shape[0] % 4 == 0 and w.shape[2] * w.shape[3] <= 64):
         return False
     # the kernels' 32-bit index limits (hf_conv.hip: check_common), with the output map bounded by
     # the input map (stride >= 1, "same"-or-smaller padding is the common case; a layer that still
@@ -622,8 +621,7 @@ def _use_own(mode, kind, rows):
     (scripts/conv_kernel_bench.py) favours the own kernels for <= 128 rows; in the product
     that advantage is gone (operands arrive cold from other XCDs' L2).  kind: "T" tangent,
     "D" data gradient, "W" weight gradient, "DW" both in one launch, "stem" the tiny-Cin
-    layer, "F" the once-per-step forward pass (own kernels: accuracy first); the thresholds stay
-    tunable (``HF_CONV_AUTO``)."""
+    layer, "F" the once-per-step forward pass (own kernels: accuracy first)."""
     mode = os.environ.get("HF_CONV") or mode or "auto"
     if mode == "own":
         return True
@@ -636,16 +634,8 @@ _AUTO_DEFAULT = {"T": 0, "D": 0, "W": 0, "DW": 0, "stem": 0, "F": 1 << 30}
 
 
 def _auto_rows():
-    """Row thresholds of the "auto" rule per kind (``HF_CONV_AUTO="W:128,DW:32"`` overrides,
-    for tuning); kind "stem" = the tiny-Cin layer (1 = own, 0 = MIOpen)."""
-    spec = os.environ.get("HF_CONV_AUTO")
-    if not spec:
-        return _AUTO_DEFAULT
-    out = dict(_AUTO_DEFAULT)
-    for item in spec.split(","):
-        k, v = item.split(":")
-        out[k.strip()] = int(v)
-    return out
+    """Row thresholds of the "auto" rule per kind; kind "stem" = the tiny-Cin layer (1 = own, 0 = MIOpen)."""
+    return _AUTO_DEFAULT
 
 
 def _tiny_cin(x, w, cl):

@@ -773,11 +773,11 @@ class HessianFree(torch.optim.Optimizer):
 
     def _engine_diag_ef(self, model, loss_func, inputs, targets, reduction):
         """``sum_i g_i^2`` (/ N) on the session's engine, or ``None`` (no session for this model / shape / loss, train
-        mode, data parallelism, ``HF_ENGINE_DIAG_EF=0``): the caller then takes the autograd construction."""
+        mode, data parallelism): the caller then takes the autograd construction."""
         import os
 
         sess = self._session
-        if (sess is None or os.environ.get("HF_ENGINE_DIAG_EF", "1") == "0" or self.process_group is not None
+        if (sess is None or self.process_group is not None
                 or reduction not in ("mean", "sum")):
             return None
         eng = sess.engine
@@ -804,9 +804,8 @@ class HessianFree(torch.optim.Optimizer):
             eng._loss_head()
             if bool(eng.bad_targets):
                 return None
-            if os.environ.get("HF_DIAG_EF_GRAPH", "1") != "0":
-                return sess.diag_ef(reduction)  # (one graph replay)
-            return eng.diag_ef(reduction)
+            # (one graph replay: 5.8 ms against 74 ms for the per-sample autograd loop, round 4)
+            return sess.diag_ef(reduction)
 
 class _SessionTrials:
     """``tfunc`` of optimizer.py:288-294 on a persistent engine session: a trial point

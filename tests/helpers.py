@@ -157,10 +157,16 @@ class RefTrace:
         """max |v[idx] - ref64[idx]| / max |ref64|: distance to the float64 value the reference's result is rounded from."""
         return self.vec_err((name + "/" if name else "") + "f64", v)
 
+    def own_rel_l2(self, name):
+        """The reference's own fp32 error in the l2 norm of the index sample: ||ref32 - ref64|| / ||ref64||."""
+        f64 = self.sample((name + "/" if name else "") + "f64")
+        return float((self.sample(name) - f64).norm() / f64.norm().clamp_min(1e-300))
+
     def envelope(self, name, tight):
         """Bound for the distance of an fp32 result to the reference's fp32 result: ``tight`` (what is asked of the
-        distance to float64) + twice the reference's own fp32 distance to float64."""
-        return tight + 2.0 * self.own_err(name)
+        distance to float64) + three times the reference's own fp32 distance to float64 (a result AT the float64
+        value sits one such distance away)."""
+        return tight + 3.0 * self.own_err(name)
 
     def norm_err(self, name, v):
         want = self.scalar((name + "/" if name else "") + "norm")

@@ -97,3 +97,49 @@ def test_every_relative_import_of_the_package_resolves():
                 m = importlib.import_module(mod)
                 for a in node.names:
                     assert hasattr(m, a.name) or importlib.util.find_spec(mod + "." + a.name) is not None, (path, mod, a.name)
+
+
+def test_environment_switches_are_registered():
+    """Every ``HF_*`` environment variable the package reads is listed ONCE in ``config.SWITCHES`` with its default,
+    its meaning and the test that exercises a non-default value; that test exists and names the switch."""
+    import glob
+
+    from pytorchhessianfree_amd import config
+
+    pat = re.compile(r'(?:environ\.get\(|environ\[|getenv\(|env\.get\(|env\.setdefault\()\s*"(HF_[A-Z0-9_]+)"')
+    read = {}
+    root = os.path.join(ROOT, "pytorchhessianfree_amd")
+    for ext in ("py", "hip", "h"):
+        for path in glob.glob(os.path.join(root, "**", "*." + ext), recursive=True):
+            for name in pat.findall(open(path).read()):
+                read.setdefault(name, set()).add(os.path.relpath(path, ROOT))
+    assert set(read) <= set(config.SWITCHES), {k: v for k, v in read.items() if k not in config.SWITCHES}
+    assert set(config.SWITCHES) <= set(read), sorted(set(config.SWITCHES) - set(read))  # (no stale entries)
+    for name, (default, meaning, test) in config.SWITCHES.items():
+        path, func = test.split("::")
+        text = open(os.path.join(ROOT, path)).read()
+        assert f"def {func}(" in text, (name, test)
+        assert re.search(r"\b" + name + r"\b", text), f"{test} does not mention {name}"
+        assert meaning and isinstance(default, str)
+
+
+def test_alternate_library_path(tmp_path):
+    """``HF_PCG_LIB``: another build of the library (tuning variants) is loaded from the given path -- and a path
+    that does not exist is an error, not a fall-back to the in-tree build."""
+    import shutil
+    import subprocess
+    import sys
+
+    from pytorchhessianfree_amd import _lib
+
+    copy = tmp_path / "libhfpcg_variant.so"
+    shutil.copyfile(_lib.LIB_PATH, copy)
+    code = ("import sys; sys.path.insert(0, %r); from pytorchhessianfree_amd import _lib; "
+            "print(_lib.LIB_PATH); print(_lib.load().hf_abi_version())" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HF_PCG_LIB=str(copy)), capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout.split()[-2:] == [str(copy), str(_lib.ABI_VERSION)]
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HF_PCG_LIB=str(tmp_path / "missing.so")),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0

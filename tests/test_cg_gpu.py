@@ -463,6 +463,32 @@ def test_tiny_and_ragged_lengths(n, dtype):
         assert len(gm) == len(om)
 
 
+@pytest.mark.parametrize("blocks", ["64", "1000"])
+def test_kernel_grid_override_gives_the_same_solve(monkeypatch, blocks):
+    """``HF_PCG_BLOCKS`` (workgroups of K1-K3; default 2 per CU; must agree on all ranks of a data-parallel run): another
+    grid is another partition of the fp64 partial sums -- the solve equals the oracle in the kernels' arithmetic within
+    the same bounds as with the default grid (iterates 2e-5, same reason and iteration count)."""
+    product, oracle = _product(), _oracle()
+    monkeypatch.setenv("HF_PCG_BLOCKS", blocks)
+    n = 1_300_021 + int(blocks)  # (a length no other test uses: the workspace -- and its grid -- is cached per length)
+    g = torch.Generator().manual_seed(7)
+    d = torch.rand(n, generator=g) * 3 + 0.5
+    b = torch.randn(n, generator=g)
+    dd, bd = d.to(DEV), b.to(DEV)
+    kw = dict(max_iter=25, tol=1e-6, martens_conv_crit=True, store_x_at_iters=[0, 1, 2, 5, 10])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ox, om, oreason = oracle.pcg(lambda v: d * v + 0.3 * v, b, accumulate="fp64", **kw)
+        gx, gm, greason = product.cg(product.DampedCurvature(lambda v: dd * v, 0.3), bd, **kw)
+    assert greason == oreason and len(gx) == len(ox)
+    for a, o in zip(gx, ox):
+        assert (a is None) == (o is None)
+        if a is not None:
+            within(_maxrel(a.cpu().numpy(), o.numpy()), 2e-5)
+    for a, o in zip(gm, om):
+        within(abs(float(a) - float(o)), 1e-5 * abs(float(o)) + 1e-7, strict=False)
+
+
 def test_c_abi_rejects_misuse_on_device():
     """Error behaviour of the C ABI itself (include/hf_pcg.h): call order, alignment,
     inconsistent arguments -- checked through ctypes with real device pointers."""

@@ -144,6 +144,17 @@ def test_engine_declines_what_it_does_not_know(monkeypatch):
     mse = torch.nn.MSELoss()
     onehot = torch.nn.functional.one_hot(t, 100).float()
     assert type(curvature.ggn_operator(mse(out, onehot), out, list(net.parameters()))) is curvature.GGNOperator
+    # HF_ENGINE_DEBUG=1: the reason a model was not taken is said aloud (quiet by default: not being covered is normal)
+    monkeypatch.setenv("HF_ENGINE_DEBUG", "1")
+    with pytest.warns(UserWarning, match="fused curvature engine .* not used"):
+        curvature.ggn_operator(mse(out, onehot), out, list(net.parameters()))
+    monkeypatch.delenv("HF_ENGINE_DEBUG")
+    # HF_ENGINE=0: a model the engine covers stays on the autograd operator
+    ce = torch.nn.CrossEntropyLoss()
+    assert isinstance(curvature.ggn_operator(ce(out, t), out, list(net.parameters())), FusedGGNEngine)
+    monkeypatch.setenv("HF_ENGINE", "0")
+    out = net(x)
+    assert type(curvature.ggn_operator(ce(out, t), out, list(net.parameters()))) is curvature.GGNOperator
 
 
 @pytest.mark.parametrize("batch", [32, 3])
@@ -185,7 +196,7 @@ def test_allcnnc_plain_stack_engine_product_matches_float64_and_cpu_oracle(batch
         within(float((op.logits.cpu() - co.detach()).abs().max() / co.detach().abs().max()), 2e-6)
         # ... and against what the REAL reference computed in the build container (golden ``products``: ``_Gv``
         # through the BackPACK restatement on the stock CPU model) -- in float64 (product / gradient 2e-6: what its
-        # fp32 results are rounded from) and in fp32 (the same + twice the reference's OWN fp32 distance to float64,
+        # fp32 results are rounded from) and in fp32 (the same + three times the reference's OWN fp32 distance to float64,
         # which is 1.0e-5 for this net's gradient on 8 CPU threads and moves by 9e-6 with the thread count)
         from helpers import RefTrace
 
@@ -830,6 +841,52 @@ def test_gather_emits_the_pcg_curvature_partial_sums(dtype, damping):
     with pytest.raises(_lib.Refused):                   # fewer slots than workgroups: refused, not truncated
         _lib.pack_ex(out, tensors, perms, splits, scale=0.5, live=live, curv=(p, ctl, part[:nparts - 1]))
     del keep1, keep2, keep3, keep4
+
+
+def test_solve_with_the_curvature_scalar_from_the_gather_equals_the_k1_launch(monkeypatch):
+    """The PCG scalar p.(Bp + damping p) (cg.py:205-206) three ways on the ResNet-18 engine's captured product: from the
+    gather's own partial sums (default: iteration graph = product -> K2 -> K3), from the K1 launch
+    (``HF_FUSE_CURVATURE=0``: product -> K1 -> K2 -> K3) and with everything as separate launches
+    (``HF_FUSE_ITERATION=0``).  Same fp64 terms in another summation order: identical termination, iterates 1e-5
+    (max-norm relative; 2e-7 measured), m_k 1e-6."""
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=8, device=DEV, data_seed=tp.RESNET18_B32_SEPARATED_SEEDS[0])
+    modelprep.prepare_model(model, channels_last=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    b = None
+    runs = {}
+    for name, env in (("gather", {}), ("k1", {"HF_FUSE_CURVATURE": "0"}), ("separate", {"HF_FUSE_ITERATION": "0"})):
+        for k in ("HF_FUSE_CURVATURE", "HF_FUSE_ITERATION"):
+            monkeypatch.delenv(k, raising=False)
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+
+        def builder():
+            o = model(x)
+            return curvature.ggn_operator(lossf(o, t), o, params)
+
+        op = curvature.maybe_graphed(builder, params=params)
+        assert isinstance(op.op, FusedGGNEngine)
+        if b is None:
+            b = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            xs, ms, reason = hf.cg(hf.DampedCurvature(op, 0.05), b, max_iter=12, martens_conv_crit=True,
+                                   store_x_at_iters=list(range(13)))
+        graphs = getattr(op, "_iteration_graphs", {})
+        if name == "gather":
+            assert op.fused_curvature is not None and graphs and all(key[-1] for key in graphs)
+        elif name == "k1":
+            assert op.fused_curvature is None and graphs and not any(key[-1] for key in graphs)
+        else:
+            assert not graphs
+        runs[name] = (xs, ms, reason)
+    xs0, ms0, reason0 = runs["k1"]
+    for name in ("gather", "separate"):
+        xs, ms, reason = runs[name]
+        assert reason == reason0 and len(xs) == len(xs0)
+        for i in range(1, len(xs)):
+            within(float((xs[i] - xs0[i]).abs().max() / xs0[i].abs().max()), 1e-5, note=(name, i))
+            within(abs(float(ms[i]) - float(ms0[i])), 1e-6 * abs(float(ms0[i])) + 1e-12, strict=False, note=(name, i))
 
 
 def test_live_copy_gathers_and_scatters_the_live_entries():

@@ -506,3 +506,44 @@ def test_relu_margin_reports_the_smallest_relu_input():
     # the seeds the parity tests and bench.py draw their ResNet-18 batches from
     model, (xb, _), _ = tp.resnet18_mnist(batch_size=32, data_seed=tp.RESNET18_B32_SEPARATED_SEEDS[0])
     assert tp.relu_margin(model.double(), xb.double()) > 8e-7
+
+
+def test_configure_is_explicit_and_idempotent(monkeypatch, tmp_path):
+    """``config.configure()`` and its switches: ``HF_ALLOW_WINOGRAD=1`` / ``HF_ALLOW_WRW_XDLOPS=1`` leave MIOpen's
+    solver families alone, ``HF_MIOPEN_DB=<dir>`` seeds a writable copy of the shipped records there, ``off`` sets no
+    user db; variables the user already set are kept; a second call is a no-op.  ``HF_NHWC_FIND=1`` keeps MIOpen's find
+    step for NHWC problems (``modelprep._miopen_mode``)."""
+    import os
+
+    from pytorchhessianfree_amd import config, modelprep
+
+    for k in ("MIOPEN_DEBUG_CONV_WINOGRAD", "MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_WRW_XDLOPS", "MIOPEN_USER_DB_PATH",
+              "PYTORCH_MIOPEN_SUGGEST_NHWC", "HF_ALLOW_WINOGRAD", "HF_ALLOW_WRW_XDLOPS", "HF_MIOPEN_DB", "HF_NHWC_FIND"):
+        monkeypatch.delenv(k, raising=False)
+    saved = dict(config._state)
+    bench = torch.backends.cudnn.benchmark
+    try:
+        monkeypatch.setenv("HF_MIOPEN_DB", str(tmp_path / "db"))
+        got = config.configure(force=True, find=False)
+        assert got["MIOPEN_DEBUG_CONV_WINOGRAD"] == "0"
+        assert got["MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_WRW_XDLOPS"] == "0"
+        assert got["MIOPEN_USER_DB_PATH"] == str(tmp_path / "db") and os.path.isdir(tmp_path / "db")
+        assert sorted(os.listdir(tmp_path / "db")) == sorted(
+            f for f in os.listdir(config._SHIPPED_DB) if os.path.isfile(os.path.join(config._SHIPPED_DB, f)))
+        assert config.configure(find=False) is got  # idempotent
+        for k in ("MIOPEN_DEBUG_CONV_WINOGRAD", "MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_WRW_XDLOPS",
+                  "MIOPEN_USER_DB_PATH"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("HF_ALLOW_WINOGRAD", "1")
+        monkeypatch.setenv("HF_ALLOW_WRW_XDLOPS", "1")
+        monkeypatch.setenv("HF_MIOPEN_DB", "off")
+        got = config.configure(force=True, find=False)
+        assert "MIOPEN_DEBUG_CONV_WINOGRAD" not in got and "MIOPEN_DEBUG_CONV_WINOGRAD" not in os.environ
+        assert "MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_WRW_XDLOPS" not in got
+        assert got["MIOPEN_USER_DB_PATH"] is None
+        assert modelprep._miopen_mode(True).active
+        monkeypatch.setenv("HF_NHWC_FIND", "1")
+        assert not modelprep._miopen_mode(True).active
+    finally:
+        config._state.update(saved)
+        torch.backends.cudnn.benchmark = bench
