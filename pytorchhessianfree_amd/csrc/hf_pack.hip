@@ -115,6 +115,19 @@ __device__ __forceinline__ void pack_block(T* __restrict__ dst, const PackArgs& 
       // transactions than the loads they follow
       const bool staged = I > 0 && (unsigned)a.chunk[lo] % slab == 0 && (unsigned)a.chunk[lo] <= TILE &&
                           (((uintptr_t)(out + j0)) & 15) == 0;
+      // (CURV: this thread's first quads of p -- what the store loop below dots with -- are requested NOW, in front
+      // of the slab loads, instead of as one more dependent round trip behind the barrier)
+      constexpr int PRE = 3;
+      VU<T> p_pre[PRE];
+      if constexpr (CURV) {
+        if (staged) {
+#pragma unroll
+          for (int k = 0; k < PRE; ++k) {
+            const unsigned t = threadIdx.x * 4 + (unsigned)k * BLOCK * 4;
+            if (t < j1u - (unsigned)j0) p_pre[k].v = *reinterpret_cast<const V*>(cv.p + j0 + t);
+          }
+        }
+      }
       for (unsigned e = (unsigned)j0 + threadIdx.x * 4; e < j1u; e += BLOCK * 4) {
         unsigned jd = e, step = 1;  // destination of the quad's first element, distance between its elements
         bool rd = true;
@@ -129,7 +142,23 @@ __device__ __forceinline__ void pack_block(T* __restrict__ dst, const PackArgs& 
 #pragma unroll
         for (int c = 0; c < W; ++c) acc.e[c] = (T)0;
         if (rd) acc.v = *reinterpret_cast<const V*>(src + e);
-        for (int sp = 1; sp < nsp; sp += 8) {
+        int sp = 1;
+        // (many slabs -- the weight gradients of large-map layers arrive as up to 128 --: sixteen in flight per lane;
+        // same split order, same bits)
+        for (; sp + 16 <= nsp; sp += 16) {
+          VU<T> tt[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+#pragma unroll
+            for (int c = 0; c < W; ++c) tt[u].e[c] = (T)0;
+            if (rd) tt[u].v = *reinterpret_cast<const V*>(src + e + (long long)(sp + u) * sps);
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int c = 0; c < W; ++c) acc.e[c] += tt[u].e[c];
+        }
+        for (; sp < nsp; sp += 8) {
           VU<T> tt[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
@@ -192,7 +221,11 @@ __device__ __forceinline__ void pack_block(T* __restrict__ dst, const PackArgs& 
           *reinterpret_cast<V*>(out + j0 + t) = v.v;
           if constexpr (CURV) {
             VU<T> pv;
-            pv.v = *reinterpret_cast<const V*>(cv.p + j0 + t);
+            const unsigned k = (t - threadIdx.x * 4) / (BLOCK * 4);
+            if (k == 0) pv = p_pre[0];
+            else if (k == 1) pv = p_pre[1];
+            else if (k == 2) pv = p_pre[2];
+            else pv.v = *reinterpret_cast<const V*>(cv.p + j0 + t);
 #pragma unroll
             for (int c = 0; c < W; ++c) cv.add(v.e[c], pv.e[c]);
           }
@@ -531,8 +564,13 @@ static int pack_impl(void* dst, const void* const* srcs, const int64_t* numels,
           const int64_t slabs = (int64_t)(TILE_BYTES / sizeof(T)) / (I * HW + HW);
           if (slabs >= 1 && !(splits && splits[2 * t] > 1) && a.live[k] == 0)
             a.chunk[k] = (int)(slabs * I * HW);  // LDS-tiled path
-          else if (a.nsplit[k] > 1 && sizeof(T) == 4 && I % 4 == 0 && I * HW <= (int64_t)(TILE_BYTES / sizeof(T)))
-            a.chunk[k] = (int)(((2048 + I * HW - 1) / (I * HW)) * I * HW);  // LDS-staged stores, >= 2048 elements
+          else if (a.nsplit[k] > 1 && sizeof(T) == 4 && I % 4 == 0 && I * HW <= (int64_t)(TILE_BYTES / sizeof(T))) {
+            // LDS-staged stores, whole [I, HW] slabs per workgroup: >= 2048 elements -- >= 512 where the source is
+            // MANY split-K slabs (a workgroup's time is then the chain of its slab batches: more, shorter workgroups;
+            // All-CNN-C's 96 x 96 x 9 weight gradient arrives as 85 slabs and used to be gathered by 32 workgroups)
+            const int64_t least = a.nsplit[k] >= 24 ? 512 : 2048;
+            a.chunk[k] = (int)(((least + I * HW - 1) / (I * HW)) * I * HW);
+          }
           else if (a.live[k] != 0 && a.nsplit[k] == 1 && I * HW <= 2 * PACK_CHUNK)
             a.chunk[k] = (int)(((PACK_CHUNK + I * HW - 1) / (I * HW)) * I * HW);  // zero stream + live stores
         }
