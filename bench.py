@@ -770,11 +770,6 @@ def main():
         achieved = k2_bytes / k2_s / 1e9 if k2_s > 0 else 0.0
         all3 = (timing["k1_ms"] + timing["k2_ms"] + timing["k3_ms"]) * 1e-3
         fused = bool(getattr(op, "_iteration_graphs", None))
-        # K1 (p.(Bp + damping p): 8 N bytes re-read) is gone where the product's own gather leaves its partial sums
-        # (hf_pack_ex_curv): the solver's kernels are then K2 + K3, 40 N (48 N) bytes per iteration
-        k1_fused = fused and any(key[-1] for key in getattr(op, "_iteration_graphs", {}))
-        if k1_fused:
-            it_bytes -= 8.0 * n
         line = {
             "metric": "GGN-matvecs/sec (damped operator calls inside the PCG loop)",
             "value": world * matvecs / dt,
@@ -816,9 +811,7 @@ def main():
                           + "; convolutions: " + (os.environ.get("HF_CONV") or "auto") + "; " + layout
                           + ("; deterministic (two products bitwise equal)" if check.get("deterministic")
                              else "; NOT bitwise repeatable (library kernels with atomics)"),
-                "iteration": ("one hipGraph launch per PCG iteration (product, whose gather also leaves K1's partial "
-                              "sums of p.(Bp + damping p) -> K2 -> K3; no K1 launch)" if fused and group is None and k1_fused
-                              else "one hipGraph launch per PCG iteration (product -> K1 -> K2 -> K3)" if fused and group is None
+                "iteration": ("one hipGraph launch per PCG iteration (product -> K1 -> K2 -> K3)" if fused and group is None
                               else "product graph A -> [all-reduce of the late layers' share on a second communicator] "
                                    "|| product graph B -> all-reduce of the rest -> scatter -> K1-K3 graph"
                               if fused and getattr(op, "split", None) is not None
@@ -867,8 +860,6 @@ def main():
                 "all_pcg_kernels": {
                     "k1_ms": timing["k1_ms"], "k2_ms": timing["k2_ms"], "k3_ms": timing["k3_ms"],
                     "alg_bytes_per_iter": it_bytes,
-                    "k1": ("no launch: the product's gather emits the partial sums (hf_pack_ex_curv), 8 N bytes "
-                           "per iteration saved" if k1_fused else "k_curvature, 8 N bytes"),
                     "achieved_GBs": it_bytes / all3 / 1e9 if all3 > 0 else 0.0,
                 },
             },

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 12
+#define HF_ABI_VERSION 11
 
 enum hf_dtype { HF_F32 = 0, HF_F64 = 1 };
 
@@ -131,14 +131,10 @@ int hf_pcg_update_p(hf_pcg_t* h, const void* y_external, void* stream);
  * `with_timing` adds a second executable with event-record nodes around K1/K2/K3;
  * `hf_pcg_graph_launch(g, timed=1, ...)` runs that one, `hf_pcg_graph_collect_timing`
  * waits for it and adds its three durations to what hf_pcg_timing_read reports.
- * `curv_part` / `curv_nparts` (NULL / 0: none): the product's own gather has already left the partial sums of
- * p.(Bp + damping p) there (hf_pack_ex_curv inside `product_graph`): the graph is then [product] -> K2 -> K3, K2
- * re-reduces those `curv_nparts` fp64 partials exactly as it would K1's -- the dot product of cg.py:206 costs no
- * launch and no second read of Bp.  The timing executable then reports 0 for K1.
  */
 typedef struct hf_pcg_graph hf_pcg_graph_t;
 int hf_pcg_graph_create(hf_pcg_graph_t** out, hf_pcg_t* h, void* product_graph,
-                        const void* Bp, double damping, int with_timing, const void* curv_part, int curv_nparts);
+                        const void* Bp, double damping, int with_timing);
 int hf_pcg_graph_update(hf_pcg_graph_t* g, const void* Bp, double damping);
 int hf_pcg_graph_launch(hf_pcg_graph_t* g, int timed, void* stream);
 int hf_pcg_graph_collect_timing(hf_pcg_graph_t* g);
@@ -195,18 +191,6 @@ int hf_pack(void* dst, const void* const* srcs, const int64_t* numels,
 int hf_pack_ex(void* dst, const void* const* srcs, const int64_t* numels, const int64_t* perm,
                const int64_t* splits, const int64_t* live, int n_tensors, double scale, int mode,
                int dtype, void* stream);
-/* hf_pack_ex (mode 0) that ALSO emits the PCG's curvature scalar: the vector it writes is B.p, and with `p` (the vector
- * the product was taken of, laid out like dst, 16-byte aligned) every workgroup adds up its share of
- *     sum_j p[j] * (dst[j] + damping * p[j])        (optimizer.py:266's damped operator inside cg.py:206's dot product;
- *                                                    the reference's two roundings per entry, fp64 accumulation)
- * and stores ONE fp64 partial: part[0 .. *nparts_out).  `ctl`: DEVICE double[2] = {damping, damping != 0}, read by the
- * kernel (the launch sits inside a captured product graph, the damping changes from solve to solve); `part_cap`:
- * slots available (HF_ERR_CAPACITY if the launch needs more).  hf_pcg_graph_create(..., part, *nparts_out) makes K2
- * take the scalar from there: K1 -- a launch that re-reads Bp and p, 8 N bytes -- disappears from the iteration. */
-int hf_pack_ex_curv(void* dst, const void* const* srcs, const int64_t* numels, const int64_t* perm,
-                    const int64_t* splits, const int64_t* live, int n_tensors, double scale, int dtype,
-                    const void* p, const void* ctl, void* part, int part_cap, int* nparts_out, void* stream);
-
 /*
  * Multi-tensor scatter for the tangent sweep, the counterpart of hf_pack: tensor t is the
  * contiguous [O, slab] block at src + src_offs[t] (a weight-shaped slice of the CG

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HF_PCG_LIB") or os.path.join(_HERE, "csrc", "libhfpcg.so")
 
 HF_F32, HF_F64 = 0, 1
-ABI_VERSION = 12
+ABI_VERSION = 11
 HF_ERR_ARG = -1  # hf_status of include/hf_pcg.h: null / negative / inconsistent argument
 HF_M_NONE, HF_M_DIAG, HF_M_EXTERNAL = 0, 1, 2
 REASONS = {
@@ -67,14 +67,7 @@ SIGNATURES = {
     "hf_pcg_curvature": (c_int, [c_void_p, c_void_p, c_double, c_void_p]),
     "hf_pcg_update_xr": (c_int, [c_void_p, c_void_p, c_double, c_void_p]),
     "hf_pcg_update_p": (c_int, [c_void_p, c_void_p, c_void_p]),
-    "hf_pcg_graph_create": (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p,
-                                    c_int]),
-    "hf_pack_ex_curv": (
-        c_int,
-        [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64),
-         ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), c_int, c_double, c_int, c_void_p, c_void_p, c_void_p, c_int,
-         ctypes.POINTER(c_int), c_void_p],
-    ),
+    "hf_pcg_graph_create": (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_double, c_int]),
     "hf_pcg_graph_update": (c_int, [c_void_p, c_void_p, c_double]),
     "hf_pcg_graph_launch": (c_int, [c_void_p, c_int, c_void_p]),
     "hf_pcg_graph_collect_timing": (c_int, [c_void_p]),
@@ -431,7 +424,7 @@ def conv2d_nhwc_backward(dx, dw, dy, x, w_t, n, h, w, c, k, r, s, stride, paddin
     return dx, dw
 
 
-def pack_ex(dst, tensors, perms, splits, scale=1.0, live=None, mode=0, curv=None):
+def pack_ex(dst, tensors, perms, splits, scale=1.0, live=None, mode=0):
     """``pack`` for sources the caller describes itself: ``perms[i] = (I, H*W)`` marks tensor i as
     stored (O, H, W, I); ``splits[i] = (count, stride)`` makes it the sum of ``count`` split-K
     slabs ``stride`` elements apart (``hf_pack_ex``); ``live[i]`` = bit mask of the kernel taps
@@ -457,17 +450,6 @@ def pack_ex(dst, tensors, perms, splits, scale=1.0, live=None, mode=0, curv=None
         lv[i] = (live or {}).get(i, 0)
     if total != dst.numel():
         raise RuntimeError(f"pack_ex: {total} source elements for a vector of {dst.numel()}")
-    if curv is not None:
-        # ``curv = (p, ctl, part)``: also the partial sums of p.(dst + damping p) (``hf_pack_ex_curv``); returns their count
-        p_vec, ctl, part = curv
-        nparts = c_int(0)
-        check(
-            lib.hf_pack_ex_curv(c_void_p(dst.data_ptr()), ptrs, numels, perm, spl, lv, n, float(scale),
-                                dtype_code(dst.dtype), c_void_p(p_vec.data_ptr()), c_void_p(ctl.data_ptr()),
-                                c_void_p(part.data_ptr()), part.numel(), ctypes.byref(nparts),
-                                current_stream_ptr(dst.device)),
-            "hf_pack_ex_curv")
-        return nparts.value
     check(
         lib.hf_pack_ex(c_void_p(dst.data_ptr()), ptrs, numels, perm, spl, lv, n, float(scale), int(mode),
                        dtype_code(dst.dtype), current_stream_ptr(dst.device)),

@@ -95,17 +95,13 @@ class _IterationGraph:
     product, for data-parallel runs where an all-reduce separates the two halves);
     the K1-K3 kernel arguments are refreshed at the start of every solve."""
 
-    def __init__(self, ws, raw_graph, Bp, damping, mode, timing, curv=None):
+    def __init__(self, ws, raw_graph, Bp, damping, mode, timing):
         self.ws, self.mode, self.timing = ws, mode, bool(timing)
         self.handle = _lib.c_void_p()
-        # ``curv = (part, nparts, ctl)``: the product's gather leaves the partial sums of p.(Bp + damping p) itself
-        # (``hf_pack_ex_curv``) -- the graph is then product -> K2 -> K3, no K1 launch
-        part, nparts = (curv[0], curv[1]) if curv is not None else (None, 0)
         _lib.check(
             ws.lib.hf_pcg_graph_create(ctypes.byref(self.handle), ws.handle,
                                        _lib.c_void_p(raw_graph) if raw_graph else None,
-                                       _lib.c_void_p(Bp.data_ptr()), float(damping), 1 if timing else 0,
-                                       _lib.c_void_p(part.data_ptr()) if part is not None else None, int(nparts)),
+                                       _lib.c_void_p(Bp.data_ptr()), float(damping), 1 if timing else 0),
             "hf_pcg_graph_create")
         self.fresh = True
 
@@ -143,18 +139,10 @@ def _iteration_graph(matvec, ws, Bp, damping, mode, with_product):
     if raw is None:
         return None
     cache = matvec.__dict__.setdefault("_iteration_graphs", {})
-    # the operator's gather may already emit K1's partial sums (engine.FusedGGNEngine.fused_curvature): only where
-    # the product graph is part of the iteration graph (no collective in between) and reads the solver's p
-    curv = getattr(matvec, "fused_curvature", None) if with_product else None
-    if curv is not None and curv[3].data_ptr() != matvec.input_buffer.data_ptr():
-        curv = None
-    key = (id(ws), mode, bool(with_product), bool(ws.timing), curv is not None)
+    key = (id(ws), mode, bool(with_product), bool(ws.timing))
     g = cache.get(key)
     if g is None:
-        g = cache[key] = _IterationGraph(ws, raw() if with_product else None, Bp, damping, mode, ws.timing, curv)
-    if curv is not None:  # the damping of THIS solve, where the captured gather reads it (async fills, no sync)
-        curv[2][0].fill_(float(damping))
-        curv[2][1].fill_(1.0 if damping != 0.0 else 0.0)
+        g = cache[key] = _IterationGraph(ws, raw() if with_product else None, Bp, damping, mode, ws.timing)
     g.refresh(Bp, damping)
     return g
 

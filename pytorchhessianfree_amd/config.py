@@ -141,9 +141,7 @@ SWITCHES = {
     "HF_GRAPH_VERIFY": ("first", "always / never: replay check of a freshly captured product graph",
                         "tests/test_optimizer_gpu.py::test_graphed_operator_refuses_a_replay_that_differs_from_the_eager_product"),
     "HF_FUSE_ITERATION": ("1", "0: product, K1, K2, K3 as separate launches (no iteration graph)",
-                          "tests/test_engine_gpu.py::test_solve_with_the_curvature_scalar_from_the_gather_equals_the_k1_launch"),
-    "HF_FUSE_CURVATURE": ("1", "0: the gather does not emit K1's partial sums (K1 stays a launch)",
-                          "tests/test_engine_gpu.py::test_solve_with_the_curvature_scalar_from_the_gather_equals_the_k1_launch"),
+                          "tests/test_engine_gpu.py::test_solve_as_one_graph_per_iteration_equals_separate_launches"),
     "HF_BN_EPILOGUE": ("1", "0: train-mode tangent partial sums by the reduction launch, not the convolution's epilogue",
                        "tests/test_engine_gpu.py::test_train_mode_prologue_form_variants_agree_and_state_is_independent_of_the_first_use_check"),
     "HF_BN_TRAIN_PAIR": ("1", "0: a downsample block's two train-mode units in launches of their own",

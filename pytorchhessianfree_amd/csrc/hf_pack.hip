@@ -6,6 +6,10 @@
 // Reference: parameters_to_vector / vector_to_parameter_list, hessianfree/utils.py:8-76, optimizer.py:462.
 #include "hf_common.h"
 
+#ifndef HF_PACK_DEEP
+#define HF_PACK_DEEP 1  // (A/B knob of round 5: 0 builds the gather with 8-deep slab batches and >= 2048-element chunks)
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -35,42 +39,6 @@ struct PackArgs {
 };
 constexpr int TILE_BYTES = 32768;  // LDS staging of the layout-permuting paths
 
-// The gather can emit the PCG's curvature scalar on the way (hf_pack_ex_curv): the vector it writes is B.p, so
-// sum p.(Bp + damping*p) -- what the solver's K1 launch computes from the same two vectors (cg.py:205-206 with the
-// damped operator of optimizer.py:266) -- costs one more read stream here instead of a launch that re-reads Bp.
-// Per block ONE fp64 partial (fixed order: bitwise repeatable); the solver's K2 re-reduces them as it does K1's.
-struct CurvArgs {
-  const void* p;      // the vector the product was taken of, laid out like dst; nullptr: no partial sums
-  const double* ctl;  // device: ctl[0] = damping, ctl[1] = damping != 0 (written per solve, read here)
-  double* part;       // [>= first + gridDim.x]
-  int first;          // this launch's first slot
-};
-
-template <typename T, bool CURV>
-struct CurvAcc {
-  double s = 0.0;
-  const T* p = nullptr;
-  T lam = (T)0;
-  bool damped = false;
-  __device__ __forceinline__ void init(const CurvArgs& c, long long dst_off) {
-    if constexpr (CURV) {
-      p = reinterpret_cast<const T*>(c.p) + dst_off;
-      lam = (T)c.ctl[0];
-      damped = c.ctl[1] != 0.0;
-    }
-  }
-  // reference: mvp(x) + damping * x (two roundings), then the dot product's term
-  __device__ __forceinline__ void add(T bp, T pp) {
-    if constexpr (CURV) s += (double)pp * (double)(damped ? (T)(bp + (T)(lam * pp)) : bp);
-  }
-  __device__ __forceinline__ void sub(T bp, T pp) {
-    if constexpr (CURV) s -= (double)pp * (double)(damped ? (T)(bp + (T)(lam * pp)) : bp);
-  }
-  __device__ __forceinline__ void at(T bp, long long j) {
-    if constexpr (CURV) add(bp, p[j]);
-  }
-};
-
 template <typename T, int OP>
 __device__ __forceinline__ T pack_op(T d, T s, T scale) {
   if (OP == 0) return (T)(scale * s);
@@ -78,12 +46,12 @@ __device__ __forceinline__ T pack_op(T d, T s, T scale) {
   return d + (T)(g * g);
 }
 
-template <typename T, int OP, bool CURV>
-__device__ __forceinline__ void pack_block(T* __restrict__ dst, const PackArgs& a, T scale, T* tile,
-                                           CurvAcc<T, CURV>& cv, const CurvArgs& cargs) {
+template <typename T, int OP>
+__global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackArgs a, T scale) {
   constexpr int W = VecOf<T>::W;
   typedef typename VecOf<T>::type V;
   constexpr unsigned TILE = TILE_BYTES / sizeof(T);
+  __shared__ __attribute__((aligned(16))) T tile[TILE];  // staging of the layout-permuting paths
   // binary search: tensor t with blk_start[t] <= blockIdx.x < blk_start[t+1]
   int lo = 0, hi = a.nt;
   while (hi - lo > 1) {
@@ -96,7 +64,6 @@ __device__ __forceinline__ void pack_block(T* __restrict__ dst, const PackArgs& 
   const long long j0 = (long long)(blockIdx.x - a.blk_start[lo]) * a.chunk[lo];
   const long long j1 = (j0 + a.chunk[lo] < numel) ? j0 + a.chunk[lo] : numel;
   T* __restrict__ out = dst + a.dst_off[lo];
-  cv.init(cargs, a.dst_off[lo]);
   if (nsp > 1) {
     // source = sum of nsp split-K slabs (the weight gradients of layers whose reduction had to
     // be split, the BatchNorm adjoint's per-row-block sums); combined in split order.  Walked
@@ -115,19 +82,6 @@ __device__ __forceinline__ void pack_block(T* __restrict__ dst, const PackArgs& 
       // transactions than the loads they follow
       const bool staged = I > 0 && (unsigned)a.chunk[lo] % slab == 0 && (unsigned)a.chunk[lo] <= TILE &&
                           (((uintptr_t)(out + j0)) & 15) == 0;
-      // (CURV: this thread's first quads of p -- what the store loop below dots with -- are requested NOW, in front
-      // of the slab loads, instead of as one more dependent round trip behind the barrier)
-      constexpr int PRE = 3;
-      VU<T> p_pre[PRE];
-      if constexpr (CURV) {
-        if (staged) {
-#pragma unroll
-          for (int k = 0; k < PRE; ++k) {
-            const unsigned t = threadIdx.x * 4 + (unsigned)k * BLOCK * 4;
-            if (t < j1u - (unsigned)j0) p_pre[k].v = *reinterpret_cast<const V*>(cv.p + j0 + t);
-          }
-        }
-      }
       for (unsigned e = (unsigned)j0 + threadIdx.x * 4; e < j1u; e += BLOCK * 4) {
         unsigned jd = e, step = 1;  // destination of the quad's first element, distance between its elements
         bool rd = true;
@@ -145,7 +99,7 @@ __device__ __forceinline__ void pack_block(T* __restrict__ dst, const PackArgs& 
         int sp = 1;
         // (many slabs -- the weight gradients of large-map layers arrive as up to 128 --: sixteen in flight per lane;
         // same split order, same bits)
-        for (; sp + 16 <= nsp; sp += 16) {
+        for (; HF_PACK_DEEP && sp + 16 <= nsp; sp += 16) {
           VU<T> tt[16];
 #pragma unroll
           for (int u = 0; u < 16; ++u) {
@@ -187,19 +141,9 @@ __device__ __forceinline__ void pack_block(T* __restrict__ dst, const PackArgs& 
 #pragma unroll
           for (int c = 0; c < W; ++c) acc.e[c] = pack_op<T, OP>((T)0, acc.e[c], scale);
           *reinterpret_cast<V*>(out + jd) = acc.v;
-          if constexpr (CURV) {
-            VU<T> pv;
-            pv.v = *reinterpret_cast<const V*>(cv.p + jd);
-#pragma unroll
-            for (int c = 0; c < W; ++c) cv.add(acc.e[c], pv.e[c]);
-          }
         } else {
 #pragma unroll
-          for (int c = 0; c < W; ++c) {
-            const T val = pack_op<T, OP>(out[jd + c * step], acc.e[c], scale);
-            out[jd + c * step] = val;
-            cv.at(val, jd + c * step);
-          }
+          for (int c = 0; c < W; ++c) out[jd + c * step] = pack_op<T, OP>(out[jd + c * step], acc.e[c], scale);
         }
       }
       if (staged) {
@@ -219,16 +163,6 @@ __device__ __forceinline__ void pack_block(T* __restrict__ dst, const PackArgs& 
 #pragma unroll
           for (int c = 0; c < W; ++c) v.e[c] = pack_op<T, OP>(OP == 1 ? d.e[c] : (T)0, v.e[c], scale);
           *reinterpret_cast<V*>(out + j0 + t) = v.v;
-          if constexpr (CURV) {
-            VU<T> pv;
-            const unsigned k = (t - threadIdx.x * 4) / (BLOCK * 4);
-            if (k == 0) pv = p_pre[0];
-            else if (k == 1) pv = p_pre[1];
-            else if (k == 2) pv = p_pre[2];
-            else pv.v = *reinterpret_cast<const V*>(cv.p + j0 + t);
-#pragma unroll
-            for (int c = 0; c < W; ++c) cv.add(v.e[c], pv.e[c]);
-          }
         }
       }
       return;
@@ -284,9 +218,7 @@ __device__ __forceinline__ void pack_block(T* __restrict__ dst, const PackArgs& 
           const unsigned hw = rem / I, i = rem - hw * I;
           j = o * slab + i * HW + hw;
         }
-        const T val = pack_op<T, OP>(out[j], acc[k], scale);
-        out[j] = val;
-        cv.at(val, j);
+        out[j] = pack_op<T, OP>(out[j], acc[k], scale);
       }
     }
     return;
@@ -307,15 +239,7 @@ __device__ __forceinline__ void pack_block(T* __restrict__ dst, const PackArgs& 
       VU<T> z;
 #pragma unroll
       for (int c = 0; c < W; ++c) z.e[c] = (T)0;
-      for (unsigned j = (unsigned)j0 + threadIdx.x * W; j < j1u; j += BLOCK * W) {
-        *reinterpret_cast<V*>(out + j) = z.v;
-        if constexpr (CURV) {  // (every entry as a zero first; the live taps' terms are corrected below)
-          VU<T> pv;
-          pv.v = *reinterpret_cast<const V*>(cv.p + j);
-#pragma unroll
-          for (int c = 0; c < W; ++c) cv.add((T)0, pv.e[c]);
-        }
-      }
+      for (unsigned j = (unsigned)j0 + threadIdx.x * W; j < j1u; j += BLOCK * W) *reinterpret_cast<V*>(out + j) = z.v;
       __syncthreads();  // (s_waitcnt vmcnt(0) + barrier: the zeros are acknowledged before any value store is issued)
       const unsigned o0 = (unsigned)j0 / slab, no = (j1u - (unsigned)j0) / slab;
       const unsigned nl = (unsigned)__popc(live);
@@ -331,13 +255,7 @@ __device__ __forceinline__ void pack_block(T* __restrict__ dst, const PackArgs& 
           seen += bit;
         }
         const unsigned ob = (o0 + ol) * slab;
-        const T val = pack_op<T, OP>((T)0, src[ob + hw * I + i], scale);
-        out[ob + i * HW + hw] = val;
-        if constexpr (CURV) {
-          const T pp = cv.p[ob + i * HW + hw];
-          cv.sub((T)0, pp);  // (products of two floats are exact in fp64: the zero term above cancels exactly)
-          cv.add(val, pp);
-        }
+        out[ob + i * HW + hw] = pack_op<T, OP>((T)0, src[ob + hw * I + i], scale);
       }
       return;
     }
@@ -353,19 +271,12 @@ __device__ __forceinline__ void pack_block(T* __restrict__ dst, const PackArgs& 
       }
       if (OP == 0 && al && j + W <= j1u) {
 #pragma unroll
-        for (int c = 0; c < W; ++c) {
-          v.e[c] = pack_op<T, OP>((T)0, v.e[c], scale);
-          cv.at(v.e[c], j + c);
-        }
+        for (int c = 0; c < W; ++c) v.e[c] = pack_op<T, OP>((T)0, v.e[c], scale);
         *reinterpret_cast<V*>(out + j) = v.v;
       } else {
 #pragma unroll
         for (int c = 0; c < W; ++c)
-          if (j + c < j1u) {
-            const T val = pack_op<T, OP>(out[j + c], v.e[c], scale);
-            out[j + c] = val;
-            cv.at(val, j + c);
-          }
+          if (j + c < j1u) out[j + c] = pack_op<T, OP>(out[j + c], v.e[c], scale);
       }
     }
     return;
@@ -385,9 +296,7 @@ __device__ __forceinline__ void pack_block(T* __restrict__ dst, const PackArgs& 
       for (unsigned t = threadIdx.x; t < len; t += BLOCK) {
         const unsigned ol = t / slab, rem = t - ol * slab;
         const unsigned i = rem / HW, hw = rem - i * HW;
-        const T val = pack_op<T, OP>(out[j0 + t], tile[(ol * HW + hw) * (I + 1) + i], scale);
-        out[j0 + t] = val;
-        cv.at(val, j0 + t);
+        out[j0 + t] = pack_op<T, OP>(out[j0 + t], tile[(ol * HW + hw) * (I + 1) + i], scale);
       }
       return;
     }
@@ -395,9 +304,7 @@ __device__ __forceinline__ void pack_block(T* __restrict__ dst, const PackArgs& 
       const long long o = j / slab;
       const unsigned rem = (unsigned)(j - o * slab);
       const unsigned i = rem / HW, hw = rem - i * HW;
-      const T val = pack_op<T, OP>(out[j], src[o * slab + (long long)hw * I + i], scale);
-      out[j] = val;
-      cv.at(val, j);
+      out[j] = pack_op<T, OP>(out[j], src[o * slab + (long long)hw * I + i], scale);
     }
     return;
   }
@@ -405,42 +312,18 @@ __device__ __forceinline__ void pack_block(T* __restrict__ dst, const PackArgs& 
   if (vec_ok) {
     const long long v0 = j0 / W, v1 = j1 / W;
     for (long long i = v0 + threadIdx.x; i < v1; i += BLOCK) {
-      VU<T> s, d, pv;
+      VU<T> s, d;
       s.v = reinterpret_cast<const V*>(src)[i];
       if (OP == 1) d.v = reinterpret_cast<const V*>(out)[i];
-      if constexpr (CURV) pv.v = reinterpret_cast<const V*>(cv.p)[i];
 #pragma unroll
-      for (int c = 0; c < W; ++c) {
-        d.e[c] = pack_op<T, OP>(d.e[c], s.e[c], scale);
-        if constexpr (CURV) cv.add(d.e[c], pv.e[c]);
-      }
+      for (int c = 0; c < W; ++c) d.e[c] = pack_op<T, OP>(d.e[c], s.e[c], scale);
       reinterpret_cast<V*>(out)[i] = d.v;
     }
-    for (long long j = v1 * W + threadIdx.x; j < j1; j += BLOCK) {
-      const T val = pack_op<T, OP>(out[j], src[j], scale);
-      out[j] = val;
-      cv.at(val, j);
-    }
+    for (long long j = v1 * W + threadIdx.x; j < j1; j += BLOCK)
+      out[j] = pack_op<T, OP>(out[j], src[j], scale);
   } else {
-    for (long long j = j0 + threadIdx.x; j < j1; j += BLOCK) {
-      const T val = pack_op<T, OP>(out[j], src[j], scale);
-      out[j] = val;
-      cv.at(val, j);
-    }
-  }
-}
-
-template <typename T, int OP, bool CURV>
-__global__ __launch_bounds__(BLOCK) void k_pack(T* __restrict__ dst, const PackArgs a, T scale, const CurvArgs cargs) {
-  __shared__ __attribute__((aligned(16))) T tile[TILE_BYTES / sizeof(T)];  // staging of the layout-permuting paths
-  CurvAcc<T, CURV> cv;
-  pack_block<T, OP, CURV>(dst, a, scale, tile, cv, cargs);
-  if constexpr (CURV) {
-    __shared__ double lds[WAVES];
-    __syncthreads();  // (the body's early returns are per block, not per thread: every thread arrives)
-    double acc[1] = {cv.s};
-    block_allreduce<1>(acc, lds);
-    if (threadIdx.x == 0) cargs.part[cargs.first + blockIdx.x] = acc[0];
+    for (long long j = j0 + threadIdx.x; j < j1; j += BLOCK)
+      out[j] = pack_op<T, OP>(out[j], src[j], scale);
   }
 }
 
@@ -528,13 +411,9 @@ __global__ __launch_bounds__(BLOCK) void k_live_copy(T* __restrict__ full, T* __
 template <typename T>
 static int pack_impl(void* dst, const void* const* srcs, const int64_t* numels,
                      const int64_t* perm, const int64_t* splits, const int64_t* live, int nt,
-                     double scale, int mode, hipStream_t s, CurvArgs curv = CurvArgs{nullptr, nullptr, nullptr, 0},
-                     int part_cap = 0, int* nparts_out = nullptr) {
+                     double scale, int mode, hipStream_t s) {
   int t = 0;
   long long off = 0;
-  if (curv.p) {
-    if (mode != 0 || !curv.ctl || !curv.part || !nparts_out || !aligned16(curv.p) || !aligned16(dst)) return HF_ERR_ARG;
-  }
   while (t < nt) {
     PackArgs a;
     memset(&a, 0, sizeof(a));
@@ -568,7 +447,7 @@ static int pack_impl(void* dst, const void* const* srcs, const int64_t* numels,
             // LDS-staged stores, whole [I, HW] slabs per workgroup: >= 2048 elements -- >= 512 where the source is
             // MANY split-K slabs (a workgroup's time is then the chain of its slab batches: more, shorter workgroups;
             // All-CNN-C's 96 x 96 x 9 weight gradient arrives as 85 slabs and used to be gathered by 32 workgroups)
-            const int64_t least = a.nsplit[k] >= 24 ? 512 : 2048;
+            const int64_t least = (HF_PACK_DEEP && a.nsplit[k] >= 24) ? 512 : 2048;
             a.chunk[k] = (int)(((least + I * HW - 1) / (I * HW)) * I * HW);
           }
           else if (a.live[k] != 0 && a.nsplit[k] == 1 && I * HW <= 2 * PACK_CHUNK)
@@ -584,18 +463,12 @@ static int pack_impl(void* dst, const void* const* srcs, const int64_t* numels,
     a.blk_start[k] = blocks;
     a.nt = k;
     if (blocks == 0) continue;
-    if (curv.p) {
-      if (curv.first + blocks > part_cap) return HF_ERR_CAPACITY;
-      hipLaunchKernelGGL((k_pack<T, 0, true>), dim3(blocks), dim3(BLOCK), 0, s, (T*)dst, a, (T)scale, curv);
-      curv.first += blocks;
-    } else if (mode == 0) {
-      hipLaunchKernelGGL((k_pack<T, 0, false>), dim3(blocks), dim3(BLOCK), 0, s, (T*)dst, a, (T)scale, curv);
-    } else {
-      hipLaunchKernelGGL((k_pack<T, 1, false>), dim3(blocks), dim3(BLOCK), 0, s, (T*)dst, a, (T)scale, curv);
-    }
+    if (mode == 0)
+      hipLaunchKernelGGL((k_pack<T, 0>), dim3(blocks), dim3(BLOCK), 0, s, (T*)dst, a, (T)scale);
+    else
+      hipLaunchKernelGGL((k_pack<T, 1>), dim3(blocks), dim3(BLOCK), 0, s, (T*)dst, a, (T)scale);
     HF_HIP(hipGetLastError());
   }
-  if (nparts_out) *nparts_out = curv.first;
   return HF_OK;
 }
 
@@ -614,20 +487,6 @@ int hf_pack_ex(void* dst, const void* const* srcs, const int64_t* numels, const 
   if (dtype == HF_F64)
     return pack_impl<double>(dst, srcs, numels, perm, splits, live, n_tensors, scale, mode,
                              (hipStream_t)stream);
-  return HF_ERR_ARG;
-}
-
-int hf_pack_ex_curv(void* dst, const void* const* srcs, const int64_t* numels, const int64_t* perm,
-                    const int64_t* splits, const int64_t* live, int n_tensors, double scale, int dtype,
-                    const void* p, const void* ctl, void* part, int part_cap, int* nparts_out, void* stream) {
-  if (!dst || !srcs || !numels || n_tensors < 0 || !p || !ctl || !part || part_cap < 1 || !nparts_out) return HF_ERR_ARG;
-  CurvArgs c{p, (const double*)ctl, (double*)part, 0};
-  if (dtype == HF_F32)
-    return pack_impl<float>(dst, srcs, numels, perm, splits, live, n_tensors, scale, 0, (hipStream_t)stream, c,
-                            part_cap, nparts_out);
-  if (dtype == HF_F64)
-    return pack_impl<double>(dst, srcs, numels, perm, splits, live, n_tensors, scale, 0, (hipStream_t)stream, c,
-                             part_cap, nparts_out);
   return HF_ERR_ARG;
 }
 

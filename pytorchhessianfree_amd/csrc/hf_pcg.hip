@@ -962,8 +962,6 @@ int hf_pcg_iterate(hf_pcg_t* h, const void* Bp, double damping, void* stream) {
 // others.
 struct hf_pcg_graph {
   hf_pcg* h;
-  const double* ext_part;  // K1's partial sums come from the product itself (hf_pack_ex_curv): no K1 node
-  int ext_nparts;
   hipGraph_t graph[2];
   hipGraphExec_t exec[2];
   hipGraphNode_t knode[2][3];
@@ -1002,13 +1000,6 @@ hipKernelNodeParams node_params(const KLaunch& k) {
   return p;
 }
 
-// K2 takes p.(Bp + damping p) from the partial sums the product's own gather left (see hf_pack_ex_curv)
-void adopt_external_partials(const hf_pcg_graph* g, KLaunch (&k)[3]) {
-  if (!g->ext_part) return;
-  k[1].pa = g->ext_part;
-  k[1].i0 = g->ext_nparts;
-}
-
 int build_iteration_graph(hf_pcg_graph* g, int which, hipGraph_t product, const KLaunch (&k)[3]) {
   const bool timed = which == 1;
   if (product) HF_HIP(hipGraphClone(&g->graph[which], product));
@@ -1022,7 +1013,6 @@ int build_iteration_graph(hf_pcg_graph* g, int which, hipGraph_t product, const 
       HF_HIP(hipGraphAddEventRecordNode(&e, g->graph[which], deps.data(), deps.size(), g->ev[i]));
       deps.assign(1, e);
     }
-    if (i == 0 && g->ext_part) continue;  // (no K1 launch: its event pair then measures an empty interval)
     hipKernelNodeParams p = node_params(k[i]);
     HF_HIP(hipGraphAddKernelNode(&g->knode[which][i], g->graph[which], deps.data(), deps.size(), &p));
     deps.assign(1, g->knode[which][i]);
@@ -1037,20 +1027,16 @@ int build_iteration_graph(hf_pcg_graph* g, int which, hipGraph_t product, const 
 }  // namespace
 
 int hf_pcg_graph_create(hf_pcg_graph_t** out, hf_pcg_t* h, void* product_graph, const void* Bp,
-                        double damping, int with_timing, const void* curv_part, int curv_nparts) {
+                        double damping, int with_timing) {
   if (!out || !h || !Bp) return HF_ERR_ARG;
   if (!h->begun || h->precond == HF_M_EXTERNAL) return HF_ERR_STATE;
   if (!aligned16(Bp)) return HF_ERR_ALIGN;
-  if (curv_part && (curv_nparts < 1 || !product_graph)) return HF_ERR_ARG;
   hf_pcg_graph* g = new (std::nothrow) hf_pcg_graph();
   if (!g) return HF_ERR_ARG;
   memset(g, 0, sizeof(*g));
   g->h = h;
-  g->ext_part = (const double*)curv_part;
-  g->ext_nparts = curv_nparts;
   KLaunch k[3];
   build_iteration(h, Bp, damping, k);
-  adopt_external_partials(g, k);
   int rc = build_iteration_graph(g, 0, (hipGraph_t)product_graph, k);
   if (!rc && with_timing) {
     for (int i = 0; i < 4 && !rc; ++i) rc = (int)hipEventCreate(&g->ev[i]);
@@ -1069,11 +1055,9 @@ int hf_pcg_graph_update(hf_pcg_graph_t* g, const void* Bp, double damping) {
   if (!aligned16(Bp)) return HF_ERR_ALIGN;
   KLaunch k[3];
   build_iteration(h, Bp, damping, k);
-  adopt_external_partials(g, k);
   for (int w = 0; w < 2; ++w) {
     if (!g->exec[w]) continue;
     for (int i = 0; i < 3; ++i) {
-      if (i == 0 && g->ext_part) continue;
       hipKernelNodeParams p = node_params(k[i]);
       HF_HIP(hipGraphExecKernelNodeSetParams(g->exec[w], g->knode[w][i], &p));
     }

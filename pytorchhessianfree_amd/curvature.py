@@ -345,11 +345,6 @@ class GraphedOperator:
         """Replay the captured local product: reads ``input_buffer``, writes ``output_buffer``."""
         self.graph.replay()
 
-    @property
-    def fused_curvature(self):
-        """A captured engine's gather leaves the PCG's K1 partial sums (``engine.FusedGGNEngine.fused_curvature``)."""
-        return getattr(self.op, "fused_curvature", None) if self.group is None else None
-
     def reduce(self, t):
         inner = getattr(self.op, "reduce", None)  # (the captured operator's own rule, if it has one)
         if inner is not None:

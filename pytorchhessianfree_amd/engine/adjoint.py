@@ -191,34 +191,7 @@ class _AdjointSweep:
             return g_feat.view(tail.y.shape)
         return _cl((g_feat / self._head_hw).view(g_feat.shape[0], -1, 1, 1).expand(tail.y.shape))
 
-    # ---- the PCG's curvature scalar from the gather ----------------------------------------------------------------
-    # The gather writes B.p; given p it also leaves the per-workgroup partial sums of p.(Bp + damping p)
-    # (``hf_pack_ex_curv``) -- what the solver's K1 launch would compute by re-reading both vectors (cg.py:205-206,
-    # optimizer.py:266).  ``cg()`` then builds its iteration graph without K1 (``fused_curvature``).  Not under data
-    # parallelism (the all-reduce comes after the gather) and not where something is added to the product after it
-    # (the Hessian of a tagged L2 term).
-    curv_enabled = True
-    _curv = None
-
-    def _curv_args(self, dot_with, out):
-        if dot_with is None:  # (a gradient sweep's gather: the product's partial sums stay what they are)
-            return None
-        if (not self.curv_enabled or self.group is not None
-                or (self.hessian and self._l2 is not None) or os.environ.get("HF_FUSE_CURVATURE", "1") == "0"
-                or dot_with.data_ptr() % 16 or out.data_ptr() % 16 or dot_with.numel() != self.n):
-            self._curv = None
-            return None
-        if getattr(self, "_curv_part", None) is None:
-            self._curv_part = torch.empty(1 << 16, dtype=torch.float64, device=self.dev)
-            self._curv_ctl = torch.zeros(2, dtype=torch.float64, device=self.dev)  # {damping, damping != 0}: cg() fills it
-        return (dot_with, self._curv_ctl, self._curv_part)
-
-    @property
-    def fused_curvature(self):
-        """``(part, nparts, ctl, p)`` if the last ``local(p)`` left the partial sums of p.(Bp + damping p), else None."""
-        return self._curv
-
-    def _gather(self, out, g_fw, g_fb, first_order=False, dot_with=None):
+    def _gather(self, out, g_fw, g_fb, first_order=False):
         """All parameter gradients into the flat vector (weight-gradient slabs summed on the way)."""
         tensors, perms, splits = self._pack_args(first_order)
         tensors = list(tensors)
@@ -233,21 +206,8 @@ class _AdjointSweep:
             tensors[self.pfw] = g_fw
             if self.pfb is not None:
                 tensors[self.pfb] = g_fb
-        self._pack_out(out, tensors, perms, splits, dot_with)
+        _lib.pack_ex(out, tensors, perms, splits, scale=self.weight, live=self._pack_live)
         return out
-
-    def _pack_out(self, out, tensors, perms, splits, dot_with):
-        curv = self._curv_args(dot_with, out)
-        if curv is None:
-            _lib.pack_ex(out, tensors, perms, splits, scale=self.weight, live=self._pack_live)
-            return
-        try:
-            nparts = _lib.pack_ex(out, tensors, perms, splits, scale=self.weight, live=self._pack_live, curv=curv)
-        except _lib.Refused:  # (more workgroups than partial-sum slots: the plain gather, K1 stays)
-            self.curv_enabled = False
-            _lib.pack_ex(out, tensors, perms, splits, scale=self.weight, live=self._pack_live)
-            return
-        self._curv = (self._curv_part, nparts, self._curv_ctl, dot_with)
 
     def _gather_range(self, out, g_fw, g_fb, lo, hi):
         """``_gather`` for the parameters ``lo ... hi-1`` only (a contiguous range of the flat vector)."""

@@ -257,7 +257,7 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
                 self._extras_join()
         finally:
             self._second, self._v = False, None
-        self._gather(out, g_fw, g_fb, dot_with=v)
+        self._gather(out, g_fw, g_fb)
         if self.hessian and self._l2 is not None:  # the regulariser's Hessian: coef on its tensors' entries
             out.addcmul_(self._l2, v, value=self.weight)
         return out

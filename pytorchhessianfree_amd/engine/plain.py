@@ -188,7 +188,7 @@ class PlainStackEngine(FusedGGNEngine):
                 self._extras_join()
         finally:
             self._second = False
-        self._gather(out, None, None, dot_with=v)
+        self._gather(out, None, None)
         if self.hessian and self._l2 is not None:  # the regulariser's Hessian: coef on its tensors' entries
             out.addcmul_(self._l2, v, value=self.weight)
         return out
@@ -205,9 +205,9 @@ class PlainStackEngine(FusedGGNEngine):
             out.addcmul_(self._l2, self._theta(), value=self.weight)
         return out
 
-    def _gather(self, out, g_fw, g_fb, first_order=False, dot_with=None):
+    def _gather(self, out, g_fw, g_fb, first_order=False):
         tensors, perms, splits = self._pack_args(first_order)
-        self._pack_out(out, list(tensors), perms, splits, dot_with)
+        _lib.pack_ex(out, list(tensors), perms, splits, scale=self.weight, live=self._pack_live)
         return out
 
     def _loss_setup(self, loss, outputs):

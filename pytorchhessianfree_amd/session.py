@@ -383,11 +383,6 @@ class EngineSession(_TwoPhaseProduct):
         return buf.clone()
 
     # ---- operator interface of cg() (see curvature.GraphedOperator) -------------------------
-    @property
-    def fused_curvature(self):
-        """The engine's gather leaves K1's partial sums (``engine.fused_curvature``): ``cg()`` drops the K1 launch."""
-        return self.engine.fused_curvature if self.group is None else None
-
     def raw_graph(self):
         return self.graph.raw_cuda_graph()
 
@@ -670,9 +665,6 @@ class AccumulatedSession:
             self.n, self.dev = e0.n, e0.dev
             self.train_bn = any(e.train_bn for e in engines)
             self.parallel = len(engines) > 1 and not self.train_bn
-            if len(set(roles[2])) > 1:  # (the sum over the chunks is what the PCG dots with: _sum_parts)
-                for e in engines:
-                    e.curv_enabled = False
             if self.parallel:  # (one level of graph branches: the chunks'; no fork inside a forked branch)
                 for e in engines:
                     e._extras_allowed = False
@@ -771,25 +763,9 @@ class AccumulatedSession:
             val = val / self.counts[0]
         self.loss_buf.copy_(val)
 
-    _curv = None
-
-    def _sum_parts(self, ks, out, dot_with=None):
-        """``out = sum of the leading rows of the parts``: one gather launch (fixed order: repeatable).  ``dot_with``:
-        the launch also leaves the partial sums of p.(out + damping p) for the PCG (``hf_pack_ex_curv``)."""
-        k = len(list(ks))
-        if (dot_with is not None and self.group is None and os.environ.get("HF_FUSE_CURVATURE", "1") != "0"
-                and not any(e.hessian and e._l2 is not None for e in self.engines)):
-            if getattr(self, "_curv_part", None) is None:
-                self._curv_part = torch.empty(1 << 16, dtype=torch.float64, device=self.dev)
-                self._curv_ctl = torch.zeros(2, dtype=torch.float64, device=self.dev)
-            try:
-                nparts = _lib.pack_ex(out, [self._parts[0]], {}, {0: (k, self.n)}, scale=1.0,
-                                      curv=(dot_with, self._curv_ctl, self._curv_part))
-                self._curv = (self._curv_part, nparts, self._curv_ctl, dot_with)
-                return
-            except _lib.Refused:
-                self._curv = None
-        _lib.pack_ex(out, [self._parts[0]], {}, {0: (k, self.n)}, scale=1.0)
+    def _sum_parts(self, ks, out):
+        """``out = sum of the leading rows of the parts``: one gather launch (fixed order: repeatable)."""
+        _lib.pack_ex(out, [self._parts[0]], {}, {0: (len(list(ks)), self.n)}, scale=1.0)
 
     def _gradient(self):
         order = self._grad_set  # (gradient-list chunks first: their parts are the leading rows)
@@ -824,7 +800,7 @@ class AccumulatedSession:
             eng.local(self.input_buffer, out=self.output_buffer)
             return
         self._fork_join(range(len(order)), one)
-        self._sum_parts(range(len(order)), self.output_buffer, dot_with=self.input_buffer)
+        self._sum_parts(range(len(order)), self.output_buffer)
 
     # ---- validity ------------------------------------------------------------------------------
     def accepts(self, model, loss_func, lists, params, reduction, counts, hessian, group):
@@ -900,14 +876,6 @@ class AccumulatedSession:
         return self.losses[slot]
 
     # ---- operator interface of cg() ------------------------------------------------------------
-    @property
-    def fused_curvature(self):
-        if self.group is not None:
-            return None
-        if len(self._mvp_set) == 1:
-            return self.engines[self._mvp_set[0]].fused_curvature
-        return self._curv
-
     def raw_graph(self):
         return self.graph.raw_cuda_graph()
 

@@ -764,99 +764,17 @@ def test_pack_and_unpack_skip_structurally_zero_taps():
     assert torch.equal(bufs[1][:, c:], v[5 + k * c * 9:].view(k, c, 3, 3))
 
 
-@pytest.mark.parametrize("damping", [0.0, 0.37])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-def test_gather_emits_the_pcg_curvature_partial_sums(dtype, damping):
-    """``hf_pack_ex_curv``: the gather that writes B.p also leaves per-workgroup fp64 partial sums of
-    p.(Bp + damping p) (cg.py:205-206 with optimizer.py:266's damped operator) -- every store path of the kernel:
-    plain vectors (aligned and not), permuted (O,H,W,I) sources through LDS and directly, split-K slabs (16-byte,
-    LDS-staged, scalar), dead-tap tensors (zero stream + live values), > 64 tensors (several launches).  The vector is
-    bitwise ``hf_pack_ex``'s; the sum of the partials equals the fp64 dot product of p with the ELEMENTWISE-ROUNDED
-    damped vector (the reference's two roundings) to 1e-13 relative (fp64 summation order only)."""
-    from pytorchhessianfree_amd import _lib
-
-    gen = torch.Generator(device=DEV).manual_seed(5)
-
-    def r_(*shape):
-        return torch.randn(*shape, device=DEV, dtype=dtype, generator=gen)
-
-    k, c = 24, 16
-    tensors, perms, splits, live = [], {}, {}, {}
-
-    def add(first, perm=None, split=None, mask=None):
-        i = len(tensors)
-        tensors.append(first)
-        if perm:
-            perms[i] = perm
-        if split:
-            splits[i] = split
-        if mask:
-            live[i] = mask
-
-    add(r_(4097))                                     # plain, vector path + scalar tail
-    add(r_(3))                                        # (makes the next destination unaligned)
-    add(r_(1000))                                     # plain, unaligned destination: scalar path
-    add(r_(1))
-    g = r_(k, 3, 3, c)                                # permuted, LDS-tiled
-    add(g.reshape(-1), perm=(c, 9))
-    g = r_(3, 700, 5, 5)                              # permuted, slab too large for the tile: direct walk
-    add(g.permute(0, 2, 3, 1).contiguous().reshape(-1), perm=(700, 25))
-    g = r_(5, 64, 3, 3, 32)                           # 5 split-K slabs, 16-byte loads, LDS-staged stores
-    add(g[0].reshape(-1), perm=(32, 9), split=(5, g[0].numel()))
-    keep1 = g
-    g = r_(3, 10, 3, 3, 6)                            # split-K, I % 4 != 0: scalar slab path
-    add(g[0].reshape(-1), perm=(6, 9), split=(3, g[0].numel()))
-    keep2 = g
-    g = r_(9, 130)                                    # partial rows of a per-channel sum: plain split path
-    add(g[0], split=(9, 130))
-    keep3 = g
-    g = r_(512, 3, 3, 64)                             # dead taps: zero stream + the centre tap's values
-    dead = torch.ones(3, 3, dtype=torch.bool, device=DEV)
-    dead[1, 1] = False
-    g[:, dead] = 0
-    add(g.reshape(-1), perm=(64, 9), mask=1 << 4)
-    g = r_(2, 40, 3, 3, 8)                            # dead taps AND slabs
-    g[:, :, dead] = 0
-    add(g[0].reshape(-1), perm=(8, 9), split=(2, g[0].numel()), mask=1 << 4)
-    keep4 = g
-    for _ in range(70):                               # > one argument table
-        add(r_(37))
-    n = sum(t.numel() for t in tensors)
-    plain = _lib.pack_ex(torch.empty(n, device=DEV, dtype=dtype), tensors, perms, splits, scale=0.5, live=live)
-    p = r_(n)
-    ctl = torch.tensor([damping, 1.0 if damping else 0.0], dtype=torch.float64, device=DEV)
-    part = torch.full((4096,), float("nan"), dtype=torch.float64, device=DEV)
-    out = torch.empty(n, device=DEV, dtype=dtype)
-    nparts = _lib.pack_ex(out, tensors, perms, splits, scale=0.5, live=live, curv=(p, ctl, part))
-    assert torch.equal(out, plain)
-    assert 0 < nparts <= 4096 and not torch.isnan(part[:nparts]).any() and torch.isnan(part[nparts:]).all()
-    lam = torch.tensor(damping, dtype=dtype, device=DEV)
-    ap = plain + lam * p if damping else plain        # (two roundings in `dtype`, as the reference's operator)
-    want = torch.dot(p.double(), ap.double())
-    got = part[:nparts].sum()
-    within(abs(float(got - want)), 1e-13 * float((p.double().abs() * ap.double().abs()).sum()))
-    again = torch.empty_like(part)
-    _lib.pack_ex(out, tensors, perms, splits, scale=0.5, live=live, curv=(p, ctl, again))
-    assert torch.equal(again[:nparts], part[:nparts])  # (fixed summation order)
-    with pytest.raises(_lib.Refused):                   # fewer slots than workgroups: refused, not truncated
-        _lib.pack_ex(out, tensors, perms, splits, scale=0.5, live=live, curv=(p, ctl, part[:nparts - 1]))
-    del keep1, keep2, keep3, keep4
-
-
-def test_solve_with_the_curvature_scalar_from_the_gather_equals_the_k1_launch(monkeypatch):
-    """The PCG scalar p.(Bp + damping p) (cg.py:205-206) three ways on the ResNet-18 engine's captured product: from the
-    gather's own partial sums (default: iteration graph = product -> K2 -> K3), from the K1 launch
-    (``HF_FUSE_CURVATURE=0``: product -> K1 -> K2 -> K3) and with everything as separate launches
-    (``HF_FUSE_ITERATION=0``).  Same fp64 terms in another summation order: identical termination, iterates 1e-5
-    (max-norm relative; 2e-7 measured), m_k 1e-6."""
+def test_solve_as_one_graph_per_iteration_equals_separate_launches(monkeypatch):
+    """The PCG loop on the ResNet-18 engine's captured product as ONE hipGraph launch per iteration (product -> K1 -> K2
+    -> K3, default) and with product, K1, K2, K3 as separate launches (``HF_FUSE_ITERATION=0``): the same kernels on
+    the same data in the same order -- identical termination, bitwise equal iterates and m_k."""
     model, (x, t), lossf = tp.resnet18_mnist(batch_size=8, device=DEV, data_seed=tp.RESNET18_B32_SEPARATED_SEEDS[0])
     modelprep.prepare_model(model, channels_last=True)
     params = [p for p in model.parameters() if p.requires_grad]
     b = None
     runs = {}
-    for name, env in (("gather", {}), ("k1", {"HF_FUSE_CURVATURE": "0"}), ("separate", {"HF_FUSE_ITERATION": "0"})):
-        for k in ("HF_FUSE_CURVATURE", "HF_FUSE_ITERATION"):
-            monkeypatch.delenv(k, raising=False)
+    for name, env in (("graph", {}), ("separate", {"HF_FUSE_ITERATION": "0"})):
+        monkeypatch.delenv("HF_FUSE_ITERATION", raising=False)
         for k, val in env.items():
             monkeypatch.setenv(k, val)
 
@@ -872,21 +790,12 @@ def test_solve_with_the_curvature_scalar_from_the_gather_equals_the_k1_launch(mo
             warnings.simplefilter("ignore")
             xs, ms, reason = hf.cg(hf.DampedCurvature(op, 0.05), b, max_iter=12, martens_conv_crit=True,
                                    store_x_at_iters=list(range(13)))
-        graphs = getattr(op, "_iteration_graphs", {})
-        if name == "gather":
-            assert op.fused_curvature is not None and graphs and all(key[-1] for key in graphs)
-        elif name == "k1":
-            assert op.fused_curvature is None and graphs and not any(key[-1] for key in graphs)
-        else:
-            assert not graphs
+        assert bool(getattr(op, "_iteration_graphs", {})) == (name == "graph")
         runs[name] = (xs, ms, reason)
-    xs0, ms0, reason0 = runs["k1"]
-    for name in ("gather", "separate"):
-        xs, ms, reason = runs[name]
-        assert reason == reason0 and len(xs) == len(xs0)
-        for i in range(1, len(xs)):
-            within(float((xs[i] - xs0[i]).abs().max() / xs0[i].abs().max()), 1e-5, note=(name, i))
-            within(abs(float(ms[i]) - float(ms0[i])), 1e-6 * abs(float(ms0[i])) + 1e-12, strict=False, note=(name, i))
+    (xs0, ms0, reason0), (xs, ms, reason) = runs["graph"], runs["separate"]
+    assert reason == reason0 and len(xs) == len(xs0)
+    for i in range(1, len(xs)):
+        assert torch.equal(xs[i], xs0[i]) and float(ms[i]) == float(ms0[i]), i
 
 
 def test_live_copy_gathers_and_scatters_the_live_entries():
