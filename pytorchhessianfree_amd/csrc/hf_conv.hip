@@ -42,6 +42,9 @@ constexpr int CT = 256;            // threads per block
 #define HF_CONV_BK 32
 #endif
 constexpr int MAX_TAPS = 64;
+#ifndef HF_CONV_FLAT96
+#define HF_CONV_FLAT96 1  // (A/B knob of round 5: 0 builds without the 96 x 128 weight-gradient configuration)
+#endif
 
 // Tile configuration: 4 waves as WM x WN, each wave owns TM x TN MFMA tiles of 32x32 (block tile
 // 32*WM*TM x 32*WN*TN), BK reduction elements per step.  Three configurations are built:
@@ -75,6 +78,13 @@ struct Cfg {
 typedef Cfg<2, 2, 1, 1, HF_CONV_BK> Small;
 typedef Cfg<2, 2, 2, 2, 16> Big;
 typedef Cfg<4, 1, 1, 3, 16> Big96;
+// Flat96 (1x4 waves, 3x1 tiles, BK 16): 96 x 128 -- WEIGHT GRADIENTS whose dY channel count is a multiple of 96
+// (All-CNN-C's 96 / 192): the 96 output rows fill the tile exactly, and the output COLUMNS are enumerated flat over
+// (kernel tap, input channel) -- dW[k][tap][c] is one contiguous [k][taps * c] matrix when every tap is live -- so a
+// 128-wide column tile may straddle taps (each staging thread keeps its own tap) and only the last of the
+// ceil(taps * c / 128) tiles is partial: 9 x 96 = 864 columns fill 96.4 % of seven tiles, where the per-tap
+// enumeration of the other configurations fills 75 % (128 x 96 rows x columns for 96 x 96).  Staged like Big.
+typedef Cfg<1, 4, 3, 1, 16> Flat96;
 
 // Division by a launch constant as multiply-high + shift (Granlund-Montgomery, n < 2^31): the host fills
 // (mul, shift) per divisor.  The prologue of a convolution workgroup decodes its tile, its K range and the
@@ -120,7 +130,7 @@ struct ConvArgs {
   int out_c;           // W: channels of X that get an output column (<= cs: X may be zero-padded)
   int slabs;           // 1: split s writes its partial result, in the output's own layout, to
   long long slab_stride;  //    out + s*slab_stride; the CONSUMER kernel sums the slabs in its prologue
-  int big;             // tile configuration this problem was set up for (0: Small, 1: Big, 2: Big96)
+  int big;             // tile configuration this problem was set up for (0: Small, 1: Big, 2: Big96, 3: Flat96)
   // Data gradient of a STRIDED convolution, decomposed by residue class of the input pixel: pixel (y, x) only
   // receives the taps with (y + pad - r) % stride == 0, so rows are enumerated class by class ((y % sh, x % sw)
   // fixed within a row tile) and every tile loops over ITS taps only -- a stride-2 3x3 layer does 9/4 taps per
@@ -130,7 +140,7 @@ struct ConvArgs {
   int cls_tap0[5];     // taps of class i: tap_r/tap_s[cls_tap0[i] .. cls_tap0[i+1])
   int cls_h[4], cls_w[4], cls_py[4], cls_px[4];  // pixels of the class: y = y'*stride_h + py, y' < cls_h
   // launch constants as divisors (filled by seal() right before the launch)
-  FastDiv fd_tiles_n, fd_tiles_m, fd_splits, fd_rw, fd_rh, fd_csteps, fd_cblocks;
+  FastDiv fd_tiles_n, fd_tiles_m, fd_splits, fd_rw, fd_rh, fd_csteps, fd_cblocks, fd_cs;
   // BNSUM instantiations (tangent convolution in front of a TRAIN-mode BatchNorm): per-channel partial sums of this
   // workgroup's tile, sum(t) and sum(t * xhat), xhat = (bn_x - bn_mean) * bn_rstd, to row (tile_m * splits + split)
   // of bn_part_1 / bn_part_x ([tiles_m * splits][nout]) -- what the reduction launch between the convolution and the
@@ -553,7 +563,9 @@ __device__ __forceinline__ void conv_nt_body(const ConvArgs& a, float* lds, int 
 // TN kernel: W.   dW[k][tap][c] = sum_m dY[m][k] * X[pix(m,tap)][c]
 //   tile_m over k (dY channels), tile_n over (live tap, BN-channel block of X)
 // ---------------------------------------------------------------------------------
-template <bool SCALAR, typename C>
+// FLAT: the output columns are enumerated flat over (tap, channel) (see Flat96): column tile tile_n covers the
+// flattened columns [tile_n * BN, ...), every staging thread decodes the tap of ITS column quad once.
+template <bool SCALAR, typename C, bool FLAT = false>
 __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int bid) {
   constexpr int BM = C::BM, BN = C::BN, BK = C::BK, HK = C::HK, LDA = C::LDA, LDB = C::LDB;
   float (*As)[BK][LDA] = reinterpret_cast<float (*)[BK][LDA]>(lds);
@@ -568,8 +580,9 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
   const int j0 = split * per, j1 = (j0 + per < a.steps) ? j0 + per : a.steps;
 
   const int cblocks = (a.cs + BN - 1) / BN;
-  const int ti = (int)fdiv((unsigned)tile_n, a.fd_cblocks), c0 = (tile_n - ti * cblocks) * BN;
-  const int rs_ = a.tap_rs[ti], r = rs_ & 255, q = rs_ >> 8;
+  int ti, c0;
+  if constexpr (FLAT) { ti = 0; c0 = tile_n * BN; }
+  else { ti = (int)fdiv((unsigned)tile_n, a.fd_cblocks); c0 = (tile_n - ti * cblocks) * BN; }
 
   // staging: thread -> rows kr, kr + RP of the step and the float4 at column 4*cq
   constexpr int CQ = C::SM / 4;     // float4 per staged row (both operands are staged SM == SN wide)
@@ -578,8 +591,16 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
   static_assert(TU == 2, "the hand-counted prefetch ring assumes 2 + 2 loads per step (TN)");
   const int kr = t / CQ, cq = t % CQ;
   const int ka = tile_m * BM + 4 * cq;  // dY channel
-  const int cb = c0 + 4 * cq;           // X channel
-  const bool aok = (ka < a.kout) & (4 * cq < BM), bkok = (cb < a.cs) & (4 * cq < BN);
+  int cb = c0 + 4 * cq;                 // X channel
+  bool bkok = (cb < a.cs) & (4 * cq < BN);
+  if constexpr (FLAT) {                 // (flattened column -> this thread's tap and channel; quads never straddle taps)
+    const int jq = c0 + 4 * cq;
+    bkok = (jq < a.ntaps * a.cs) & (4 * cq < BN);
+    ti = bkok ? (int)fdiv((unsigned)jq, a.fd_cs) : 0;
+    cb = jq - ti * a.cs;
+  }
+  const int rs_ = a.tap_rs[ti], r = rs_ & 255, q = rs_ >> 8;
+  const bool aok = (ka < a.kout) & (4 * cq < BM);
 
   auto fetch = [&](int step, float4 (&ra)[TU], float4 (&rb)[TU]) -> unsigned {
     unsigned ok = 0;
@@ -726,9 +747,14 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
   }
   __syncthreads();
   // output element (k, tap, c) at (k*RS + tap)*cs + c: rows = k, "columns" = c within this tap
-  float* base = a.out + (size_t)(r * a.S + q) * a.out_c;
-  finish_tile<C>(a, acc, tile, split, wm, wn, lane, base, tile_m * BM, c0, a.kout, a.out_c,
-                 a.R * a.S * a.out_c, &flag);
+  if constexpr (FLAT) {  // (every tap live, out_c == cs: the columns ARE the flattened (tap, c) index)
+    finish_tile<C>(a, acc, tile, split, wm, wn, lane, a.out, tile_m * BM, c0, a.kout, a.ntaps * a.cs,
+                   a.R * a.S * a.out_c, &flag);
+  } else {
+    float* base = a.out + (size_t)(r * a.S + q) * a.out_c;
+    finish_tile<C>(a, acc, tile, split, wm, wn, lane, base, tile_m * BM, c0, a.kout, a.out_c,
+                   a.R * a.S * a.out_c, &flag);
+  }
 }
 
 template <bool SCALAR, typename C, bool CLS = false, bool BNSUM = false>
@@ -749,10 +775,10 @@ __global__ __launch_bounds__(CT) void k_conv_nt_unpack(const ConvArgs a, const h
   else hf_shared::unpack_block<float>(usrc, u, blockIdx.x - (unsigned)conv_blocks);
 }
 
-template <bool SCALAR, typename C>
+template <bool SCALAR, typename C, bool FLAT = false>
 __global__ __launch_bounds__(CT) void k_conv_tn(const ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
-  conv_tn_body<SCALAR, C>(a, lds, blockIdx.x);
+  conv_tn_body<SCALAR, C, FLAT>(a, lds, blockIdx.x);
 }
 
 // Data gradient AND weight gradient of one layer in ONE launch: both read the same dY,
@@ -771,6 +797,7 @@ __global__ __launch_bounds__(CT) void k_conv_dw(const ConvArgs d, const ConvArgs
   } else {
     if (ANYBIG && w.big == 1) conv_tn_body<false, Big>(w, lds, blockIdx.x - nblocks_d);
     else if (ANYBIG && w.big == 2) conv_tn_body<false, Big96>(w, lds, blockIdx.x - nblocks_d);
+    else if (ANYBIG && w.big == 3) conv_tn_body<false, Flat96, true>(w, lds, blockIdx.x - nblocks_d);
     else conv_tn_body<false, Small>(w, lds, blockIdx.x - nblocks_d);
   }
 }
@@ -806,6 +833,7 @@ __device__ __forceinline__ void group_run(const ConvArgs& a, int tn, float* lds,
   if (tn) {
     if (ANYBIG && a.big == 1) conv_tn_body<false, Big>(a, lds, local);
     else if (ANYBIG && a.big == 2) conv_tn_body<false, Big96>(a, lds, local);
+    else if (ANYBIG && a.big == 3) conv_tn_body<false, Flat96, true>(a, lds, local);
     else conv_tn_body<false, Small>(a, lds, local);
   } else {
     if (ANYBIG && a.big == 1) conv_nt_body<false, Big, CLS>(a, lds, local);
@@ -918,6 +946,7 @@ void seal(ConvArgs& a, int direction) {
   a.fd_rh = make_fastdiv(a.rh);
   a.fd_csteps = make_fastdiv((a.cs + bk - 1) / bk);
   a.fd_cblocks = make_fastdiv((a.cs + bn - 1) / bn);
+  a.fd_cs = make_fastdiv(a.cs);
   (void)direction;
 }
 
@@ -938,6 +967,7 @@ void launch_one(int direction, const ConvArgs& a_in, int64_t blocks, hipStream_t
     if (a.scalar) hipLaunchKernelGGL((k_conv_tn<true, Small>), grid, block, 0, stream, a);
     else if (a.big == 1) hipLaunchKernelGGL((k_conv_tn<false, Big>), grid, block, 0, stream, a);
     else if (a.big == 2) hipLaunchKernelGGL((k_conv_tn<false, Big96>), grid, block, 0, stream, a);
+    else if (a.big == 3) hipLaunchKernelGGL((k_conv_tn<false, Flat96, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((k_conv_tn<false, Small>), grid, block, 0, stream, a);
   }
 }
@@ -961,7 +991,8 @@ inline int hf_env_dclass() { return 1; }  // (strided data gradients are enumera
 
 inline int hf_env_big() { return -1; }  // (-1: by geometry; 0 / 1 force a configuration when bisecting)
 
-int want_big(int direction, int64_t rows, int64_t dim_m, int64_t dim_n, int64_t red, int64_t mult, bool scalar) {
+int want_big(int direction, int64_t rows, int64_t dim_m, int64_t dim_n, int64_t red, int64_t mult, bool scalar,
+             bool all_taps = false) {
   // dim_m x dim_n: the output matrix (NT: rows x nout; TN: kout x cs per tap, `mult` = live taps of them);
   // red: length of the reduction; rows: GEMM rows of the layer.
   // Returns 0 (Small), 1 (Big: 128x128) or 2 (Big96: 128x96), whichever wastes less of its tiles.
@@ -970,8 +1001,15 @@ int want_big(int direction, int64_t rows, int64_t dim_m, int64_t dim_n, int64_t 
   if (force == 0) return 0;
   auto fill = [](int64_t d, int64_t t) { return (double)d / (double)(((d + t - 1) / t) * t); };
   const double f128 = fill(dim_m, 128) * fill(dim_n, 128), f96 = fill(dim_m, 128) * fill(dim_n, 96);
-  const int kind = f96 > f128 + 1e-9 ? 2 : 1;
-  const bool fits = (kind == 2 ? f96 : f128) >= 0.7;
+  int kind = f96 > f128 + 1e-9 ? 2 : 1;
+  double fbest = kind == 2 ? f96 : f128;
+  // weight gradients with every tap live and a dY channel count that is a multiple of 96: Flat96 (see its typedef)
+  int64_t flat_tiles = 0;
+  if (HF_CONV_FLAT96 && direction == 2 && all_taps && dim_m % 96 == 0 && dim_n % 4 == 0) {
+    const double fflat = fill(mult * dim_n, 128);
+    if (fflat > fbest + 0.05) { kind = 3; fbest = fflat; flat_tiles = (dim_m / 96) * ((mult * dim_n + 127) / 128); }
+  }
+  const bool fits = fbest >= 0.7;
   if (force > 0) return fits ? kind : 0;
   // ... and only where the launch has enough work to give ~3 workgroups per CU a K loop of >= 8 steps of 16 each
   // (a looser rule -- any reduction of >= 64 steps, splits capped at 8 steps per workgroup -- was measured to put
@@ -979,7 +1017,8 @@ int want_big(int direction, int64_t rows, int64_t dim_m, int64_t dim_n, int64_t 
   // tiles lose to the 64x64 ones, whose prologue / epilogue are a quarter the size (ResNet-50 on 64x64
   // images, batch 32: 260 matvecs/s with the 64x64 tiles everywhere, 228 -> 198 with the 128-wide ones wherever
   // they fit; All-CNN-C's 8192-row layers, 9 steps per workgroup: 128x96 tiles 37 us, 64x64 tiles 64 us)
-  const int64_t tiles = ((dim_m + 127) / 128) * ((dim_n + (kind == 2 ? 95 : 127)) / (kind == 2 ? 96 : 128)) * mult;
+  const int64_t tiles = kind == 3 ? flat_tiles
+                                  : ((dim_m + 127) / 128) * ((dim_n + (kind == 2 ? 95 : 127)) / (kind == 2 ? 96 : 128)) * mult;
   const int64_t steps = (red + Big::BK - 1) / Big::BK;
   return (fits && rows >= 2048 && tiles * steps >= BIG_TARGET_BLOCKS * 8) ? kind : 0;
 }
@@ -1061,8 +1100,9 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
       }
   }
   a.big = direction <= 1 ? want_big(direction, rows, rows, a.nout, (int64_t)cls_taps_max * a.cs, 1, a.scalar)
-                         : want_big(direction, rows, a.kout, a.cs, rows, a.ntaps, a.scalar);
-  const int BM = a.big ? Big::BM : Small::BM, BN = a.big == 2 ? Big96::BN : a.big ? Big::BN : Small::BN;
+                         : want_big(direction, rows, a.kout, a.cs, rows, a.ntaps, a.scalar, a.ntaps == (int)(r * s));
+  const int BM = a.big == 3 ? Flat96::BM : a.big ? Big::BM : Small::BM;
+  const int BN = a.big == 2 ? Big96::BN : a.big ? Big::BN : Small::BN;
   const int BK = a.big ? Big::BK : Small::BK;
   if (direction <= 1) {
     a.tiles_m = (int)((rows + BM - 1) / BM);
@@ -1084,7 +1124,7 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
     }
   } else {
     a.tiles_m = (a.kout + BM - 1) / BM;
-    a.tiles_n = a.ntaps * ((a.cs + BN - 1) / BN);
+    a.tiles_n = a.big == 3 ? (a.ntaps * a.cs + BN - 1) / BN : a.ntaps * ((a.cs + BN - 1) / BN);
     red_steps = (rows + BK - 1) / BK;
   }
   a.steps = (int)red_steps;

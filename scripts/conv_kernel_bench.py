@@ -3,7 +3,7 @@ PyTorch-ROCm -> MIOpen on the convolution shapes of one ResNet-18 (28x28, batch 
 product.  Each op is timed as a hipGraph of 20 back-to-back launches (what a product replay
 does), per direction: T = tangent (2*Cin channels), D = data gradient, W = weight gradient.
 
-    python scripts/conv_kernel_bench.py [--blocks 512]
+    python scripts/conv_kernel_bench.py [--big 1] [--no-reduce 1]
 """
 import argparse
 import json
@@ -56,15 +56,12 @@ def cl(t):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--blocks", type=int, default=0)
     ap.add_argument("--no-reduce", type=int, default=0,
                     help="1: also time the slab-mode launches (hf_conv2d_nhwc_slabs: split-K partial results left "
                          "for the consumer kernel's prologue, as the fused curvature engine runs them)")
     ap.add_argument("--big", type=int, default=0, help="1: the large-M shapes (All-CNN-C, ResNet-50) instead")
     args = ap.parse_args()
     shapes = BIG_SHAPES if args.big else SHAPES
-    if args.blocks:
-        os.environ["HF_CONV_BLOCKS"] = str(args.blocks)
     torch.backends.cudnn.benchmark = False  # immediate mode on the shipped find-db, as the product runs
     for name, n, h, w, c, k, r, st, pd in shapes:
         stride, pad = (st, st), (pd, pd)

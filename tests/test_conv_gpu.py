@@ -38,6 +38,7 @@ GEOMS = [
     (32, 32, 32, 96, 96, 3, 3, (1, 1), (1, 1)),    # All-CNN-C conv2: 32768 rows
     (32, 16, 16, 96, 192, 3, 3, (2, 2), (1, 1)),   # strided, 96 -> 192
     (8, 16, 16, 192, 192, 3, 3, (1, 1), (0, 0)),   # no padding, ragged row tile (8*14*14 = 1568 rows: small config)
+    (32, 16, 16, 192, 192, 3, 3, (1, 1), (1, 1)),  # All-CNN-C conv5: weight gradient on 96 x 128 tiles, columns flat over (tap, c)
     (32, 12, 12, 192, 100, 1, 1, (1, 1), (0, 0)),  # 1x1, 100 output channels (ragged column tile)
     (16, 16, 16, 256, 128, 1, 1, (1, 1), (0, 0)),  # ResNet-50-like 1x1 reduction
 ]
