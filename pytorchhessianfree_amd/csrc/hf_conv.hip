@@ -45,6 +45,9 @@ constexpr int MAX_TAPS = 64;
 #ifndef HF_CONV_FLAT96
 #define HF_CONV_FLAT96 1  // (A/B knob of round 5: 0 builds without the 96 x 128 weight-gradient configuration)
 #endif
+#ifndef HF_FLAT96_MIN_WORK
+#define HF_FLAT96_MIN_WORK 2048  // (tiles x K-steps from which a weight gradient takes Flat96; A/B: 6144 = the Big rule)
+#endif
 
 // Tile configuration: 4 waves as WM x WN, each wave owns TM x TN MFMA tiles of 32x32 (block tile
 // 32*WM*TM x 32*WN*TN), BK reduction elements per step.  Three configurations are built:
@@ -992,7 +995,7 @@ inline int hf_env_dclass() { return 1; }  // (strided data gradients are enumera
 inline int hf_env_big() { return -1; }  // (-1: by geometry; 0 / 1 force a configuration when bisecting)
 
 int want_big(int direction, int64_t rows, int64_t dim_m, int64_t dim_n, int64_t red, int64_t mult, bool scalar,
-             bool all_taps = false) {
+             bool all_taps = false, bool slab_mode = false) {
   // dim_m x dim_n: the output matrix (NT: rows x nout; TN: kout x cs per tap, `mult` = live taps of them);
   // red: length of the reduction; rows: GEMM rows of the layer.
   // Returns 0 (Small), 1 (Big: 128x128) or 2 (Big96: 128x96), whichever wastes less of its tiles.
@@ -1020,7 +1023,12 @@ int want_big(int direction, int64_t rows, int64_t dim_m, int64_t dim_n, int64_t 
   const int64_t tiles = kind == 3 ? flat_tiles
                                   : ((dim_m + 127) / 128) * ((dim_n + (kind == 2 ? 95 : 127)) / (kind == 2 ? 96 : 128)) * mult;
   const int64_t steps = (red + Big::BK - 1) / Big::BK;
-  return (fits && rows >= 2048 && tiles * steps >= BIG_TARGET_BLOCKS * 8) ? kind : 0;
+  // (Flat96 weight gradients: a third of that work already pays -- All-CNN-C's stride-2 layers, 8192 / 2048 output rows,
+  // ran 58 / 35 us on 36 / 72 64x64 tiles with 8 / 4 splits against MIOpen's 24 / 23 us)
+  // (slab mode only: with the in-launch ticket reduction of the stand-alone calls a deep split makes the last
+  // arriver's sum the longest chain of the launch -- 52 -> 87 us measured)
+  const int64_t least = (kind == 3 && slab_mode) ? HF_FLAT96_MIN_WORK : BIG_TARGET_BLOCKS * 8;
+  return (fits && rows >= 2048 && tiles * steps >= least) ? kind : 0;
 }
 
 int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void* mat, int64_t n, int64_t h,
@@ -1100,7 +1108,8 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
       }
   }
   a.big = direction <= 1 ? want_big(direction, rows, rows, a.nout, (int64_t)cls_taps_max * a.cs, 1, a.scalar)
-                         : want_big(direction, rows, a.kout, a.cs, rows, a.ntaps, a.scalar, a.ntaps == (int)(r * s));
+                         : want_big(direction, rows, a.kout, a.cs, rows, a.ntaps, a.scalar, a.ntaps == (int)(r * s),
+                                    slab_splits >= 0);
   const int BM = a.big == 3 ? Flat96::BM : a.big ? Big::BM : Small::BM;
   const int BN = a.big == 2 ? Big96::BN : a.big ? Big::BN : Small::BN;
   const int BK = a.big ? Big::BK : Small::BK;

@@ -100,7 +100,7 @@ def main():
         for key, mul in (("T", 2.0), ("D", 1.0), ("W", 1.0)):
             for impl in ("own", "slab", "miopen"):
                 if f"{key}_{impl}" in line:
-                    line[f"{key}_{impl}_TF"] = mul * gf / line[f"{key}_{impl}"] * 1e-3 * 1e3
+                    line[f"{key}_{impl}_TF"] = mul * gf / line[f"{key}_{impl}"] * 1e3  # GFLOP / us = PFLOP/s
         print(json.dumps({k_: (round(v, 2) if isinstance(v, float) else v) for k_, v in line.items()}), flush=True)
 
 
