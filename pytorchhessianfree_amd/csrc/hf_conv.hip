@@ -45,6 +45,9 @@ constexpr int MAX_TAPS = 64;
 #ifndef HF_CONV_FLAT96
 #define HF_CONV_FLAT96 1  // (A/B knob of round 5: 0 builds without the 96 x 128 weight-gradient configuration)
 #endif
+#ifndef HF_DCLASS_NOSPLIT
+#define HF_DCLASS_NOSPLIT 1
+#endif
 #ifndef HF_FLAT96_MIN_WORK
 #define HF_FLAT96_MIN_WORK 2048  // (tiles x K-steps from which a weight gradient takes Flat96; A/B: 6144 = the Big rule)
 #endif
@@ -876,7 +879,10 @@ namespace {
 // hides (~1.0 us at BK = 32, ~1.5 us at BK = 64; the fp32 MFMA work itself is 0.43 / 0.86 us),
 // a split run pays ~3 us to publish and collect tickets plus ~0.15 us per slab the last
 // arriver sums; workgroups beyond two per CU queue.
-constexpr int64_t BIG_TARGET_BLOCKS = 768;  // workgroups a 128-wide launch is split towards (measured: below)
+#ifndef HF_BIG_TARGET_BLOCKS
+#define HF_BIG_TARGET_BLOCKS 768
+#endif
+constexpr int64_t BIG_TARGET_BLOCKS = HF_BIG_TARGET_BLOCKS;  // workgroups a 128-wide launch is split towards (measured: below)
 constexpr int64_t FEW_TILES = 8;            // up to this many output tiles ...
 constexpr int64_t FEW_TILES_CAP = 96;       // ... a weight gradient may be split this deep (default measured on ResNet-18)
 
@@ -1142,6 +1148,10 @@ int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void
     a.slabs = 1;
     a.slab_stride = slab_stride;
     int sp = slab_splits > 0 ? slab_splits : choose_splits(tiles, red_steps, target_blocks, 0, true, BK);
+    // strided data gradients by residue class: the classes' K loops differ by up to 4x (1 ... 4 taps of a 3x3 / stride 2
+    // kernel) and a uniform split leaves the short ones with 2 steps per workgroup -- with one workgroup per CU already
+    // there, do not split (A/B knob HF_DCLASS_NOSPLIT)
+    if (HF_DCLASS_NOSPLIT && slab_splits == 0 && ncls > 0 && a.big && tiles >= 256) sp = 1;
     if (sp > red_steps) sp = (int)red_steps;
     while (sp > 1 && ((red_steps + sp - 1) / sp) * (sp - 1) >= red_steps) --sp;
     a.splits = sp < 1 ? 1 : sp;
