@@ -882,6 +882,9 @@ namespace {
 #ifndef HF_BIG_TARGET_BLOCKS
 #define HF_BIG_TARGET_BLOCKS 768
 #endif
+#ifndef HF_BIG_MIN_WORK
+#define HF_BIG_MIN_WORK 6144  // (output tiles x K-steps from which a problem takes a 128-wide configuration)
+#endif
 constexpr int64_t BIG_TARGET_BLOCKS = HF_BIG_TARGET_BLOCKS;  // workgroups a 128-wide launch is split towards (measured: below)
 constexpr int64_t FEW_TILES = 8;            // up to this many output tiles ...
 constexpr int64_t FEW_TILES_CAP = 96;       // ... a weight gradient may be split this deep (default measured on ResNet-18)
@@ -1033,7 +1036,7 @@ int want_big(int direction, int64_t rows, int64_t dim_m, int64_t dim_n, int64_t 
   // ran 58 / 35 us on 36 / 72 64x64 tiles with 8 / 4 splits against MIOpen's 24 / 23 us)
   // (slab mode only: with the in-launch ticket reduction of the stand-alone calls a deep split makes the last
   // arriver's sum the longest chain of the launch -- 52 -> 87 us measured)
-  const int64_t least = (kind == 3 && slab_mode) ? HF_FLAT96_MIN_WORK : BIG_TARGET_BLOCKS * 8;
+  const int64_t least = (kind == 3 && slab_mode) ? HF_FLAT96_MIN_WORK : HF_BIG_MIN_WORK;
   return (fits && rows >= 2048 && tiles * steps >= least) ? kind : 0;
 }
 
