@@ -880,8 +880,8 @@ namespace {
 // a split run pays ~3 us to publish and collect tickets plus ~0.15 us per slab the last
 // arriver sums; workgroups beyond two per CU queue.
 #ifndef HF_BIG_TARGET_BLOCKS
-#define HF_BIG_TARGET_BLOCKS 768
-#endif
+#define HF_BIG_TARGET_BLOCKS 512  // (whole-bench A/B, profiles/r05_big_target_blocks_ab*.jsonl: 256 / 384 / 512 / 768 / 1024 ->
+#endif                            //  configs[3] 576 / 579 / 601 / 582 / 544, All-CNN-C GGN 761 / 782 / 817 / 817 / 754)
 #ifndef HF_BIG_MIN_WORK
 #define HF_BIG_MIN_WORK 6144  // (output tiles x K-steps from which a problem takes a 128-wide configuration)
 #endif
