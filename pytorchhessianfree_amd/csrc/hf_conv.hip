@@ -900,7 +900,9 @@ int choose_splits(int64_t tiles, int64_t steps, int target_blocks, int64_t ws_by
     // The 128-wide configurations (bk == 16) run one MFMA-heavy workgroup per CU at 256: a second and
     // third resident workgroup fill the matrix pipe while the first stages its next tile (measured on
     // the All-CNN-C shapes, scripts/conv_kernel_bench.py --big 1: 256 / 512 / 768 workgroups ->
-    // tangent 76 / 93 / 99, data gradient 68 / 83 / 87, weight gradient 39 / 52 / 65 TFLOP/s)
+    // tangent 76 / 93 / 99, data gradient 68 / 83 / 87, weight gradient 39 / 52 / 65 TFLOP/s stand-alone.  INSIDE the
+    // product every further split is one more slab for the consumer kernel to read, and a Hessian product runs a
+    // second launch on a parallel graph branch: the whole bench prefers 512 to 768 -- HF_BIG_TARGET_BLOCKS)
     const bool big = bk != Small::BK;
     best = ((big ? BIG_TARGET_BLOCKS : 256) + tiles - 1) / tiles;
     if (big && best > steps / 8) best = steps / 8;  // (>= 8 steps per workgroup)
