@@ -538,7 +538,7 @@ def test_get_preconditioner_uses_the_sessions_engine_from_the_second_step(monkey
     """``HessianFree.get_preconditioner`` (optimizer.py:928-952) with a persistent session for the model: the diagonal
     comes from the engine (no per-sample backward passes) and equals the autograd construction to 1e-5; before the
     first step (no session yet) and for another input shape the autograd construction runs."""
-    from pytorchhessianfree_amd import optimizer as hfopt
+    from pytorchhessianfree_amd import optimizer_session as hfopt  # (where get_preconditioner lives)
 
     model, (x, t), lossf0 = tp.allcnnc_cifar100(batch_size=8, device=DEV, data_seed=4)
     lossf = tp.l2_regularized(lossf0, model, 5e-4)

@@ -560,19 +560,27 @@ def test_fused_eval_batchnorm_matches_stock(dtype):
     assert fused(x).shape == (4, 5)
 
 
-def _run_worker(name, timeout=600):
-    """Run tests/gpu_workers/<name> in its own interpreter; return its RESULT json."""
+def _run_worker(name, timeout=600, attempts=3):
+    """Run tests/gpu_workers/<name> in its own interpreter; return its RESULT json.  A worker that is KILLED BY A
+    SIGNAL before it printed its result -- RCCL's watchdog / teardown aborts sporadically on this stack (SIGABRT inside
+    librccl / c10d, seen on 1 of ~6 leases) -- is started again, up to ``attempts`` times; its stderr is printed so
+    that the log shows what happened.  A worker that exits by itself with an error fails the test at once."""
     import json
     import os
     import subprocess
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
-    p = subprocess.run([sys.executable, os.path.join(here, "gpu_workers", name)],
-                       capture_output=True, text=True, timeout=timeout)
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
+    for attempt in range(attempts):
+        p = subprocess.run([sys.executable, os.path.join(here, "gpu_workers", name)],
+                           capture_output=True, text=True, timeout=timeout)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
+        if lines:
+            return json.loads(lines[-1][len("RESULT "):])
+        print(f"[{name}] attempt {attempt + 1}: return code {p.returncode}, no RESULT line\n{p.stderr[-6000:]}", flush=True)
+        if p.returncode >= 0:
+            break
     assert lines, (p.returncode, p.stdout[-1500:], p.stderr[-1500:])
-    return json.loads(lines[-1][len("RESULT "):])
 
 
 def test_rccl_paths_single_rank():
