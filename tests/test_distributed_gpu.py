@@ -138,19 +138,30 @@ def test_bench_gpus_2_starts_two_ranks_itself():
 # The drop-in API under data parallelism: HessianFree(prepared ResNet-18, graph_matvec=True,
 # process_group=...).step -> fused engine + persistent session + chunked / overlapped all-reduce
 # ---------------------------------------------------------------------------------------------------------
-def _launch_session_ranks(out, world, mode="steps", backend="gloo", timeout=900, env_extra=None):
-    port = _free_port()
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **(env_extra or {}))
-        procs.append(subprocess.Popen(
-            [sys.executable, os.path.join(HERE, "gpu_workers", "dp_session_ranks.py"), str(out), mode, backend],
-            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    logs = [p.communicate(timeout=timeout) for p in procs]
-    for p, (so, se) in zip(procs, logs):
-        assert p.returncode == 0, (so[-2000:], se[-3000:])
-    return [np.load(out / f"rank{r}.npz") for r in range(world)]
+def _launch_session_ranks(out, world, mode="steps", backend="gloo", timeout=900, env_extra=None, attempts=3):
+    """Start ``world`` rank processes of tests/gpu_workers/dp_session_ranks.py and load what they saved.  Ranks KILLED
+    BY A SIGNAL (RCCL's watchdog / teardown aborts sporadically on this stack, see test_optimizer_gpu._run_worker) are
+    started again, up to ``attempts`` times; a rank that exits by itself with an error fails the test at once."""
+    for attempt in range(attempts):
+        port = _free_port()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **(env_extra or {}))
+            procs.append(subprocess.Popen(
+                [sys.executable, os.path.join(HERE, "gpu_workers", "dp_session_ranks.py"), str(out), mode, backend],
+                env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        logs = [p.communicate(timeout=timeout) for p in procs]
+        codes = [p.returncode for p in procs]
+        if all(c == 0 for c in codes):
+            return [np.load(out / f"rank{r}.npz") for r in range(world)]
+        for c, (so, se) in zip(codes, logs):
+            if c != 0:
+                print(f"[dp_session_ranks {mode} {backend}] attempt {attempt + 1}: return code {c}\n{se[-4000:]}", flush=True)
+        if not any(c < 0 for c in codes):  # (no rank was killed by a signal: a real failure)
+            break
+    for c, (so, se) in zip(codes, logs):
+        assert c == 0, (so[-2000:], se[-3000:])
 
 
 def _check_against_cpu(r0, tol_final=1e-4):
