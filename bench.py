@@ -832,7 +832,6 @@ def main():
                     "ms": allreduce_ms,
                     "overlap_two_graphs": bool(args.overlap),
                     "product_mode": ("two-phase (chunked / overlapped)"
-                                     + (", both graphs chained into one launch" if getattr(op, "use_chain", False) else "")
                                      if getattr(op, "split", None) is not None
                                      else "single graph + one compact all-reduce"),
                     "product_mode_timing_ms": getattr(op, "mode_timing", None),

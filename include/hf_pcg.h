@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HF_ABI_VERSION 11
+#define HF_ABI_VERSION 12
 
 enum hf_dtype { HF_F32 = 0, HF_F64 = 1 };
 
@@ -139,20 +139,6 @@ int hf_pcg_graph_update(hf_pcg_graph_t* g, const void* Bp, double damping);
 int hf_pcg_graph_launch(hf_pcg_graph_t* g, int timed, void* stream);
 int hf_pcg_graph_collect_timing(hf_pcg_graph_t* g);
 int hf_pcg_graph_destroy(hf_pcg_graph_t* g);
-
-/*
- * Two captured hipGraphs (hipGraph_t as void*; both are copied, the caller keeps ownership) as ONE launch:
- * A -> event-record node `mid` -> B.  For the data-parallel curvature product (the `result += N * mb_result` of
- * optimizer.py:677-684 across GPUs, once per PCG iteration): A = the part of the sweep after which the late
- * layers' share of the product is final, B = the rest; a second stream waits for `mid`
- * (hf_graph_chain_wait_mid) and all-reduces that share while B is still running -- without the second graph
- * launch (and its ~14 us device-side gap) that two separately launched graphs cost.
- */
-typedef struct hf_graph_chain hf_graph_chain_t;
-int hf_graph_chain_create(hf_graph_chain_t** out, void* graph_a, void* graph_b);
-int hf_graph_chain_launch(hf_graph_chain_t* c, void* stream);
-int hf_graph_chain_wait_mid(hf_graph_chain_t* c, void* stream); /* hipStreamWaitEvent(stream, mid) */
-int hf_graph_chain_destroy(hf_graph_chain_t* c);
 
 /* Non-blocking: reads the pinned host mirror the device writes at termination
  * (fills done/reason and, once done, n_iters = the terminating iteration). */

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HF_PCG_LIB") or os.path.join(_HERE, "csrc", "libhfpcg.so")
 
 HF_F32, HF_F64 = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 HF_ERR_ARG = -1  # hf_status of include/hf_pcg.h: null / negative / inconsistent argument
 HF_M_NONE, HF_M_DIAG, HF_M_EXTERNAL = 0, 1, 2
 REASONS = {
@@ -72,10 +72,6 @@ SIGNATURES = {
     "hf_pcg_graph_launch": (c_int, [c_void_p, c_int, c_void_p]),
     "hf_pcg_graph_collect_timing": (c_int, [c_void_p]),
     "hf_pcg_graph_destroy": (c_int, [c_void_p]),
-    "hf_graph_chain_create": (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_void_p]),
-    "hf_graph_chain_launch": (c_int, [c_void_p, c_void_p]),
-    "hf_graph_chain_wait_mid": (c_int, [c_void_p, c_void_p]),
-    "hf_graph_chain_destroy": (c_int, [c_void_p]),
     "hf_pcg_poll": (c_int, [c_void_p, ctypes.POINTER(Status)]),
     "hf_pcg_finish": (c_int, [c_void_p, ctypes.POINTER(Status), c_void_p]),
     "hf_pcg_read_nonpos": (

@@ -148,8 +148,6 @@ SWITCHES = {
                          "tests/test_engine_gpu.py::test_train_mode_prologue_form_variants_agree_and_state_is_independent_of_the_first_use_check"),
     "HF_CHUNKED_ALLREDUCE": ("auto", "0 / 1: force the single-graph resp. the two-phase data-parallel product",
                              "tests/test_distributed_gpu.py::test_step_two_ranks_engine_session_equals_cpu_whole_batch"),
-    "HF_CHUNK_ONEGRAPH": ("0", "1: the two phase graphs chained into one launch (opt-in, 1-rank RCCL only so far)",
-                          "tests/test_distributed_gpu.py::test_step_one_rank_rccl_two_phase_product_as_one_launch"),
     "HF_PCG_BLOCKS": ("0", "workgroups of the PCG vector kernels (0: 2 per CU); must agree on all ranks",
                       "tests/test_cg_gpu.py::test_kernel_grid_override_gives_the_same_solve"),
     "HF_PCG_LIB": ("", "path of another build of libhfpcg.so (tuning variants)",

@@ -1101,52 +1101,6 @@ int hf_pcg_graph_destroy(hf_pcg_graph_t* g) {
   return HF_OK;
 }
 
-// ---- two captured graphs as ONE launch with a hand-over event in between -----------------------------------
-struct hf_graph_chain {
-  hipGraph_t graph;
-  hipGraphExec_t exec;
-  hipEvent_t mid;
-};
-
-int hf_graph_chain_create(hf_graph_chain_t** out, void* graph_a, void* graph_b) {
-  if (!out || !graph_a || !graph_b) return HF_ERR_ARG;
-  hf_graph_chain* c = new (std::nothrow) hf_graph_chain();
-  if (!c) return HF_ERR_ARG;
-  memset(c, 0, sizeof(*c));
-  int rc = (int)hipEventCreateWithFlags(&c->mid, hipEventDisableTiming);
-  if (!rc) rc = (int)hipGraphClone(&c->graph, (hipGraph_t)graph_a);
-  std::vector<hipGraphNode_t> deps;
-  if (!rc) rc = graph_leaves(c->graph, deps);
-  hipGraphNode_t ev = nullptr, child = nullptr;
-  if (!rc) rc = (int)hipGraphAddEventRecordNode(&ev, c->graph, deps.data(), deps.size(), c->mid);
-  if (!rc) rc = (int)hipGraphAddChildGraphNode(&child, c->graph, &ev, 1, (hipGraph_t)graph_b);
-  if (!rc) rc = (int)hipGraphInstantiate(&c->exec, c->graph, nullptr, nullptr, 0);
-  if (rc) { hf_graph_chain_destroy(c); return rc; }
-  *out = c;
-  return HF_OK;
-}
-
-int hf_graph_chain_launch(hf_graph_chain_t* c, void* stream) {
-  if (!c || !c->exec) return HF_ERR_ARG;
-  HF_HIP(hipGraphLaunch(c->exec, (hipStream_t)stream));
-  return HF_OK;
-}
-
-int hf_graph_chain_wait_mid(hf_graph_chain_t* c, void* stream) {
-  if (!c || !c->mid) return HF_ERR_ARG;
-  HF_HIP(hipStreamWaitEvent((hipStream_t)stream, c->mid, 0));
-  return HF_OK;
-}
-
-int hf_graph_chain_destroy(hf_graph_chain_t* c) {
-  if (!c) return HF_OK;
-  if (c->exec) (void)hipGraphExecDestroy(c->exec);
-  if (c->graph) (void)hipGraphDestroy(c->graph);
-  if (c->mid) (void)hipEventDestroy(c->mid);
-  delete c;
-  return HF_OK;
-}
-
 static void fill_status(const hf_pcg* h, const DevState* st, hf_pcg_status* out) {
   out->done = st->done;
   out->reason = st->done;

@@ -98,5 +98,3 @@ int hf_allreduce_sum_multi(hf_comm_t* c, void* const* bufs, const int64_t* ns, i
   if (first) return 1000 + first;
   return rc ? 1000 + rc : HF_OK;
 }
-
-

@@ -39,6 +39,43 @@ from .curvature import GraphedOperator
 from .engine import FusedGGNEngine, ce_loss_spec
 
 
+def _runs_beside(cand, cur):
+    """Whether work on stream ``cand`` executes while ``cur`` is busy: a few ms of streaming updates on ``cur``, a
+    trivial kernel on ``cand``; concurrent iff the trivial one has finished while the updates have not."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    long_done, short_done = torch.cuda.Event(), torch.cuda.Event()
+    big = torch.zeros(1 << 26, device=dev)
+    scratch = torch.zeros(64, device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(cur):
+        for _ in range(24):
+            big.add_(1.0)
+        long_done.record(cur)
+    with torch.cuda.stream(cand):
+        scratch.add_(1.0)
+        short_done.record(cand)
+    short_done.synchronize()
+    beside = not long_done.query()
+    long_done.synchronize()
+    return beside
+
+
+def _concurrent_stream(cur, candidates=8):
+    """A side stream whose work runs BESIDE ``cur``'s.  HIP streams of one priority share four hardware queues; a
+    side stream that lands on the compute stream's queue (one pool stream in four) runs in line with the sweep
+    instead of beside it: its all-reduce hides nothing (stand-in kernels: scripts/experiments/stream_handover.hip,
+    profiles/r05_stream_handover.jsonl; in the session: profiles/r05_two_phase_side_stream.jsonl).  Probed, not
+    assumed: the first of a few pool streams that demonstrably overlaps with ``cur``; the last one tried if none
+    does.  (On a 1-rank group, where the collective is the identity, an in-line side stream is the CHEAPER one --
+    no cross-queue dependency, ~725 instead of ~790 us per iteration; it is not taken for that.)"""
+    cand = None
+    for _ in range(candidates):
+        cand = torch.cuda.Stream()
+        if _runs_beside(cand, cur):
+            break
+    return cand
+
+
 class _TwoPhaseProduct:
     """The data-parallel engine product as TWO hipGraphs with the all-reduce chunked by stage and overlapped
     with the sweep (the ``result += N * mb_result`` of optimizer.py:677-684 across GPUs, once per PCG iteration):
@@ -52,7 +89,8 @@ class _TwoPhaseProduct:
         wait for the side stream; scatter the staged sums back into the full vector; K1-K3 graph
 
     Two plain hipGraphs and events BETWEEN graph launches (fork / join nodes inside one graph cost ~45 us
-    each on this stack).  On 2 ranks the result is bitwise the single all-reduce's (a + b in either
+    each on this stack; so does every dependency between two hardware queues, whatever carries it -- events,
+    stream-ordered value writes / waits, an event node inside a chained launch: DESIGN.md section 7).  On 2 ranks the result is bitwise the single all-reduce's (a + b in either
     order); on more ranks every rank still receives identical sums -- which is all the lockstep rule of
     ``cg()`` needs.  ResNet-18 on 28x28 inputs: layer3 + layer4 + fc are 14.2 of the 16.9 MB that travel and
     are final after ~60 % of the product, so ~0.3 ms of sweep remain to hide their all-reduce.
@@ -62,9 +100,7 @@ class _TwoPhaseProduct:
     group`` on the instance."""
 
     split = None
-    _side = None
-    _chain = None       # hf_graph_chain_t*: G_a -> mid event -> G_b as ONE launch (direct RCCL only)
-    use_chain = False
+    _side = None        # the stream the tail's all-reduce runs on (probed: work on it runs BESIDE the compute stream's)
 
     @staticmethod
     def plan_phases(eng, tail_fraction=None):
@@ -99,8 +135,7 @@ class _TwoPhaseProduct:
         eng._live_copy(self.output_buffer, False, part="head")
 
     def _capture_phases(self):
-        """(on ``self.stream``, warmed up) the two graphs of one product -- and, where the library can chain them,
-        both as ONE launch with a hand-over event in between (``hf_graph_chain_*``)."""
+        """(on ``self.stream``, warmed up) the two graphs of one product."""
         self.g_a = torch.cuda.CUDAGraph(keep_graph=True)
         with torch.cuda.graph(self.g_a, stream=self.stream):
             self._phase_a()
@@ -109,30 +144,6 @@ class _TwoPhaseProduct:
             self._phase_b()
         self.g_a.instantiate()
         self.g_b.instantiate()
-        self._chain, self.use_chain = None, False
-        # (opt-in: the chained launch -- an event-record node inside the graph, a host hipStreamWaitEvent right after
-        # the launch -- has only ever run on a 1-rank RCCL group, where the all-reduce is the identity; until a
-        # multi-rank RCCL run shows it bitwise equal to the two-launch form it is not a candidate of the measured choice)
-        mode = os.environ.get("HF_CHUNK_ONEGRAPH", "0")
-        if mode == "1":
-            handle = _lib.c_void_p()
-            rc = _lib.load().hf_graph_chain_create(_lib.ctypes.byref(handle), _lib.c_void_p(self.g_a.raw_cuda_graph()),
-                                                   _lib.c_void_p(self.g_b.raw_cuda_graph()))
-            if rc == 0:
-                self._chain = handle
-                self.use_chain = mode == "1"
-            elif mode == "1":
-                import warnings
-
-                warnings.warn(f"hf_graph_chain_create failed with code {rc}: the two-phase product stays two launches")
-
-    def __del__(self):
-        chain, self._chain = getattr(self, "_chain", None), None
-        if chain is not None:
-            try:
-                _lib.load().hf_graph_chain_destroy(chain)
-            except Exception:  # noqa: BLE001
-                pass
 
     def replay_phases(self):
         self.g_a.replay()
@@ -150,29 +161,19 @@ class _TwoPhaseProduct:
         cur = torch.cuda.current_stream()
         side_comm = hfdist.side_comm(tail[0], group)
         if side_comm is not None and self._side is None:
-            self._side = torch.cuda.Stream()
+            self._side = _concurrent_stream(cur)
             self._ev_a, self._ev_t = torch.cuda.Event(), torch.cuda.Event()
         works = []
-        if side_comm is not None and self.use_chain and self._chain is not None:
-            # ONE launch: G_a -> mid event -> G_b; the side stream waits for the mid event only
-            lib = _lib.load()
-            _lib.check(lib.hf_graph_chain_launch(self._chain, _lib.c_void_p(cur.cuda_stream)), "hf_graph_chain_launch")
-            _lib.check(lib.hf_graph_chain_wait_mid(self._chain, _lib.c_void_p(self._side.cuda_stream)),
-                       "hf_graph_chain_wait_mid")
+        self.g_a.replay()
+        if side_comm is not None:
+            self._ev_a.record(cur)
+            self._side.wait_event(self._ev_a)
             with torch.cuda.stream(self._side):
                 side_comm.all_reduce_sum_multi(tail)
                 self._ev_t.record(self._side)
         else:
-            self.g_a.replay()
-            if side_comm is not None:
-                self._ev_a.record(cur)
-                self._side.wait_event(self._ev_a)
-                with torch.cuda.stream(self._side):
-                    side_comm.all_reduce_sum_multi(tail)
-                    self._ev_t.record(self._side)
-            else:
-                works = [torch.distributed.all_reduce(piece, group=group, async_op=True) for piece in tail]
-            self.g_b.replay()
+            works = [torch.distributed.all_reduce(piece, group=group, async_op=True) for piece in tail]
+        self.g_b.replay()
         hfdist.all_reduce_sum_multi(head, group)
         if side_comm is not None:
             cur.wait_event(self._ev_t)
@@ -415,21 +416,11 @@ class EngineSession(_TwoPhaseProduct):
         if self._split_plan is None or self.group is None:
             return self.split is not None
         dist = torch.distributed
-        from . import distributed as hfdist
-
         sync = torch.zeros(2, dtype=torch.float64, device=self.engine.dev)
-        # candidates: single graph; two launches; (direct RCCL only) the two graphs chained into ONE launch
-        chain_ok = self._chain is not None and hfdist.side_comm(self.output_buffer, self.group) is not None
-        # (one candidate list for all ranks: a rank whose chain could not be built must not time a shorter list)
-        flag = torch.tensor([1.0 if chain_ok else 0.0], dtype=torch.float64, device=self.engine.dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        chain_ok = bool(flag.item() > 0.5)
-        cands = [("single_graph", None, False), ("two_phase", self._split_plan, False)]
-        if chain_ok:
-            cands.append(("two_phase_one_launch", self._split_plan, True))
+        cands = [("single_graph", None), ("two_phase", self._split_plan)]
         times = []
-        for _name, split, chain in cands:
-            self.split, self.use_chain = split, chain
+        for _name, split in cands:
+            self.split = split
             for _ in range(3):
                 self.replay_and_reduce()
             dist.all_reduce(sync, group=self.group)  # (every rank starts the timed replays together)
@@ -442,13 +433,8 @@ class EngineSession(_TwoPhaseProduct):
         t = torch.tensor(times, dtype=torch.float64, device=self.engine.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         times = t.tolist()
-        self.mode_timing = {name + "_ms": v * 1e3 for (name, _s, _c), v in zip(cands, times)}
-        self.mode_timing.setdefault("two_phase_ms", times[1] * 1e3)
-        best = min(range(1, len(cands)), key=lambda i: times[i])
-        if times[best] < 0.97 * times[0]:
-            self.split, self.use_chain = cands[best][1], cands[best][2]
-        else:
-            self.split, self.use_chain = None, False
+        self.mode_timing = {name + "_ms": v * 1e3 for (name, _s), v in zip(cands, times)}
+        self.split = self._split_plan if times[1] < 0.97 * times[0] else None
         return self.split is not None
 
     def reduce(self, t):

@@ -109,7 +109,11 @@ def main(outdir, mode="steps", backend="gloo"):
             from pytorchhessianfree_amd import distributed as hfdist
 
             out["reduce_bytes"] = np.array([sess.reduce_bytes, 4 * sess.n])
-            out["use_chain"] = np.array([int(bool(getattr(sess, "use_chain", False)))])
+            side = getattr(sess, "_side", None)
+            if isinstance(side, torch.cuda.Stream):  # the side stream's work must run BESIDE the compute stream's (probed at creation)
+                from pytorchhessianfree_amd.session import _runs_beside
+
+                out["side_runs_beside"] = np.array([int(_runs_beside(side, torch.cuda.current_stream()))])
             timing = getattr(sess, "mode_timing", None)
             out["mode_timing"] = np.array([timing["single_graph_ms"], timing["two_phase_ms"]] if timing else [0.0, 0.0])
             out["comm_path"] = np.array([hfdist.path_name(sess.output_buffer, group)])

@@ -369,3 +369,4 @@ def test_session_is_reverified_against_the_models_own_forward(monkeypatch, switc
         final = step(2)
     assert opt._session is None and opt._session_off
     assert final < opt.state["init_losses"][-1]
+
