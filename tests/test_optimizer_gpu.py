@@ -735,7 +735,7 @@ def test_train_mode_batchnorm_product_and_solve_match_reference():
     assert greason == str(ref.array("reason")) and len(gx) - 1 == int(ref.scalar("n_iters"))
     for i in range(1, min(len(gx), 6)):
         rel = ref.vec_rel_l2(f"x/{i}", gx[i])
-        within(rel, 1e-4, note=(i, rel))
+        within(rel, 1.5e-4, note=(i, rel))  # (2.1e-5 ... 3.4e-5 measured)
 
 
 def test_allcnnc_hessian_step_with_diag_fisher_preconditioner():
