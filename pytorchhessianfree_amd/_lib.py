@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HF_PCG_LIB") or os.path.join(_HERE, "csrc", "libhfpcg.so")
 
 HF_F32, HF_F64 = 0, 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 HF_ERR_ARG = -1  # hf_status of include/hf_pcg.h: null / negative / inconsistent argument
 HF_M_NONE, HF_M_DIAG, HF_M_EXTERNAL = 0, 1, 2
 REASONS = {
@@ -136,6 +136,8 @@ SIGNATURES = {
     "hf_bn_forward_train": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int] + [c_void_p] * 4
                             + [c_double] * 3 + [c_void_p] * 3 + [c_int64, c_int, c_int64, c_int64, c_int, c_void_p]),
     "hf_chan_affine_train_pair": (c_int, [c_void_p, c_int, c_void_p]),
+    "hf_bn_train_hessian_coeffs": (c_int, [c_void_p] * 7 + [c_int] + [c_void_p] * 5 + [c_double, c_int64, c_int, c_void_p]),
+    "hf_bn_train_hessian_apply": (c_int, [c_void_p] * 5 + [c_int, c_int64] + [c_void_p] * 4 + [c_int64, c_int64, c_int, c_void_p]),
     "hf_bn_stats_rows": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "hf_bn_adjoint_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64,
                                   c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),

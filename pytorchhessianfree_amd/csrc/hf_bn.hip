@@ -940,6 +940,77 @@ __global__ __launch_bounds__(BLOCK) void k_softmax_ce_hvp(T* __restrict__ out,
     out[base + j] = scale * (p[base + j] * (v[base + j] - d));
 }
 
+// ---- Hessian product through a TRAIN-mode BatchNorm (forward-over-reverse, optimizer.py:450-455) --------------
+// z = gamma * xhat + beta, xhat = (a - mean(a)) * rstd(a).  With the step's first-order cotangents g_z (masked), g_a
+// and the tangent sweep's a' (dot quantities: derivatives along v; m = rows):
+//   S1 = mean(a'),  Sx = mean(a' xhat),  xhat' = rstd (a' - S1 - xhat Sx),  rstd'/rstd = -rstd Sx
+//   g_gamma' = sum(g_z' xhat + g_z xhat') = sum(g_z' xhat) + rstd sum(g_z a') - rstd (S1 g_beta + Sx g_gamma)
+//   g_a'     = (rstd'/rstd) g_a + rstd [ G' - mean(G') - xhat' mean(G xhat) - xhat mean(G' xhat + G xhat') ],
+//              G = gamma g_z,  G' = v_gamma g_z + gamma g_z'
+//            = c0 g_a + c1 g_z + c2 g_z' + c3 a' + c4 xhat + c5          (per-channel c0 ... c5, below)
+// k_bn_train_hessian_coeffs adds the partial rows of the five row reductions up (fp64, row order) and writes the six
+// coefficient vectors and the closed-form share of g_gamma' as one more partial row for the gather;
+// k_bn_train_hessian_apply is the elementwise pass (a' arrives as the tangent convolution's split-K slabs).
+__global__ __launch_bounds__(BLOCK) void k_bn_train_hessian_coeffs(
+    float* __restrict__ coef, float* __restrict__ gw_corr, const float* __restrict__ sum_gx2,
+    const float* __restrict__ sum_g2, const float* __restrict__ sum_ga, const float* __restrict__ sum_tx,
+    const float* __restrict__ sum_t1, int nparts, const float* __restrict__ g_gamma1,
+    const float* __restrict__ g_beta1, const float* __restrict__ gamma, const float* __restrict__ v_gamma,
+    const float* __restrict__ rstd, double count, int C) {
+  const int c = blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= C) return;
+  double s_gx = 0.0, s_g = 0.0, s_ga = 0.0, s_tx = 0.0, s_t1 = 0.0;
+  for (int p = 0; p < nparts; ++p) {
+    s_gx += (double)sum_gx2[(size_t)p * C + c];
+    s_g += (double)sum_g2[(size_t)p * C + c];
+    s_ga += (double)sum_ga[(size_t)p * C + c];
+    s_tx += (double)sum_tx[(size_t)p * C + c];
+    s_t1 += (double)sum_t1[(size_t)p * C + c];
+  }
+  const double r = rstd[c], gam = gamma[c], dgam = v_gamma[c], gg = g_gamma1[c], gb = g_beta1[c];
+  const double S1 = s_t1 / count, Sx = s_tx / count;
+  const double corr = -r * (S1 * gb + Sx * gg);
+  const double dgg = s_gx + s_ga + corr;                  // g_gamma'
+  const double mG = (dgam * gb + gam * s_g) / count;      // mean(G')
+  const double m2 = (dgam * gg + gam * dgg) / count;      // mean(G' xhat + G xhat')
+  const double mGx = gam * gg / count;                    // mean(G xhat)
+  coef[0 * C + c] = (float)(-r * Sx);
+  coef[1 * C + c] = (float)(r * dgam);
+  coef[2 * C + c] = (float)(r * gam);
+  coef[3 * C + c] = (float)(-r * r * mGx);
+  coef[4 * C + c] = (float)(r * r * mGx * Sx - r * m2);
+  coef[5 * C + c] = (float)(-r * mG + r * r * mGx * S1);
+  gw_corr[c] = (float)corr;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_bn_train_hessian_apply(
+    float* __restrict__ out, const float* __restrict__ ga1, const float* __restrict__ gz1,
+    const float* __restrict__ gz2, const float* __restrict__ t, int t_splits, long long t_slab,
+    const float* __restrict__ a, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ coef, unsigned total4, unsigned C) {
+  for (unsigned q = blockIdx.x * BLOCK + threadIdx.x; q < total4; q += gridDim.x * BLOCK) {
+    const unsigned i = 4 * q, c = i % C;
+    F4 k0 = ld4(coef + c), k1 = ld4(coef + C + c), k2 = ld4(coef + 2 * C + c), k3 = ld4(coef + 3 * C + c),
+       k4 = ld4(coef + 4 * C + c), k5 = ld4(coef + 5 * C + c);
+    const F4 mu = ld4(mean + c), rs = ld4(rstd + c);
+    const F4 va = ld4(ga1 + i), v1 = ld4(gz1 + i), v2 = ld4(gz2 + i), xa = ld4(a + i);
+    F4 ta = ld4(t + i);
+    for (int sp = 1; sp < t_splits; ++sp) {  // the tangent convolution's slabs, in split order
+      const F4 s = ld4(t + (long long)sp * t_slab + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ta.e[e] += s.e[e];
+    }
+    F4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xa.e[e] - mu.e[e]) * rs.e[e];
+      o.e[e] = ((k0.e[e] * va.e[e] + k1.e[e] * v1.e[e]) + (k2.e[e] * v2.e[e] + k3.e[e] * ta.e[e])) +
+               (k4.e[e] * xh + k5.e[e]);
+    }
+    *reinterpret_cast<F4*>(out + i) = o;
+  }
+}
+
 }  // namespace
 
 int hf_bn_adjoint_pre(void* g_out, void* ga_out, const void* gy_a, int a_splits, int64_t a_slab,
@@ -1329,3 +1400,36 @@ int hf_bn_stats_rows(void* a_out, const void* a, int splits, int64_t slab_stride
   return HF_OK;
 }
 
+int hf_bn_train_hessian_coeffs(void* coef, void* gw_corr, const void* sum_gx2, const void* sum_g2, const void* sum_ga,
+                               const void* sum_tx, const void* sum_t1, int nparts, const void* g_gamma1,
+                               const void* g_beta1, const void* gamma, const void* v_gamma, const void* rstd,
+                               double count, int64_t c, int dtype, void* stream) {
+  if (!coef || !gw_corr || !sum_gx2 || !sum_g2 || !sum_ga || !sum_tx || !sum_t1 || nparts < 1 || !g_gamma1 ||
+      !g_beta1 || !gamma || !v_gamma || !rstd || !(count > 0.0) || c <= 0 || c > 0x7fffffffLL || dtype != HF_F32)
+    return HF_ERR_ARG;
+  hipLaunchKernelGGL(k_bn_train_hessian_coeffs, dim3((unsigned)((c + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,
+                     (hipStream_t)stream, (float*)coef, (float*)gw_corr, (const float*)sum_gx2, (const float*)sum_g2,
+                     (const float*)sum_ga, (const float*)sum_tx, (const float*)sum_t1, nparts, (const float*)g_gamma1,
+                     (const float*)g_beta1, (const float*)gamma, (const float*)v_gamma, (const float*)rstd, count,
+                     (int)c);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}
+
+int hf_bn_train_hessian_apply(void* out, const void* ga1, const void* gz1, const void* gz2, const void* t, int t_splits,
+                              int64_t t_slab, const void* a, const void* mean, const void* rstd, const void* coef,
+                              int64_t rows, int64_t c, int dtype, void* stream) {
+  if (!out || !ga1 || !gz1 || !gz2 || !t || t_splits < 1 || (t_splits > 1 && t_slab <= 0) || !a || !mean || !rstd ||
+      !coef || rows <= 0 || c <= 0 || c % 4 || rows * c > 0x7fffffffLL || dtype != HF_F32)
+    return HF_ERR_ARG;
+  if (!aligned16(out) || !aligned16(ga1) || !aligned16(gz1) || !aligned16(gz2) || !aligned16(t) || !aligned16(a) ||
+      !aligned16(mean) || !aligned16(rstd) || !aligned16(coef) || (t_slab & 3))
+    return HF_ERR_ALIGN;
+  const int64_t total4 = rows * c / 4;
+  hipLaunchKernelGGL(k_bn_train_hessian_apply, dim3(wide_grid(total4)), dim3(BLOCK), 0, (hipStream_t)stream,
+                     (float*)out, (const float*)ga1, (const float*)gz1, (const float*)gz2, (const float*)t, t_splits,
+                     (long long)t_slab, (const float*)a, (const float*)mean, (const float*)rstd, (const float*)coef,
+                     (unsigned)total4, (unsigned)c);
+  HF_HIP(hipGetLastError());
+  return HF_OK;
+}

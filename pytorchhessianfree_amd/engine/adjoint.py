@@ -42,8 +42,9 @@ class _AdjointSweep:
 
     def _adjoint_unit(self, u, srcs):
         """srcs: up to two (tensor, splits, slab_stride) cotangents of the unit's output."""
-        self._bn_adjoint(u, srcs)
-        if not (self._second and u.bn is not None):
+        second = self._second and u.bn is not None
+        self._bn_adjoint(u, srcs, reduce_only=second and u.train)
+        if not second:
             self._conv_adjoint(u)
             return
         # ---- Hessian product: the tangent of the backward sweep through this unit --------------------------
@@ -53,10 +54,23 @@ class _AdjointSweep:
         v_gamma = v[self._offs[u.pg]: self._offs[u.pg] + k]
         if not self._extras_parallel:
             self._hessian_extras(u)
-        # the convolution's cotangent tangent:  g_a' + g_z * rstd * v_gamma
-        _lib.check(lib.hf_chan_affine_ex(
-            _ptr(u.gah), _ptr(u.g1), None, None, _ptr(u.rstd), _ptr(v_gamma), None, None, _ptr(u.ga), None, 0, n, k,
-            oh * ow, 1, 0, 0, 1, 0, _lib.HF_F32, st), "hf_chan_affine_ex")
+        if u.train:
+            # batch statistics: the per-channel finalisation of the five row reductions (this pass's g_z' sums, the
+            # tangent sweep's a' sums), then  g_a' = c0 g_a + c1 g_z + c2 g_z' + c3 a' + c4 xhat + c5
+            rb = u.rb
+            _lib.check(lib.hf_bn_train_hessian_coeffs(
+                _ptr(u.hcoef), _ptr(u.gw[2 * rb:]), _ptr(u.gw), _ptr(u.gb), _ptr(u.gw[rb:]), _ptr(u.hx), _ptr(u.h1), rb,
+                _ptr(u.gg1), _ptr(u.gb1), _ptr(u.scale), _ptr(v_gamma), _ptr(u.rstd), float(n * oh * ow), k,
+                _lib.HF_F32, st), "hf_bn_train_hessian_coeffs")
+            _lib.check(lib.hf_bn_train_hessian_apply(
+                _ptr(u.gah), _ptr(u.ga1), _ptr(u.g1), _ptr(u.g), _ptr(u.tbuf), u.sT, u.tbuf.shape[1], _ptr(u.a),
+                _ptr(u.mean), _ptr(u.rstd), _ptr(u.hcoef), n * oh * ow, k, _lib.HF_F32, st),
+                "hf_bn_train_hessian_apply")
+        else:
+            # the convolution's cotangent tangent:  g_a' + g_z * rstd * v_gamma
+            _lib.check(lib.hf_chan_affine_ex(
+                _ptr(u.gah), _ptr(u.g1), None, None, _ptr(u.rstd), _ptr(v_gamma), None, None, _ptr(u.ga), None, 0, n,
+                k, oh * ow, 1, 0, 0, 1, 0, _lib.HF_F32, st), "hf_chan_affine_ex")
         if self._extras_mode == 2 and not u.im2col and not u.first:
             # the chain's launch also computes conv_D(g_a, V) -- the one extra term the chain itself needs next
             _lib.conv_group_slabs([(1, u.dbuf, u.gah, u.wT, u.geo, u.sD, 0, 0), (2, u.wbuf, u.x, u.gah, u.geo, u.sW, 0, 0),
@@ -68,7 +82,9 @@ class _AdjointSweep:
         """How many data-gradient slabs the consumers of ``u``'s input cotangent must sum in the current sweep."""
         return u.nD if self._second else u.sD
 
-    def _bn_adjoint(self, u, srcs, ga=None):
+    def _bn_adjoint(self, u, srcs, ga=None, reduce_only=False):
+        """``reduce_only`` (train mode inside a Hessian product): the masked cotangent and its per-channel sums only --
+        the elementwise pass is ``hf_bn_train_hessian_apply``'s."""
         ga = u.ga if ga is None else ga
         if not 1 <= len(srcs) <= 2:
             raise RuntimeError(f"{u.name}: {len(srcs)} consumers")
@@ -86,6 +102,8 @@ class _AdjointSweep:
                 None, _ptr(u.gw), _ptr(u.gb), _ptr(u.g), _ptr(a), sa, la, _ptr(b), sb, lb, _ptr(u.a),
                 _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.y) if u.relu else None, n, k, oh * ow, 1,
                 u.rb, _lib.HF_F32, st), "hf_chan_affine_bwd_ex")
+            if reduce_only:
+                return
             _lib.check(lib.hf_chan_affine_train(
                 _ptr(ga), _ptr(u.g), _ptr(u.a), _ptr(u.mean), _ptr(u.rstd), _ptr(u.scale), _ptr(u.gw),
                 _ptr(u.gb), u.rb, None, None, float(n * oh * ow), None, None, n, k, oh * ow, 0, 0, 1, 0,

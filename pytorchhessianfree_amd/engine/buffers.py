@@ -134,6 +134,8 @@ class _Buffers:
                     u.rb = 1
             # (Hessian: the scale's second-order term arrives as `rb` more partial rows for hf_pack_ex to add)
             u.gw_rows = u.rb * (2 if (self.hessian and u.bn is not None) else 1)
+            if self.hessian and u.train:
+                u.gw_rows += 1  # (+ the closed-form share of the scale's second-order term: hf_bn_train_hessian_coeffs)
             u.gw = torch.empty((u.gw_rows, k), dtype=f32, device=dev)
             u.gb = torch.empty((u.rb, k), dtype=f32, device=dev)
             if u.train:
@@ -150,8 +152,19 @@ class _Buffers:
                 # for the elementwise pass to add up)
                 tp_rows = -(-u.rows // 64) * u.sT
                 u.epi = (not u.im2col and not u.first and hasattr(u, "xcat")
-                         and tp_rows <= 256
+                         and tp_rows <= 256 and not self.hessian
                          and os.environ.get("HF_BN_EPILOGUE", "1") != "0")
+                if self.hessian:
+                    # Hessian products (hf_bn_train_hessian_*): the tangent sweep's partial sums must outlive the
+                    # adjoint's (which share gw / gb in a GGN product); six coefficient vectors; the layer's
+                    # first-order parameter gradients (per step)
+                    if u.pg is None or u.pb is None:
+                        raise _Unsupported(f"{u.name}: Hessian products need an affine train-mode BatchNorm")
+                    u.hx = torch.empty((u.rb, k), dtype=f32, device=dev)
+                    u.h1 = torch.empty((u.rb, k), dtype=f32, device=dev)
+                    u.hcoef = torch.empty((6, k), dtype=f32, device=dev)
+                    u.gg1 = torch.zeros(k, dtype=f32, device=dev)
+                    u.gb1 = torch.zeros(k, dtype=f32, device=dev)
                 if u.epi:
                     u.tp1 = torch.empty((tp_rows, k), dtype=f32, device=dev)
                     u.tpx = torch.empty((tp_rows, k), dtype=f32, device=dev)

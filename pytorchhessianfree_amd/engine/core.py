@@ -91,6 +91,8 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
     # piecewise constant): per unit, besides the GGN's terms, conv_D(g, V) and conv_W(t_x, g) (g: the step's
     # first-order cotangent, kept by the gradient sweep) as MORE SLABS of the same buffers, and the BatchNorm
     # scale's own second-order terms  g_a' += g_z * rstd * v_gamma ,  g_gamma' += sum g_z * rstd * t_a .
+    # TRAIN-mode BatchNorm (round 5): the batch statistics' share of the adjoint's tangent in closed form per channel
+    # (hf_bn_train_hessian_coeffs / _apply; the formulas stand in csrc/hf_bn.hip and DESIGN.md section 4.3).
     supports_hessian = True
 
     def __init__(self, model, loss, outputs, params, weight, group, hessian=False):
@@ -108,9 +110,6 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
         self._offs = offs
         self.train_bn = False
         self._layout(model)
-        if self.hessian and self.train_bn:
-            raise _Unsupported("Hessian products with train-mode BatchNorm (batch statistics couple the samples: "
-                               "cross terms the engine does not carry)")
         if self.hessian:
             for u in self.units:
                 u.needs_g = True  # (the first-order masked cotangent of every unit is kept)
@@ -229,6 +228,11 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
             if self.hessian:
                 self._swap_first_order()
         self._gather(out, g_fw, g_fb, first_order=True)
+        if self.hessian and self.train_bn:
+            for u in self.units:  # the layer's own first-order parameter gradients: hf_bn_train_hessian_coeffs reads them
+                if u.train:
+                    torch.sum(u.gw[:u.rb], 0, out=u.gg1)
+                    torch.sum(u.gb, 0, out=u.gb1)
         if self._l2 is not None:
             out.addcmul_(self._l2, self._theta(), value=self.weight)
         return out

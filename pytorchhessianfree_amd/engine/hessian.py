@@ -17,7 +17,7 @@ class _HessianExtras:
         results and the step's first-order cotangents: the scale's  sum_rows g_z * rstd * t_a  (t_a = the sum of the
         tangent convolution's slabs, still in place) as `rb` more partial rows of the gw buffer, and conv_D(g_a, V) /
         conv_W(t_x, g_a) as MORE SLABS of the same buffers (the consumers sum them anyway)."""
-        if u.bn is not None:
+        if u.bn is not None and not u.train:  # (train mode: the tangent sweep left this sum, engine/tangent.py)
             n, k, oh, ow = u.a.shape
             _lib.check(_lib.load().hf_chan_affine_bwd_ex(
                 None, _ptr(u.gw[u.rb:]), None, None, _ptr(u.tbuf), u.sT, u.tbuf.shape[1], None, 1, 0, _ptr(u.g1),

@@ -22,11 +22,20 @@ class _TangentSweep:
             # pass adds them up in its prologue
             lib, st = _lib.load(), _lib.current_stream_ptr(self.dev)
             px, p1, nparts = u.gw, u.gb, u.rb
+            if self.hessian:
+                # the adjoint of a Hessian product reads these sums again (hf_bn_train_hessian_coeffs): rows of their
+                # own -- and  rstd * sum_rows g_z * t_a  (g_z: the step's first-order masked cotangent) as the second
+                # `rb` rows of gw, where the gather expects the scale's second-order share
+                px, p1 = u.hx, u.h1
+                _lib.check(lib.hf_chan_affine_bwd_ex(
+                    None, _ptr(u.gw[u.rb:]), None, None, _ptr(u.tbuf), u.sT, u.tbuf.shape[1], None, 1, 0, _ptr(u.g1),
+                    _ptr(self._zeros(k)), _ptr(u.rstd), None, None, n, k, oh * ow, 1, u.rb, _lib.HF_F32, st),
+                    "hf_chan_affine_bwd_ex")
             if u.tsum:
                 px, p1, nparts = u.tpx, u.tp1, u.tp1.shape[0]
             else:
                 _lib.check(lib.hf_chan_affine_bwd_ex(
-                    None, _ptr(u.gw), _ptr(u.gb), None, _ptr(u.tbuf), u.sT, u.tbuf.shape[1], None, 1, 0, _ptr(u.a),
+                    None, _ptr(px), _ptr(p1), None, _ptr(u.tbuf), u.sT, u.tbuf.shape[1], None, 1, 0, _ptr(u.a),
                     _ptr(u.mean), _ptr(u.rstd), None, None, n, k, oh * ow, 1, u.rb, _lib.HF_F32, st),
                     "hf_chan_affine_bwd_ex")
             _lib.check(lib.hf_chan_affine_train(

@@ -270,6 +270,19 @@ def make_resnet18():
     mg.save("convnet_resnet18.npz", store)
 
 
+def make_resnet18_train_hessian():
+    """``curvature_opt="hessian"`` on the TRAIN-mode ResNet-18 (the model of examples/run_resnet18_mnist.py:19-35, which
+    never calls ``model.eval()``), batch 16: the reference's ``_Hv`` (optimizer.py:450-455) -- one product, and a short
+    damped solve on it.  A file of its own: the other ResNet-18 traces stay byte-identical."""
+    store = {}
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=16, device="cpu", data_seed=5)
+    model.train()
+    B, grad, idx, B64 = run_solve(store, "train_hessian_solve", model, lambda m: lossf, x, t, "hessian", 1.0,
+                                  dict(max_iter=6, martens_conv_crit=True, store_x_at_iters=list(range(7))))
+    put_product(store, "train_hessian_product", B, grad.numel(), idx, seed=7, B64=B64)
+    mg.save("convnet_resnet18_train_hessian.npz", store)
+
+
 def make_allcnnc():
     store = {}
     run_steps(store, "ggn_steps", tp.allcnnc_cifar100, (11, 12, 13), 3, mk=dict(batch_size=32))
@@ -338,7 +351,7 @@ def make_mlp25m():
 
 if __name__ == "__main__":
     torch.set_num_threads(THREADS)
-    makers = {"resnet18": make_resnet18, "allcnnc": make_allcnnc, "bottleneck": make_bottleneck, "mlp25m": make_mlp25m}
+    makers = {"resnet18": make_resnet18, "resnet18_train_hessian": make_resnet18_train_hessian, "allcnnc": make_allcnnc, "bottleneck": make_bottleneck, "mlp25m": make_mlp25m}
     only = sys.argv[1:] or list(makers)
     for name in only:
         t0 = time.time()

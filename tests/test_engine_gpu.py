@@ -324,6 +324,108 @@ def test_resnet18_engine_hessian_product_matches_float64_and_cpu_oracle(batch):
     assert isinstance(ggn, FusedGGNEngine) and not ggn.hessian
 
 
+def test_resnet18_train_mode_hessian_product_and_solve_on_the_engine():
+    """``curvature_opt="hessian"`` on the TRAIN-mode ResNet-18 -- the model of examples/run_resnet18_mnist.py:19-35, which
+    never calls ``model.eval()`` -- on the fused engine: the batch statistics' second-order terms by
+    ``hf_bn_train_hessian_coeffs`` / ``hf_bn_train_hessian_apply`` (reference optimizer.py:450-455 through BackPACK's
+    double backward).  Against (i) float64 double backward of the STOCK train-mode model on the engine's own ReLU
+    decisions: 2e-5 max-norm relative (6.6e-6 measured; batch 32: 3.1e-6, stock fp32 autograd there: 6.1e-6); bitwise
+    repeatable, symmetric;
+    (ii) the REAL reference's ``_Hv`` on the stock CPU model (golden ``train_hessian_product``, batch 16): the
+    envelope rule; gradient likewise; (iii) a six-iteration damped solve against the reference's ``cg`` on its own
+    product (golden ``train_hessian_solve``): same termination reason and iteration count, the non-positive-curvature
+    warnings at the same iterations, iterates rel-l2."""
+    import warnings
+
+    from helpers import RefTrace
+
+    ref = RefTrace("resnet18_train_hessian", "train_hessian_solve")
+    prod = RefTrace("resnet18_train_hessian", "train_hessian_product")
+    cm, (cx, ct), lossf = tp.resnet18_mnist(batch_size=16, device="cpu", data_seed=5)
+    ref.check_inputs(list(cm.parameters()), cx)
+    model, x, t = cm.to(DEV), cx.to(DEV), ct.to(DEV)
+    model.train()
+    modelprep.prepare_model(model, channels_last=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    op = curvature.hessian_operator(lossf(out, t), out, params)
+    assert type(op) is FusedGGNEngine and op.hessian and op.train_bn and op.train_own
+    v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(13))
+    got = op(v).clone()
+    for _ in range(2):
+        assert torch.equal(op(v), got)
+    masks = [(u.y > 0) for u in op.units if u.relu]
+    m64, (x64, t64), l64 = tp.resnet18_mnist(batch_size=16, device=DEV, data_seed=5)
+    m64 = m64.double().train()
+    _replay_relu_decisions(m64, masks)
+    p64 = [p for p in m64.parameters() if p.requires_grad]
+    want = curvature.HessianOperator(l64(m64(x64.double()), t64), p64)(v.double())
+    err = float((got.double() - want).abs().max() / want.abs().max())
+    worst, off = [], 0
+    for name, p in model.named_parameters():
+        a, b = got[off:off + p.numel()].double(), want[off:off + p.numel()]
+        worst.append((float((a - b).abs().max() / want.abs().max()), name))
+        off += p.numel()
+    within(err, 2e-5, note=(err, sorted(worst, reverse=True)[:6]))  # (batch 16: 6.6e-6 measured; batch 32: 3.1e-6)
+    u = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(14))
+    a, b = float(u.double() @ got.double()), float(v.double() @ op(u).double())
+    within(abs(a - b), 1e-4 * abs(a), strict=False)
+    # (ii) the reference's own numbers
+    got_p = op(prod.probe().to(DEV))
+    within(prod.vec_err64("", got_p), 1e-5)
+    within(prod.vec_err("", got_p), prod.envelope("", 1e-5))
+    grad = op.gradient()
+    within(ref.vec_err64("grad", grad), 1e-5)
+    within(ref.vec_err("grad", grad), ref.envelope("grad", 1e-5))
+    # (iii) the solve
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        xs, ms, reason = hf.cg(hf.DampedCurvature(op, 1.0), -grad, max_iter=6, martens_conv_crit=True,
+                               store_x_at_iters=list(range(7)))
+    assert reason == str(ref.array("reason")) and len(xs) - 1 == int(ref.scalar("n_iters"))
+    nonpos = sorted(int(str(w.message).split("iteration ")[1].split(".")[0]) for w in rec
+                    if "Directional curvature" in str(w.message))
+    assert nonpos == ref.array("nonpos_iters").tolist(), (nonpos, ref.array("nonpos_iters"))
+    for i in range(1, len(xs)):
+        rel = ref.vec_rel_l2(f"x/{i}", xs[i])
+        within(rel, 1e-3, note=(i, rel))
+
+
+def test_train_mode_hessian_step_through_the_session_equals_the_autograd_path():
+    """One default ``HessianFree.step()`` with ``curvature_opt="hessian"`` on the train-mode ResNet-18: the persistent
+    session over the Hessian engine against this package's autograd path (``curvature.HessianOperator``: double
+    backward through the stock train-mode layers on MIOpen) -- same damping schedule and termination reason,
+    iteration counts +-2, initial loss 1e-5, final loss 1e-3."""
+    import warnings
+
+    def run(engine):
+        model, (x, t), lossf = tp.resnet18_mnist(batch_size=16, device=DEV, data_seed=5)
+        model.train()
+        modelprep.prepare_model(model, channels_last=True)
+        opt = hf.HessianFree(model.parameters(), curvature_opt="hessian", graph_matvec=engine, cg_max_iter=20)
+        if not engine:
+            opt._session_off = True
+
+        def forward():
+            out = model(x)
+            return lossf(out, t), out
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            final = opt.step(forward)
+        return opt, final
+
+    a, fa = run(True)
+    assert a._session is not None and a._session.engine.hessian and a._session.engine.train_bn
+    b, fb = run(False)
+    assert b._session is None
+    within(abs(a.state["init_losses"][0] - b.state["init_losses"][0]), 1e-5 * abs(b.state["init_losses"][0]), strict=False)
+    assert a.state["dampings"] == b.state["dampings"] and a.state["cg_reasons"] == b.state["cg_reasons"]
+    within(abs(a.state["num_cg_iters"][0] - b.state["num_cg_iters"][0]), 2, strict=False)
+    within(abs(fa - fb), 1e-3 * abs(fb), strict=False)
+    assert fa < a.state["init_losses"][0]
+
+
 def test_resnet18_hessian_step_through_the_session_matches_reference_trace():
     """One default ``HessianFree.step()`` with ``curvature_opt="hessian"`` on the ResNet-18 workload through the
     persistent session over the Hessian engine, against the reference's own step (golden ``hessian_step``: stock
