@@ -383,14 +383,15 @@ int hf_bn_forward_train(void* y, void* y2, int64_t y2_ld, const void* a, const v
  * second-order masked cotangent g_z' (m = rows; S1 = mean(a'), Sx = mean(a' xhat)):
  *   g_gamma' = sum(g_z' xhat) + rstd sum(g_z a') - rstd (S1 g_beta + Sx g_gamma)
  *   g_a'     = c0 g_a + c1 g_z + c2 g_z' + c3 a' + c4 xhat + c5
- * hf_bn_train_hessian_coeffs adds up the `nparts` partial rows ([nparts][c] floats each, fp64 sums in row order) of
- * sum(g_z' xhat), sum(g_z'), rstd sum(g_z a'), sum(a' xhat), sum(a') -- what hf_chan_affine_bwd_ex leaves -- and
+ * hf_bn_train_hessian_coeffs adds up the partial rows ([rows][c] floats each, fp64 sums in row order) of
+ * sum(g_z' xhat), sum(g_z'), rstd sum(g_z a') (`nparts` rows: what hf_chan_affine_bwd_ex leaves) and of sum(a' xhat),
+ * sum(a') (`nparts_t` rows: hf_chan_affine_bwd_ex's, or the tangent convolution's epilogue sums) and
  * writes coef ([6][c]) and the closed-form share of g_gamma' (gw_corr, [c]: one more partial row for hf_pack_ex);
  * g_gamma1 / g_beta1: the first-order parameter gradients of the layer.  hf_bn_train_hessian_apply is the elementwise
  * pass; a' arrives as the tangent convolution's `t_splits` split-K slabs.  fp32 NHWC, c % 4 == 0.
  */
 int hf_bn_train_hessian_coeffs(void* coef, void* gw_corr, const void* sum_gx2, const void* sum_g2, const void* sum_ga,
-                               const void* sum_tx, const void* sum_t1, int nparts, const void* g_gamma1,
+                               int nparts, const void* sum_tx, const void* sum_t1, int nparts_t, const void* g_gamma1,
                                const void* g_beta1, const void* gamma, const void* v_gamma, const void* rstd,
                                double count, int64_t c, int dtype, void* stream);
 int hf_bn_train_hessian_apply(void* out, const void* ga1, const void* gz1, const void* gz2, const void* t, int t_splits,

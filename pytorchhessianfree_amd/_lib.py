@@ -136,7 +136,8 @@ SIGNATURES = {
     "hf_bn_forward_train": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int] + [c_void_p] * 4
                             + [c_double] * 3 + [c_void_p] * 3 + [c_int64, c_int, c_int64, c_int64, c_int, c_void_p]),
     "hf_chan_affine_train_pair": (c_int, [c_void_p, c_int, c_void_p]),
-    "hf_bn_train_hessian_coeffs": (c_int, [c_void_p] * 7 + [c_int] + [c_void_p] * 5 + [c_double, c_int64, c_int, c_void_p]),
+    "hf_bn_train_hessian_coeffs": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p, c_int] + [c_void_p] * 5
+                                   + [c_double, c_int64, c_int, c_void_p]),
     "hf_bn_train_hessian_apply": (c_int, [c_void_p] * 5 + [c_int, c_int64] + [c_void_p] * 4 + [c_int64, c_int64, c_int, c_void_p]),
     "hf_bn_stats_rows": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "hf_bn_adjoint_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int64,

@@ -954,19 +954,37 @@ __global__ __launch_bounds__(BLOCK) void k_softmax_ce_hvp(T* __restrict__ out,
 __global__ __launch_bounds__(BLOCK) void k_bn_train_hessian_coeffs(
     float* __restrict__ coef, float* __restrict__ gw_corr, const float* __restrict__ sum_gx2,
     const float* __restrict__ sum_g2, const float* __restrict__ sum_ga, const float* __restrict__ sum_tx,
-    const float* __restrict__ sum_t1, int nparts, const float* __restrict__ g_gamma1,
+    const float* __restrict__ sum_t1, int nparts, int nparts_t, const float* __restrict__ g_gamma1,
     const float* __restrict__ g_beta1, const float* __restrict__ gamma, const float* __restrict__ v_gamma,
     const float* __restrict__ rstd, double count, int C) {
-  const int c = blockIdx.x * BLOCK + threadIdx.x;
-  if (c >= C) return;
-  double s_gx = 0.0, s_g = 0.0, s_ga = 0.0, s_tx = 0.0, s_t1 = 0.0;
-  for (int p = 0; p < nparts; ++p) {
-    s_gx += (double)sum_gx2[(size_t)p * C + c];
-    s_g += (double)sum_g2[(size_t)p * C + c];
-    s_ga += (double)sum_ga[(size_t)p * C + c];
-    s_tx += (double)sum_tx[(size_t)p * C + c];
-    s_t1 += (double)sum_t1[(size_t)p * C + c];
+  // 32 channels x 8 row lanes per workgroup: lane rl adds rows rl, rl + 8, ... (fp64, increasing), the eight shares are
+  // combined in lane order -- a fixed summation order, and at most nparts / 8 dependent round trips instead of nparts
+  constexpr int CH = 32, RL = BLOCK / CH;
+  __shared__ double red[5][RL][CH];
+  const int cl = threadIdx.x % CH, rl = threadIdx.x / CH, c = blockIdx.x * CH + cl;
+  double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  if (c < C) {
+    for (int p = rl; p < nparts; p += RL) {
+      s[0] += (double)sum_gx2[(size_t)p * C + c];
+      s[1] += (double)sum_g2[(size_t)p * C + c];
+      s[2] += (double)sum_ga[(size_t)p * C + c];
+    }
+    for (int p = rl; p < nparts_t; p += RL) {  // (the tangent sweep's sums: a reduction launch's or the convolution epilogue's)
+      s[3] += (double)sum_tx[(size_t)p * C + c];
+      s[4] += (double)sum_t1[(size_t)p * C + c];
+    }
   }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) red[k][rl][cl] = s[k];
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    double t = red[k][0][cl];
+    for (int j = 1; j < RL; ++j) t += red[k][j][cl];
+    s[k] = t;
+  }
+  const double s_gx = s[0], s_g = s[1], s_ga = s[2], s_tx = s[3], s_t1 = s[4];
   const double r = rstd[c], gam = gamma[c], dgam = v_gamma[c], gg = g_gamma1[c], gb = g_beta1[c];
   const double S1 = s_t1 / count, Sx = s_tx / count;
   const double corr = -r * (S1 * gb + Sx * gg);
@@ -1401,15 +1419,16 @@ int hf_bn_stats_rows(void* a_out, const void* a, int splits, int64_t slab_stride
 }
 
 int hf_bn_train_hessian_coeffs(void* coef, void* gw_corr, const void* sum_gx2, const void* sum_g2, const void* sum_ga,
-                               const void* sum_tx, const void* sum_t1, int nparts, const void* g_gamma1,
+                               int nparts, const void* sum_tx, const void* sum_t1, int nparts_t, const void* g_gamma1,
                                const void* g_beta1, const void* gamma, const void* v_gamma, const void* rstd,
                                double count, int64_t c, int dtype, void* stream) {
-  if (!coef || !gw_corr || !sum_gx2 || !sum_g2 || !sum_ga || !sum_tx || !sum_t1 || nparts < 1 || !g_gamma1 ||
+  if (!coef || !gw_corr || !sum_gx2 || !sum_g2 || !sum_ga || !sum_tx || !sum_t1 || nparts < 1 || nparts_t < 1 || !g_gamma1 ||
       !g_beta1 || !gamma || !v_gamma || !rstd || !(count > 0.0) || c <= 0 || c > 0x7fffffffLL || dtype != HF_F32)
     return HF_ERR_ARG;
-  hipLaunchKernelGGL(k_bn_train_hessian_coeffs, dim3((unsigned)((c + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,
+  hipLaunchKernelGGL(k_bn_train_hessian_coeffs, dim3((unsigned)((c + 31) / 32)), dim3(BLOCK), 0,
                      (hipStream_t)stream, (float*)coef, (float*)gw_corr, (const float*)sum_gx2, (const float*)sum_g2,
-                     (const float*)sum_ga, (const float*)sum_tx, (const float*)sum_t1, nparts, (const float*)g_gamma1,
+                     (const float*)sum_ga, (const float*)sum_tx, (const float*)sum_t1, nparts, nparts_t,
+                     (const float*)g_gamma1,
                      (const float*)g_beta1, (const float*)gamma, (const float*)v_gamma, (const float*)rstd, count,
                      (int)c);
   HF_HIP(hipGetLastError());

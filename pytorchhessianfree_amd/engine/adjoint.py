@@ -58,9 +58,10 @@ class _AdjointSweep:
             # batch statistics: the per-channel finalisation of the five row reductions (this pass's g_z' sums, the
             # tangent sweep's a' sums), then  g_a' = c0 g_a + c1 g_z + c2 g_z' + c3 a' + c4 xhat + c5
             rb = u.rb
+            tx, t1, nparts_t = u.tsums
             _lib.check(lib.hf_bn_train_hessian_coeffs(
-                _ptr(u.hcoef), _ptr(u.gw[2 * rb:]), _ptr(u.gw), _ptr(u.gb), _ptr(u.gw[rb:]), _ptr(u.hx), _ptr(u.h1), rb,
-                _ptr(u.gg1), _ptr(u.gb1), _ptr(u.scale), _ptr(v_gamma), _ptr(u.rstd), float(n * oh * ow), k,
+                _ptr(u.hcoef), _ptr(u.gw[2 * rb:]), _ptr(u.gw), _ptr(u.gb), _ptr(u.gw[rb:]), rb, _ptr(tx), _ptr(t1),
+                nparts_t, _ptr(u.gg1), _ptr(u.gb1), _ptr(u.scale), _ptr(v_gamma), _ptr(u.rstd), float(n * oh * ow), k,
                 _lib.HF_F32, st), "hf_bn_train_hessian_coeffs")
             _lib.check(lib.hf_bn_train_hessian_apply(
                 _ptr(u.gah), _ptr(u.ga1), _ptr(u.g1), _ptr(u.g), _ptr(u.tbuf), u.sT, u.tbuf.shape[1], _ptr(u.a),

@@ -152,7 +152,7 @@ class _Buffers:
                 # for the elementwise pass to add up)
                 tp_rows = -(-u.rows // 64) * u.sT
                 u.epi = (not u.im2col and not u.first and hasattr(u, "xcat")
-                         and tp_rows <= 256 and not self.hessian
+                         and tp_rows <= 256
                          and os.environ.get("HF_BN_EPILOGUE", "1") != "0")
                 if self.hessian:
                     # Hessian products (hf_bn_train_hessian_*): the tangent sweep's partial sums must outlive the

@@ -33,7 +33,8 @@ class _TangentSweep:
                     "hf_chan_affine_bwd_ex")
             if u.tsum:
                 px, p1, nparts = u.tpx, u.tp1, u.tp1.shape[0]
-            else:
+            u.tsums = (px, p1, nparts)  # (a Hessian product's adjoint reads them again)
+            if not u.tsum:
                 _lib.check(lib.hf_chan_affine_bwd_ex(
                     None, _ptr(px), _ptr(p1), None, _ptr(u.tbuf), u.sT, u.tbuf.shape[1], None, 1, 0, _ptr(u.a),
                     _ptr(u.mean), _ptr(u.rstd), None, None, n, k, oh * ow, 1, u.rb, _lib.HF_F32, st),
