@@ -308,9 +308,12 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
         else:
             want = GGNOperator(loss, self.outputs, self.params).local(v)
         err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
-        if not err < FusedGGNEngine.verify_tol:
+        # (Hessian products through batch statistics: stock fp32 double backward is itself 6e-6 from float64 on the
+        # train-mode ResNet-18, this engine 3e-6 ... 7e-6 -- two fp32 results may be the sum of both apart)
+        tol = FusedGGNEngine.verify_tol * (3.0 if (self.hessian and self.train_bn) else 1.0)
+        if not err < tol:
             exc = _Unsupported(f"engine {'Hessian ' if self.hessian else ''}product differs from the autograd product by {err:.2e} "
-                               f"(tolerance {FusedGGNEngine.verify_tol:.1e}); using the autograd operator")
+                               f"(tolerance {tol:.1e}); using the autograd operator")
             exc.loud = True
             raise exc
         verified.add(key)
