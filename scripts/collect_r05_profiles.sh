@@ -21,7 +21,7 @@ python scripts/pmc_traffic.py /tmp/pmck_FETCH_SIZE /tmp/pmck_WRITE_SIZE 11175370
 rm -rf /tmp/pmck_FETCH_SIZE /tmp/pmck_WRITE_SIZE
 # other workloads
 : > "$OUT/r05_other_workloads.jsonl"
-for args in "--workload allcnnc" "--workload allcnnc --curvature hessian --precond 1 --damping 1.0" "--workload resnet50" "--workload resnet18 --bn train" "--workload resnet18 --curvature hessian" "--workload resnet18 --acc 16,16"; do
+for args in "--workload allcnnc" "--workload allcnnc --curvature hessian --precond 1 --damping 1.0" "--workload resnet50" "--workload resnet18 --bn train" "--workload resnet18 --curvature hessian" "--workload resnet18 --bn train --curvature hessian" "--workload resnet18 --acc 16,16"; do
   python bench.py $args --steps 3 --warmup 1 >> "$OUT/r05_other_workloads.jsonl" 2>> "$OUT/other.err"
 done
 # data-parallel paths that one GPU can exercise
