@@ -547,3 +547,48 @@ def test_configure_is_explicit_and_idempotent(monkeypatch, tmp_path):
     finally:
         config._state.update(saved)
         torch.backends.cudnn.benchmark = bench
+
+
+def test_train_mode_batchnorm_hessian_closed_forms():
+    """The closed forms behind ``hf_bn_train_hessian_coeffs`` / ``hf_bn_train_hessian_apply`` (csrc/hf_bn.hip; Hessian
+    products, optimizer.py:450-455, through a BatchNorm that normalises with BATCH statistics): the tangent of the
+    layer's adjoint from the row sums the sweeps take -- against float64 double backward through
+    ``z = gamma * xhat + beta, y = relu(z)`` under a loss with a non-trivial second derivative, 1e-12."""
+    dt = torch.float64
+    gen = torch.Generator().manual_seed(0)
+    m, k, eps = 37, 5, 1e-5
+    a = torch.randn(m, k, dtype=dt, generator=gen).requires_grad_()
+    gam = torch.randn(k, dtype=dt, generator=gen).requires_grad_()
+    bet = torch.randn(k, dtype=dt, generator=gen).requires_grad_()
+    wl = torch.randn(m, k, dtype=dt, generator=gen)
+    mu = a.mean(0)
+    r = (((a - mu) ** 2).mean(0) + eps).rsqrt()
+    xh = (a - mu) * r
+    z = gam * xh + bet
+    y = torch.relu(z)
+    loss = (y * wl).sum() + (y ** 3).sum() / 3
+    ga, gg, gb = torch.autograd.grad(loss, (a, gam, bet), create_graph=True)
+    da = torch.randn(m, k, dtype=dt, generator=gen)
+    dgam, dbet = torch.randn(k, dtype=dt, generator=gen), torch.randn(k, dtype=dt, generator=gen)
+    want_a, want_g, want_b = torch.autograd.grad((ga * da).sum() + (gg * dgam).sum() + (gb * dbet).sum(), (a, gam, bet))
+    with torch.no_grad():
+        mask = (z > 0).to(dt)
+        g_z = mask * (wl + y ** 2)                     # first-order masked cotangent
+        g_gam, g_bet = (g_z * xh).sum(0), g_z.sum(0)   # first-order parameter gradients
+        G = gam * g_z
+        g_a = r * (G - G.mean(0) - xh * (G * xh).mean(0))
+        assert torch.allclose(g_a, ga, atol=1e-12) and torch.allclose(g_gam, gg, atol=1e-12)
+        # tangent sweep
+        S1, Sx = da.mean(0), (da * xh).mean(0)
+        dxh = r * (da - S1 - xh * Sx)
+        dy = mask * (dgam * xh + gam * dxh + dbet)
+        dg_z = mask * (2 * y * dy)                     # second-order masked cotangent (the loss' own curvature)
+        # the five row sums the kernels read, then the closed forms
+        s_gx, s_g, s_ga = (dg_z * xh).sum(0), dg_z.sum(0), r * (g_z * da).sum(0)
+        corr = -r * (S1 * g_bet + Sx * g_gam)
+        dgg = s_gx + s_ga + corr
+        mG, m2, mGx = (dgam * g_bet + gam * s_g) / m, (dgam * g_gam + gam * dgg) / m, gam * g_gam / m
+        c = (-r * Sx, r * dgam, r * gam, -r * r * mGx, r * r * mGx * Sx - r * m2, -r * mG + r * r * mGx * S1)
+        got_a = c[0] * g_a + c[1] * g_z + c[2] * dg_z + c[3] * da + c[4] * xh + c[5]
+    assert float((got_a - want_a).abs().max()) < 1e-12
+    assert float((dgg - want_g).abs().max()) < 1e-12 and float((s_g - want_b).abs().max()) < 1e-12
