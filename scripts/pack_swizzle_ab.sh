@@ -1,8 +1,9 @@
 #!/bin/bash
 # Same-box A/B of the LDS swizzle key of k_pack's permuting path: the headline bench and the rocprofv3 average of
-# k_pack, two repetitions.  Variant 1 (conflict-free stores: key = word / (32 * HW) instead of word >> 6) is not in the
-# tree -- measured neutral, profiles/r05_pack_swizzle_ab.jsonl; the patch is in the history (commit message
-# "k_pack: conflict-free LDS stores measured neutral").
+# k_pack, two repetitions (profiles/r05_pack_swizzle_ab.jsonl).  Variant 1 -- conflict-free stores: the key of the
+# in-quad XOR is  __umulhi(word, 0xFFFFFFFFu / (32 * HW) + 1)  instead of  word >> 6 , in the staging store and in the
+# 16-byte read that undoes it -- measured neutral and is NOT in the tree; the script expects the two libraries as
+# build_variants/libhfpcg_swz{0,1}.so.
 OUT=${1:-gpurun_out/r5swz}; mkdir -p $OUT; export TMPDIR=/tmp
 : > $OUT/ab.jsonl
 for rep in 1 2; do for v in 0 1; do
