@@ -298,8 +298,8 @@ def test_m_iters_are_the_quadratic(dim, precond, warm):
         x64 = x.cpu().double()
         q = 0.5 * x64 @ (A64 @ x64) - b64 @ x64
         # the reference asserts atol=1e-7 on CPU for |m| = O(1e-1..1); the GPU
-        # value carries fp32 rounding of r and x: 2e-6 absolute
-        within(abs(float(m) - float(q)), 2e-6)
+        # value carries fp32 rounding of r and x: 3e-6 absolute (9.3e-7 the worst over the round's leases)
+        within(abs(float(m) - float(q)), 3e-6)
 
 
 @pytest.mark.parametrize("dim", [3, 10, 50])
