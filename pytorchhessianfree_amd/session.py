@@ -351,11 +351,15 @@ class EngineSession(_TwoPhaseProduct):
         self._override_out = None
         self._cache = {}
         self.steps += 1
+        self._first_order_fresh = False
         return eng.loss_buf
+
+    _first_order_fresh = False  # (Hessian engines: the gradient sweep of this step has left its cotangents)
 
     def gradient(self):
         """``weight * grad`` at the parameters of the last forward replay (static buffer)."""
         self.g_grad.replay()
+        self._first_order_fresh = True
         return self.grad_buffer
 
     def forward_loss(self, slot):
@@ -448,6 +452,11 @@ class EngineSession(_TwoPhaseProduct):
     def local(self, v, out=None):
         if v.data_ptr() != self.input_buffer.data_ptr():
             self.input_buffer.copy_(v)
+        if not self._first_order_fresh and getattr(self.engine, "hessian", False):
+            # a Hessian product reads the step's first-order cotangents: a caller who takes products right after
+            # ``begin_step`` (``step`` itself takes the gradient first) gets them from a gradient replay here
+            self.g_grad.replay()
+            self._first_order_fresh = True
         self.replay_local()
         if out is not None:
             out.copy_(self.output_buffer)
@@ -830,6 +839,7 @@ class AccumulatedSession:
         if verify:
             self._verify(slots)
         self.steps += 1
+        self._first_order_fresh = False
         self.base_loss = self.reduce_losses(self.loss_buf.reshape(1)).tolist()[0] if reduce else vals[0]
         return self.base_loss
 
@@ -851,8 +861,11 @@ class AccumulatedSession:
             torch.distributed.all_reduce(vals, group=self.group)
         return vals
 
+    _first_order_fresh = False  # (Hessian engines: the gradient sweep of this step has left its cotangents)
+
     def gradient(self):
         self.g_grad.replay()
+        self._first_order_fresh = True
         if self.group is not None:
             self.engine.reduce(self.grad_buffer, self.group)
         return self.grad_buffer
@@ -879,6 +892,11 @@ class AccumulatedSession:
     def local(self, v, out=None):
         if v.data_ptr() != self.input_buffer.data_ptr():
             self.input_buffer.copy_(v)
+        if not self._first_order_fresh and self.hessian:
+            # (as EngineSession.local: products taken right after ``begin_step`` -- ``acc_linearise`` hands the
+            # gradient to ``step`` unevaluated -- need this step's first-order cotangents)
+            self.g_grad.replay()
+            self._first_order_fresh = True
         self.graph.replay()
         if out is not None:
             out.copy_(self.output_buffer)

@@ -223,3 +223,47 @@ def test_acc_step_train_mode_batchnorm_session_equals_generic_accumulation(monke
     assert torch.equal(sess(v), got)
     want = a._acc_mvp(model, lossf, chunks, "ggn", "mean", v)
     within(float((got - want).abs().max() / want.abs().max()), 2e-3)
+
+
+def test_acc_step_train_mode_hessian_session_equals_generic_accumulation(monkeypatch):
+    """``curvature_opt="hessian"`` with TRAIN-mode BatchNorm through ``acc_step``: one Hessian engine per chunk (the
+    batch statistics' second-order terms by ``hf_bn_train_hessian_*``; every chunk normalised with ITS statistics, as
+    the reference's accumulation does, optimizer.py:600-700) against this package's generic accumulation
+    (``HF_ACC_SESSION=0``: ``curvature.HessianOperator`` per chunk), chunks [8, 8], one call: initial loss 1e-5, final
+    loss 1e-3, same damping schedule and termination reason, iteration counts +-2; the accumulated product against
+    the generic accumulated product at the same point 1e-4, bitwise repeatable.  (The product is taken right after
+    ``acc_linearise``, which hands the gradient to ``step`` unevaluated: the session refreshes the first-order cotangents
+    a Hessian product reads by itself.)"""
+    def run(session):
+        monkeypatch.setenv("HF_ACC_SESSION", "1" if session else "0")
+        model, (x, t), lossf = tp.resnet18_mnist(batch_size=16, device=DEV, data_seed=5)
+        model.train()
+        modelprep.prepare_model(model, channels_last=True)
+        opt = hf.HessianFree(model.parameters(), curvature_opt="hessian", graph_matvec=True, cg_max_iter=20)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            final = opt.acc_step(model, lossf, _chunks(x, t, (8, 8)), reduction="mean")
+        return opt, final, model, lossf, (x, t)
+
+    a, fa, model, lossf, (x, t) = run(True)
+    sess = a._acc_session
+    assert sess is not None and sess.train_bn and len(sess.engines) == 2
+    assert all(e.hessian and e.train_bn for e in sess.engines)
+    b, fb, _, _, _ = run(False)
+    assert b._acc_session is None
+    within(abs(a.state["init_losses"][0] - b.state["init_losses"][0]), 1e-5 * abs(b.state["init_losses"][0]), strict=False)
+    assert a.state["dampings"] == b.state["dampings"] and a.state["cg_reasons"] == b.state["cg_reasons"]
+    within(abs(a.state["num_cg_iters"][0] - b.state["num_cg_iters"][0]), 2, strict=False)
+    within(abs(fa - fb), 1e-3 * abs(fb), strict=False)
+    assert fa < a.state["init_losses"][0]
+    monkeypatch.setenv("HF_ACC_SESSION", "1")
+    chunks = _chunks(x, t, (8, 8))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, _, _, s2 = a.acc_linearise(model, lossf, chunks, chunks, chunks, "mean")
+    assert s2 is sess
+    v = torch.randn(sess.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    got = sess(v).clone()
+    assert torch.equal(sess(v), got)
+    want = a._acc_mvp(model, lossf, chunks, "hessian", "mean", v)
+    within(float((got - want).abs().max() / want.abs().max()), 1e-4)  # (9.8e-6 measured)
