@@ -372,3 +372,49 @@ def test_session_is_reverified_against_the_models_own_forward(monkeypatch, switc
     assert opt._session is None and opt._session_off
     assert final < opt.state["init_losses"][-1]
 
+
+
+@pytest.mark.parametrize("options", [
+    dict(use_linesearch=False, lr=0.5),
+    dict(adapt_damping=False),
+    dict(use_cg_backtracking=False),
+    dict(use_linesearch=False, use_cg_backtracking=False, adapt_damping=False, lr=0.3, damping=2.0),
+    dict(cg_max_iter=7),
+    dict(damping=0.1),
+], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+def test_session_follows_every_optimizer_option_like_the_generic_path(options):
+    """The constructor's switches (optimizer.py:23-124: constant learning rate instead of the line search, no LM
+    adaptation, no CG-backtracking, iteration cap, initial damping) on the persistent session against this package's
+    generic path, two steps each: the same learning rates, damping schedule, termination reasons, iteration counts and
+    back-tracking choices; losses 1e-3 (<= 1.4e-4 measured).  ``step`` returns ``None`` without the line search, as
+    the reference does (optimizer.py:325-330, :363)."""
+    def run(session):
+        model, _, lossf = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=SEEDS[0])
+        modelprep.prepare_model(model, channels_last=True)
+        opt = hf.HessianFree(model.parameters(), graph_matvec=True, **options)
+        if not session:
+            opt._session_off = True
+        finals = []
+        for i in range(2):
+            _, (x, t), _ = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=SEEDS[i])
+
+            def forward():
+                out = model(x)
+                return lossf(out, t), out
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                f = opt.step(forward)
+            assert (f is None) == (options.get("use_linesearch") is False)
+            with torch.no_grad():
+                finals.append(float(f) if f is not None else float(forward()[0]))
+        return opt, finals
+
+    a, fa = run(True)
+    b, fb = run(False)
+    assert a._session is not None and a._session.steps == 2 and b._session is None
+    for key in ("learning_rates", "dampings", "cg_reasons", "num_cg_iters"):
+        assert list(a.state[key]) == list(b.state[key]), (key, a.state[key], b.state[key])
+    assert [int(i) for i in a.state["best_cg_iters"]] == [int(i) for i in b.state["best_cg_iters"]]
+    for x, y in zip(a.state["init_losses"] + fa, b.state["init_losses"] + fb):
+        within(abs(x - y), 1e-3 * abs(y), strict=False)
