@@ -418,3 +418,40 @@ def test_session_follows_every_optimizer_option_like_the_generic_path(options):
     assert [int(i) for i in a.state["best_cg_iters"]] == [int(i) for i in b.state["best_cg_iters"]]
     for x, y in zip(a.state["init_losses"] + fa, b.state["init_losses"] + fb):
         within(abs(x - y), 1e-3 * abs(y), strict=False)
+
+
+def test_checkpoint_and_resume_on_the_session_path_is_bitwise():
+    """``torch.optim.Optimizer.state_dict`` / ``load_state_dict`` (the reference is a plain torch optimizer: warm start
+    ``state["x0"]``, optimizer.py:268, :516, and the damping in its param group) with the persistent session: one step,
+    checkpoint of model + optimizer, two more steps -- against a fresh model + optimizer that load the checkpoint and
+    take the same two steps on a newly built session: final losses, damping schedule and iteration counts identical
+    (the engine is bitwise repeatable)."""
+    import copy
+
+    def make():
+        model, _, lossf = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=SEEDS[0])
+        modelprep.prepare_model(model, channels_last=True)
+        return model, lossf, hf.HessianFree(model.parameters(), graph_matvec=True)
+
+    def step(model, lossf, opt, i):
+        _, (x, t), _ = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=SEEDS[i])
+
+        def forward():
+            out = model(x)
+            return lossf(out, t), out
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return float(opt.step(forward))
+
+    m, lossf, o = make()
+    step(m, lossf, o, 0)
+    saved_model, saved_opt = copy.deepcopy(m.state_dict()), copy.deepcopy(o.state_dict())
+    want = [step(m, lossf, o, 1), step(m, lossf, o, 2)]
+    m2, lossf2, o2 = make()
+    m2.load_state_dict(saved_model)
+    o2.load_state_dict(saved_opt)
+    got = [step(m2, lossf2, o2, 1), step(m2, lossf2, o2, 2)]
+    assert o2._session is not None and o2._session.steps == 2
+    assert got == want, (got, want)
+    assert o2.state["dampings"] == o.state["dampings"] and o2.state["num_cg_iters"] == o.state["num_cg_iters"]
