@@ -216,7 +216,7 @@ def _run_train_mode_steps(steps, session):
 def test_train_mode_batchnorm_session_equals_generic_path():
     """TRAIN-mode BatchNorm (what the reference's ResNet example runs, examples/run_resnet18_mnist.py:19-35: no
     ``model.eval()``): the persistent session serves such a model with its own batch-statistics forward pass
-    (``hf_bn_batch_stats``) -- three default steps on fresh batches against this package's generic path (stock
+    (``hf_bn_stats_rows`` + ``hf_bn_forward_train``) -- three default steps on fresh batches against this package's generic path (stock
     train-mode layers, engine rebuilt per step).  Stated tolerance: first step's losses 1e-5 / 1e-3, same damping
     schedule, iteration counts +-2; the second step's losses 1e-3 / 1e-1 (sanity); the third step starts from parameters that
     differ like any two fp32 train-mode runs (products scatter ~1e-3 between two forward passes, DESIGN.md
