@@ -45,6 +45,10 @@ def parse():
                     help="Tikhonov damping; 1e-3 keeps all 250 iterations numerically alive "
                          "(with 1.0 this random-init problem converges to fp32 round-off in ~15)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rung-timeout", default="480,360,300,300",
+                    help="multi-rank runs: wall-clock bound in seconds of each rung of the data-parallel fallback ladder "
+                         "(comma-separated, the last value repeats; see RUNGS): a rung whose ranks have not all reached "
+                         "the end by then is ended and the next one starts with fresh rank processes")
     ap.add_argument("--watchdog", type=float, default=900.0,
                     help="multi-rank runs: seconds after which a rank that is still waiting (a peer died, a "
                          "collective hangs) dumps its stack and exits non-zero instead of blocking for good")
@@ -107,52 +111,154 @@ def parse():
                     help="comma-separated chunk sizes (e.g. 16,16; they must add up to --batch): drive "
                          "HessianFree.acc_step's path (optimizer.py:519-606) -- loss / gradient / products "
                          "accumulated over the chunks by the accumulated engine session -- instead of step's")
+    ap.add_argument("--freeze", default="", choices=["", "stem+layer1"],
+                    help="stem+layer1: requires_grad = False on the stem and layer1 of the ResNet workloads -- the "
+                         "optimizer then works in the subspace of trainable parameters (optimizer.py:121-123, "
+                         "utils.py:31-32); the engine's sweeps start / end at the first trainable layer")
     ap.add_argument("--l2", type=float, default=-1.0,
                     help="L2 regularisation weight added to the loss as in examples/example_utils.py:77-81 "
                          "(-1: 5e-4 for --workload allcnnc with --curvature hessian, else 0)")
     return ap.parse_args()
 
 
-def launch_ranks(args):
-    """``python bench.py --gpus N`` without a launcher: start N rank processes (one per
-    GPU) and relay rank 0's JSON line.  The parent only counts devices and starts the ranks as
-    fresh child processes (nothing is exec'ed over a process that has touched the GPU).
-    With fewer devices than ranks (a 1-GPU box) the ranks share devices and
-    talk over gloo -- a functional check of the multi-rank path, not a scaling number."""
-    import socket
-    import subprocess
+# The data-parallel fallback ladder of ``bench.py --gpus N`` (N > 1).  The first 8-GPU contact of this path must not be
+# able to fail totally: each rung is a FRESH set of rank processes (children of supervisors that never touch the GPU;
+# nothing is re-exec'ed) with a wall-clock bound; the first rung on which every rank reaches the end wins, and the line
+# says which one it was and what failed above it (``config.allreduce.rung`` / ``rungs_failed``).
+RUNGS = [
+    # (name, environment of the rank processes, torch.distributed backend or None = --backend)
+    ("session picks two-phase (chunked / overlapped all-reduce on a second communicator) or single graph by "
+     "validation + timing; direct RCCL on the compute stream", {}, None),
+    ("single product graph + one compact all-reduce; direct RCCL on the compute stream",
+     {"HF_CHUNKED_ALLREDUCE": "0"}, None),
+    ("single product graph + torch.distributed.all_reduce (no communicator of the package's own)",
+     {"HF_CHUNKED_ALLREDUCE": "0", "HF_DIRECT_RCCL": "0"}, None),
+    ("single product graph + torch.distributed.all_reduce over gloo (host-staged: a functional fallback, not a "
+     "scaling number)", {"HF_CHUNKED_ALLREDUCE": "0", "HF_DIRECT_RCCL": "0"}, "gloo"),
+]
 
+
+def supervise(args):
+    """Runs the rank processes of a multi-rank bench as CHILDREN, rung by rung (``RUNGS``), and relays rank 0's JSON
+    line.  Two ways in: without a launcher (``python bench.py --gpus N``: this one process supervises all N ranks and
+    hosts the rendezvous store) and under ``torch.distributed.run`` (every launched process supervises ITS rank; the
+    launcher's store carries the rendezvous of every rung under its own prefix, plus a 'this rung failed' key so that
+    all supervisors give a rung up together).  A rung counts as done for a rank when its child wrote its marker file
+    -- after the final barrier of the run -- whatever the teardown does afterwards.  The supervisor never initialises
+    the GPU (``device_count`` only)."""
+    import datetime
+    import signal
+    import subprocess
+    import tempfile
+
+    import torch
+    from torch.distributed import TCPStore
+
+    launcher = "WORLD_SIZE" in os.environ
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    # poll: a rank that dies (out of memory, a failed check) would leave the others waiting in
-    # their next collective for good -- end them and report the failure
-    rc = 0
-    while any(p.poll() is None for p in procs):
-        for p in procs:
-            if p.poll() not in (None, 0):
-                rc = abs(p.returncode)
-        if rc:
-            time.sleep(2.0)  # (let the failing rank's siblings print what they have)
-            for p in procs:
-                if p.poll() is None:
-                    p.terminate()
-            for p in procs:
+    if launcher:
+        world = int(os.environ["WORLD_SIZE"])
+        ranks = [(int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"])))]
+        addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"])
+        store = TCPStore(addr, port, is_master=False, timeout=datetime.timedelta(seconds=300))
+    else:
+        import socket
+
+        world = args.gpus
+        ranks = [(r, r) for r in range(world)]
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        addr = "127.0.0.1"
+        store = TCPStore(addr, port, is_master=True, wait_for_workers=False,
+                         timeout=datetime.timedelta(seconds=300))
+    oversubscribed = world > ndev  # several ranks per device: gloo (RCCL wants one device per rank)
+    base_backend = "gloo" if (oversubscribed and args.backend == "nccl") else args.backend
+    timeouts = [float(v) for v in str(args.rung_timeout).split(",")]
+    tmp = tempfile.mkdtemp(prefix="hf_bench_")
+    failed, seen_backends = [], set()
+    argv = [a for a in sys.argv[1:]]
+    for k, (name, env_extra, backend) in enumerate(RUNGS):
+        backend = backend or base_backend
+        key = (backend, tuple(sorted(env_extra.items())))
+        if key in seen_backends:  # (on a shared device every rung already talks gloo: the last rung is the third)
+            continue
+        seen_backends.add(key)
+        if args.chunk >= 0 and k == 0:
+            env_extra = dict(env_extra, HF_CHUNKED_ALLREDUCE="1" if args.chunk else "0")
+        limit = timeouts[min(k, len(timeouts) - 1)]
+        prefix = f"hf_bench/rung{k}"
+        procs = []
+        for rank, local_rank in ranks:
+            marker = os.path.join(tmp, f"rung{k}.rank{rank}.done")
+            out_path = os.path.join(tmp, f"rung{k}.rank{rank}.out")
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world),
+                       MASTER_ADDR=addr, MASTER_PORT=str(port), HF_BENCH_CHILD="1", HF_BENCH_RUNG=str(k),
+                       HF_BENCH_RUNG_NAME=name, HF_BENCH_RUNGS_FAILED=json.dumps(failed),
+                       HF_BENCH_STORE_PREFIX=prefix, HF_BENCH_DONE=marker, HF_BENCH_BACKEND=backend,
+                       HF_BENCH_WATCHDOG=str(limit + 20.0), **env_extra)  # (a last line of defence: the bound is the supervisor's)
+            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)  # (the child takes the store it is told, as a client)
+            fout = open(out_path, "w")
+            procs.append((rank, marker, out_path, fout,
+                          subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=fout)))
+        t0, why = time.time(), None
+        fail_key = prefix + "/failed"
+        while True:
+            states = [(p.poll(), os.path.exists(m)) for _r, m, _o, _f, p in procs]
+            if all(done for _rc, done in states) or all(rc is not None for rc, _d in states):
+                break
+            bad = [(r, p.returncode) for (r, m, _o, _f, p), (rc, done) in zip(procs, states)
+                   if rc not in (None, 0) and not done]
+            if bad:
+                why = f"rank {bad[0][0]} exited with code {bad[0][1]} after {time.time() - t0:.0f} s"
+            elif time.time() - t0 > limit:
+                why = f"no result within the rung's wall-clock bound of {limit:.0f} s (a rank hangs)"
+            if why is not None:
                 try:
-                    p.wait(timeout=10)
-                except subprocess.TimeoutExpired:
-                    p.kill()
-            break
-        time.sleep(0.05)
-    raise SystemExit(rc or max(abs(p.returncode or 0) for p in procs))
+                    store.set(fail_key, why)
+                except Exception:  # noqa: BLE001
+                    pass
+                break
+            try:
+                if store.check([fail_key]):
+                    why = "another rank's supervisor gave the rung up: " + store.get(fail_key).decode(errors="replace")
+                    break
+            except Exception:  # noqa: BLE001
+                pass
+            time.sleep(0.1)
+        if why is None and not all(os.path.exists(m) for _r, m, _o, _f, _p in procs):
+            bad = [(r, p.returncode) for r, m, _o, _f, p in procs if not os.path.exists(m)]
+            why = f"rank {bad[0][0]} ended with code {bad[0][1]} before the end of the run"
+            try:
+                store.set(fail_key, why)
+            except Exception:  # noqa: BLE001
+                pass
+        # every rank process of this rung ends here, success or not (a finished rank gets a moment for its teardown)
+        deadline = time.time() + (20.0 if why is None else 2.0)
+        for _r, _m, _o, _f, p in procs:
+            while p.poll() is None and time.time() < deadline:
+                time.sleep(0.05)
+            if p.poll() is None:
+                p.send_signal(signal.SIGTERM)
+        for _r, _m, _o, fout, p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+            fout.close()
+        if why is None:
+            for rank, _m, out_path, _f, _p in procs:
+                if rank == 0:
+                    for ln in open(out_path).read().splitlines():
+                        if ln.startswith("{"):
+                            print(ln, flush=True)
+            raise SystemExit(0)
+        print(f"[bench] rung {k} ({name}) failed: {why}", file=sys.stderr, flush=True)
+        failed.append({"rung": k, "name": name, "why": why})
+    raise SystemExit(3)
 
 
 def build_problem(args, device, rank):
@@ -166,8 +272,14 @@ def build_problem(args, device, rank):
     # with a float64 one, and one ReLU sign decided differently moves it by 1e-4 of its max-norm
     seeds = tp.RESNET18_B32_SEPARATED_SEEDS
     if args.workload == "resnet18" and args.batch == 32 and rank < len(seeds):
-        return make(batch_size=32, seed=0, device=device, data_seed=seeds[rank])
-    return make(batch_size=args.batch, seed=0, device=device, data_seed=1000 + rank)
+        prob = make(batch_size=32, seed=0, device=device, data_seed=seeds[rank])
+    else:
+        prob = make(batch_size=args.batch, seed=0, device=device, data_seed=1000 + rank)
+    if args.freeze:
+        if args.workload == "allcnnc":
+            raise SystemExit("bench --freeze: a ResNet workload")
+        tp.freeze_stem_and_layer1(prob[0])
+    return prob
 
 
 def cpu_baseline(args):
@@ -294,6 +406,8 @@ def full_step_timing(args, device, n_steps=8, warmup=2):
     model, _, lossf = make(batch_size=args.batch, seed=0, device=device, data_seed=seeds[0])
     if args.bn == "train":
         model.train()
+    if args.freeze:
+        tp.freeze_stem_and_layer1(model)
     l2 = args.l2 if args.l2 >= 0 else (5e-4 if (args.workload == "allcnnc" and args.curvature == "hessian") else 0.0)
     if l2 > 0:
         lossf = tp.l2_regularized(lossf, model, l2)
@@ -408,8 +522,9 @@ def main():
         os.environ["HF_ENGINE"] = "0"
     if args.channels_last < 0:
         args.channels_last = 1  # NHWC: the fused engine (ResNets) / +10 % (All-CNN-C), DESIGN.md section 6
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        launch_ranks(args)  # does not return
+    child = os.environ.get("HF_BENCH_CHILD") == "1"
+    if not child and (args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1):
+        supervise(args)  # does not return: rank processes are its children, rung by rung
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -422,6 +537,9 @@ def main():
     oversubscribed = world > ndev  # several ranks per device: gloo (RCCL wants one device per rank)
     if oversubscribed and args.backend == "nccl":
         args.backend = "gloo"
+    if child:
+        args.backend = os.environ.get("HF_BENCH_BACKEND", args.backend)
+        args.watchdog = min(args.watchdog, float(os.environ.get("HF_BENCH_WATCHDOG", args.watchdog)))
     local_dev = local_rank % ndev
     torch.cuda.set_device(local_dev)
     device = torch.device("cuda", local_dev)
@@ -616,7 +734,7 @@ def main():
         check["deterministic"] = bool(torch.equal(op.local(check["v"]).double(), got))
         return op, grad, diag, n, err
 
-    group, allreduce_ms, comm_path = None, None, "none"
+    group, allreduce_ms, comm_path, ranks_seen = None, None, "none", 1
     if dist_on:
         import torch.distributed as dist
 
@@ -645,10 +763,15 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
+            kw = {}
+            if child:  # (a rung of the ladder: the supervisor's store, this rung's keys under their own prefix)
+                base = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), is_master=False,
+                                     timeout=limit)
+                kw = dict(store=dist.PrefixStore(os.environ["HF_BENCH_STORE_PREFIX"], base), rank=rank, world_size=world)
             if args.backend == "nccl":
-                dist.init_process_group("nccl", device_id=device, timeout=limit)
+                dist.init_process_group("nccl", device_id=device, timeout=limit, **kw)
             else:
-                dist.init_process_group(args.backend, timeout=limit)
+                dist.init_process_group(args.backend, timeout=limit, **kw)
             dist.barrier()
         finally:
             sys.stdout.flush()
@@ -657,11 +780,12 @@ def main():
         group = dist.group.WORLD
         world = dist.get_world_size(group)  # what the backend reports is what gets printed
         state["group"] = group
-        if os.environ.get("HF_BENCH_FAIL_RANK") == str(rank):  # test hook: a rank that dies mid-run
+        if os.environ.get("HF_BENCH_FAIL_RANK") == str(rank):  # test hook: a rank that dies mid-run (on every rung)
             os._exit(3)
         # the data-parallel product: --chunk 1 two-phase (chunked / overlapped all-reduce), 0 single graph + one
-        # compact all-reduce, -1 (default) whichever the session measures to be faster on this communicator
-        if args.chunk >= 0:
+        # compact all-reduce, -1 (default) whichever the session validates and measures to be faster on this
+        # communicator (a rung of the ladder below the first has it in its environment already)
+        if args.chunk >= 0 and not (child and int(os.environ.get("HF_BENCH_RUNG", "0")) > 0):
             os.environ["HF_CHUNKED_ALLREDUCE"] = "1" if args.chunk else "0"
     args.overlap = max(args.overlap, 0)  # (the autograd two-graph split: only on request)
     op, grad, diag, n, err = checked(bool(args.channels_last), overlap=bool(args.overlap))
@@ -706,7 +830,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)  # one number, on every rank
         allreduce_ms = float(tt.item())
         comm_path = hfdist.path_name(probe, group)
+        ranks_seen = hfdist.ranks_seen(group, device)
         del probe
+        if ranks_seen != world:  # (before anything is printed: such a run is not a data-parallel run)
+            raise SystemExit(f"bench: world {world} but the product's collective sums over {ranks_seen} rank(s)")
     b = -grad
     A = hf.DampedCurvature(op, args.damping)
     M = hf.DiagonalPreconditioner(diag, args.damping, 0.75) if diag is not None else None
@@ -755,12 +882,29 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # CG-iters/sec to Martens' criterion (second half of BASELINE.json's metric)
+    # CG-iters/sec to Martens' criterion (second half of BASELINE.json's metric), twice: at the timed region's damping
+    # (--damping; the reference's fixture `solve_martens` of this problem: 36 iterations at 1e-3) and at the
+    # optimizer's DEFAULT damping 1.0 (the reference's own trace of this problem never reaches Martens'
+    # test there: it ends by tolerance after 12-15 iterations -- cg.py:95-115 evaluates Martens' test first, then the
+    # iteration count, NaN, the tolerances), through exactly the call `HessianFree.step` makes (tol 1e-5, max_iter 250)
     barrier()
     t1 = time.perf_counter()
     xs_m, _, reason_m = solve(martens=True)
     barrier()
     dt_m = time.perf_counter() - t1
+    A_default = hf.DampedCurvature(op, 1.0)
+
+    def solve_default():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return hf.cg(A_default, b, M=M, max_iter=250, martens_conv_crit=True, store_x_at_iters=None)
+
+    solve_default()  # (graph arguments of the new operator object: once, untimed)
+    barrier()
+    t1 = time.perf_counter()
+    xs_d, _, reason_d = solve_default()
+    barrier()
+    dt_d = time.perf_counter() - t1
 
     if rank == 0:
         k2_s = timing["k2_ms"] * 1e-3
@@ -791,13 +935,17 @@ def main():
                             + f", max_iter {args.iters}), "
                             f"damping {args.damping}"
                             + (" (SURVEY.md 8(d) states 1.0: with 1.0 this random-init problem is at fp32 round-off "
-                               "after ~15 iterations and 250 iterations cannot be sustained; the Martens-terminated leg "
-                               "`cg_to_martens` and `step_ms` run the optimizer's default 1.0)"
+                               "after ~15 iterations and 250 iterations cannot be sustained; `cg_to_martens` is the "
+                               "Martens-terminated solve at THIS damping, `cg_default_damping` the solve at the "
+                               "optimizer's default 1.0 -- which ends by tolerance, as the reference's --, and `step_ms` "
+                               "runs complete default steps, damping 1.0 + LM)"
                                if args.damping != 1.0 and not hessian else "")
                             + f", {args.bn}-mode BN, CE-mean"
                             + (f" + L2 {l2:g}" if l2 > 0 else "") + ", x0=0, tol=0"
                             + (", diag empirical-Fisher preconditioner ^-0.75 (per-sample autograd)" if M is not None else "")
-                            + (f", acc_step path: chunks {acc_sizes} accumulated" if acc_sizes else ""),
+                            + (f", acc_step path: chunks {acc_sizes} accumulated" if acc_sizes else "")
+                            + (f", FROZEN: {args.freeze} (requires_grad = False; N counts the trainable entries)"
+                               if args.freeze else ""),
                 "parallelism": f"dp{world} (batch sharded, {args.batch} samples per GPU, one all-reduce per matvec: the "
                                "4N-byte vector, or only its entries that can be non-zero with the fused engine -- "
                                "config.allreduce.bytes; `value` counts SHARD products: every rank's operator call "
@@ -826,10 +974,20 @@ def main():
                                     else "HessianFree.linearise(forward): the operator step() itself hands to cg() "
                                          "(generic path)" if state["opt"] is not None
                                     else "built by bench.py (--overlap 1, experimental)"),
+                "path_report": (state["opt"].path_report() if state["opt"] is not None else None),
                 "termination": reason,
                 "allreduce": None if allreduce_ms is None else {
                     "path": comm_path, "bytes": int(getattr(getattr(op, "op", op), "reduce_bytes", 4 * n)),
                     "ms": allreduce_ms,
+                    "backend": args.backend,
+                    "world": world,
+                    "ranks_seen": ranks_seen,
+                    "ranks_seen_note": f"world {world}: ranks seen by the product's own collective path = {ranks_seen}",
+                    "rung": int(os.environ.get("HF_BENCH_RUNG", "0")),
+                    "rung_name": os.environ.get("HF_BENCH_RUNG_NAME", "(no ladder: single rank process)"),
+                    "rungs_failed": json.loads(os.environ.get("HF_BENCH_RUNGS_FAILED", "[]")),
+                    "validation": getattr(op, "mode_validation", None),
+                    "side_stream_runs_beside_compute": getattr(op, "side_runs_beside", None),
                     "overlap_two_graphs": bool(args.overlap),
                     "product_mode": ("two-phase (chunked / overlapped)"
                                      if getattr(op, "split", None) is not None
@@ -839,8 +997,14 @@ def main():
                                             1: "forced two-phase"}.get(args.chunk)},
             },
             "cg_iters_per_s": world * args.steps * solves_per_step * iters_done / dt,
-            "cg_to_martens": {"iters": len(xs_m) - 1, "reason": reason_m,
-                              "iters_per_s": (len(xs_m) - 1) / dt_m},
+            "cg_to_martens": {"damping": args.damping, "iters": len(xs_m) - 1, "reason": reason_m,
+                              "iters_per_s": (len(xs_m) - 1) / dt_m,
+                              "call": "cg(A, b, max_iter=--iters, tol=0, martens_conv_crit=True, store_x_at_iters=[0])"},
+            "cg_default_damping": {"damping": 1.0, "iters": len(xs_d) - 1, "reason": reason_d,
+                                   "iters_per_s": (len(xs_d) - 1) / dt_d,
+                                   "call": "cg(A, b, max_iter=250, martens_conv_crit=True, store_x_at_iters=None): "
+                                           "the call HessianFree.step makes (optimizer.py:265-274), wall time incl. "
+                                           "A(x0), the backtracking grid's snapshots and the final sync"},
             "roofline": {
                 "bound": "hbm",
                 "kernel": "k_update_xr (K2)",
@@ -900,6 +1064,10 @@ def main():
         print(json.dumps(line), flush=True)
     if group is not None:
         torch.distributed.barrier()
+        marker = os.environ.get("HF_BENCH_DONE")
+        if marker:  # (the run is complete on every rank: whatever the teardown does, this rung counts)
+            with open(marker, "w") as fh:
+                fh.write("done\n")
         torch.distributed.destroy_process_group()
         import faulthandler
 

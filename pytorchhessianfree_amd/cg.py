@@ -29,6 +29,7 @@ There is NO CPU fallback: CPU tensors raise ``RuntimeError``.
 
 import ctypes
 import os
+import weakref
 from math import ceil, log
 from warnings import warn
 
@@ -168,7 +169,7 @@ class _Workspace:
         self.p = torch.empty(n, dtype=dtype, device=device)
         self.timing = False
         self._events = [torch.cuda.Event() for _ in range(_LAG + 2)]
-        self.checked_groups = set()
+        self.checked_groups = weakref.WeakSet()  # (by group OBJECT: an id() is recycled once a group is gone)
 
     def event(self, it):
         """Recycled completion events: at most _LAG + 1 are pending at any time."""
@@ -195,7 +196,7 @@ def _check_ranks_agree(ws, group):
     partial-sum order).  Checked once per (workspace, group): ranks on GPUs with
     different CU counts or different ``HF_PCG_BLOCKS`` are refused up front instead of
     dead-locking in a later all-reduce."""
-    if id(group) in ws.checked_groups:
+    if group in ws.checked_groups:
         return
     dist = torch.distributed
     mine = int(os.environ.get("HF_PCG_BLOCKS", "0")) or 2 * torch.cuda.get_device_properties(
@@ -207,7 +208,7 @@ def _check_ranks_agree(ws, group):
         raise RuntimeError(
             f"data-parallel PCG needs the same kernel grid on every rank (got {lo}..{hi} blocks): "
             "set HF_PCG_BLOCKS to one value on all ranks")
-    ws.checked_groups.add(id(group))
+    ws.checked_groups.add(group)
 
 
 def _as_operand(t, like, name):

@@ -148,6 +148,11 @@ SWITCHES = {
                          "tests/test_engine_gpu.py::test_train_mode_prologue_form_variants_agree_and_state_is_independent_of_the_first_use_check"),
     "HF_CHUNKED_ALLREDUCE": ("auto", "0 / 1: force the single-graph resp. the two-phase data-parallel product",
                              "tests/test_distributed_gpu.py::test_step_two_ranks_engine_session_equals_cpu_whole_batch"),
+    "HF_DIRECT_RCCL": ("1", "0: every collective through torch.distributed (no communicator of the package's own)",
+                       "tests/test_distributed_gpu.py::test_bench_ladder_reaches_the_plainest_rung"),
+    "HF_TEST_DP_FAULT": ("", "test hook: hang / raise / mismatch[:not_plain] -- the last rank misbehaves in a data-parallel "
+                             "session product (session._inject_fault)",
+                         "tests/test_distributed_gpu.py::test_bench_ladder_falls_past_a_rung_that_hangs"),
     "HF_PCG_BLOCKS": ("0", "workgroups of the PCG vector kernels (0: 2 per CU); must agree on all ranks",
                       "tests/test_cg_gpu.py::test_kernel_grid_override_gives_the_same_solve"),
     "HF_PCG_LIB": ("", "path of another build of libhfpcg.so (tuning variants)",

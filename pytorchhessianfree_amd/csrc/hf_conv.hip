@@ -753,9 +753,12 @@ __device__ __forceinline__ void conv_tn_body(const ConvArgs& a, float* lds, int 
   }
   __syncthreads();
   // output element (k, tap, c) at (k*RS + tap)*cs + c: rows = k, "columns" = c within this tap
-  if constexpr (FLAT) {  // (every tap live, out_c == cs: the columns ARE the flattened (tap, c) index)
-    finish_tile<C>(a, acc, tile, split, wm, wn, lane, a.out, tile_m * BM, c0, a.kout, a.ntaps * a.cs,
-                   a.R * a.S * a.out_c, &flag);
+  if constexpr (FLAT) {
+    // every tap live and out_c == cs: the columns ARE the flattened (tap, c) index.  A zero-padded operand
+    // (out_c < cs) is only let through with a single tap (apply_out_c): the columns are then the channels, and the
+    // padded ones are cut off here -- with several taps they would land in the next tap's / row's first entries
+    finish_tile<C>(a, acc, tile, split, wm, wn, lane, a.out, tile_m * BM, c0, a.kout,
+                   a.ntaps == 1 ? a.out_c : a.ntaps * a.cs, a.R * a.S * a.out_c, &flag);
   } else {
     float* base = a.out + (size_t)(r * a.S + q) * a.out_c;
     finish_tile<C>(a, acc, tile, split, wm, wn, lane, base, tile_m * BM, c0, a.kout, a.out_c,
@@ -1042,6 +1045,17 @@ int want_big(int direction, int64_t rows, int64_t dim_m, int64_t dim_n, int64_t 
   return (fits && rows >= 2048 && tiles * steps >= least) ? kind : 0;
 }
 
+// The `out_c` of a weight-gradient problem (X zero-padded to cs channels, dW has out_c <= cs of them) is applied AFTER
+// setup() has chosen the tile configuration: Flat96 enumerates its output columns flat over (tap, channel), which a
+// padded operand breaks unless there is a single tap (the padded columns of one row raced with the next
+// row's first entries and the last row wrote past the slab) -- refused, loudly, instead.
+static int apply_out_c(ConvArgs& a, int64_t out_c) {
+  if (!out_c) return HF_OK;
+  if (a.big == 3 && out_c != a.cs && a.ntaps != 1) return HF_ERR_ARG;
+  a.out_c = (int)out_c;
+  return HF_OK;
+}
+
 int64_t setup(ConvArgs& a, int direction, void* out, const void* act, const void* mat, int64_t n, int64_t h,
               int64_t w, int64_t c, int64_t k, int64_t r, int64_t s, int64_t stride_h, int64_t stride_w,
               int64_t pad_h, int64_t pad_w, int64_t act_ld, float* ws, int64_t ws_bytes, int* tickets,
@@ -1272,7 +1286,7 @@ int hf_conv2d_nhwc_slabs(int direction, void* out, const void* act, const void* 
                                pad_w, act_ld, nullptr, 0, nullptr, 0, 0, splits, slab_stride, mat_ld);
   if (blocks <= 0) return (int)blocks;
   if (a.splits != splits) return HF_ERR_ARG;  // ask hf_conv2d_nhwc_plan first
-  if (out_c) a.out_c = (int)out_c;
+  if (apply_out_c(a, out_c)) return HF_ERR_ARG;
   launch_one(direction, a, blocks, (hipStream_t)stream);
   HF_HIP(hipGetLastError());
   return HF_OK;
@@ -1360,7 +1374,7 @@ int hf_conv2d_nhwc_dw_slabs(const hf_conv_problem* d, const hf_conv_problem* w, 
                       q.mat_ld);
     if (blocks[i] <= 0) return (int)blocks[i];
     if (a[i].splits != q.splits || a[i].scalar) return HF_ERR_ARG;
-    if (q.out_c) a[i].out_c = (int)q.out_c;
+    if (apply_out_c(a[i], q.out_c)) return HF_ERR_ARG;
   }
   const dim3 grid((unsigned)(blocks[0] + blocks[1]));
   (void)grid;
@@ -1438,7 +1452,7 @@ int hf_conv2d_nhwc_group_slabs(const hf_conv_problem* problems, int n_problems, 
     if (blocks <= 0) return (int)blocks;
     if (q.a[i].splits != pr.splits) return HF_ERR_ARG;  // ask hf_conv2d_nhwc_plan first
     if (q.a[i].scalar) return HF_ERR_ARG;               // the grouped launch has the 16-byte gather variant only
-    if (pr.out_c) q.a[i].out_c = (int)pr.out_c;
+    if (apply_out_c(q.a[i], pr.out_c)) return HF_ERR_ARG;
     q.tn[i] = pr.direction == 2;
     q.start[i] = (int)total;
     total += blocks;

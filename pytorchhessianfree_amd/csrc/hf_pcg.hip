@@ -209,8 +209,14 @@ __global__ __launch_bounds__(BLOCK) void k_init_finalize(DevState* __restrict__ 
 // next) while K2 / K3 themselves get ~1 us slower: default policy there, and for small vectors (All-CNN-C: 5.5 MB,
 // L2-resident between kernels).
 // NT covers: K1 both read streams; K2 the x / b / Bp loads and the x store (r and p are re-read by K3 right
-// after).  K3 keeps the default policy: its r was written by K2 a moment ago and is still on-die (a non-temporal
-// r load cost K3 24.8 -> 26.9 us at N = 11.2 M).
+// after).  K3 keeps the default policy up to HF_K3_NT_MIN elements: its r was written by K2 a moment ago and is still
+// on-die (a non-temporal r load cost K3 24.8 -> 26.9 us at N = 11.2 M).  From 64 M elements (256 MiB per vector:
+// ONE vector fills the Infinity Cache) nothing K2 wrote is on-die any more and nothing K3 writes survives until the
+// product reads it: r / p / minv loads and the p store go non-temporal there (round 6; N = 100 M: DESIGN.md
+// section 6.1, profiles/r06_pcg_kernel_bench.jsonl).
+#ifndef HF_K3_NT_MIN
+#define HF_K3_NT_MIN 64000000LL
+#endif
 #define HF_LD(NTFLAG, dst, ptr)                                                             \
   {                                                                                         \
     if constexpr (NTFLAG) {                                                                 \
@@ -440,8 +446,8 @@ __global__ __launch_bounds__(BLOCK) void k_update_p(
     if (i < nvec) {                                                         \
       if (MODE == HF_M_EXTERNAL) vr[u].v = reinterpret_cast<const V*>(yext)[i]; \
       else HF_LD(NT, vr[u].v, reinterpret_cast<const V*>(r) + i)            \
-      vp[u].v = reinterpret_cast<const V*>(p)[i];                           \
-      if (MODE == HF_M_DIAG) vm[u].v = reinterpret_cast<const V*>(minv)[i]; \
+      HF_LD(NT, vp[u].v, reinterpret_cast<const V*>(p) + i)                 \
+      if (MODE == HF_M_DIAG) HF_LD(NT, vm[u].v, reinterpret_cast<const V*>(minv) + i) \
     }                                                                       \
   }
   HF_K3_LOAD();  // in flight while beta and the termination tests are evaluated
@@ -506,7 +512,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_p(
           const T y = (MODE == HF_M_DIAG) ? (T)(vm[u].e[c] * vr[u].e[c]) : vr[u].e[c];
           vp[u].e[c] = (-y) + (T)(beta * vp[u].e[c]);   // p = -y + beta*p   cg.py:224
         }
-        reinterpret_cast<V*>(p)[i] = vp[u].v;
+        HF_ST(NT, reinterpret_cast<V*>(p) + i, vp[u].v)
       }
     }
     base += (long long)gridDim.x * tile;
@@ -841,8 +847,7 @@ static void build_k2(hf_pcg* h, const void* Bp, double damping, KLaunch& k) {
 
 template <typename T>
 static void build_k3(hf_pcg* h, const void* yext, KLaunch& k) {
-  const bool nt = false;  // (see HF_LD: K3's operands are on-die)
-  (void)nt_streams;
+  const bool nt = h->n >= HF_K3_NT_MIN;  // (see HF_LD: below that K3's operands are on-die)
   switch (h->precond) {
     case HF_M_NONE: k.func = nt ? (const void*)&k_update_p<T, HF_M_NONE, U3, true> : (const void*)&k_update_p<T, HF_M_NONE, U3, false>; break;
     case HF_M_DIAG: k.func = nt ? (const void*)&k_update_p<T, HF_M_DIAG, U3, true> : (const void*)&k_update_p<T, HF_M_DIAG, U3, false>; break;

@@ -196,20 +196,23 @@ class GGNOperator(_Operator):
             flatten_into(g, head, out=out[:offset], scale=self.weight)
 
 
-def ggn_operator(loss, outputs, params, weight=1.0, group=None):
+def ggn_operator(loss, outputs, params, weight=1.0, group=None, why=None):
     """The GGN operator for ``(loss, outputs)``: the fused curvature engine (engine.py) when
     ``outputs`` comes from a prepared model of a family it knows (conv - eval-BatchNorm - ReLU
     units with residual connections, NHWC fp32), else the autograd operator above."""
     if isinstance(outputs, torch.Tensor) and getattr(outputs, "_hf_model", None) is not None:
         from .engine import FusedGGNEngine
 
-        eng = FusedGGNEngine.try_build(loss, outputs, list(params), weight=weight, group=group)
+        eng = FusedGGNEngine.try_build(loss, outputs, list(params), weight=weight, group=group, why=why)
         if eng is not None:
             return eng
+    elif why is not None:
+        why.append("the model is not a prepared one (modelprep.prepare_model(model, channels_last=True) installs the "
+                   "layers the fused engine reads)")
     return GGNOperator(loss, outputs, params, weight=weight, group=group)
 
 
-def hessian_operator(loss, outputs, params, grad_with_graph=None, weight=1.0, group=None):
+def hessian_operator(loss, outputs, params, grad_with_graph=None, weight=1.0, group=None, why=None):
     """The Hessian operator for ``loss``: the fused curvature engine in Hessian mode (engine.py:
     forward-over-reverse on the package's own kernels) when ``outputs`` comes from a prepared model of
     a family it covers (plain conv-ReLU stacks with a softmax cross-entropy, optionally plus a tagged
@@ -217,9 +220,13 @@ def hessian_operator(loss, outputs, params, grad_with_graph=None, weight=1.0, gr
     if isinstance(outputs, torch.Tensor) and getattr(outputs, "_hf_model", None) is not None:
         from .engine import FusedGGNEngine
 
-        eng = FusedGGNEngine.try_build(loss, outputs, list(params), weight=weight, group=group, hessian=True)
+        eng = FusedGGNEngine.try_build(loss, outputs, list(params), weight=weight, group=group, hessian=True,
+                                       why=why)
         if eng is not None:
             return eng
+    elif why is not None:
+        why.append("the model is not a prepared one (modelprep.prepare_model(model, channels_last=True) installs the "
+                   "layers the fused engine reads)")
     return HessianOperator(loss, params, grad_with_graph=grad_with_graph, weight=weight, group=group)
 
 

@@ -22,12 +22,15 @@ import ctypes
 import os
 import sys
 import warnings
+import weakref
 
 import torch
 
 from . import _lib
 
-_comms = {}
+# Communicators are kept PER GROUP OBJECT (weakly): a registry keyed by ``id(group)`` outlives the group, and CPython
+# hands the address of a collected group to the next one -- which would then inherit a communicator of other ranks.
+_comms = weakref.WeakKeyDictionary()
 
 
 class _DirectComm:
@@ -81,8 +84,14 @@ class _DirectComm:
         return pieces
 
 
+def direct_enabled():
+    """``HF_DIRECT_RCCL=0`` keeps every collective on ``torch.distributed`` (no communicator of the package's own):
+    the plainest rung of ``bench.py``'s data-parallel ladder."""
+    return os.environ.get("HF_DIRECT_RCCL", "1") != "0"
+
+
 def _wants_direct(t, group):
-    if not (t.is_cuda and t.is_contiguous()):
+    if not direct_enabled() or not (t.is_cuda and t.is_contiguous()):
         return False
     if t.dtype not in (torch.float32, torch.float64):
         return False
@@ -95,8 +104,7 @@ def _wants_direct(t, group):
 def _direct_comm(group):
     """The group's direct communicator, ``None`` if it could not be created (decided
     collectively: either every rank has one or none uses it)."""
-    key = id(group)
-    if key not in _comms:
+    if group not in _comms:
         comm = None
         try:
             comm = _DirectComm(group)
@@ -105,11 +113,11 @@ def _direct_comm(group):
         ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32,
                           device=torch.device("cuda", torch.cuda.current_device()))
         torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=group)
-        _comms[key] = comm if int(ok.item()) == 1 else None
-    return _comms[key]
+        _comms[group] = comm if int(ok.item()) == 1 else None
+    return _comms[group]
 
 
-_side_comms = {}
+_side_comms = weakref.WeakKeyDictionary()
 
 
 def side_comm(t, group):
@@ -118,8 +126,7 @@ def side_comm(t, group):
     RCCL communicator are not allowed to overlap).  ``None`` when the direct path is off."""
     if group is None or not _wants_direct(t, group) or _direct_comm(group) is None:
         return None
-    key = id(group)
-    if key not in _side_comms:
+    if group not in _side_comms:
         comm = None
         try:
             comm = _DirectComm(group)
@@ -128,8 +135,20 @@ def side_comm(t, group):
         ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32,
                           device=torch.device("cuda", torch.cuda.current_device()))
         torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=group)
-        _side_comms[key] = comm if int(ok.item()) == 1 else None
-    return _side_comms[key]
+        _side_comms[group] = comm if int(ok.item()) == 1 else None
+    return _side_comms[group]
+
+
+def ranks_seen(group, device):
+    """How many ranks the collective path of this package actually sums over: every rank contributes 1.0 to ONE
+    all-reduce issued exactly as a product's is (direct RCCL communicator when that is the path, else
+    ``torch.distributed``).  ``bench.py`` prints it (``config.allreduce.ranks_seen``): a world of N whose collective
+    sees fewer than N ranks is not a data-parallel run."""
+    if group is None:
+        return 1
+    one = torch.ones(4, dtype=torch.float32, device=device)
+    all_reduce_sum(one, group)
+    return int(round(float(one[0].item())))
 
 
 def path_name(t, group):

@@ -125,7 +125,7 @@ class _AdjointSweep:
         if u.im2col:
             self._conv_slabs(2, u.wbuf, u.cols_pad, ga, u.geo_w, u.sW, out_c=u.jcols)
             return
-        if u.first:  # the network input needs no gradient
+        if u.first or u.no_dgrad:  # the network input (or the output of frozen layers) needs no gradient
             self._conv_slabs(2, u.wbuf, u.x, ga, u.geo, u.sW)
             return
         # (Measured and rejected, round 4: the weight gradient -- off the adjoint chain, only the gather reads it -- as
@@ -150,7 +150,8 @@ class _AdjointSweep:
             incoming = {id(tail): [(g_last, 1, 0)]}
         pool_srcs = None
         first = len(self.blocks) - 1 if first is None else first
-        for bi in range(first, last_block - 1, -1):
+        stop = max(last_block, self.dead_blocks)  # (dead blocks: nobody needs their cotangents)
+        for bi in range(first, stop - 1, -1):
             chain, ds, _x = self.blocks[bi]
             head, last = chain[0], chain[-1]
             for k in range(len(chain) - 1, -1, -1):
@@ -165,14 +166,23 @@ class _AdjointSweep:
                     else:
                         self._bn_adjoint(u, incoming.pop(id(u)))
                         self._bn_adjoint(ds, [(last.g, 1, 0)])
-                    _lib.conv_group_slabs(
-                        [(1, u.dbuf, u.ga, u.wT, u.geo, u.sD, 0, 0), (2, u.wbuf, u.x, u.ga, u.geo, u.sW, 0, 0),
-                         (1, ds.dbuf, ds.ga, ds.wT, ds.geo, ds.sD, 0, 0), (2, ds.wbuf, ds.x, ds.ga, ds.geo, ds.sW, 0, 0)],
-                        self.dev)
+                    if u.no_dgrad:  # (the block input carries no tangent: the two weight gradients only)
+                        _lib.conv_group_slabs(
+                            [(2, u.wbuf, u.x, u.ga, u.geo, u.sW, 0, 0), (2, ds.wbuf, ds.x, ds.ga, ds.geo, ds.sW, 0, 0)],
+                            self.dev)
+                    else:
+                        _lib.conv_group_slabs(
+                            [(1, u.dbuf, u.ga, u.wT, u.geo, u.sD, 0, 0), (2, u.wbuf, u.x, u.ga, u.geo, u.sW, 0, 0),
+                             (1, ds.dbuf, ds.ga, ds.wT, ds.geo, ds.sD, 0, 0),
+                             (2, ds.wbuf, ds.x, ds.ga, ds.geo, ds.sW, 0, 0)], self.dev)
                 else:
                     self._adjoint_unit(u, incoming.pop(id(u)))
                 if k > 0:
                     incoming.setdefault(id(chain[k - 1]), []).append((u.dbuf, self._dslabs(u), u.dbuf.shape[1]))
+            if head.no_dgrad:  # (everything in front of this block is frozen: the sweep ends here)
+                if ds is not None and not group:
+                    self._adjoint_unit(ds, [(last.g, 1, 0)])
+                return None
             # the block input receives conv1's data gradient and the residual branch's cotangent
             srcs = [(head.dbuf, self._dslabs(head), head.dbuf.shape[1])]
             if ds is not None:
@@ -191,6 +201,8 @@ class _AdjointSweep:
         """Block 0's input is the pooled stem output: sum its two cotangents, undo the max-pool,
         then the stem's own adjoint."""
         s = self.stem
+        if s.dead or pool_srcs is None:  # (frozen stem: nothing to differentiate)
+            return
         ks, st_, pd, dl, cm = self.pool_args
         pn, ph, pw, poh, pow_, c0 = self._pool_geometry()
         (a, sa, la), (b, sb, lb) = pool_srcs
@@ -270,6 +282,13 @@ class _AdjointSweep:
             tensors, perms, splits = [None] * len(self.params), {}, {}
             self._pack_live = {}
             for u in self.units:
+                if u.pw is None:  # (frozen weight: its gradient slabs, if the fused launch wrote any, are not gathered)
+                    for pi, buf, rows in ((u.pg, u.gw, u.gw_rows), (u.pb, u.gb, u.rb)):
+                        if pi is not None:
+                            tensors[pi] = buf[0]
+                            if rows > 1:
+                                splits[pi] = (rows, u.cout)
+                    continue
                 tensors[u.pw] = u.wbuf[0]
                 if not u.im2col:
                     k, c, r, s_ = u.conv.weight.shape

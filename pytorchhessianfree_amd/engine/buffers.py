@@ -87,7 +87,8 @@ class _Buffers:
                 u.wcat = torch.zeros((k, 2 * c, r, s), dtype=f32, device=dev).contiguous(memory_format=cl)
                 u.wT = torch.empty((c, r, s, k), dtype=f32, device=dev)  # (I, H, W, O)
                 u.live = _live_taps(h, w, r, s, u.conv.stride, u.conv.padding)
-                self._tangent_slots[id(u)] = (self._offs[u.pw], u.wcat, c, u.live)
+                if u.pw is not None:  # (a frozen weight: its W half is copied from the parameter, its v_W half stays 0)
+                    self._tangent_slots[id(u)] = (self._offs[u.pw], u.wcat, c, u.live)
             oh, ow = u.a.shape[2], u.a.shape[3]
             u.rows, u.cout = n * oh * ow, k
             # split-K slab buffers
@@ -97,7 +98,7 @@ class _Buffers:
                 u.sD = 0
             else:
                 u.sT, u.sW = self._plan(0, u), self._plan(2, u)
-                u.sD = 0 if u.first else self._plan(1, u)
+                u.sD = 0 if (u.first or u.no_dgrad or u.dead) else self._plan(1, u)
                 u.sF = self._plan(0, u, forward=True)
             u.tbuf = torch.empty((max(u.sT, u.sF), u.rows * k), dtype=f32, device=dev)
             # Hessian products add, per layer, conv_W(t_x, g) to the weight gradient and conv_D(g, V) to the
@@ -181,7 +182,12 @@ class _Buffers:
         self._slot_list = list(self._tangent_slots.values())
         self._carry_ok = True  # (the stem's launch carries the v_W scatter; False once the library refused it)
         # (I, H, W, O) copies: the weights (once per step) and, for Hessian products, V (per product)
-        self._wt_slots = [(self._offs[u.pw], u.wT, u.x.shape[1]) for u in self.units if not u.im2col and not u.first]
+        self._wt_slots = [(self._offs[u.pw], u.wT, u.x.shape[1]) for u in self.units
+                          if not u.im2col and not u.first and u.pw is not None and u.sD]
+        # frozen convolution weights: constants the flat parameter vector does not hold -- their W half / (I, H, W, O)
+        # copy come from the parameter itself (`refresh_frozen`: at construction and whenever it was written to)
+        self._frozen_w = [u for u in self.units if not u.im2col and u.pw is None]
+        self._frozen_seen = {}
         self._vt_slots = [(self._offs[u.pw], u.vT, u.x.shape[1]) for u in self.units
                           if self.hessian and not u.im2col and u.sD]
         self._allocate_pool()
@@ -240,8 +246,23 @@ class _Buffers:
             if u.bn is not None and not u.train and u.bn.running_var._version != u.rstd_version:
                 torch.rsqrt(u.bn.running_var + u.bn.eps, out=u.rstd)
                 u.rstd_version = u.bn.running_var._version
+        self.refresh_frozen()
         if targets is not None:
             self.set_targets(targets)
+
+    def refresh_frozen(self):
+        """W halves and (I, H, W, O) copies of FROZEN convolution weights (not part of the flat vector the scatter
+        launches read): copied when the parameter was written to or re-bound since the last look (eager, once per
+        batch: never inside a captured graph)."""
+        for u in self._frozen_w:
+            w = u.conv.weight
+            seen = (w._version, w.data_ptr())
+            if self._frozen_seen.get(id(u)) != seen:
+                c = u.x.shape[1]
+                u.wcat[:, :c].copy_(w.detach())
+                if u.sD:
+                    u.wT.copy_(w.detach().permute(1, 2, 3, 0))
+                self._frozen_seen[id(u)] = seen
 
     def set_targets(self, targets):
         if getattr(self, "_targets", None) is None:
@@ -264,7 +285,7 @@ class _Buffers:
             _lib.unpack_tangent(flat, self._slot_list, half=0)
         else:
             for u in self.units:
-                if not u.im2col:
+                if not u.im2col and u.pw is not None:
                     c = u.x.shape[1]
                     u.wcat[:, :c].copy_(self.params[u.pw].detach())
         if transposed:
@@ -272,7 +293,7 @@ class _Buffers:
                 _lib.unpack_tangent(flat, self._wt_slots, half=2)
             else:
                 for u in self.units:
-                    if not u.im2col and not u.first:
+                    if not u.im2col and not u.first and u.pw is not None and u.sD:
                         u.wT.copy_(self.params[u.pw].detach().permute(1, 2, 3, 0))
 
     def _zeros(self, k):

@@ -38,6 +38,8 @@ class _Unit:
         self.res_identity = False  # ... or the block input itself
         self.consumers = 0
         self.src = None           # what the convolution reads: "input", "pool" or the producing unit
+        self.dead = False         # frozen, behind frozen layers only: no tangent, no cotangent (topology._mark_dead_prefix)
+        self.no_dgrad = False     # a live unit whose input carries no tangent: its data gradient is not needed
 
     # per-channel affine map behind the convolution: BatchNorm statistics / scale / shift, or a bias
     @property

@@ -59,12 +59,22 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
 
     # ------------------------------------------------------------------------------------
     @classmethod
-    def try_build(cls, loss, outputs, params, weight=1.0, group=None, hessian=False):
+    def try_build(cls, loss, outputs, params, weight=1.0, group=None, hessian=False, why=None):
+        """The engine for the model that produced ``outputs``, or ``None``; ``why`` (a list) receives one line per
+        reason it was not taken -- what ``HessianFree.path_report()`` and its one-time warning quote."""
+        why = [] if why is None else why
         if os.environ.get("HF_ENGINE", "1") == "0":
+            why.append("the fused engine is switched off (HF_ENGINE=0)")
             return None
         ref = getattr(outputs, "_hf_model", None)
         model = ref() if ref is not None else None
-        if model is None or not outputs.is_cuda or outputs.dtype != torch.float32 or outputs.dim() != 2:
+        if model is None:
+            why.append("the model is not a prepared one (modelprep.prepare_model(model, channels_last=True) installs "
+                       "the layers the fused engine reads)")
+            return None
+        if not outputs.is_cuda or outputs.dtype != torch.float32 or outputs.dim() != 2:
+            why.append(f"the model output is not a CUDA float32 [batch, classes] tensor (got {outputs.dtype}, "
+                       f"{tuple(outputs.shape)}, {outputs.device})")
             return None
         from .plain import PlainStackEngine
 
@@ -77,11 +87,13 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
             except _Unsupported as exc:
                 # (a model the engine does not cover is the normal case: quiet unless asked;
                 # a product that FAILED its check is always reported)
+                why.append(f"{kind.__name__}: {exc}")
                 if os.environ.get("HF_ENGINE_DEBUG") or getattr(exc, "loud", False):
                     warnings.warn(f"fused curvature engine ({kind.__name__}) not used: {exc}")
                 if getattr(exc, "loud", False):
                     return None
             except _lib.Refused as exc:  # a kernel refused its arguments (alignment, size limits ...)
+                why.append(f"{kind.__name__}: a kernel refused its arguments: {exc}")
                 warnings.warn(f"fused curvature engine ({kind.__name__}) not used: {exc}")
                 return None
         return None
@@ -109,7 +121,11 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
             o += p.numel()
         self._offs = offs
         self.train_bn = False
+        self.frozen_any, self.dead_blocks = False, 0
         self._layout(model)
+        if self.frozen_any and self.hessian:
+            raise _Unsupported("Hessian products with frozen layer parameters (requires_grad = False) are not covered "
+                               "by the engine; GGN products are")
         if self.hessian:
             for u in self.units:
                 u.needs_g = True  # (the first-order masked cotangent of every unit is kept)
@@ -191,6 +207,7 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
             for w in tensors:
                 i = self._index.get(id(w))
                 if i is None:
+                    # (a frozen tensor would add a constant to the loss value the engine's own loss head reports)
                     raise _Unsupported("a regularised tensor is not among the optimizer's parameters")
                 d[self._offs[i]: self._offs[i] + w.numel()] += float(coef)
         self._l2 = d

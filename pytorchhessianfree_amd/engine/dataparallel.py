@@ -43,7 +43,7 @@ class _DataParallel:
         the compact staging vector by ``hf_live_copy``, all-reduced there and scattered back."""
         if not hasattr(self, "_live_segs"):
             self._live_segs = None
-            masked = {u.pw: u for u in self.units if not u.im2col and getattr(u, "live", 0)}
+            masked = {u.pw: u for u in self.units if not u.im2col and getattr(u, "live", 0) and u.pw is not None}
             segs, dead, run_start = [], 0, None  # (full offset, count in the full vector, period, mask)
             brk = getattr(self, "_seg_break", None)  # parameter index at which a dense run must end
             self._seg_cut = None                     # (chunked all-reduce: the suffix starts a segment)

@@ -19,8 +19,8 @@ class _DiagEF:
         cotangents ARE the per-sample cotangents -- followed, per sample, by the weight-gradient convolutions on that
         sample's rows and one squaring gather (``hf_pack_ex`` mode 1).  A tagged L2 term (each per-sample loss of
         the reference carries it whole) enters in closed form: sum (a_i + b)^2 = sum a_i^2 + 2 b sum a_i + N b^2."""
-        if self.loss_spec is None or self.train_bn:
-            raise RuntimeError("engine.diag_ef needs a softmax cross-entropy loss and eval-mode BatchNorm")
+        if self.loss_spec is None or self.train_bn or self.frozen_any:
+            raise RuntimeError("engine.diag_ef needs a softmax cross-entropy loss, eval-mode BatchNorm and no frozen layer")
         if self.loss_spec["reduction"] != reduction:
             raise RuntimeError("engine.diag_ef: the loss's reduction differs from the requested one")
         n = self.x_in.shape[0]

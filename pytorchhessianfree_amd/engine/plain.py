@@ -88,6 +88,8 @@ class PlainStackEngine(FusedGGNEngine):
         self.units, self.tail, self.blocks = units, units[-1], []
         self.stem, self.pool_args, self.fc, self.pfw, self.pfb = None, None, None, None, None
         self.model_ref, self._in_shape = model, tuple(x_in.shape)
+        if self.frozen_any:
+            raise _Unsupported("frozen layer parameters: the plain-stack engine covers fully trainable stacks")
         used = {i for u in units for i in (u.pw, u.pb) if i is not None}
         if used != set(range(len(self.params))):
             raise _Unsupported("the parameter list has entries the engine's layers do not cover")

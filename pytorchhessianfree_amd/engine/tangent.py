@@ -82,8 +82,8 @@ class _TangentSweep:
             n, k, oh, ow = u.a.shape
             q.out, q.a, q.x = u.tout.data_ptr(), u.tbuf.data_ptr(), u.a.data_ptr()
             q.mean, q.rstd, q.w = u.bn.running_mean.data_ptr(), u.rstd.data_ptr(), u.bn.weight.data_ptr()
-            q.q = v.data_ptr() + 4 * self._offs[u.pg]
-            q.r = v.data_ptr() + 4 * self._offs[u.pb]
+            q.q = v.data_ptr() + 4 * self._offs[u.pg] if u.pg is not None else None  # (frozen scale / shift: no tangent)
+            q.r = v.data_ptr() + 4 * self._offs[u.pb] if u.pb is not None else None
             q.add, q.mask_src, q.relu_self = None, (u.y.data_ptr() if u.relu else None), 0
             q.n, q.c, q.hw, q.out_ld, q.add_ld = n, k, oh * ow, u.tout_ld, 0
             q.a_splits, q.a_slab = u.sT, u.tbuf.shape[1]
@@ -95,7 +95,14 @@ class _TangentSweep:
         slice of ``v`` itself).  ``carry_scatter``: the launch also carries the scatter of every other layer's v_W
         into its ``[W | v_W]`` operand (``hf_conv2d_nhwc_slabs_unpack``) -- nothing in the stem reads those."""
         s = self.stem
-        vw = v[self._offs[s.pw]: self._offs[s.pw] + s.conv.weight.numel()]
+        if s.dead:  # (frozen stem: its output carries no tangent -- only the scatter it would have carried is left)
+            if carry_scatter and self._slot_list:
+                _lib.unpack_tangent(v, self._slot_list)
+            return
+        if s.pw is None:  # (frozen stem weight under a trainable BatchNorm: conv(x, 0) = 0)
+            vw = self._zeros(s.conv.weight.numel())
+        else:
+            vw = v[self._offs[s.pw]: self._offs[s.pw] + s.conv.weight.numel()]
         if not (carry_scatter and self._conv_carrying_scatter(s, vw, s.sT, v, 1)):
             if carry_scatter:
                 _lib.unpack_tangent(v, self._slot_list)  # v_W halves of all [W | v_W] operands: one launch
@@ -130,7 +137,7 @@ class _TangentSweep:
 
     def _tangent_blocks(self, v):
         group = self._grouping()
-        for chain, ds, _x in self.blocks:
+        for chain, ds, _x in self.blocks[self.dead_blocks:]:  # (dead blocks: frozen, behind frozen layers -- no tangent)
             head = chain[0]
             paired = False
             if ds is not None and group:

@@ -11,11 +11,16 @@ from .common import _Unit, _Unsupported, _cl, _same
 class _Topology:
     # ---- topology ---------------------------------------------------------------------
     def _param(self, p):
+        """Index of a layer parameter in the optimizer's (trainable) list; ``None``: the layer has no such parameter
+        or it is FROZEN (``requires_grad = False``: it is a constant of the product -- no tangent, no gradient entry;
+        reference utils.py:31-32 skips it the same way)."""
         if p is None:
             return None
         i = self._index.get(id(p))
         if i is None:
-            raise _Unsupported("a layer parameter is not among the optimizer's parameters")
+            if p.requires_grad:
+                raise _Unsupported("a trainable layer parameter is not among the optimizer's parameters")
+            self.frozen_any = True
         return i
 
     def _layout(self, model):
@@ -40,6 +45,7 @@ class _Topology:
 
         units = []
         group_is_set = self.group is not None
+        self.frozen_any = False
 
         def make_unit(name, conv, bn, relu_expected):
             if type(conv) is not nn.Conv2d or conv.bias is not None or conv.groups != 1:
@@ -135,12 +141,44 @@ class _Topology:
             raise _Unsupported("the network output is not the classifier's output")
         self.fc, self.feat = fc, fc_x
         self.pfw, self.pfb = self._param(fc.weight), self._param(fc.bias)
+        if self.pfw is None or (fc.bias is not None and self.pfb is None):
+            raise _Unsupported("the classifier layer is frozen (the engine covers frozen convolution / BatchNorm layers)")
         self.units = units
         self.tail = self.blocks[-1][0][-1]
         self.train_bn = any(u.train for u in units)
-        used = {i for u in units for i in (u.pw, u.pg, u.pb)} | {self.pfw} | ({self.pfb} if self.pfb is not None else set())
+        used = {i for u in units for i in (u.pw, u.pg, u.pb) if i is not None} | {self.pfw} | (
+            {self.pfb} if self.pfb is not None else set())
         if used != set(range(len(self.params))):
             raise _Unsupported("the parameter list has entries the engine's layers do not cover")
+        self._mark_dead_prefix()
+
+    def _mark_dead_prefix(self):
+        """Frozen layers at the INPUT end of the net: a unit all of whose parameters are frozen and whose input carries
+        no tangent produces no tangent either -- the tangent sweep starts at the first unit with a trainable parameter
+        (its input tangent is zero: only ``conv(x, v_W)`` is left) and the adjoint sweep stops there (that unit needs
+        its weight gradient, nobody needs its data gradient).  ``dead_blocks``: how many leading blocks are dead
+        (only behind a dead stem); ``u.dead``; ``u.no_dgrad`` (a live unit that reads a tangent-free input)."""
+        def frozen(u):
+            return u.pw is None and u.pg is None and u.pb is None
+
+        for u in self.units:
+            u.dead = u.no_dgrad = False
+        self.dead_blocks = 0
+        self.stem.dead = frozen(self.stem)
+        if not self.stem.dead:
+            return
+        for chain, ds, _x in self.blocks:
+            if not all(frozen(u) for u in chain + ([ds] if ds is not None else [])):
+                break
+            for u in chain + ([ds] if ds is not None else []):
+                u.dead = True
+            self.dead_blocks += 1
+        if self.dead_blocks == len(self.blocks):
+            raise _Unsupported("every convolution / BatchNorm layer is frozen (only the classifier is trained)")
+        chain, ds, _x = self.blocks[self.dead_blocks]
+        chain[0].no_dgrad = True
+        if ds is not None:
+            ds.no_dgrad = True
 
     def layer_signature(self):
         """What the captured graphs of a session bake in about the model's layers besides shapes: module
@@ -155,8 +193,8 @@ class _Topology:
         (the adjoint sweep finishes them first: ResNet-18 on 28x28 inputs, layer3 + layer4 + fc = 14 of
         17 MB after ~60 % of the product), with the flat offset of that suffix; ``None`` if the layout does
         not allow it."""
-        if not self.blocks or self.fc is None:
-            return None
+        if not self.blocks or self.fc is None or self.frozen_any:
+            return None  # (frozen layers: the single-graph form; the late / early split is laid out for the full net)
         live = self._live_counts()
         total = sum(live)
         acc = live[self.pfw] + (live[self.pfb] if self.pfb is not None else 0)
@@ -179,7 +217,7 @@ class _Topology:
     def _live_counts(self):
         counts = [p.numel() for p in self.params]
         for u in self.units:
-            if not u.im2col and getattr(u, "live", 0):
+            if not u.im2col and getattr(u, "live", 0) and u.pw is not None:
                 rs = u.conv.weight.shape[2] * u.conv.weight.shape[3]
                 counts[u.pw] = u.conv.weight.numel() // rs * bin(u.live).count("1")
         return counts

@@ -102,6 +102,8 @@ class HessianFree(_Accumulation, _SessionSteps, torch.optim.Optimizer):
 
         self._acc_comm = process_group  # group `_acc` sums over (None: this process only)
         self._acc_comm_active = False   # True while `acc_step` runs its data-parallel `step`
+        self._in_acc_step = False       # True while `acc_step` runs `step` at all
+        self._session_decline = None    # why the persistent session was not taken (last refusal)
         self._acc_counts = {}           # id(datalist) -> samples over all ranks (per acc_step)
         self._arena = None
         self._cg = cg  # the HIP PCG; tests swap in the CPU oracle to check host logic
@@ -113,6 +115,10 @@ class HessianFree(_Accumulation, _SessionSteps, torch.optim.Optimizer):
         self._acc_session = None
         self._acc_session_failures = 0
         self._acc_session_off = False
+        # which path the last step() / acc_step() took and why a faster one was declined (`path_report`)
+        self._paths = {"step": None, "acc_step": None}
+        self._declines = {"step": None, "acc_step": None}
+        self._slow_path_warned = set()
 
     # ------------------------------------------------------------------------
     # helpers
@@ -144,6 +150,41 @@ class HessianFree(_Accumulation, _SessionSteps, torch.optim.Optimizer):
     def _flat(self, tensors):
         """parameters_to_vector replacement (+ shard weight)."""
         return curvature.flatten_into(tensors, self._params_list, scale=self.shard_weight)
+
+    # the paths a step can take, fastest first (DESIGN.md section 4)
+    PATHS = {
+        "session": "persistent engine session (engine, product graph, PCG iteration graph kept across steps)",
+        "acc-session": "accumulated engine session (acc_step on the fused engine, graphs kept across calls)",
+        "engine-graphed": "fused engine rebuilt and re-captured every step (hipGraph replay per product)",
+        "autograd-graphed": "autograd sweeps re-captured every step (hipGraph replay per product)",
+        "eager": "eager launches (no hipGraph)",
+        "user": "user-supplied gradient / product",
+    }
+
+    def path_report(self):
+        """Which path the last ``step()`` / ``acc_step()`` took -- ``session`` | ``acc-session`` | ``engine-graphed`` |
+        ``autograd-graphed`` | ``eager`` | ``user`` -- and, where a faster one exists and was declined, the reason
+        (which layer / loss / parameter subset / shape the engine or the session refused).  All of the speed of this
+        package lives in the engine and its sessions; this is where to look when a step is slower than expected."""
+        out = {}
+        for kind in ("step", "acc_step"):
+            path = self._paths[kind]
+            out[kind] = None if path is None else {
+                "path": path, "what": self.PATHS[path], "declined": self._declines[kind]}
+        return out
+
+    def _note_path(self, kind, path, decline=None):
+        """Record the path of this call; with ``graph_matvec=True`` a call that ends BELOW the session warns -- once
+        per optimizer and kind of call, with the reason."""
+        self._paths[kind] = path
+        self._declines[kind] = decline if path not in ("session", "acc-session") else None
+        top = "session" if kind == "step" else "acc-session"
+        if (self.graph_matvec and path not in (top, "user") and self.device.type == "cuda"
+                and kind not in self._slow_path_warned):
+            self._slow_path_warned.add(kind)
+            warn(f"HessianFree(graph_matvec=True).{kind}() runs on the slower path '{path}' ({self.PATHS[path]}), not "
+                 f"on the {self.PATHS[top].split(' (')[0]}"
+                 + (f": {decline}" if decline else "") + ".  See HessianFree.path_report().")
 
     def _ensure_arena(self):
         if self._arena is None:
@@ -284,7 +325,8 @@ class HessianFree(_Accumulation, _SessionSteps, torch.optim.Optimizer):
         self._ensure_arena()
         curvature_opt = self._group["curvature_opt"]
         user_grad, user_mvp = grad is not None, mvp is not None
-        holder = {}
+        holder = {"why": []}
+        kind = "acc_step" if self._in_acc_step else "step"
 
         def setup():
             """Forward pass (+ gradient, + curvature operator).  Runs on the capture
@@ -305,12 +347,13 @@ class HessianFree(_Accumulation, _SessionSteps, torch.optim.Optimizer):
                 return curvature.hessian_operator(
                     loss, outputs, self._params_list,
                     grad_with_graph=None if (grads is None or any(g is None for g in grads)) else grads,
-                    weight=self.shard_weight, group=self.process_group)
+                    weight=self.shard_weight, group=self.process_group, why=holder["why"])
             return curvature.ggn_operator(loss, outputs, self._params_list,
-                                          weight=self.shard_weight, group=self.process_group)
+                                          weight=self.shard_weight, group=self.process_group, why=holder["why"])
 
         sess = _session  # (acc_step: the accumulated session has already been brought to this step's data)
         if sess is not None:
+            self._note_path("acc_step", "acc-session")
             return sess, sess.gradient(), sess.base_loss, sess
         if (self.graph_matvec and not user_mvp and not user_grad
                 and self.device.type == "cuda" and not self._session_off and self._cg is cg):
@@ -318,6 +361,7 @@ class HessianFree(_Accumulation, _SessionSteps, torch.optim.Optimizer):
         if sess is not None:
             mvp = sess
             grad = self._reduce_vector(sess.gradient())
+            self._note_path("step", "session")
         else:
             if self.graph_matvec and not user_mvp and self.device.type == "cuda":
                 mvp = curvature.maybe_graphed(setup, params=self._params_list)
@@ -327,6 +371,17 @@ class HessianFree(_Accumulation, _SessionSteps, torch.optim.Optimizer):
             if not user_grad:
                 grad = holder["grad"]
             init_loss = self._reduce_scalar(holder["loss"].item())
+            if kind == "step":  # (acc_step's generic accumulation has reported itself: `_acc_session_step`)
+                if user_mvp:
+                    path = "user"
+                elif isinstance(mvp, curvature.GraphedOperator):
+                    path = "engine-graphed" if "engine" in getattr(getattr(mvp, "op", None), "mode", "") else "autograd-graphed"
+                else:
+                    path = "eager"
+                decline = self._session_decline if self.graph_matvec and not user_mvp and not user_grad else None
+                if holder["why"] and not decline:
+                    decline = "; ".join(dict.fromkeys(holder["why"]))
+                self._note_path("step", path, decline)
         return mvp, grad, init_loss, sess
 
     def _test_forward_determinisitc(self, forward):

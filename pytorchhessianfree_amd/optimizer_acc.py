@@ -26,12 +26,14 @@ class _Accumulation:
         saved = (self.process_group, self.shard_weight)
         self.process_group, self.shard_weight = None, 1.0
         self._acc_comm_active = self._acc_comm is not None
+        self._in_acc_step = True
         try:
             return self.step(forward=forward, grad=grad, mvp=mvp, M_func=M_func,
                              test_deterministic=test_deterministic, _session=sess)
         finally:
             self.process_group, self.shard_weight = saved
             self._acc_comm_active = False
+            self._in_acc_step = False
             self._acc_counts = {}
 
     def acc_linearise(self, model, loss_func, loss_datalist, grad_datalist=None, mvp_datalist=None,
@@ -71,18 +73,28 @@ class _Accumulation:
         reused while model, loss, list structure and chunk shapes stay the same), or ``None`` -- then the generic
         accumulation runs (and after repeated refusals the session is not tried again).  Under data
         parallelism the decision is taken for all ranks together (one MIN all-reduce)."""
-        if not (self.graph_matvec and self.device.type == "cuda" and not self._acc_session_off and self._cg is cg):
+        if not (self.graph_matvec and self.device.type == "cuda" and self._cg is cg):
+            self._note_path("acc_step", "eager")  # (not asked for graphs / no GPU: nothing was declined)
+            return None
+        if self._acc_session_off:
+            self._note_path("acc_step", "eager", self._acc_decline)
             return None
         sess = self._acc_session_step_local(model, loss_func, lists, reduction, curvature_opt)
         if self._acc_comm is not None:
             ok = torch.tensor([1 if sess is not None else 0], dtype=torch.int32, device=self.device)
             torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=self._acc_comm)
             if int(ok.item()) == 0:
+                if sess is not None:
+                    self._acc_decline = "another rank's accumulated session was refused (the ranks decide together)"
                 self._acc_session, self._acc_session_off = None, True
-                return None
+                sess = None
             if sess is not None:  # (the count-weighted loss summed over the ranks)
                 sess.base_loss = sess.reduce_losses(sess.loss_buf.reshape(1)).tolist()[0]
+        if sess is None:
+            self._note_path("acc_step", "eager", self._acc_decline)
         return sess
+
+    _acc_decline = None  # why the accumulated session was not taken (last refusal)
 
     def _acc_session_step_local(self, model, loss_func, lists, reduction, curvature_opt):
         import os
@@ -101,6 +113,7 @@ class _Accumulation:
             dlists = tuple([(dev(x), dev(t)) for x, t in dl] for dl in lists)
         except (TypeError, ValueError, AttributeError):
             self._acc_session_off = True
+            self._acc_decline = "the data lists are not lists of (inputs, targets) tensor pairs"
             return None
         counts = [self._total_count(dl) for dl in lists]
         hessian = curvature_opt == "hessian"
@@ -109,23 +122,27 @@ class _Accumulation:
         slots = sess.accepts(*args) if sess is not None else None
         if slots is None:
             self._acc_session = sess = None
+            why = []
             sess = AccumulatedSession.try_create(model, loss_func, dlists, self._params_list, reduction, counts,
-                                                 hessian=hessian, group=self._acc_comm)
+                                                 hessian=hessian, group=self._acc_comm, why=why)
             slots = sess.accepts(*args) if sess is not None else None
             if slots is None:
+                self._acc_decline = ("; ".join(dict.fromkeys(why)) if why else
+                                     "a freshly built accumulated session does not accept this call's own data lists")
                 self._acc_session_failures += 1
                 if self._acc_session_failures >= 2:
                     self._acc_session_off = True
+                    self._acc_decline += " (refused twice: not tried again)"
                 return None
             self._acc_session = sess
         every = 1 if os.environ.get("HF_SESSION_VERIFY") == "1" else int(os.environ.get("HF_SESSION_VERIFY_EVERY", "16"))
         try:
             sess.begin_step(slots, verify=every > 0 and sess.steps > 0 and sess.steps % every == 0,
                             reduce=self._acc_comm is None)
-        except _NoEngine:
-            warn("accumulated engine session: it no longer reproduces the model (or a target is outside the "
-                 "classes); using the generic accumulation from now on")
+        except _NoEngine as exc:
+            warn(f"accumulated engine session: {exc.reason}; using the generic accumulation from now on")
             self._acc_session, self._acc_session_off = None, True
+            self._acc_decline = exc.reason + " (session ended: not tried again)"
             return None
         self._acc_session_failures = 0
         return sess

@@ -18,6 +18,8 @@ class _SessionSteps:
         reproduced by the session's own forward pass; its autograd graph names the targets.  Returns
         ``(session, initial loss)`` or ``(None, None)`` -- then the generic path runs (and after
         repeated failures the session is not tried again)."""
+        if self._session_off:
+            return None, None
         sess, a, b = self._session_step_local(forward)
         if self.process_group is not None:
             # one decision for all ranks: the session path and the generic path issue different
@@ -28,6 +30,8 @@ class _SessionSteps:
                 # EVERY rank switches the session off, whether it had one or not: a rank whose session was
                 # merely refused this once would otherwise issue this all-reduce again on the next step while
                 # its peers go straight to the generic path's gradient all-reduce
+                if sess is not None:
+                    self._session_decline = "another rank's session was refused (the ranks decide together)"
                 self._session, self._session_off = None, True
                 return None, None
         if sess is None:
@@ -54,6 +58,8 @@ class _SessionSteps:
             loss, outputs = forward()
         if not isinstance(outputs, torch.Tensor) or loss.grad_fn is None:
             self._session_off = True
+            self._session_decline = ("`forward()` does not return (loss with an autograd graph, model output tensor): "
+                                     "the session reads targets and loss structure off that graph")
             return None, None, None
         sess = self._session
         args = (loss, outputs, self._params_list, self.shard_weight, self.process_group)
@@ -64,13 +70,20 @@ class _SessionSteps:
         if spec is None:
             self._session = sess = None
             verify = False
+            why = []
             if getattr(outputs, "_hf_model", None) is not None:
-                sess = EngineSession.try_create(*args, hessian=hessian)
+                sess = EngineSession.try_create(*args, hessian=hessian, why=why)
+            else:
+                why.append("the model is not a prepared one (modelprep.prepare_model(model, channels_last=True) "
+                           "installs the layers the fused engine reads)")
             spec = sess.accepts(*args) if sess is not None else None
             if spec is None:
+                self._session_decline = ("; ".join(dict.fromkeys(why)) if why else
+                                         "a freshly built session does not accept this step's own forward pass")
                 self._session_failures += 1
                 if self._session_failures >= 2:
                     self._session_off = True
+                    self._session_decline += " (refused twice: not tried again)"
                 return None, None, None
             self._session = sess
         own = sess.begin_step(outputs, spec)
@@ -85,6 +98,8 @@ class _SessionSteps:
                  + (f" (logits differ by {drift:.1e} from the model's own forward pass)" if verify else "")
                  + "; using the generic path from now on")
             self._session, self._session_off = None, True
+            self._session_decline = (f"the session's forward pass gave loss {b!r} where `forward()` gave {a!r}"
+                                     " (session ended: not tried again)")
             return None, None, None
         self._session_failures = 0
         return sess, a, b
@@ -117,7 +132,7 @@ class _SessionSteps:
                 or reduction not in ("mean", "sum")):
             return None
         eng = sess.engine
-        if (model is not eng.model_ref or eng.train_bn or eng.loss_spec is None
+        if (model is not eng.model_ref or eng.train_bn or eng.loss_spec is None or getattr(eng, "frozen_any", False)
                 or not isinstance(inputs, torch.Tensor) or tuple(inputs.shape) != tuple(eng.x_in.shape)):
             return None
         from .engine import ce_loss_spec

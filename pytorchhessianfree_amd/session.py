@@ -41,14 +41,22 @@ from .engine import FusedGGNEngine, ce_loss_spec
 
 def _runs_beside(cand, cur):
     """Whether work on stream ``cand`` executes while ``cur`` is busy: a few ms of streaming updates on ``cur``, a
-    trivial kernel on ``cand``; concurrent iff the trivial one has finished while the updates have not."""
+    trivial kernel on ``cand``; concurrent iff the trivial one has finished while the updates have not.  The
+    scratch vector is sized from the free memory (256 MiB at most, ~1/16 of what is free at least 4 MiB; more passes
+    over a smaller vector keep ``cur`` busy for the same few ms) so that a nearly full GPU cannot fail a
+    data-parallel step here; ``None`` if even that cannot be allocated (the caller then takes a plain stream)."""
     dev = torch.device("cuda", torch.cuda.current_device())
     long_done, short_done = torch.cuda.Event(), torch.cuda.Event()
-    big = torch.zeros(1 << 26, device=dev)
-    scratch = torch.zeros(64, device=dev)
+    try:
+        free = torch.cuda.mem_get_info(dev)[0]
+        n = max(1 << 20, min(1 << 26, int(free // 64)))  # elements (x 4 bytes)
+        big = torch.zeros(n, device=dev)
+        scratch = torch.zeros(64, device=dev)
+    except RuntimeError:  # (out of memory)
+        return None
     torch.cuda.synchronize()
     with torch.cuda.stream(cur):
-        for _ in range(24):
+        for _ in range(max(24, 24 * (1 << 26) // n)):
             big.add_(1.0)
         long_done.record(cur)
     with torch.cuda.stream(cand):
@@ -68,12 +76,13 @@ def _concurrent_stream(cur, candidates=8):
     assumed: the first of a few pool streams that demonstrably overlaps with ``cur``; the last one tried if none
     does.  (On a 1-rank group, where the collective is the identity, an in-line side stream is the CHEAPER one --
     no cross-queue dependency, ~725 instead of ~790 us per iteration; it is not taken for that.)"""
-    cand = None
+    cand, beside = None, False
     for _ in range(candidates):
         cand = torch.cuda.Stream()
-        if _runs_beside(cand, cur):
+        beside = _runs_beside(cand, cur)
+        if beside or beside is None:
             break
-    return cand
+    return cand, bool(beside)
 
 
 class _TwoPhaseProduct:
@@ -102,6 +111,7 @@ class _TwoPhaseProduct:
 
     split = None
     _side = None        # the stream the tail's all-reduce runs on (probed: work on it runs BESIDE the compute stream's)
+    side_runs_beside = None
 
     @staticmethod
     def plan_phases(eng, tail_fraction=None):
@@ -157,12 +167,15 @@ class _TwoPhaseProduct:
         eng, group = self.engine, self.group
         if group is None:
             return self.replay_phases()
+        _inject_fault("two_phase", group)
         head = eng._reduce_pieces(self.output_buffer, "head")
         tail = eng._reduce_pieces(self.output_buffer, "tail")
         cur = torch.cuda.current_stream()
         side_comm = hfdist.side_comm(tail[0], group)
         if side_comm is not None and self._side is None:
-            self._side = _concurrent_stream(cur)
+            # (the probe's verdict is kept: ``side_runs_beside`` -- False: no pool stream was seen to overlap with the
+            # compute stream, or the probe could not allocate its scratch; the tail's all-reduce then hides less)
+            self._side, self.side_runs_beside = _concurrent_stream(cur)
             self._ev_a, self._ev_t = torch.cuda.Event(), torch.cuda.Event()
         works = []
         self.g_a.replay()
@@ -181,6 +194,7 @@ class _TwoPhaseProduct:
         for work in works:
             work.wait()
         eng._live_copy(self.output_buffer, True)
+        _inject_fault("two_phase", group, self.output_buffer)
 
 
 class EngineSession(_TwoPhaseProduct):
@@ -190,24 +204,32 @@ class EngineSession(_TwoPhaseProduct):
 
     # ------------------------------------------------------------------------------------
     @classmethod
-    def try_create(cls, loss, outputs, params, weight=1.0, group=None, hessian=False):
+    def try_create(cls, loss, outputs, params, weight=1.0, group=None, hessian=False, why=None):
         """A session for the model that produced ``outputs`` (``None`` if the engine does not cover
-        it or the loss is not a plain softmax cross-entropy)."""
-        if os.environ.get("HF_SESSION", "1") == "0" or not torch.cuda.is_available():
+        it or the loss is not a plain softmax cross-entropy; ``why``, a list, then receives the reason)."""
+        why = [] if why is None else why
+        if os.environ.get("HF_SESSION", "1") == "0":
+            why.append("the persistent session is switched off (HF_SESSION=0)")
+            return None
+        if not torch.cuda.is_available():
+            why.append("no GPU")
             return None
         if ce_loss_spec(loss, outputs) is None:
+            why.append(_loss_decline(loss, outputs))
             return None
         holder = {}
 
         def builder():
             holder["eng"] = FusedGGNEngine.try_build(loss, outputs, list(params), weight=weight, group=group,
-                                                     hessian=hessian)
+                                                     hessian=hessian, why=why)
             return holder["eng"]
 
         sess = cls.__new__(cls)
         try:
             sess._build(builder, params)
-        except _NoEngine:
+        except _NoEngine as exc:
+            if not why:
+                why.append(exc.reason)
             return None
         return sess
 
@@ -223,7 +245,9 @@ class EngineSession(_TwoPhaseProduct):
                 eng = builder()
             if eng is None or eng.loss_spec is None:
                 cur.wait_stream(self.stream)
-                raise _NoEngine()
+                raise _NoEngine("the fused engine does not cover this model" if eng is None else
+                                "the engine's own forward pass does not reproduce this train-mode model, or the loss "
+                                "is not a plain softmax cross-entropy")
             self.op = self.engine = eng
             self.n, self.group, self.params = eng.n, eng.group, eng.params
             self.weight = eng.weight
@@ -259,7 +283,10 @@ class EngineSession(_TwoPhaseProduct):
             self._split_plan = self.split
             if self.split is not None:
                 self._capture_phases()
-        self.mode_pending = self.split is not None and os.environ.get("HF_CHUNKED_ALLREDUCE", "auto") == "auto"
+        # (data parallel: ``choose_product_mode`` validates the forms on the live communicator -- and, policy
+        # ``auto``, times them -- before the first solve)
+        self.mode_pending = eng.group is not None
+        self.mode_validation = self.mode_timing = None
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
         self.calls = 0
@@ -401,28 +428,91 @@ class EngineSession(_TwoPhaseProduct):
     def replay_and_reduce(self):
         """One product over all ranks: ``input_buffer`` -> summed product in ``output_buffer``."""
         if self.split is None:
+            _inject_fault("single_graph", self.group)
             self.graph.replay()
             self.engine.reduce(self.output_buffer, self.group)
+            _inject_fault("single_graph", self.group, self.output_buffer)
         else:
             self.reduce_phases()
 
     def choose_product_mode(self, reps=8):
-        """Data parallel, ``HF_CHUNKED_ALLREDUCE=auto`` (default): time a few products with the single graph +
-        one compact all-reduce and with the two-phase chunked / overlapped all-reduce -- on THIS communicator,
-        THIS machine -- and keep the faster (two-phase only if it gains >= 3 %).  The chunked form hides most of
-        the all-reduce behind the sweep but costs a graph launch, a stream hand-over and a gather more; which
-        wins depends on the link (measured on one MI355X with a 1-rank RCCL group: single 1 438-1 452 matvecs/s,
-        two-phase 1 296; projected at 8 GPUs over xGMI: two-phase).  COLLECTIVE: every rank
-        of the group must call it at the same point (``HessianFree`` does, after the ranks have agreed to use
-        the session); all ranks reach the same decision (MAX all-reduce of the timings)."""
+        """Data parallel, once per session, COLLECTIVE (every rank of the group calls it at the same point --
+        ``HessianFree`` does, after the ranks have agreed to use the session).
+
+        1. VALIDATION on the live communicator (``mode_validation``): ONE product of a fixed pseudo-random vector in
+           each form the session holds.  Every rank must hold the same bits (MIN / MAX all-reduce of two 64-bit digests
+           of the result): the lockstep rule of ``cg()`` -- every rank takes the same branch without talking --
+           rests on exactly that.  The single-graph form failing it is an error (nothing below it can work); the
+           two-phase form failing it, or differing from the single-graph form by more than 1e-6 of its max-norm, is
+           dropped with a warning and the session stays on the single graph.
+        2. ``HF_CHUNKED_ALLREDUCE=auto`` (default) TIMING: a few products with the single graph + one compact
+           all-reduce and with the two-phase chunked / overlapped all-reduce -- on THIS communicator, THIS machine --
+           and keep the faster (two-phase only if it gains >= 3 %).  The chunked form hides most of the all-reduce
+           behind the sweep but costs a graph launch, a stream hand-over and a gather more; which wins depends on the
+           link (measured on one MI355X with a 1-rank RCCL group: single 1 438-1 452 matvecs/s, two-phase 1 296;
+           projected at 8 GPUs over xGMI: two-phase).  One decision for all ranks (MAX
+           all-reduce of the timings)."""
         import time
+        from warnings import warn
 
         self.mode_pending = False
-        if self._split_plan is None or self.group is None:
+        if self.group is None:
             return self.split is not None
         dist = torch.distributed
-        sync = torch.zeros(2, dtype=torch.float64, device=self.engine.dev)
-        cands = [("single_graph", None), ("two_phase", self._split_plan)]
+        dev = self.engine.dev
+        policy = os.environ.get("HF_CHUNKED_ALLREDUCE", "auto")
+        cands = [("single_graph", None)]
+        if self._split_plan is not None:
+            cands.append(("two_phase", self._split_plan))
+        # ---- 1. every form: identical on all ranks, the forms equal to rounding
+        saved_input = self.input_buffer.clone()
+        gen = torch.Generator(device=dev).manual_seed(20240229)  # (the same vector on every rank)
+        self.input_buffer.copy_(torch.randn(self.n, device=dev, generator=gen))
+        if getattr(self.engine, "hessian", False) and not self._first_order_fresh:
+            self.g_grad.replay()
+            self._first_order_fresh = True
+        weights = torch.arange(self.n, device=dev, dtype=torch.int64) % 1021 + 1
+        report, results = {}, {}
+        for name, split in cands:
+            self.split = split
+            self.replay_and_reduce()
+            out = self.output_buffer
+            bits = out.view(torch.int32).to(torch.int64)
+            digest = torch.stack([bits.sum(), (bits * weights).sum()])
+            lo, hi = digest.clone(), digest.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            report[name + "_identical_on_all_ranks"] = bool(torch.equal(lo, hi))
+            results[name] = out.clone()
+        del weights
+        self.input_buffer.copy_(saved_input)
+        if not report["single_graph_identical_on_all_ranks"]:
+            self.mode_validation = report
+            raise RuntimeError("data-parallel curvature product: the ranks hold DIFFERENT sums after the all-reduce "
+                               "(single product graph + one all-reduce); the lockstep PCG cannot run on this communicator")
+        two_phase_ok = len(cands) == 2
+        if two_phase_ok:
+            ref = results["single_graph"]
+            rel = ((results["two_phase"] - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).reshape(1).double()
+            dist.all_reduce(rel, op=dist.ReduceOp.MAX, group=self.group)
+            report["two_phase_vs_single_graph"] = float(rel.item())
+            two_phase_ok = report["two_phase_identical_on_all_ranks"] and float(rel.item()) <= 1e-6
+            if not two_phase_ok:
+                warn("data-parallel curvature product: the two-phase (chunked / overlapped all-reduce) form "
+                     + ("gives different sums on different ranks" if not report["two_phase_identical_on_all_ranks"]
+                        else f"differs from the single-graph form by {float(rel.item()):.1e} of its max-norm")
+                     + " on this communicator; keeping the single product graph + one compact all-reduce")
+        report["two_phase_kept_as_candidate"] = bool(two_phase_ok)
+        self.mode_validation = report
+        del results
+        self.split = None
+        if not two_phase_ok:
+            return False
+        if policy != "auto":  # (forced two-phase: "0" never gets a split plan)
+            self.split = self._split_plan
+            return True
+        # ---- 2. timing
+        sync = torch.zeros(2, dtype=torch.float64, device=dev)
         times = []
         for _name, split in cands:
             self.split = split
@@ -435,7 +525,7 @@ class EngineSession(_TwoPhaseProduct):
                 self.replay_and_reduce()
             torch.cuda.synchronize()
             times.append((time.perf_counter() - t0) / reps)
-        t = torch.tensor(times, dtype=torch.float64, device=self.engine.dev)
+        t = torch.tensor(times, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         times = t.tolist()
         self.mode_timing = {name + "_ms": v * 1e3 for (name, _s), v in zip(cands, times)}
@@ -474,6 +564,17 @@ class EngineSession(_TwoPhaseProduct):
             out.copy_(self.output_buffer)
             return out
         return self.output_buffer
+
+
+def _loss_decline(loss, outputs):
+    """Why ``ce_loss_spec`` did not recognise the loss, in the user's terms."""
+    fn = getattr(loss, "grad_fn", None)
+    name = fn.name() if fn is not None else "no autograd node"
+    if not isinstance(outputs, torch.Tensor) or outputs.dim() != 2:
+        return "the model output is not a [batch, classes] tensor"
+    return ("the loss is not a plain softmax cross-entropy on the model output (F.cross_entropy / nn.CrossEntropyLoss "
+            "with class-index targets, no class weights, no label smoothing, no ignored target; the loss ends in "
+            f"{name}): the session evaluates loss, gradient and loss Hessian in closed form for that loss only")
 
 
 def _quadratic_signature(spec):
@@ -582,22 +683,41 @@ class AccumulatedSession:
     Under data parallelism (``process_group``) every rank holds ITS lists; the counts are totals over all ranks
     and the summed product / gradient / losses are all-reduced once more (compact layout of the engine)."""
 
-    mode = ("accumulated engine session: one fused curvature engine per data chunk on parallel graph branches, "
-            "weighted sum by one gather launch; engine, graphs and PCG iteration graph kept across acc_step calls")
+    @property
+    def mode(self):
+        if len(self.engines) == 1 and self.merged:
+            return ("accumulated engine session: the chunks carry one per-sample weight and the model does not couple "
+                    "samples, so they run as ONE batch on one fused curvature engine (" + FusedGGNEngine.mode + "); engine, "
+                    "graphs and PCG iteration graph kept across acc_step calls")
+        return ("accumulated engine session: one fused curvature engine per data chunk"
+                + (" (chunks of equal per-sample weight merged)" if self.merged else "")
+                + (" on parallel graph branches" if self.parallel else ", in sequence")
+                + ", weighted sum by one gather launch; engine, graphs and PCG iteration graph kept across acc_step calls")
 
     # ------------------------------------------------------------------------------------
     @classmethod
-    def try_create(cls, model, loss_func, lists, params, reduction, counts, hessian=False, group=None):
+    def try_create(cls, model, loss_func, lists, params, reduction, counts, hessian=False, group=None, why=None):
         """``lists = (loss_datalist, grad_datalist, mvp_datalist)`` on the device; ``counts`` their total sample
-        counts (over all ranks).  ``None`` when the engine does not cover the model / loss."""
-        if os.environ.get("HF_ACC_SESSION", "1") == "0" or not torch.cuda.is_available():
+        counts (over all ranks).  ``None`` when the engine does not cover the model / loss (``why``, a list, then
+        receives the reason)."""
+        why = [] if why is None else why
+        if os.environ.get("HF_ACC_SESSION", "1") == "0":
+            why.append("the accumulated session is switched off (HF_ACC_SESSION=0)")
+            return None
+        if not torch.cuda.is_available():
+            why.append("no GPU")
             return None
         if not getattr(model, "_hf_engine_hooks", False):
+            why.append("the model is not a prepared one (modelprep.prepare_model(model, channels_last=True) installs "
+                       "the layers the fused engine reads)")
             return None
         sess = cls.__new__(cls)
+        sess._why = why
         try:
             sess._build(model, loss_func, lists, list(params), reduction, counts, hessian, group)
-        except _NoEngine:
+        except _NoEngine as exc:
+            if not why:
+                why.append(exc.reason)
             return None
         return sess
 
@@ -616,11 +736,54 @@ class AccumulatedSession:
             roles.append(tuple(idx))
         return slots, roles
 
+    @staticmethod
+    def _merge_groups(model, slots, roles):
+        """Which distinct chunks may run as ONE batch on ONE engine.  The accumulated quantities are
+        ``sum_k w_k q_k`` with ``q_k`` a mean / sum over the samples of chunk k (optimizer.py:677-684): chunks that
+        appear in the same lists the same number of times carry the same weight PER SAMPLE (``1 / sum N`` resp. 1), so
+        for a model that does not couple the samples of a batch their concatenation IS the accumulation -- the
+        reference's own test states it (tests/test_optimizer_acc.py:116-175: [7, 8] chunks == one batch of 15).  Not
+        merged: a model with a train-mode BatchNorm or an active dropout layer (per-chunk statistics / masks are part
+        of the reference's result), chunks that differ in more than the batch size.  Returns lists of slot indices,
+        in order of first appearance."""
+        coupled = any((isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training)
+                      or (isinstance(m, torch.nn.modules.dropout._DropoutNd) and m.training and m.p > 0)
+                      for m in model.modules())
+        groups, index = [], {}
+        for k, (x, t) in enumerate(slots):
+            key = (tuple(sum(1 for j in r if j == k) for r in roles), tuple(x.shape[1:]), x.dtype, tuple(t.shape[1:]),
+                   t.dtype) if not coupled else k
+            if key not in index:
+                index[key] = len(groups)
+                groups.append([])
+            groups[index[key]].append(k)
+        return groups
+
+    def _merged(self, slots):
+        """The data of the engines: per group of chunks their concatenation (a group of one: the chunk itself)."""
+        return [slots[g[0]] if len(g) == 1 else
+                (torch.cat([slots[k][0] for k in g]), torch.cat([slots[k][1] for k in g])) for g in self.groups]
+
     def _build(self, model, loss_func, lists, params, reduction, counts, hessian, group):
         slots, roles = self._plan(lists)
         if not slots or any(len(r) == 0 for r in roles):
-            raise _NoEngine()
+            raise _NoEngine("an empty data list")
         self.model, self.loss_func, self.reduction, self.hessian = model, loss_func, reduction, bool(hessian)
+        self.chunk_roles, self.chunk_shapes = roles, [tuple(x.shape) for x, _ in slots]
+        for x, t in slots:
+            if not (isinstance(x, torch.Tensor) and isinstance(t, torch.Tensor) and x.dim() >= 1 and t.dim() == 1
+                    and t.shape[0] == x.shape[0]):
+                raise _NoEngine("a data chunk is not (float32 inputs, 1-D class-index targets)")
+        # chunks that carry the same per-sample weight in every list run as ONE batch on ONE engine (round 6: the
+        # default call -- one list for loss, gradient and curvature -- is then a single engine on the whole batch:
+        # 1 450+ instead of 1 280 matvecs/s for chunks [16, 16], no graph branches)
+        self.groups = self._merge_groups(model, slots, roles)
+        self.merged = any(len(g) > 1 for g in self.groups)
+        of_slot = {k: gi for gi, g in enumerate(self.groups) for k in g}
+        roles = [tuple(gi for gi, g in enumerate(self.groups) for _ in range(sum(1 for j in r if j == g[0])))
+                 for r in roles]
+        slots = self._merged(slots)
+        del of_slot
         self.roles, self.counts = roles, tuple(float(c) for c in counts)
         self.shapes = [tuple(x.shape) for x, _ in slots]
         self.group, self.params = group, params
@@ -635,18 +798,24 @@ class AccumulatedSession:
             for x, t in slots:
                 if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and t.dim() == 1):
                     cur.wait_stream(self.stream)
-                    raise _NoEngine()
+                    raise _NoEngine("a data chunk is not (float32 inputs, 1-D class-index targets)")
                 with torch.enable_grad():
                     out = model(x)
                     loss = loss_func(out, t)
                     spec = ce_loss_spec(loss, out) if isinstance(out, torch.Tensor) and out.dim() == 2 else None
                     eng = None
-                    if spec is not None and spec["reduction"] == reduction:
+                    if spec is None:
+                        self._why.append(_loss_decline(loss, out))
+                    elif spec["reduction"] != reduction:
+                        self._why.append(f"the loss function reduces by '{spec['reduction']}', acc_step was asked for "
+                                         f"reduction='{reduction}'")
+                    else:
                         # (group=None: the ranks' sum is taken once, after the chunks' sum)
-                        eng = FusedGGNEngine.try_build(loss, out, params, weight=1.0, group=None, hessian=hessian)
+                        eng = FusedGGNEngine.try_build(loss, out, params, weight=1.0, group=None, hessian=hessian,
+                                                       why=self._why)
                 if eng is None or eng.loss_spec is None:
                     cur.wait_stream(self.stream)
-                    raise _NoEngine()
+                    raise _NoEngine("the fused engine does not cover this model / loss")
                 engines.append(eng)
                 del out, loss
             self.engines = engines
@@ -655,7 +824,8 @@ class AccumulatedSession:
             # chunks' spatial shape, so all chunks must share everything but the batch size)
             if any(tuple(sh[1:]) != tuple(self.shapes[0][1:]) for sh in self.shapes):
                 cur.wait_stream(self.stream)
-                raise _NoEngine()
+                raise _NoEngine("the data chunks differ in more than their batch size: "
+                                + ", ".join(str(sh) for sh in self.shapes))
             e0 = engines[0]
             self.engine = e0
             self.n, self.dev = e0.n, e0.dev
@@ -802,7 +972,7 @@ class AccumulatedSession:
     def accepts(self, model, loss_func, lists, params, reduction, counts, hessian, group):
         slots, roles = self._plan(lists)
         if (model is not self.model or loss_func is not self.loss_func or reduction != self.reduction
-                or bool(hessian) != self.hessian or group is not self.group or roles != self.roles
+                or bool(hessian) != self.hessian or group is not self.group or roles != self.chunk_roles
                 or tuple(float(c) for c in counts) != self.counts):
             return None
         # (what the captured graphs bake in about the layers -- module identities, every BatchNorm's mode / eps /
@@ -810,15 +980,17 @@ class AccumulatedSession:
         # eval() model with one train-mode BatchNorm is a train_bn session)
         if any(eng.layer_signature() != sig for eng, sig in zip(self.engines, self._layers)):
             return None
-        if [tuple(x.shape) for x, _ in slots] != self.shapes:
+        if [tuple(x.shape) for x, _ in slots] != self.chunk_shapes:
             return None
+        if self._merge_groups(model, slots, roles) != self.groups:
+            return None  # (a dropout / BatchNorm layer changed mode: the chunks must no longer / may now be merged)
         if len(params) != len(self.params) or any(a is not b for a, b in zip(params, self.params)):
             return None
         e0 = self.engines[0]
         if e0._flat_params is None or e0._flat_params.data_ptr() != e0.params[0].data_ptr():
             return None
-        for (x, t), eng in zip(slots, self.engines):
-            if not x.is_cuda or x.dtype != torch.float32 or tuple(t.shape) != tuple(eng._targets.shape):
+        for x, t in slots:
+            if not x.is_cuda or x.dtype != torch.float32 or t.dim() != 1 or t.shape[0] != x.shape[0]:
                 return None
         return slots
 
@@ -827,7 +999,7 @@ class AccumulatedSession:
         """New data + current parameters into every engine; returns the accumulated loss (``reduce``: summed over
         the ranks here; else the caller does it -- after the ranks have agreed to use the session at all)."""
         with torch.no_grad():
-            for (x, t), eng in zip(slots, self.engines):
+            for (x, t), eng in zip(self._merged(slots), self.engines):
                 eng.set_batch(x.detach(), t)
             self.g_wT.replay()
             (self.g_fwd_still if self._fresh else self.g_fwd_all).replay()
@@ -835,7 +1007,7 @@ class AccumulatedSession:
             bad = torch.stack([eng.bad_targets.float().reshape(()) for eng in self.engines]).sum()
             vals = torch.stack([self.loss_buf.float().reshape(()), bad]).tolist()
         if vals[1]:
-            raise _NoEngine()
+            raise _NoEngine("a target is outside the classes")
         if verify:
             self._verify(slots)
         self.steps += 1
@@ -849,10 +1021,11 @@ class AccumulatedSession:
         x, _ = slots[0]
         with torch.no_grad():
             want = self.model._hf_stock_model_forward(x)
-        got = self.engines[0].logits
+        got = self.engines[0].logits[: want.shape[0]]  # (chunk 0 leads the first engine's batch)
         err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
         if not err < 1e-4:
-            raise _NoEngine()
+            raise _NoEngine(f"the captured graphs no longer reproduce the model's own forward pass (logits differ by "
+                            f"{err:.1e})")
 
     def reduce_losses(self, vals):
         """Sum over ranks of (already count-weighted) loss values, as float64."""
@@ -909,4 +1082,38 @@ class AccumulatedSession:
 
 
 class _NoEngine(Exception):
-    pass
+    """The session does not serve this model / loss / data; ``str(exc)`` says why (``HessianFree.path_report()``)."""
+
+    def __init__(self, reason="the fused engine does not cover this model / loss"):
+        super().__init__(reason)
+        self.reason = reason
+
+
+def _inject_fault(site, group, buf=None):
+    """TEST HOOK ``HF_TEST_DP_FAULT=<kind>[:<where>]`` (tests/test_distributed_gpu.py: the data-parallel fallback
+    ladder of ``bench.py --gpus N``): makes the LAST rank of the group misbehave in a data-parallel session product.
+    ``kind``: ``hang`` (sleeps for good before the product), ``raise`` (RuntimeError), ``mismatch`` (its copy of the
+    summed product is off by one in entry 0 -- the ranks no longer hold identical sums).  ``where``: ``two_phase``
+    (default: only the two-phase form) or ``not_plain`` (either form, unless the run is the plainest configuration:
+    ``HF_CHUNKED_ALLREDUCE=0`` and ``HF_DIRECT_RCCL=0``)."""
+    spec = os.environ.get("HF_TEST_DP_FAULT", "")
+    if not spec or group is None:
+        return
+    kind, _, where = spec.partition(":")
+    where = where or "two_phase"
+    if where == "two_phase":
+        active = site == "two_phase"
+    else:
+        active = not (os.environ.get("HF_CHUNKED_ALLREDUCE", "auto") == "0" and os.environ.get("HF_DIRECT_RCCL", "1") == "0")
+    dist = torch.distributed
+    if not active or dist.get_rank(group) != dist.get_world_size(group) - 1:
+        return
+    if buf is None:
+        if kind == "hang":
+            import time
+
+            time.sleep(3600.0)
+        elif kind == "raise":
+            raise RuntimeError(f"HF_TEST_DP_FAULT: injected failure in the {site} product")
+    elif kind == "mismatch":
+        buf[:1] += 1.0

@@ -181,6 +181,17 @@ def relu_margin(model, inputs):
 RESNET18_B32_SEPARATED_SEEDS = (1483, 1377, 2116, 1101, 3097, 1322, 1192, 1187)
 
 
+def freeze_stem_and_layer1(model):
+    """``requires_grad = False`` on the stem (conv1, bn1) and layer1 of a ResNet: the optimizer then works "in the
+    subspace of trainable parameters" (reference optimizer.py:121-123, utils.py:31-32; its own test problem freezes
+    its first layer, tests/test_utils.py:39-43).  Returns the model."""
+    layer1 = list(model.layers)[:2] if hasattr(model, "layers") else [model.layer1]  # (torchvision's layer1: 2 blocks)
+    for mod in (model.conv1, model.bn1, *layer1):
+        for p in mod.parameters():
+            p.requires_grad_(False)
+    return model
+
+
 def count_trainable(model):
     return sum(p.numel() for p in model.parameters() if p.requires_grad)
 

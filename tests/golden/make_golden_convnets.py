@@ -86,12 +86,14 @@ def put_state(store, key, opt, finals):
 
 
 def run_steps(store, key, make, seeds, steps, curv="ggn", l2=0.0, precond=False, acc=None, opt_kw=None, mk=None,
-              train=False):
+              train=False, prep=None):
     """``steps`` calls of the reference's ``step`` (``acc``: ``acc_step`` on chunks of those sizes) on fresh batches."""
     mk, opt_kw = mk or {}, opt_kw or {}
     model, _, lossf0 = make(device="cpu", data_seed=seeds[0], **mk)
     if train:
         model.train()
+    if prep is not None:  # (e.g. freezing layers: the optimizer then works in the subspace of trainable parameters)
+        prep(model)
     lossf = tp.l2_regularized(lossf0, model, l2) if l2 else lossf0
     params = [p for p in model.parameters() if p.requires_grad]
     idx = put_index(store, key, params)
@@ -283,6 +285,23 @@ def make_resnet18_train_hessian():
     mg.save("convnet_resnet18_train_hessian.npz", store)
 
 
+def make_resnet18_frozen():
+    """The ResNet-18 of configs[1] with its stem and layer1 FROZEN (``requires_grad = False``: the reference computes
+    "in the subspace of trainable parameters", optimizer.py:121-123, utils.py:31-32; its own test problem freezes the
+    first layer, tests/test_utils.py:39-43): three default steps, the gradient / one GGN product (+ float64 twins) and
+    a short damped solve on the 11 017 482-entry trainable vector.  A file of its own: the other traces stay
+    byte-identical."""
+    store = {}
+    run_steps(store, "steps", tp.resnet18_mnist, SEEDS, 3, mk=dict(batch_size=32), prep=tp.freeze_stem_and_layer1)
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=SEEDS[0])
+    tp.freeze_stem_and_layer1(model)
+    B, grad, idx, B64 = run_solve(store, "solve_martens", model, lambda m: lossf, x, t, "ggn", 1e-3,
+                                  dict(max_iter=40, martens_conv_crit=True, store_x_at_iters=list(range(41))),
+                                  sample_iters=set(range(0, 12)))
+    put_product(store, "ggn_product", B, grad.numel(), idx, seed=53, B64=B64)
+    mg.save("convnet_resnet18_frozen.npz", store)
+
+
 def make_allcnnc():
     store = {}
     run_steps(store, "ggn_steps", tp.allcnnc_cifar100, (11, 12, 13), 3, mk=dict(batch_size=32))
@@ -351,7 +370,8 @@ def make_mlp25m():
 
 if __name__ == "__main__":
     torch.set_num_threads(THREADS)
-    makers = {"resnet18": make_resnet18, "resnet18_train_hessian": make_resnet18_train_hessian, "allcnnc": make_allcnnc, "bottleneck": make_bottleneck, "mlp25m": make_mlp25m}
+    makers = {"resnet18": make_resnet18, "resnet18_train_hessian": make_resnet18_train_hessian,
+              "resnet18_frozen": make_resnet18_frozen, "allcnnc": make_allcnnc, "bottleneck": make_bottleneck, "mlp25m": make_mlp25m}
     only = sys.argv[1:] or list(makers)
     for name in only:
         t0 = time.time()

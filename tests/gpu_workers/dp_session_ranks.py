@@ -109,11 +109,15 @@ def main(outdir, mode="steps", backend="gloo"):
             from pytorchhessianfree_amd import distributed as hfdist
 
             out["reduce_bytes"] = np.array([sess.reduce_bytes, 4 * sess.n])
-            side = getattr(sess, "_side", None)
-            if isinstance(side, torch.cuda.Stream):  # the side stream's work must run BESIDE the compute stream's (probed at creation)
-                from pytorchhessianfree_amd.session import _runs_beside
-
-                out["side_runs_beside"] = np.array([int(_runs_beside(side, torch.cuda.current_stream()))])
+            # the side stream's work should run BESIDE the compute stream's: the verdict of the probe the session ran
+            # when it picked the stream (kept on the session; not re-probed here: a wall-clock race)
+            if getattr(sess, "side_runs_beside", None) is not None:
+                out["side_runs_beside"] = np.array([int(bool(sess.side_runs_beside))])
+            val = getattr(sess, "mode_validation", None) or {}
+            out["validation"] = np.array([int(bool(val.get("single_graph_identical_on_all_ranks", False))),
+                                          int(bool(val.get("two_phase_identical_on_all_ranks", False))),
+                                          int(bool(val.get("two_phase_kept_as_candidate", False)))])
+            out["validation_rel"] = np.array([float(val.get("two_phase_vs_single_graph", -1.0))])
             timing = getattr(sess, "mode_timing", None)
             out["mode_timing"] = np.array([timing["single_graph_ms"], timing["two_phase_ms"]] if timing else [0.0, 0.0])
             out["comm_path"] = np.array([hfdist.path_name(sess.output_buffer, group)])

@@ -78,8 +78,10 @@ def test_acc_step_on_engine_equals_step_on_whole_batch_and_is_repeatable():
     accumulated session serves both steps, and a second run of the same two calls is BITWISE equal."""
     acc, fa = _resnet_runs("acc", 2)
     sess = acc._acc_session
-    assert sess is not None and sess.steps == 2 and len(sess.engines) == 2
-    assert "engine" in sess.mode
+    # (eval-mode BatchNorm couples no samples and both chunks carry the weight 1 / 32 per sample: ONE engine on the
+    # concatenated chunks -- session.AccumulatedSession._merge_groups)
+    assert sess is not None and sess.steps == 2 and len(sess.engines) == 1 and sess.groups == [[0, 1]]
+    assert "engine" in sess.mode and "ONE batch" in sess.mode
     whole, fw = _resnet_runs("step", 2)
     assert whole._session is not None
     _same_trace(acc, fa, whole, fw)
@@ -103,7 +105,8 @@ def test_acc_step_on_engine_matches_reference_trace_with_ragged_chunks():
 
     ref = RefTrace("resnet18", "acc_20_12")
     acc, fa = _resnet_runs("acc", 2, sizes=(20, 12), cg_max_iter=6)
-    assert acc._acc_session is not None and acc._acc_session.shapes[0][0] == 20
+    assert acc._acc_session is not None and acc._acc_session.chunk_shapes[0][0] == 20
+    assert acc._acc_session.shapes[0][0] == 32 and acc._acc_session.merged
     within(abs(fa[0] - ref.finals[0]), 1e-4 * abs(ref.finals[0]), strict=False)
     compare_trace(acc.state, fa, ref, final_tol=(1e-4, 1e-3))
 
@@ -122,7 +125,10 @@ def test_acc_product_gradient_and_loss_equal_generic_accumulation():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         forward, grad, mvp, sess = opt.acc_linearise(model, lossf, loss_dl, grad_dl, mvp_dl, "mean")
-    assert sess is not None and grad is None and mvp is None and len(sess.engines) == 6
+    # (six chunks, three lists: the two chunks of a list carry one per-sample weight and run as one batch -- three
+    # engines of 32 / 32 / 16 samples on parallel graph branches)
+    assert sess is not None and grad is None and mvp is None and len(sess.engines) == 3
+    assert sess.groups == [[0, 1], [2, 3], [4, 5]] and [sh[0] for sh in sess.shapes] == [32, 32, 16]
     want_loss = float(opt._acc_loss(model, lossf, loss_dl, "mean"))
     within(abs(sess.base_loss - want_loss), 1e-6 * abs(want_loss), strict=False)
     want_grad = opt._acc_grad(model, lossf, grad_dl, "mean")
@@ -165,11 +171,35 @@ def test_acc_step_falls_back_for_models_the_engine_does_not_cover():
     """An MLP with an MSE loss (the reference's own acc tests): no engine, the generic accumulation runs."""
     model, (x, t), lossf = tp.small_nn(device=DEV)
     opt = hf.HessianFree(model.parameters(), graph_matvec=True, cg_max_iter=5)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
+    with pytest.warns(UserWarning, match=r"graph_matvec=True\)\.acc_step\(\) runs on the slower path 'eager'.*not a prepared one"):
         opt.acc_step(model, lossf, _chunks(x, t, (16, 16)), reduction="mean")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
         opt.acc_step(model, lossf, _chunks(x, t, (16, 16)), reduction="mean")
+    assert not [w for w in rec if "slower path" in str(w.message)]  # (once per optimizer)
     assert opt._acc_session is None
+    rep = opt.path_report()["acc_step"]
+    assert rep["path"] == "eager" and "refused twice" in rep["declined"]
+    # a prepared ResNet: another loss, a reduction the loss function does not have, chunks of different image size
+    net, (xr, tr), ce = tp.resnet18_mnist(batch_size=8, device=DEV, data_seed=SEEDS[0])
+    modelprep.prepare_model(net, channels_last=True)
+    cases = [
+        (torch.nn.CrossEntropyLoss(label_smoothing=0.1), "mean", _chunks(xr, tr, (4, 4)), "not a plain softmax cross-entropy"),
+        (ce, "sum", _chunks(xr, tr, (4, 4)), "reduces by 'mean', acc_step was asked for reduction='sum'"),
+        (ce, "mean", [(xr[:4].contiguous(), tr[:4].contiguous()),
+                      (xr[4:, :, :20, :20].contiguous(), tr[4:].contiguous())], "differ in more than their batch size"),
+    ]
+    for lossf_c, reduction, chunks, text in cases:
+        opt = hf.HessianFree(net.parameters(), graph_matvec=True, cg_max_iter=2)
+        with pytest.warns(UserWarning, match=r"acc_step\(\) runs on the slower path"):
+            opt.acc_step(net, lossf_c, chunks, reduction=reduction)
+        assert text in opt.path_report()["acc_step"]["declined"], opt.path_report()
+    opt = hf.HessianFree(net.parameters(), graph_matvec=True, cg_max_iter=2)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        opt.acc_step(net, ce, _chunks(xr, tr, (4, 4)), reduction="mean")
+    assert not [w for w in rec if "slower path" in str(w.message)]
+    assert opt.path_report()["acc_step"]["path"] == "acc-session" and opt.path_report()["acc_step"]["declined"] is None
 
 
 def test_acc_step_train_mode_batchnorm_session_equals_generic_accumulation(monkeypatch):

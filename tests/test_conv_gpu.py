@@ -273,3 +273,48 @@ def test_tangent_convolution_with_batchnorm_partial_sums_in_its_epilogue(geom):
     assert torch.equal(p1c, p1) and torch.equal(pxc, px)
     # a wrong number of partial rows is refused (the caller then takes the two-launch path)
     assert not _lib.conv_group_slabs_bnsum(probs, [(a, mean, rstd, px[:-1], p1[:-1])], DEV)
+
+
+def test_weight_gradient_of_a_zero_padded_operand_on_the_flat_96_row_tiles():
+    """a weight gradient whose X operand is zero-padded to ``cs`` channels (``out_c < cs``: the engine's
+    im2col'd stem pads its rows to 16-byte multiples) must not take the Flat96 configuration's flat (tap, channel)
+    column enumeration as it is -- the padded columns of one row landed in the next row's first entries and the last
+    row wrote past the slab.  kout = 96, cs = 244, out_c = 243: with ONE tap (the im2col form) the flat tiles run and
+    cut the padded column off (result against float64, the float behind the slab untouched); with 3 x 3 taps the
+    launch is refused (HF_ERR_ARG), never silently wrong."""
+    gen = torch.Generator(device=DEV).manual_seed(17)
+    rows, cs, out_c, k = 16384, 244, 243, 96
+    x = torch.zeros(rows, cs, device=DEV)
+    x[:, :out_c] = torch.randn(rows, out_c, device=DEV, generator=gen)
+    gy = torch.randn(rows, k, device=DEV, generator=gen)
+    sp = _lib.conv_plan(2, rows, 1, 1, cs, k, 1, 1, (1, 1), (0, 0))
+    guard = 7.0
+    buf = torch.full((sp * k * out_c + 64,), guard, device=DEV)
+    out = buf[: sp * k * out_c].view(sp, k * out_c)
+    _lib.conv2d_nhwc_slabs(2, out, x, gy, rows, 1, 1, cs, k, 1, 1, (1, 1), (0, 0), sp, out_c=out_c)
+    got = out.sum(0).view(k, out_c)
+    want = gy.double().t() @ x[:, :out_c].double()
+    within(float((got.double() - want).abs().max() / want.abs().max()), 2e-5)
+    assert bool((buf[sp * k * out_c:] == guard).all())  # nothing written behind the last row
+    out2 = torch.empty_like(out)
+    _lib.conv2d_nhwc_slabs(2, out2, x, gy, rows, 1, 1, cs, k, 1, 1, (1, 1), (0, 0), sp, out_c=out_c)
+    assert torch.equal(out, out2)
+    # several taps: 32 x 16 x 16 maps of 244 channels, 3 x 3 -- Flat96 territory (96 rows, every tap live)
+    n, h, w_ = 32, 16, 16
+    x4 = _cl(torch.zeros(n, cs, h, w_, device=DEV))
+    gy4 = _cl(torch.randn(n, k, h, w_, device=DEV, generator=gen))
+    sp4 = _lib.conv_plan(2, n, h, w_, cs, k, 3, 3, (1, 1), (1, 1))
+    out4 = torch.empty((sp4, k * 9 * out_c), device=DEV)
+    p = _lib.c_void_p
+    rc = _lib.load().hf_conv2d_nhwc_slabs(2, p(out4.data_ptr()), p(x4.data_ptr()), p(gy4.data_ptr()), n, h, w_, cs, k, 3, 3,
+                                          1, 1, 1, 1, 0, 0, out_c, sp4, out4.shape[1], _lib.HF_F32,
+                                          _lib.current_stream_ptr(out4.device))
+    if rc != _lib.HF_ERR_ARG:  # (another tile configuration was planned for this shape: then it must be RIGHT)
+        _lib.check(rc, "hf_conv2d_nhwc_slabs")
+        x4[:, :out_c] = torch.randn(n, out_c, h, w_, device=DEV, generator=gen)
+        _lib.conv2d_nhwc_slabs(2, out4, x4, gy4, n, h, w_, cs, k, 3, 3, (1, 1), (1, 1), sp4, out_c=out_c)
+        w0 = torch.zeros(k, out_c, 3, 3, device=DEV, dtype=torch.float64, requires_grad=True)
+        y = torch.nn.functional.conv2d(x4[:, :out_c].double(), w0, None, 1, 1)
+        (gw,) = torch.autograd.grad(y, w0, gy4.double())
+        got4 = out4.sum(0).view(k, 3, 3, out_c).permute(0, 3, 1, 2)
+        within(float((got4.double() - gw).abs().max() / gw.abs().max()), 2e-5)

@@ -161,7 +161,25 @@ def test_session_is_refused_for_other_losses_and_models():
     params = [p for p in model.parameters() if p.requires_grad]
     out = model(x)
     smooth = torch.nn.CrossEntropyLoss(label_smoothing=0.1)
-    assert EngineSession.try_create(smooth(out, t), out, params) is None
+    why = []
+    assert EngineSession.try_create(smooth(out, t), out, params, why=why) is None
+    assert len(why) == 1 and "not a plain softmax cross-entropy" in why[0]
+    # ... and through the optimizer: ONE warning per optimizer that names the path taken and the reason; the report
+    opt = hf.HessianFree(model.parameters(), graph_matvec=True, cg_max_iter=4)
+
+    def fwd_smooth():
+        o = model(x)
+        return smooth(o, t), o
+
+    with pytest.warns(UserWarning, match=r"graph_matvec=True\)\.step\(\) runs on the slower path .*not a plain softmax cross-entropy"):
+        opt.step(fwd_smooth)
+    rep = opt.path_report()["step"]
+    assert rep["path"] in ("engine-graphed", "autograd-graphed") and "softmax cross-entropy" in rep["declined"]
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        opt.step(fwd_smooth)
+    assert not [w for w in rec if "slower path" in str(w.message)]  # (once per optimizer)
+    assert "refused twice" in opt.path_report()["step"]["declined"]
     # shape change between steps: the session is rebuilt, not reused
     opt = hf.HessianFree(model.parameters(), graph_matvec=True, cg_max_iter=8)
     lossf = torch.nn.CrossEntropyLoss()
@@ -177,6 +195,7 @@ def test_session_is_refused_for_other_losses_and_models():
             final = opt.step(forward)
         assert final < opt.state["init_losses"][-1]
         assert opt._session is not None and tuple(opt._session.engine.x_in.shape)[0] == batch
+        assert opt.path_report()["step"] == {"path": "session", "what": opt.PATHS["session"], "declined": None}
     # a plain MLP: no engine, generic path
     mlp, (xm, tm), lm = tp.mwe_mlp(device=DEV)
     opt = hf.HessianFree(mlp.parameters(), graph_matvec=True)
@@ -185,11 +204,30 @@ def test_session_is_refused_for_other_losses_and_models():
         o = mlp(xm)
         return lm(o, tm), o
 
+    with pytest.warns(UserWarning, match=r"slower path 'autograd-graphed'.*not a prepared one"):
+        opt.step(fwd)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         opt.step(fwd)
-        opt.step(fwd)
     assert opt._session is None
+    assert opt.path_report()["step"]["path"] == "autograd-graphed"
+    # an unprepared conv net (stock layers): the reason says what to call
+    stock, (xs_, ts_), ls_ = tp.resnet18_mnist(batch_size=4, device=DEV, data_seed=SEEDS[0])
+    opt = hf.HessianFree(stock.parameters(), graph_matvec=True, cg_max_iter=2)
+
+    def fwd_stock():
+        o = stock(xs_)
+        return ls_(o, ts_), o
+
+    with pytest.warns(UserWarning, match=r"slower path .*prepare_model"):
+        opt.step(fwd_stock)
+    # graph_matvec=False: the user did not ask for the fast path -- no warning, the report still says what ran
+    opt = hf.HessianFree(mlp.parameters())
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        opt.step(fwd)
+    assert not [w for w in rec if "slower path" in str(w.message)]
+    assert opt.path_report()["step"]["path"] == "eager" and opt.path_report()["acc_step"] is None
 
 
 def _run_train_mode_steps(steps, session):
@@ -455,3 +493,69 @@ def test_checkpoint_and_resume_on_the_session_path_is_bitwise():
     assert o2._session is not None and o2._session.steps == 2
     assert got == want, (got, want)
     assert o2.state["dampings"] == o.state["dampings"] and o2.state["num_cg_iters"] == o.state["num_cg_iters"]
+
+
+def test_frozen_stem_and_layer1_engine_product_and_session_steps_match_reference_trace():
+    """The engine on a TRAINABLE SUBSET (the reference computes "in the subspace of trainable parameters",
+    optimizer.py:121-123, utils.py:31-32; its own test problem freezes its first layer, tests/test_utils.py:39-43):
+    ResNet-18 with stem + layer1 frozen, N = 11 017 482 of 11 175 370 entries.  The frozen units are DEAD for the
+    sweeps (no tangent flows out of them, no cotangent is needed behind them): the tangent sweep starts and the adjoint
+    sweep ends at layer2.  Against the REAL reference on the stock CPU model (golden ``convnet_resnet18_frozen.npz``):
+    gradient 5e-6, one GGN product 2e-6 of its float64 twin and inside the fp32 envelope of the reference's own fp32
+    product, three default steps through the persistent session (same tolerances as the unfrozen trace), the update of
+    the first step (cosine > 0.999 on the index sample); the frozen parameters stay bitwise what they were."""
+    from helpers import RefTrace, compare_trace
+    from pytorchhessianfree_amd.engine import FusedGGNEngine
+
+    ref_s, ref_p, ref_t = (RefTrace("resnet18_frozen", k) for k in ("solve_martens", "ggn_product", "steps"))
+    cm, (cx, _), _ = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=SEEDS[0])
+    tp.freeze_stem_and_layer1(cm)
+    cp = [p for p in cm.parameters() if p.requires_grad]
+    ref_s.check_inputs(cp, cx)
+    ref_t.check_inputs(cp)
+    assert sum(p.numel() for p in cp) == 11017482
+    model = tp.freeze_stem_and_layer1(cm).to(DEV)
+    frozen0 = [p.detach().clone() for p in model.parameters() if not p.requires_grad]
+    modelprep.prepare_model(model, channels_last=True)
+    lossf = torch.nn.CrossEntropyLoss()
+    opt = hf.HessianFree(model.parameters(), graph_matvec=True)
+    opt._ensure_arena()
+    params = opt._params_list
+    _, (x, t), _ = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=SEEDS[0])
+    out = model(x)
+    why = []
+    sess = EngineSession.try_create(lossf(out, t), out, params, why=why)
+    assert sess is not None, why
+    eng = sess.engine
+    assert isinstance(eng, FusedGGNEngine) and eng.frozen_any and eng.stem.dead and eng.dead_blocks == 2
+    assert eng.n == 11017482
+    within(abs(float(eng.loss_buf) - ref_s.scalar("loss")), 2e-6 * abs(ref_s.scalar("loss")), strict=False)
+    got = sess.gradient()
+    within(ref_s.vec_err("grad", got), 5e-6)
+    got_p = sess(ref_p.probe().to(DEV)).clone()
+    within(ref_p.vec_err64("", got_p), 2e-6)
+    within(ref_p.vec_err("", got_p), ref_p.envelope("", 2e-6))
+    assert torch.equal(sess(ref_p.probe().to(DEV)), got_p)  # (own kernels only: bitwise repeatable)
+    del sess, eng, out
+    # three default steps through the drop-in API
+    finals, before = [], opt._arena.theta.clone()
+    for i in range(3):
+        _, (xb, tb), _ = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=SEEDS[i])
+        ref_t.check_inputs(x=xb, step=i)
+        xb, tb = xb.to(DEV), tb.to(DEV)
+
+        def forward():
+            o = model(xb)
+            return lossf(o, tb), o
+
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            finals.append(opt.step(forward))
+        assert not [w for w in rec if "slower path" in str(w.message)], [str(w.message) for w in rec]
+        if i == 0:
+            assert ref_t.vec_cos("update/0", opt._arena.theta - before) > 0.999
+    assert opt._session is not None and opt._session.steps == 3
+    assert opt.path_report()["step"]["path"] == "session"
+    compare_trace(opt.state, finals, ref_t)
+    for a, b in zip(frozen0, [p for p in model.parameters() if not p.requires_grad]):
+        assert torch.equal(a, b.detach())

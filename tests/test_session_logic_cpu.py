@@ -199,3 +199,36 @@ def test_accumulated_session_plans_engines_by_chunk_identity():
     assert roles == [(0, 1), (1, 2), (2,)]
     slots, roles = AccumulatedSession._plan(([a, a], [a], [a]))
     assert len(slots) == 1 and roles == [(0, 0), (0,), (0,)]
+
+
+def test_accumulated_session_merges_chunks_of_equal_per_sample_weight():
+    """Chunks that appear in the same lists the same number of times carry one per-sample weight (optimizer.py:
+    677-684: ``N_k / sum N`` per chunk = ``1 / sum N`` per sample): for a model that does not couple the samples of
+    a batch they run as ONE batch (the reference's own statement, tests/test_optimizer_acc.py:116-175).  Not merged:
+    a train-mode BatchNorm / active dropout anywhere in the model, chunks of different shape, chunks with different
+    list membership."""
+    from pytorchhessianfree_amd.session import AccumulatedSession
+
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Dropout(0.5)).eval()
+    mk = lambda n, hw=8: (torch.zeros(n, 3, hw, hw), torch.zeros(n, dtype=torch.int64))  # noqa: E731
+    a, b, c, d = mk(20), mk(12), mk(8), mk(8, hw=6)
+    slots, roles = AccumulatedSession._plan(([a, b], [a, b], [a, b]))
+    assert AccumulatedSession._merge_groups(net, slots, roles) == [[0, 1]]
+    # distinct lists: one group per list
+    slots, roles = AccumulatedSession._plan(([a, b], [b, c], [c]))
+    assert AccumulatedSession._merge_groups(net, slots, roles) == [[0], [1], [2]]
+    slots, roles = AccumulatedSession._plan(([a, b], [c, mk(4)], [a, b]))
+    assert AccumulatedSession._merge_groups(net, slots, roles) == [[0, 1], [2, 3]]
+    # a chunk listed twice weighs twice per sample: its own group
+    slots, roles = AccumulatedSession._plan(([a, a, b], [a, b], [a, b]))
+    assert AccumulatedSession._merge_groups(net, slots, roles) == [[0], [1]]
+    # another image size
+    slots, roles = AccumulatedSession._plan(([c, d],) * 3)
+    assert AccumulatedSession._merge_groups(net, slots, roles) == [[0], [1]]
+    # batch-coupled layers: per-chunk statistics / masks are part of the reference's result
+    slots, roles = AccumulatedSession._plan(([a, b],) * 3)
+    net[1].train()
+    assert AccumulatedSession._merge_groups(net, slots, roles) == [[0], [1]]
+    net[1].eval()
+    net[2].train()
+    assert AccumulatedSession._merge_groups(net, slots, roles) == [[0], [1]]
