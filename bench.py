@@ -155,7 +155,11 @@ def supervise(args):
     from torch.distributed import TCPStore
 
     launcher = "WORLD_SIZE" in os.environ
-    ndev = torch.cuda.device_count()
+    # (test plumbing, tests/test_distributed_cpu.py: the ladder's control flow with stand-in rank processes on a box
+    # without a GPU -- HF_BENCH_FAKE_DEVICES / HF_BENCH_CHILD_CMD; the real rank processes are this script itself)
+    ndev = int(os.environ.get("HF_BENCH_FAKE_DEVICES", "0")) or torch.cuda.device_count()
+    child_cmd = (json.loads(os.environ["HF_BENCH_CHILD_CMD"]) if os.environ.get("HF_BENCH_CHILD_CMD")
+                 else [sys.executable, os.path.abspath(__file__)])
     if ndev < 1:
         raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU fallback")
     if launcher:
@@ -202,7 +206,7 @@ def supervise(args):
             env.pop("TORCHELASTIC_USE_AGENT_STORE", None)  # (the child takes the store it is told, as a client)
             fout = open(out_path, "w")
             procs.append((rank, marker, out_path, fout,
-                          subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=fout)))
+                          subprocess.Popen(child_cmd + argv, env=env, stdout=fout)))
         t0, why = time.time(), None
         fail_key = prefix + "/failed"
         while True:

@@ -33,6 +33,6 @@ the autograd operator.  The first product of every model signature is compared w
 operator's product on a random vector.
 """
 
-from .common import _Unsupported, _live_taps, ce_loss_spec  # noqa: F401
+from .common import _Unsupported, _live_taps, ce_loss_spec, loss_spec_of, mse_loss_spec  # noqa: F401
 from .core import FusedGGNEngine  # noqa: F401
 from .plain import PlainStackEngine  # noqa: F401

@@ -265,6 +265,13 @@ class _Buffers:
                 self._frozen_seen[id(u)] = seen
 
     def set_targets(self, targets):
+        if targets.dtype.is_floating_point:  # a mean-squared-error loss: targets of the outputs' shape
+            if getattr(self, "_targets", None) is None:
+                self._targets = torch.empty_like(self.logits)
+                self._onehot = None
+                self.bad_targets = torch.zeros((), dtype=torch.bool, device=self.dev)
+            self._targets.copy_(targets)
+            return
         if getattr(self, "_targets", None) is None:
             self._targets = torch.empty_like(targets)
             self._onehot = torch.zeros_like(self.logits)

@@ -90,10 +90,45 @@ def ce_loss_spec(loss, outputs, check_values=True):
             return None
     except AttributeError:
         return None
-    spec = {"reduction": reduction, "targets": targets.detach()}
+    spec = {"kind": "ce", "reduction": reduction, "targets": targets.detach()}
     if fn is not loss.grad_fn:
         spec["quadratic"] = loss._hf_quadratic
     return spec
+
+
+def mse_loss_spec(loss, outputs):
+    """``{"kind": "mse", "reduction", "targets"}`` if ``loss`` is ``F.mse_loss(outputs, targets)`` (``nn.MSELoss``,
+    mean or sum) with constant targets of the outputs' shape -- the loss of the reference's own examples and tests
+    (examples/run_mwe.py:19, tests/test_utils.py:47) -- read off the autograd graph; else ``None``.  Its gradient
+    w.r.t. the outputs is ``2 c (outputs - targets)`` and its Hessian ``2 c I`` with ``c = 1 / numel`` (mean) or 1
+    (sum): the loss head of optimizer.py:457-462 in closed form."""
+    fn = getattr(loss, "grad_fn", None)
+    try:
+        if fn is None or fn.name() != "MseLossBackward0" or outputs.dim() != 2:
+            return None
+        src = fn.next_functions[0][0]
+        if outputs.grad_fn is not None:
+            if src is not outputs.grad_fn:
+                return None
+        elif src is None or getattr(src, "variable", None) is not outputs:
+            return None  # (a leaf: the logits a persistent session handed out)
+        if len(fn.next_functions) > 1 and fn.next_functions[1][0] is not None:
+            return None  # (targets that are themselves differentiated)
+        reduction = {1: "mean", 2: "sum"}.get(fn._saved_reduction)
+        targets = fn._saved_target
+        if reduction is None or tuple(targets.shape) != tuple(outputs.shape) or targets.dtype != outputs.dtype:
+            return None
+    except AttributeError:
+        return None
+    return {"kind": "mse", "reduction": reduction, "targets": targets.detach()}
+
+
+def loss_spec_of(loss, outputs, check_values=True):
+    """The losses the engine evaluates itself -- loss value, gradient and loss Hessian w.r.t. the model output in closed
+    form, on its own forward pass (what lets ONE engine serve many steps and trial points): a plain softmax
+    cross-entropy (``ce_loss_spec``) or a mean-squared error (``mse_loss_spec``); else ``None``."""
+    spec = ce_loss_spec(loss, outputs, check_values)
+    return spec if spec is not None else mse_loss_spec(loss, outputs)
 
 
 class _Node:

@@ -40,7 +40,7 @@ import torch
 
 from .. import _lib
 from ..curvature import GGNOperator, _Operator
-from .common import _Node, _Unsupported, _ce_node, ce_loss_spec
+from .common import _Node, _Unsupported, _ce_node, ce_loss_spec, loss_spec_of  # noqa: F401
 from .adjoint import _AdjointSweep
 from .buffers import _Buffers
 from .dataparallel import _DataParallel
@@ -179,19 +179,26 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
         # a plain softmax cross-entropy (checked numerically above): the engine can then evaluate
         # loss, probabilities and d loss / d logits itself, on its own forward pass -- which is what
         # lets ONE engine serve many steps and trial points (``session.EngineSession``)
+        # ... or a mean-squared error (round 6; the loss of the reference's own examples / tests): gradient
+        # 2c (out - t), Hessian 2c I
         self.loss_spec = None
-        if self._ce is not None and (not self.train_bn or self.train_own):
-            spec = ce_loss_spec(loss, outputs)
-            if spec is not None:
+        if not self.train_bn or self.train_own:
+            spec = loss_spec_of(loss, outputs)
+            if spec is not None and (spec["kind"] == "mse" or self._ce is not None):
                 self.loss_spec = spec
                 self._set_quadratic(spec.get("quadratic"))
                 self.set_targets(spec["targets"])
+                if spec["kind"] == "mse":
+                    self._ce = None
+                    self._mse2 = 2.0 / float(outputs.numel()) if spec["reduction"] == "mean" else 2.0
                 self._loss_head()
-                self._ce = (self._p, self._ce[1])  # the static buffer the own forward pass refreshes
-                self._dl = None                     # (nothing of this step's autograd graph is kept)
+                if spec["kind"] == "ce":
+                    self._ce = (self._p, self._ce[1])  # the static buffer the own forward pass refreshes
+                self._dl = None                        # (nothing of this step's autograd graph is kept)
         if self.hessian:
             if self.loss_spec is None:
-                raise _Unsupported("Hessian products on the engine need a plain softmax cross-entropy loss")
+                raise _Unsupported("Hessian products on the engine need a plain softmax cross-entropy or mean-squared-"
+                                   "error loss")
             self.gradient()  # fills the first-order cotangents the Hessian products read
 
     def _set_quadratic(self, terms):
@@ -226,7 +233,7 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
             raise RuntimeError("engine.gradient needs a softmax cross-entropy loss")
         if out is None:
             out = torch.empty(self.n, dtype=torch.float32, device=self.dev)
-        g = (self._p - self._onehot) * self._ce[1]  # d loss / d logits
+        g = self._dlogits()  # d loss / d logits
         fw = self.fc.weight.detach()
         g_fw = g.t() @ self.feat
         g_fb = g.sum(0) if self.pfb is not None else None
@@ -254,7 +261,16 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
             out.addcmul_(self._l2, self._theta(), value=self.weight)
         return out
 
-    _loss_hessian = GGNOperator._loss_hessian
+    def _dlogits(self):
+        """``d loss / d logits`` of the engine's own loss head at the current logits."""
+        if self.loss_spec["kind"] == "mse":
+            return (self.logits - self._targets) * self._mse2
+        return (self._p - self._onehot) * self._ce[1]
+
+    def _loss_hessian(self, Jv):
+        if self.loss_spec is not None and self.loss_spec["kind"] == "mse":
+            return Jv * self._mse2
+        return GGNOperator._loss_hessian(self, Jv)
 
     # ---- the product -------------------------------------------------------------------------
     def local(self, v, out=None):

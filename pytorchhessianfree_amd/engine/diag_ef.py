@@ -58,7 +58,7 @@ class _DiagEF:
         if self.fc is not None:
             # linear head: the per-sample weight gradient is the outer product g_i x feat_i, so the sum of its squares
             # is (g o g)^T (feat o feat)
-            g = (self._p - self._onehot) * (self._ce[1] * scale)
+            g = self._dlogits() * scale
             nf = self.fc.weight.numel()
             out[self._offs[self.pfw]: self._offs[self.pfw] + nf].copy_(((g * g).t() @ (self.feat * self.feat)).reshape(-1))
             if self.pfb is not None:

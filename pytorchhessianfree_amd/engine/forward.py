@@ -91,9 +91,12 @@ class _Forward:
     def _loss_head(self):
         """Softmax probabilities and the cross-entropy value of the current logits (the reference's
         ``forward()[0]``, optimizer.py:216-229; same ATen ops as ``F.cross_entropy``)."""
-        torch.softmax(self.logits, 1, out=self._p)
-        lsm = torch.log_softmax(self.logits, 1)
-        val = torch.nn.functional.nll_loss(lsm, self._targets, reduction=self.loss_spec["reduction"])
+        if self.loss_spec["kind"] == "mse":  # (same ATen op as ``F.mse_loss`` / ``nn.MSELoss``)
+            val = torch.nn.functional.mse_loss(self.logits, self._targets, reduction=self.loss_spec["reduction"])
+        else:
+            torch.softmax(self.logits, 1, out=self._p)
+            lsm = torch.log_softmax(self.logits, 1)
+            val = torch.nn.functional.nll_loss(lsm, self._targets, reduction=self.loss_spec["reduction"])
         if getattr(self, "_l2", None) is not None:
             theta = self._theta()
             val = val + 0.5 * torch.dot(self._l2 * theta, theta)

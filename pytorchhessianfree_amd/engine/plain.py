@@ -214,5 +214,5 @@ class PlainStackEngine(FusedGGNEngine):
 
     def _loss_setup(self, loss, outputs):
         FusedGGNEngine._loss_setup(self, loss, outputs)
-        if self.loss_spec is None:
+        if self.loss_spec is None or self.loss_spec["kind"] != "ce":
             raise _Unsupported("the plain-stack engine needs a plain softmax cross-entropy loss")

@@ -92,6 +92,8 @@ class _Accumulation:
                 sess.base_loss = sess.reduce_losses(sess.loss_buf.reshape(1)).tolist()[0]
         if sess is None:
             self._note_path("acc_step", "eager", self._acc_decline)
+        else:
+            self._note_path("acc_step", "acc-session")
         return sess
 
     _acc_decline = None  # why the accumulated session was not taken (last refusal)

@@ -135,7 +135,7 @@ class _SessionSteps:
         if (model is not eng.model_ref or eng.train_bn or eng.loss_spec is None or getattr(eng, "frozen_any", False)
                 or not isinstance(inputs, torch.Tensor) or tuple(inputs.shape) != tuple(eng.x_in.shape)):
             return None
-        from .engine import ce_loss_spec
+        from .engine import loss_spec_of
         from .modelprep import session_forward
         from .session import _quadratic_signature
 
@@ -145,8 +145,9 @@ class _SessionSteps:
         if out is not getattr(sess, "_override_out", None):
             return None  # (the session did not answer this forward pass: another mode / shape)
         loss = loss_func(out, targets)
-        spec = ce_loss_spec(loss, out, check_values=False)
-        if (spec is None or spec["reduction"] != reduction or spec["reduction"] != eng.loss_spec["reduction"]
+        spec = loss_spec_of(loss, out, check_values=False)
+        if (spec is None or spec["kind"] != eng.loss_spec["kind"] or spec["reduction"] != reduction
+                or spec["reduction"] != eng.loss_spec["reduction"]
                 or _quadratic_signature(spec) != _quadratic_signature(eng.loss_spec)
                 or tuple(spec["targets"].shape) != tuple(eng._targets.shape)):
             return None

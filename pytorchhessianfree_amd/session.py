@@ -36,7 +36,7 @@ import torch
 
 from . import _lib
 from .curvature import GraphedOperator
-from .engine import FusedGGNEngine, ce_loss_spec
+from .engine import FusedGGNEngine, loss_spec_of
 
 
 def _runs_beside(cand, cur):
@@ -214,7 +214,7 @@ class EngineSession(_TwoPhaseProduct):
         if not torch.cuda.is_available():
             why.append("no GPU")
             return None
-        if ce_loss_spec(loss, outputs) is None:
+        if loss_spec_of(loss, outputs) is None:
             why.append(_loss_decline(loss, outputs))
             return None
         holder = {}
@@ -330,8 +330,9 @@ class EngineSession(_TwoPhaseProduct):
             return None
         if eng._flat_params.data_ptr() != eng.params[0].data_ptr():
             return None  # the parameters moved (arena rebuilt): a fresh session is needed
-        spec = ce_loss_spec(loss, outputs, check_values=False)
-        if spec is None or spec["reduction"] != eng.loss_spec["reduction"]:
+        spec = loss_spec_of(loss, outputs, check_values=False)
+        if (spec is None or spec["kind"] != eng.loss_spec["kind"]
+                or spec["reduction"] != eng.loss_spec["reduction"]):
             return None
         if _quadratic_signature(spec) != _quadratic_signature(eng.loss_spec):
             return None  # (another regulariser: coefficients or tensors differ)
@@ -573,8 +574,9 @@ def _loss_decline(loss, outputs):
     if not isinstance(outputs, torch.Tensor) or outputs.dim() != 2:
         return "the model output is not a [batch, classes] tensor"
     return ("the loss is not a plain softmax cross-entropy on the model output (F.cross_entropy / nn.CrossEntropyLoss "
-            "with class-index targets, no class weights, no label smoothing, no ignored target; the loss ends in "
-            f"{name}): the session evaluates loss, gradient and loss Hessian in closed form for that loss only")
+            "with class-index targets, no class weights, no label smoothing, no ignored target) nor a mean-squared "
+            f"error against constant targets of the outputs' shape (the loss ends in {name}): the session evaluates "
+            "loss, gradient and loss Hessian in closed form for these two only")
 
 
 def _quadratic_signature(spec):
@@ -771,9 +773,9 @@ class AccumulatedSession:
         self.model, self.loss_func, self.reduction, self.hessian = model, loss_func, reduction, bool(hessian)
         self.chunk_roles, self.chunk_shapes = roles, [tuple(x.shape) for x, _ in slots]
         for x, t in slots:
-            if not (isinstance(x, torch.Tensor) and isinstance(t, torch.Tensor) and x.dim() >= 1 and t.dim() == 1
+            if not (isinstance(x, torch.Tensor) and isinstance(t, torch.Tensor) and x.dim() >= 1 and t.dim() in (1, 2)
                     and t.shape[0] == x.shape[0]):
-                raise _NoEngine("a data chunk is not (float32 inputs, 1-D class-index targets)")
+                raise _NoEngine("a data chunk is not (float32 inputs, class-index or [batch, outputs] targets)")
         # chunks that carry the same per-sample weight in every list run as ONE batch on ONE engine (round 6: the
         # default call -- one list for loss, gradient and curvature -- is then a single engine on the whole batch:
         # 1 450+ instead of 1 280 matvecs/s for chunks [16, 16], no graph branches)
@@ -796,13 +798,13 @@ class AccumulatedSession:
         engines = []
         with torch.cuda.stream(self.stream), torch.no_grad():
             for x, t in slots:
-                if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and t.dim() == 1):
+                if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and t.dim() in (1, 2)):
                     cur.wait_stream(self.stream)
-                    raise _NoEngine("a data chunk is not (float32 inputs, 1-D class-index targets)")
+                    raise _NoEngine("a data chunk is not (float32 inputs, class-index or [batch, outputs] targets)")
                 with torch.enable_grad():
                     out = model(x)
                     loss = loss_func(out, t)
-                    spec = ce_loss_spec(loss, out) if isinstance(out, torch.Tensor) and out.dim() == 2 else None
+                    spec = loss_spec_of(loss, out) if isinstance(out, torch.Tensor) and out.dim() == 2 else None
                     eng = None
                     if spec is None:
                         self._why.append(_loss_decline(loss, out))
@@ -990,7 +992,7 @@ class AccumulatedSession:
         if e0._flat_params is None or e0._flat_params.data_ptr() != e0.params[0].data_ptr():
             return None
         for x, t in slots:
-            if not x.is_cuda or x.dtype != torch.float32 or t.dim() != 1 or t.shape[0] != x.shape[0]:
+            if not x.is_cuda or x.dtype != torch.float32 or t.dim() not in (1, 2) or t.shape[0] != x.shape[0]:
                 return None
         return slots
 

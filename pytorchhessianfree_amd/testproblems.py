@@ -208,6 +208,14 @@ def resnet18_mnist(batch_size=32, seed=0, device="cpu", data_seed=None):
     return model.to(device), (inputs.to(device), targets.to(device)), nn.CrossEntropyLoss()
 
 
+def resnet18_mnist_mse(batch_size=32, seed=0, device="cpu", data_seed=None):
+    """The same model and inputs with the loss of the reference's own examples and tests (``nn.MSELoss``,
+    examples/run_mwe.py:19, tests/test_utils.py:47): targets = the one-hot rows of the same integer targets."""
+    model, (inputs, targets), _ = resnet18_mnist(batch_size, seed, "cpu", data_seed)
+    onehot = torch.nn.functional.one_hot(targets, 10).to(torch.float32)
+    return model.to(device), (inputs.to(device), onehot.to(device)), nn.MSELoss()
+
+
 def resnet50_small_images(batch_size=32, seed=0, device="cpu", data_seed=None, image=64):
     """BASELINE.json configs[4]: a ResNet-50-sized parameter vector (25 557 032);
     eval-mode BN, inputs U[0,1) [B,3,image,image], 1000 classes, CE-mean."""

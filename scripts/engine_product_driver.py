@@ -130,14 +130,6 @@ class Recorder:
         return [(name, rd, wr, 8.0 * n * c * hw)]
 
     @staticmethod
-    def _cost_hf_bn_adjoint_rows_train(gx, gw, gb, gres, gy, s1, l1, gy2, s2, l2, x, mean, rstd, w, mask, n, c, hw, rb,
-                                       ticket, q_out, r_out, fw, vq, vr, count, dtype, stream):
-        tot = 4 * n * c * hw
-        rd = tot * (s1 + (s2 if gy2 else 0) + (1 if x else 0) + (1 if mask else 0))
-        wr = tot * ((1 if gx else 0) + (1 if gres else 0))
-        return [("k_bn_adjoint_rows_train", rd, wr, 8.0 * n * c * hw)]
-
-    @staticmethod
     def _cost_hf_chan_affine_train(out, a, x, mean, rstd, w, px, p1, nparts, vq, vr, count, add, mask, n, c, hw, old,
                                    ald, splits, slab, dtype, stream):
         tot = 4 * n * c * hw
@@ -169,17 +161,6 @@ class Recorder:
                 rd += 4 * q.n * oh * ow * q.k * q.splits
                 wr += 4 * 2 * b.part_rows * q.k
         return [("k_conv_group" if count > 1 else "k_conv_nt<false", rd, wr, fl)]
-
-    @staticmethod
-    def _cost_hf_bn_rows_train_apply(out, old, gw, gb, gres, gy, s1, l1, gy2, s2, l2, x, mean, rstd, mask, n, c, hw, rb,
-                                     bar, q_out, r_out, fw, vq, vr, count, add, ald, omask, dtype, stream):
-        tot = 4 * n * c * hw
-        rd = tot * (s1 + (s2 if gy2 else 0) + 2 + (1 if mask else 0) + (1 if add else 0) + (1 if omask else 0))
-        return [("k_bn_rows_train_apply", rd, 2 * tot, 16.0 * n * c * hw)]
-
-    @staticmethod
-    def _cost_hf_bn_train_coeffs(q_out, r_out, px, p1, nparts, w, rstd, vq, vr, count, c, dtype, stream):
-        return [("k_bn_train_coeffs", 4 * 2 * nparts * c, 4 * 2 * c, 0.0)]
 
     @staticmethod
     def _cost_hf_chan_affine_bwd_pair(problems, dtype, stream):

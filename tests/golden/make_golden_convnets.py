@@ -159,7 +159,7 @@ def run_solve(store, key, model, loss_of, x, t, curv, lam, cg_kw, diag_precond=F
     m64, lossf64, x64 = double_twin(model, loss_of, x)
     p64 = [p for p in m64.parameters() if p.requires_grad]
     out64 = m64(x64)
-    loss64 = lossf64(out64, t)
+    loss64 = lossf64(out64, t.double() if t.dtype.is_floating_point else t)  # (class indices stay; MSE targets follow)
     put_vec(store, key + "/grad/f64", parameters_to_vector(torch.autograd.grad(loss64, p64, retain_graph=True)), idx)
     store[key + "/loss_f64"] = np.array(float(loss64.detach()))
     store[key + "/loss"] = np.array(float(loss.detach()))
@@ -289,7 +289,7 @@ def make_resnet18_frozen():
     """The ResNet-18 of configs[1] with its stem and layer1 FROZEN (``requires_grad = False``: the reference computes
     "in the subspace of trainable parameters", optimizer.py:121-123, utils.py:31-32; its own test problem freezes the
     first layer, tests/test_utils.py:39-43): three default steps, the gradient / one GGN product (+ float64 twins) and
-    a short damped solve on the 11 017 482-entry trainable vector.  A file of its own: the other traces stay
+    a short damped solve on the 11 024 138-entry trainable vector.  A file of its own: the other traces stay
     byte-identical."""
     store = {}
     run_steps(store, "steps", tp.resnet18_mnist, SEEDS, 3, mk=dict(batch_size=32), prep=tp.freeze_stem_and_layer1)
@@ -300,6 +300,20 @@ def make_resnet18_frozen():
                                   sample_iters=set(range(0, 12)))
     put_product(store, "ggn_product", B, grad.numel(), idx, seed=53, B64=B64)
     mg.save("convnet_resnet18_frozen.npz", store)
+
+
+def make_resnet18_mse():
+    """The ResNet-18 of configs[1] under the loss of the reference's own examples and tests (``nn.MSELoss``,
+    examples/run_mwe.py:19, tests/test_utils.py:47) against one-hot targets: two default steps, the gradient / one GGN
+    product (+ float64 twins) and a short damped solve.  A file of its own."""
+    store = {}
+    run_steps(store, "steps", tp.resnet18_mnist_mse, SEEDS, 2, mk=dict(batch_size=32))
+    model, (x, t), lossf = tp.resnet18_mnist_mse(batch_size=32, device="cpu", data_seed=SEEDS[0])
+    B, grad, idx, B64 = run_solve(store, "solve_martens", model, lambda m: lossf, x, t, "ggn", 1e-3,
+                                  dict(max_iter=30, martens_conv_crit=True, store_x_at_iters=list(range(31))),
+                                  sample_iters=set(range(0, 12)))
+    put_product(store, "ggn_product", B, grad.numel(), idx, seed=59, B64=B64)
+    mg.save("convnet_resnet18_mse.npz", store)
 
 
 def make_allcnnc():
@@ -371,7 +385,7 @@ def make_mlp25m():
 if __name__ == "__main__":
     torch.set_num_threads(THREADS)
     makers = {"resnet18": make_resnet18, "resnet18_train_hessian": make_resnet18_train_hessian,
-              "resnet18_frozen": make_resnet18_frozen, "allcnnc": make_allcnnc, "bottleneck": make_bottleneck, "mlp25m": make_mlp25m}
+              "resnet18_frozen": make_resnet18_frozen, "resnet18_mse": make_resnet18_mse, "allcnnc": make_allcnnc, "bottleneck": make_bottleneck, "mlp25m": make_mlp25m}
     only = sys.argv[1:] or list(makers)
     for name in only:
         t0 = time.time()

@@ -123,3 +123,56 @@ def test_two_ranks_acc_step_with_distinct_data_lists(tmp_path, curv, reduction):
     np.testing.assert_allclose(r0["init_losses"], g[f"{key}/state/init_losses"], rtol=1e-5)
     assert r0["num_cg_iters"].tolist() == g[f"{key}/state/num_cg_iters"].tolist()
     np.testing.assert_allclose(r0["dampings"], g[f"{key}/state/dampings"], rtol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The control flow of ``bench.py``'s data-parallel fallback ladder (bench.supervise / bench.RUNGS) with stand-in
+# rank processes (tests/cpu_workers/ladder_child.py: the real rendezvous -- the supervisor's store, a prefix per rung,
+# gloo -- and scripted failures), both ways in: without a launcher and under ``torch.distributed.run`` (what the
+# round driver runs for N > 1: every launched process supervises its own rank, the launcher's store carries the
+# rendezvous of every rung and the 'this rung failed' key).  The real thing runs in tests/test_distributed_gpu.py.
+# ---------------------------------------------------------------------------------------------------------
+def _ladder(env_extra, launcher, rung_timeout="60,60", world=2, timeout=300):
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_USE_AGENT_STORE")}
+    env.update(HF_BENCH_FAKE_DEVICES=str(world), OMP_NUM_THREADS="1",
+               HF_BENCH_CHILD_CMD=json.dumps([sys.executable, os.path.join(HERE, "cpu_workers", "ladder_child.py")]),
+               **env_extra)
+    bench = [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--backend", "gloo",
+             "--rung-timeout", rung_timeout]
+    if launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + bench
+    else:
+        cmd = [sys.executable] + bench
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, lines
+
+
+@pytest.mark.parametrize("launcher", [False, True], ids=["own-launcher", "torchrun"])
+def test_bench_ladder_control_flow_with_stand_in_ranks(launcher):
+    # nothing fails: the first rung prints the one line
+    p, lines = _ladder({}, launcher)
+    assert p.returncode == 0 and len(lines) == 1, (p.stdout[-1500:], p.stderr[-3000:])
+    assert lines[0]["rung"] == 0 and lines[0]["rungs_failed"] == [] and lines[0]["n_gpus"] == 2
+    assert lines[0]["env"] == {"HF_CHUNKED_ALLREDUCE": None, "HF_DIRECT_RCCL": None, "HF_BENCH_BACKEND": "gloo"}
+    # the last rank dies on rungs 0 and 1: the third rung (no communicator of the package's own) prints the line and
+    # names what failed above it; every supervisor gave the failed rungs up (no orphan waits for the bound)
+    p, lines = _ladder({"STUB_FAIL_RUNGS": "0,1"}, launcher)
+    assert p.returncode == 0 and len(lines) == 1, (p.stdout[-1500:], p.stderr[-3000:])
+    assert lines[0]["rung"] == 2 and [f["rung"] for f in lines[0]["rungs_failed"]] == [0, 1]
+    assert lines[0]["env"]["HF_CHUNKED_ALLREDUCE"] == "0" and lines[0]["env"]["HF_DIRECT_RCCL"] == "0"
+    # a rank that hangs: the rung's wall-clock bound ends it, the next rung runs
+    p, lines = _ladder({"STUB_HANG_RUNGS": "0"}, launcher, rung_timeout="8,60")
+    assert p.returncode == 0 and len(lines) == 1, (p.stdout[-1500:], p.stderr[-3000:])
+    assert lines[0]["rung"] == 1 and "wall-clock bound" in lines[0]["rungs_failed"][0]["why"]
+    # a rank that aborts in its teardown AFTER the run is complete (marker written): the rung counts
+    p, lines = _ladder({"STUB_TEARDOWN_CRASH_RUNGS": "0"}, launcher)
+    assert p.returncode == 0 and len(lines) == 1 and lines[0]["rung"] == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    # every rung fails: non-zero, no line
+    p, lines = _ladder({"STUB_FAIL_RUNGS": "0,1,2,3"}, launcher)
+    assert p.returncode != 0 and not lines

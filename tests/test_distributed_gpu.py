@@ -139,9 +139,14 @@ def test_bench_gpus_2_starts_two_ranks_itself():
 # process_group=...).step -> fused engine + persistent session + chunked / overlapped all-reduce
 # ---------------------------------------------------------------------------------------------------------
 def _launch_session_ranks(out, world, mode="steps", backend="gloo", timeout=900, env_extra=None, attempts=3):
-    """Start ``world`` rank processes of tests/gpu_workers/dp_session_ranks.py and load what they saved.  Ranks KILLED
-    BY A SIGNAL (RCCL's watchdog / teardown aborts sporadically on this stack, see test_optimizer_gpu._run_worker) are
-    started again, up to ``attempts`` times; a rank that exits by itself with an error fails the test at once."""
+    """Start ``world`` rank processes of tests/gpu_workers/dp_session_ranks.py and load what they saved.  The ranks are
+    started again (up to ``attempts`` times, every restart recorded and counted against the suite's budget:
+    tol.note_retry) ONLY for the known teardown abort of RCCL / c10d on this stack: every failed rank was killed by a
+    signal and had either written its result file already or names the communication library in its stderr
+    (tol.is_teardown_abort).  Any other death -- a rank that exits by itself with an error, a signal inside the
+    package's own kernels before the result exists -- fails the test at once."""
+    import tol
+
     for attempt in range(attempts):
         port = _free_port()
         procs = []
@@ -155,11 +160,17 @@ def _launch_session_ranks(out, world, mode="steps", backend="gloo", timeout=900,
         codes = [p.returncode for p in procs]
         if all(c == 0 for c in codes):
             return [np.load(out / f"rank{r}.npz") for r in range(world)]
-        for c, (so, se) in zip(codes, logs):
+        known = True
+        for r, (c, (so, se)) in enumerate(zip(codes, logs)):
             if c != 0:
                 print(f"[dp_session_ranks {mode} {backend}] attempt {attempt + 1}: return code {c}\n{se[-4000:]}", flush=True)
-        if not any(c < 0 for c in codes):  # (no rank was killed by a signal: a real failure)
+                known = known and tol.is_teardown_abort(c, se, (out / f"rank{r}.npz").exists())
+        if not known:  # (a real failure)
             break
+        tol.note_retry(f"dp_session_ranks {mode} {backend} world {world}", [c for c in codes if c != 0][0], logs[0][1])
+        for r in range(world):  # (a fresh attempt must deliver fresh results)
+            if (out / f"rank{r}.npz").exists():
+                (out / f"rank{r}.npz").unlink()
     for c, (so, se) in zip(codes, logs):
         assert c == 0, (so[-2000:], se[-3000:])
 
@@ -181,10 +192,18 @@ def _check_against_cpu(r0, tol_final=1e-4):
     for a, b in zip(r0["num_cg_iters"].tolist(), st["num_cg_iters"][:n]):
         within(abs(a - b), 2, strict=False)
     # (the first step 1e-4; a later step starts from fp32-different parameters and back-tracking / the line search
-    # pick between nearly tied candidates: 1.6e-4 measured, 5e-4 stated)
+    # pick between nearly tied candidates: 1.6e-4 measured, 5e-4 stated -- only the loss VALUE carries the looser
+    # bound: the back-tracked iterate of every step must be the reference's or its neighbour on the storing grid,
+    # the learning rates are compared exactly above)
     for i, (a, b) in enumerate(zip(r0["finals"].tolist(), finals[:n])):
         within(abs(a - b), (tol_final if i == 0 else max(tol_final, 5e-4)) * abs(b), strict=False, note=(i, a, b))
+    grid = sorted({int(np.ceil(1.3 ** j)) - 1 for j in range(40)})  # (the storing grid of cg.py:152-170)
 
+    def pos(v):
+        return min(range(len(grid)), key=lambda i: abs(grid[i] - int(v)))
+
+    for a, b in zip(r0["best_cg_iters"].tolist(), st["best_cg_iters"][:n]):
+        assert abs(pos(a) - pos(b)) <= 1, (r0["best_cg_iters"].tolist(), st["best_cg_iters"][:n])
 
 @pytest.fixture(scope="module")
 def session_two_ranks(tmp_path_factory):
@@ -367,7 +386,7 @@ def test_bench_ladder_falls_to_the_single_graph_rung_when_the_two_phase_form_rai
 def test_bench_ladder_falls_past_a_rung_that_hangs():
     """``hang``: the last rank never returns from its first two-phase product; its peer waits in the collective.  The
     rung's wall-clock bound ends both, the next rung runs on fresh processes."""
-    rec, ar, err = _bench_two_ranks("hang", extra=("--rung-timeout", "150,300"))
+    rec, ar, err = _bench_two_ranks("hang", extra=("--rung-timeout", "75,300"))
     assert ar["rung"] == 1 and [f["rung"] for f in ar["rungs_failed"]] == [0]
     assert "wall-clock bound" in ar["rungs_failed"][0]["why"]
 
@@ -379,3 +398,24 @@ def test_bench_ladder_reaches_the_plainest_rung():
     rec, ar, err = _bench_two_ranks("raise:not_plain")
     assert ar["rung"] == 2 and [f["rung"] for f in ar["rungs_failed"]] == [0, 1]
     assert "torch.distributed.all_reduce" in ar["path"]
+
+
+def test_bench_under_torchrun_two_ranks_on_one_device():
+    """What the round driver runs for N > 1: ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``.
+    Every launched process supervises ITS rank as a child (it never touches the GPU), the launcher's store carries the
+    rendezvous; rank 0's supervisor prints the one line.  Two ranks share the one device over gloo: functional."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup",
+         "1", "--iters", "20", "--no-cpu-baseline"],
+        env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    ar = rec["config"]["allreduce"]
+    assert rec["n_gpus"] == 2 and ar["rung"] == 0 and ar["rungs_failed"] == [] and ar["ranks_seen"] == 2
+    assert ar["validation"]["single_graph_identical_on_all_ranks"] is True
+    assert "session" in rec["config"]["path_report"]["step"]["path"]

@@ -562,9 +562,12 @@ def test_fused_eval_batchnorm_matches_stock(dtype):
 
 def _run_worker(name, timeout=600, attempts=3):
     """Run tests/gpu_workers/<name> in its own interpreter; return its RESULT json.  A worker that is KILLED BY A
-    SIGNAL before it printed its result -- RCCL's watchdog / teardown aborts sporadically on this stack (SIGABRT inside
-    librccl / c10d, seen on 1 of ~6 leases) -- is started again, up to ``attempts`` times; its stderr is printed so
-    that the log shows what happened.  A worker that exits by itself with an error fails the test at once."""
+    SIGNAL before it printed its result is started again (up to ``attempts`` times) ONLY when its stderr carries the
+    signature of the known teardown abort of RCCL / c10d on this stack (SIGABRT inside librccl / the process group's
+    watchdog, seen on 1 of ~6 leases: tol.is_teardown_abort); every restart is recorded and counted against the
+    suite's budget (tol.note_retry).  Any other death fails the test at once."""
+    import tol
+
     import json
     import os
     import subprocess
@@ -578,8 +581,9 @@ def _run_worker(name, timeout=600, attempts=3):
         if lines:
             return json.loads(lines[-1][len("RESULT "):])
         print(f"[{name}] attempt {attempt + 1}: return code {p.returncode}, no RESULT line\n{p.stderr[-6000:]}", flush=True)
-        if p.returncode >= 0:
+        if not tol.is_teardown_abort(p.returncode, p.stderr, False):
             break
+        tol.note_retry(name, p.returncode, p.stderr)
     assert lines, (p.returncode, p.stdout[-1500:], p.stderr[-1500:])
 
 

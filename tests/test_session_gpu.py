@@ -498,7 +498,7 @@ def test_checkpoint_and_resume_on_the_session_path_is_bitwise():
 def test_frozen_stem_and_layer1_engine_product_and_session_steps_match_reference_trace():
     """The engine on a TRAINABLE SUBSET (the reference computes "in the subspace of trainable parameters",
     optimizer.py:121-123, utils.py:31-32; its own test problem freezes its first layer, tests/test_utils.py:39-43):
-    ResNet-18 with stem + layer1 frozen, N = 11 017 482 of 11 175 370 entries.  The frozen units are DEAD for the
+    ResNet-18 with stem + layer1 frozen, N = 11 024 138 of 11 175 370 entries.  The frozen units are DEAD for the
     sweeps (no tangent flows out of them, no cotangent is needed behind them): the tangent sweep starts and the adjoint
     sweep ends at layer2.  Against the REAL reference on the stock CPU model (golden ``convnet_resnet18_frozen.npz``):
     gradient 5e-6, one GGN product 2e-6 of its float64 twin and inside the fp32 envelope of the reference's own fp32
@@ -513,7 +513,7 @@ def test_frozen_stem_and_layer1_engine_product_and_session_steps_match_reference
     cp = [p for p in cm.parameters() if p.requires_grad]
     ref_s.check_inputs(cp, cx)
     ref_t.check_inputs(cp)
-    assert sum(p.numel() for p in cp) == 11017482
+    assert sum(p.numel() for p in cp) == 11024138
     model = tp.freeze_stem_and_layer1(cm).to(DEV)
     frozen0 = [p.detach().clone() for p in model.parameters() if not p.requires_grad]
     modelprep.prepare_model(model, channels_last=True)
@@ -528,7 +528,7 @@ def test_frozen_stem_and_layer1_engine_product_and_session_steps_match_reference
     assert sess is not None, why
     eng = sess.engine
     assert isinstance(eng, FusedGGNEngine) and eng.frozen_any and eng.stem.dead and eng.dead_blocks == 2
-    assert eng.n == 11017482
+    assert eng.n == 11024138
     within(abs(float(eng.loss_buf) - ref_s.scalar("loss")), 2e-6 * abs(ref_s.scalar("loss")), strict=False)
     got = sess.gradient()
     within(ref_s.vec_err("grad", got), 5e-6)
@@ -559,3 +559,52 @@ def test_frozen_stem_and_layer1_engine_product_and_session_steps_match_reference
     compare_trace(opt.state, finals, ref_t)
     for a, b in zip(frozen0, [p for p in model.parameters() if not p.requires_grad]):
         assert torch.equal(a, b.detach())
+
+
+def test_mse_loss_engine_product_and_session_steps_match_reference_trace():
+    """A mean-squared-error head on the engine / session (the loss of the reference's own examples and tests:
+    ``nn.MSELoss``, examples/run_mwe.py:19, tests/test_utils.py:47; ``_Gv`` takes any loss, optimizer.py:457-462):
+    loss Hessian ``(2 / numel) I``, gradient ``(2 / numel)(out - t)`` in the softmax head's place.  ResNet-18 against
+    one-hot targets, against the REAL reference on the stock CPU model (golden ``convnet_resnet18_mse.npz``): loss
+    2e-6, gradient 5e-6, one GGN product 2e-6 of its float64 twin and inside the reference's fp32 envelope, two
+    default steps through the persistent session (the tolerances of the cross-entropy trace)."""
+    from helpers import RefTrace, compare_trace
+
+    ref_s, ref_p, ref_t = (RefTrace("resnet18_mse", k) for k in ("solve_martens", "ggn_product", "steps"))
+    cm, (cx, _), lossf = tp.resnet18_mnist_mse(batch_size=32, device="cpu", data_seed=SEEDS[0])
+    cp = [p for p in cm.parameters() if p.requires_grad]
+    ref_s.check_inputs(cp, cx)
+    ref_t.check_inputs(cp)
+    model = cm.to(DEV)
+    modelprep.prepare_model(model, channels_last=True)
+    opt = hf.HessianFree(model.parameters(), graph_matvec=True)
+    opt._ensure_arena()
+    params = opt._params_list
+    _, (x, t), _ = tp.resnet18_mnist_mse(batch_size=32, device=DEV, data_seed=SEEDS[0])
+    out = model(x)
+    why = []
+    sess = EngineSession.try_create(lossf(out, t), out, params, why=why)
+    assert sess is not None, why
+    assert sess.engine.loss_spec["kind"] == "mse"
+    within(abs(float(sess.engine.loss_buf) - ref_s.scalar("loss")), 2e-6 * abs(ref_s.scalar("loss")), strict=False)
+    within(ref_s.vec_err("grad", sess.gradient()), 5e-6)
+    got_p = sess(ref_p.probe().to(DEV)).clone()
+    within(ref_p.vec_err64("", got_p), 2e-6)
+    within(ref_p.vec_err("", got_p), ref_p.envelope("", 2e-6))
+    del sess, out
+    finals = []
+    for i in range(2):
+        _, (xb, tb), _ = tp.resnet18_mnist_mse(batch_size=32, device="cpu", data_seed=SEEDS[i])
+        ref_t.check_inputs(x=xb, step=i)
+        xb, tb = xb.to(DEV), tb.to(DEV)
+
+        def forward():
+            o = model(xb)
+            return lossf(o, tb), o
+
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            finals.append(opt.step(forward))
+        assert not [w for w in rec if "slower path" in str(w.message)], [str(w.message) for w in rec]
+    assert opt._session is not None and opt._session.steps == 2 and opt.path_report()["step"]["path"] == "session"
+    compare_trace(opt.state, finals, ref_t)

@@ -232,3 +232,26 @@ def test_accumulated_session_merges_chunks_of_equal_per_sample_weight():
     net[1].eval()
     net[2].train()
     assert AccumulatedSession._merge_groups(net, slots, roles) == [[0], [1]]
+
+
+def test_mse_loss_spec_reads_the_loss_structure():
+    """``engine.mse_loss_spec`` / ``loss_spec_of``: the loss of the reference's own examples and tests (``nn.MSELoss``,
+    examples/run_mwe.py:19, tests/test_utils.py:47) is recognised structurally -- mean / sum, constant targets of the
+    outputs' shape, OF the given outputs -- and nothing else is."""
+    from pytorchhessianfree_amd.engine import loss_spec_of, mse_loss_spec
+
+    lin = torch.nn.Linear(4, 5)
+    out = lin(torch.randn(6, 4))
+    t = torch.randn(6, 5)
+    spec = mse_loss_spec(torch.nn.MSELoss()(out, t), out)
+    assert spec is not None and spec["kind"] == "mse" and spec["reduction"] == "mean" and torch.equal(spec["targets"], t)
+    assert mse_loss_spec(torch.nn.functional.mse_loss(out, t, reduction="sum"), out)["reduction"] == "sum"
+    assert loss_spec_of(torch.nn.MSELoss()(out, t), out)["kind"] == "mse"
+    assert loss_spec_of(torch.nn.functional.cross_entropy(out, torch.randint(0, 5, (6,))), out)["kind"] == "ce"
+    assert mse_loss_spec(torch.nn.functional.mse_loss(2.0 * out, t), out) is None       # not the error OF `outputs`
+    assert mse_loss_spec(torch.nn.functional.mse_loss(out, lin(torch.randn(6, 4))), out) is None  # differentiated targets
+    assert mse_loss_spec(torch.nn.functional.l1_loss(out, t), out) is None
+    assert mse_loss_spec(torch.nn.functional.mse_loss(out, t, reduction="none").mean(), out) is None
+    assert mse_loss_spec(torch.nn.functional.mse_loss(out, t) + 0.1 * out.sum(), out) is None
+    leaf = out.detach().clone().requires_grad_(True)  # (logits handed out as a leaf by a persistent session)
+    assert mse_loss_spec(torch.nn.functional.mse_loss(leaf, t), leaf) is not None

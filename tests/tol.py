@@ -27,7 +27,33 @@ def within(value, bound, strict=True, note=None):
     return True
 
 
+# Worker processes that are started again: only for the known RCCL / c10d teardown abort -- the process was
+# killed by a signal AND either had already delivered its result or its stderr carries the teardown's signature --, every
+# restart is recorded here, and the suite allows RETRY_BUDGET of them in total: a genuine SIGSEGV / SIGABRT inside
+# libhfpcg.so that shows up in one run of three can then no longer pass silently.
+RETRY_BUDGET = 3
+_RETRIES = []
+_TEARDOWN = ("rccl", "nccl", "processgroup", "c10d", "watchdog", "hipipc", "heartbeat")
+
+
+def is_teardown_abort(returncode, stderr, delivered):
+    """A worker killed by a signal (``returncode < 0``) whose death is the communication library's teardown abort:
+    it had written its result before it died, or its stderr names RCCL / the c10d process group / its watchdog."""
+    if returncode is None or returncode >= 0:
+        return False
+    text = (stderr or "").lower()
+    return bool(delivered) or any(word in text for word in _TEARDOWN)
+
+
+def note_retry(what, returncode, stderr_tail=""):
+    _RETRIES.append({"retry": what, "returncode": returncode, "stderr_tail": stderr_tail[-400:],
+                     "test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]})
+    assert len(_RETRIES) <= RETRY_BUDGET, ("more worker restarts than the suite's budget", _RETRIES)
+
+
 def dump(path):
     with open(path, "a") as fh:
         for rec in sorted(_SITES.values(), key=lambda r: -r["worst_ratio"]):
+            fh.write(json.dumps(rec) + "\n")
+        for rec in _RETRIES:
             fh.write(json.dumps(rec) + "\n")
