@@ -1039,7 +1039,7 @@ def main():
                 if val is not None:
                     line["roofline"]["traffic"] = val
                     line["roofline"]["traffic_source"] = (
-                        "static: profiles/traffic.json (round 5 binary, scripts/collect_r05_profiles.sh) -- rocprofv3 "
+                        "static: profiles/traffic.json (round 6 binary, scripts/collect_r06_profiles.sh) -- rocprofv3 "
                         "--pmc FETCH_SIZE / WRITE_SIZE passes taken on scripts/pcg_kernel_bench.py (the same kernel at "
                         "the same N; --pmc aborts this full command on this stack), not re-measured in this run")
             except Exception:

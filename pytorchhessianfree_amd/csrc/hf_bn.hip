@@ -531,6 +531,13 @@ __global__ __launch_bounds__(BLOCK) void k_bn_adjoint_rows(
 // Both column sums in one pass (all loads of both partial-row sets in flight together).  scratch: 8 * BLOCK doubles.
 // `between()` runs right after the first batch of partial-row loads is issued: the caller's own independent loads go
 // there, so that one round trip covers both.
+// HF_FCS_BATCH: how many partial rows of each set a thread keeps in flight per round trip.  The rows come out of the
+// memory-side cache (~0.6-1 us per dependent round trip); the consumers of a train-mode BatchNorm add up 64 ... 256 rows
+// per channel, i.e. 16 ... 32 per thread: 4 per batch = 4 ... 8 dependent round trips in the prologue of a launch that
+// otherwise takes ~4.6 us.  The order of the additions does not depend on it (bitwise the same sums).
+#ifndef HF_FCS_BATCH
+#define HF_FCS_BATCH 4
+#endif
 template <typename Between>
 __device__ __forceinline__ void final_column_sums2(const float* __restrict__ rows_a, const float* __restrict__ rows_b,
                                                    unsigned nrows, unsigned C, double* scratch, double* out_a,
@@ -539,18 +546,19 @@ __device__ __forceinline__ void final_column_sums2(const float* __restrict__ row
   const unsigned tx = threadIdx.x % quads, ty = threadIdx.x / quads;
   const bool live = ty < G;
   double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  F4 va[4], vb[4];
+  constexpr int NB = HF_FCS_BATCH;  // partial rows of each set in flight per thread and round trip
+  F4 va[NB], vb[NB];
   auto issue = [&](unsigned p0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NB; ++u) {
       const unsigned p = p0 + u * G < nrows ? p0 + u * G : 0u;
       va[u] = ld4(rows_a + (size_t)p * C + 4 * tx);
       vb[u] = ld4(rows_b + (size_t)p * C + 4 * tx);
     }
   };
-  auto add = [&](unsigned p0) {  // four partial rows of each set, added in row order
+  auto add = [&](unsigned p0) {  // NB partial rows of each set, added in row order
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < NB; ++u)
       if (p0 + u * G < nrows) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { a[k] += (double)va[u].e[k]; a[4 + k] += (double)vb[u].e[k]; }
@@ -564,14 +572,14 @@ __device__ __forceinline__ void final_column_sums2(const float* __restrict__ row
     // (pins the first use of the rows BEHIND the caller's loads: without it the compiler adds them up -- and waits
     // for them -- before it issues those)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NB; ++u) {
       asm volatile("" : "+v"(va[u].e[0]), "+v"(va[u].e[1]), "+v"(va[u].e[2]), "+v"(va[u].e[3]) : : "memory");
       asm volatile("" : "+v"(vb[u].e[0]), "+v"(vb[u].e[1]), "+v"(vb[u].e[2]), "+v"(vb[u].e[3]) : : "memory");
     }
     add(ty);
   }
   if (live) {
-    for (unsigned p0 = ty + 4 * G; p0 < nrows; p0 += 4 * G) { issue(p0); add(p0); }
+    for (unsigned p0 = ty + NB * G; p0 < nrows; p0 += NB * G) { issue(p0); add(p0); }
 #pragma unroll
     for (int k = 0; k < 8; ++k) scratch[(k * G + ty) * quads + tx] = a[k];
   }

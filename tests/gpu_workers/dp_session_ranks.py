@@ -13,8 +13,9 @@ curvature is a plain sum over samples, so shards of 16 + 16 equal one batch of 3
 mode: ``steps`` (default; the two-phase product forced) | ``auto`` (the session's measured choice between the
 single-graph and the two-phase product) | ``asym`` (rank 1's session creation is forced to fail on the first step: every
 rank must fall back together) | ``acc`` (``acc_step``: every rank passes ITS shard as two chunks -- the
-accumulated engine session under data parallelism) | ``die`` (the last rank exits mid-run: the others must not hang
-for good -- used through bench.py's launcher test instead).
+accumulated engine session under data parallelism) | ``frozen`` (stem + layer1 of the model frozen: the engine on a
+trainable subset under data parallelism -- single product graph, compact all-reduce of the trainable entries) | ``die``
+(the last rank exits mid-run: the others must not hang for good -- used through bench.py's launcher test instead).
 """
 
 import os
@@ -54,6 +55,8 @@ def main(outdir, mode="steps", backend="gloo"):
     out = {}
     try:
         model, _, lossf = tp.resnet18_mnist(batch_size=32, device=DEV, data_seed=SEEDS[0])
+        if mode == "frozen":
+            tp.freeze_stem_and_layer1(model)
         modelprep.prepare_model(model, channels_last=True)
         opt = hf.HessianFree(model.parameters(), graph_matvec=True, process_group=group)
         if mode == "asym" and rank == 1:

@@ -175,14 +175,14 @@ def _launch_session_ranks(out, world, mode="steps", backend="gloo", timeout=900,
         assert c == 0, (so[-2000:], se[-3000:])
 
 
-def _check_against_cpu(r0, tol_final=1e-4):
+def _check_against_cpu(r0, tol_final=1e-4, family="resnet18"):
     """Against the REAL reference's single-process run on the whole 32-sample batches (tests/golden/
     convnet_resnet18.npz, ``steps``: ``hessianfree.optimizer.HessianFree.step`` x 2 on the stock CPU model).  The
     rank workers build the same model and batches from the same seeds (digests checked in
     tests/test_session_gpu.py::test_session_steps_match_reference_trace)."""
     from helpers import RefTrace
 
-    ref = RefTrace("resnet18", "steps")
+    ref = RefTrace(family, "steps")
     st, finals = ref.state, ref.finals
     n = len(r0["init_losses"])
     np.testing.assert_allclose(r0["init_losses"], st["init_losses"][:n], rtol=1e-5)
@@ -284,6 +284,24 @@ def test_acc_step_two_ranks_accumulated_engine_session(tmp_path):
     assert r0["session_calls"].tolist() == r1["session_calls"].tolist()
     assert np.array_equal(r0["product_checksum"], r1["product_checksum"])
     _check_against_cpu(r0, tol_final=5e-4)
+
+
+def test_step_two_ranks_frozen_layers_engine_session_equals_reference_whole_batch(tmp_path):
+    """The engine on a trainable subset under data parallelism: stem + layer1 frozen (N = 11 024 138), shards of
+    16 + 16, two default steps through the drop-in API against the REAL reference's whole-batch run on the frozen
+    model (golden ``convnet_resnet18_frozen.npz``).  Both ranks take the persistent session (single product graph: the
+    late / early split of the two-phase form is laid out for the full net), stay bitwise identical, only the live
+    trainable entries travel, lockstep call counts."""
+    r0, r1 = _launch_session_ranks(tmp_path, 2, mode="frozen")
+    assert r0["session_mode"].tolist() == [1, 1] and r1["session_mode"].tolist() == [1, 1]
+    assert np.array_equal(r0["params"], r1["params"]) and r0["params"].shape[1] == 11024138
+    for r in (r0, r1):
+        assert r["session_calls"].tolist() == [n + 1 + 1 for n in r["num_cg_iters"].tolist()]
+        within(float(r["product_rel_err"][0]), 1e-6)
+    assert np.array_equal(r0["product_checksum"], r1["product_checksum"])
+    moved, full = (int(x) for x in r0["reduce_bytes"])
+    assert moved < 0.5 * full and full == 4 * 11024138
+    _check_against_cpu(r0, family="resnet18_frozen")
 
 
 def test_step_two_ranks_one_session_refused_falls_back_together(tmp_path):
