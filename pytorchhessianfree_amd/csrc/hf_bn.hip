@@ -534,9 +534,13 @@ __global__ __launch_bounds__(BLOCK) void k_bn_adjoint_rows(
 // HF_FCS_BATCH: how many partial rows of each set a thread keeps in flight per round trip.  The rows come out of the
 // memory-side cache (~0.6-1 us per dependent round trip); the consumers of a train-mode BatchNorm add up 64 ... 256 rows
 // per channel, i.e. 16 ... 32 per thread: 4 per batch = 4 ... 8 dependent round trips in the prologue of a launch that
-// otherwise takes ~4.6 us.  The order of the additions does not depend on it (bitwise the same sums).
+// otherwise takes ~4.6 us.  The order of the additions does not depend on it (bitwise the same sums).  Measured, same box
+// (profiles/r06_fcs_batch_ab.jsonl, bench.py --bn train): 4 -> 1 174 / 1 190, 8 -> 1 211 / 1 208, 16 -> 1 201 / 1 202
+// matvecs/s.  (A column-blocked workgroup mapping -- 64 rows x 16 channels, a quarter ... a 32nd of the redundant
+// partial-row traffic and one round trip -- was built and measured at NO gain: 1 196-1 199 against 1 200,
+// profiles/r06_colblock_rejected.jsonl; removed.)
 #ifndef HF_FCS_BATCH
-#define HF_FCS_BATCH 4
+#define HF_FCS_BATCH 8
 #endif
 template <typename Between>
 __device__ __forceinline__ void final_column_sums2(const float* __restrict__ rows_a, const float* __restrict__ rows_b,

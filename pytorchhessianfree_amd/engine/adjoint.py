@@ -51,7 +51,7 @@ class _AdjointSweep:
         lib, st = _lib.load(), _lib.current_stream_ptr(self.dev)
         n, k, oh, ow = u.a.shape
         v = self._v
-        v_gamma = v[self._offs[u.pg]: self._offs[u.pg] + k]
+        v_gamma = v[self._offs[u.pg]: self._offs[u.pg] + k] if u.pg is not None else self._zeros(k)  # (frozen scale)
         if not self._extras_parallel:
             self._hessian_extras(u)
         if u.train:
@@ -72,7 +72,7 @@ class _AdjointSweep:
             _lib.check(lib.hf_chan_affine_ex(
                 _ptr(u.gah), _ptr(u.g1), None, None, _ptr(u.rstd), _ptr(v_gamma), None, None, _ptr(u.ga), None, 0, n,
                 k, oh * ow, 1, 0, 0, 1, 0, _lib.HF_F32, st), "hf_chan_affine_ex")
-        if self._extras_mode == 2 and not u.im2col and not u.first:
+        if self._extras_mode == 2 and not u.im2col and not u.first and u.sD:
             # the chain's launch also computes conv_D(g_a, V) -- the one extra term the chain itself needs next
             _lib.conv_group_slabs([(1, u.dbuf, u.gah, u.wT, u.geo, u.sD, 0, 0), (2, u.wbuf, u.x, u.gah, u.geo, u.sW, 0, 0),
                                    (1, u.dbuf[u.sD:], u.ga1, u.vT, u.geo, u.sD, 0, 0)], self.dev)
@@ -267,7 +267,7 @@ class _AdjointSweep:
             tensors, perms, splits = self._pack_args()
             splits = dict(splits)
             for u in self.units:
-                if u.nW != u.sW:
+                if u.pw is not None and u.nW != u.sW:
                     if u.sW > 1:
                         splits[u.pw] = (u.sW, u.wbuf.shape[1])
                     else:

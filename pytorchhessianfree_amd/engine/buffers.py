@@ -115,7 +115,8 @@ class _Buffers:
                     u.g1 = torch.empty_like(u.a)   # ... and of the BatchNorm output (masked), per step
                     u.gah = torch.empty_like(u.a)  # g_a' + g_z * rstd * v_gamma: what the convolutions' adjoints read
                 if u.sD:
-                    u.vT = torch.empty((c, r, s, k), dtype=f32, device=dev)  # V as (I, H, W, O), per product
+                    # V as (I, H, W, O), per product (a frozen weight has V = 0: zeros, never scattered into)
+                    u.vT = torch.zeros((c, r, s, k), dtype=f32, device=dev)
             u.g = torch.empty_like(u.a) if u.needs_g else None  # masked cotangent of the unit's output
             u.ga = torch.empty_like(u.a)   # cotangent of the convolution output
             # the BatchNorm adjoint shares the rows among `rb` workgroups per channel column; the
@@ -159,7 +160,7 @@ class _Buffers:
                     # Hessian products (hf_bn_train_hessian_*): the tangent sweep's partial sums must outlive the
                     # adjoint's (which share gw / gb in a GGN product); six coefficient vectors; the layer's
                     # first-order parameter gradients (per step)
-                    if u.pg is None or u.pb is None:
+                    if u.bn.weight is None or u.bn.bias is None:  # (frozen scale / shift are fine: constants)
                         raise _Unsupported(f"{u.name}: Hessian products need an affine train-mode BatchNorm")
                     u.hx = torch.empty((u.rb, k), dtype=f32, device=dev)
                     u.h1 = torch.empty((u.rb, k), dtype=f32, device=dev)
@@ -189,7 +190,7 @@ class _Buffers:
         self._frozen_w = [u for u in self.units if not u.im2col and u.pw is None]
         self._frozen_seen = {}
         self._vt_slots = [(self._offs[u.pw], u.vT, u.x.shape[1]) for u in self.units
-                          if self.hessian and not u.im2col and u.sD]
+                          if self.hessian and not u.im2col and u.sD and u.pw is not None]
         self._allocate_pool()
         self._allocate_head()
         # the parameters as ONE flat vector, when they are consecutive views of one (the optimizer's

@@ -123,9 +123,6 @@ class FusedGGNEngine(_Topology, _Buffers, _Forward, _TangentSweep, _AdjointSweep
         self.train_bn = False
         self.frozen_any, self.dead_blocks = False, 0
         self._layout(model)
-        if self.frozen_any and self.hessian:
-            raise _Unsupported("Hessian products with frozen layer parameters (requires_grad = False) are not covered "
-                               "by the engine; GGN products are")
         if self.hessian:
             for u in self.units:
                 u.needs_g = True  # (the first-order masked cotangent of every unit is kept)

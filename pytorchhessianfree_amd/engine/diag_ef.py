@@ -19,8 +19,8 @@ class _DiagEF:
         cotangents ARE the per-sample cotangents -- followed, per sample, by the weight-gradient convolutions on that
         sample's rows and one squaring gather (``hf_pack_ex`` mode 1).  A tagged L2 term (each per-sample loss of
         the reference carries it whole) enters in closed form: sum (a_i + b)^2 = sum a_i^2 + 2 b sum a_i + N b^2."""
-        if self.loss_spec is None or self.train_bn or self.frozen_any:
-            raise RuntimeError("engine.diag_ef needs a softmax cross-entropy loss, eval-mode BatchNorm and no frozen layer")
+        if self.loss_spec is None or self.train_bn:
+            raise RuntimeError("engine.diag_ef needs a softmax cross-entropy / MSE loss and eval-mode BatchNorm")
         if self.loss_spec["reduction"] != reduction:
             raise RuntimeError("engine.diag_ef: the loss's reduction differs from the requested one")
         n = self.x_in.shape[0]
@@ -39,12 +39,18 @@ class _DiagEF:
         tensors, perms, splits = self._diag_pack
         for i in range(n):
             for u in self.units:
+                if u.dead:  # (frozen, behind frozen layers only: the sweep left no cotangent here, nothing is gathered)
+                    continue
                 ga = (u.ga1 if first_order else u.ga)[i:i + 1]
-                if u.im2col:
+                if u.pw is None:
+                    pass  # (frozen weight: no entry)
+                elif u.im2col:
                     self._conv_slabs(2, u.wps, u.cols_pad[i:i + 1], ga, u.geo_w1, u.sW1, out_c=u.jcols)
                 else:
                     self._conv_slabs(2, u.wps, u.x[i:i + 1], ga, u.geo1, u.sW1)
                 k, hw = u.a.shape[1], u.a.shape[2] * u.a.shape[3]
+                if u.pg is None and u.pb is None:
+                    continue
                 if u.bn is not None:
                     g = (u.g1 if first_order else u.g)[i:i + 1]
                     _lib.check(lib.hf_chan_affine_bwd_ex(
@@ -90,13 +96,14 @@ class _DiagEF:
                 n_, h, w, c, k_, r, s_, sd, pd = u.geo1
                 u.sW1 = _lib.conv_plan(2, 1, h, w, c, k_, r, s_, sd, pd)
             u.wps = torch.zeros((u.sW1, u.conv.weight.numel()), dtype=f32, device=dev)  # dead taps stay 0
-            tensors[u.pw] = u.wps[0]
-            if not u.im2col:
-                k_, c, r, s_ = u.conv.weight.shape
-                if r * s_ > 1:
-                    perms[u.pw] = (c, r * s_)
-            if u.sW1 > 1:
-                splits[u.pw] = (u.sW1, u.wps.shape[1])
+            if u.pw is not None:
+                tensors[u.pw] = u.wps[0]
+                if not u.im2col:
+                    k_, c, r, s_ = u.conv.weight.shape
+                    if r * s_ > 1:
+                        perms[u.pw] = (c, r * s_)
+                if u.sW1 > 1:
+                    splits[u.pw] = (u.sW1, u.wps.shape[1])
             u.gws = torch.zeros((1, k), dtype=f32, device=dev)
             u.gbs = torch.zeros((1, k), dtype=f32, device=dev)
             if u.pg is not None:

@@ -17,13 +17,15 @@ class _HessianExtras:
         results and the step's first-order cotangents: the scale's  sum_rows g_z * rstd * t_a  (t_a = the sum of the
         tangent convolution's slabs, still in place) as `rb` more partial rows of the gw buffer, and conv_D(g_a, V) /
         conv_W(t_x, g_a) as MORE SLABS of the same buffers (the consumers sum them anyway)."""
+        if u.dead:  # (frozen, behind frozen layers only: no tangent reaches it, no cotangent is needed behind it)
+            return
         if u.bn is not None and not u.train:  # (train mode: the tangent sweep left this sum, engine/tangent.py)
             n, k, oh, ow = u.a.shape
             _lib.check(_lib.load().hf_chan_affine_bwd_ex(
                 None, _ptr(u.gw[u.rb:]), None, None, _ptr(u.tbuf), u.sT, u.tbuf.shape[1], None, 1, 0, _ptr(u.g1),
                 _ptr(self._zeros(k)), _ptr(u.rstd), None, None, n, k, oh * ow, 1, u.rb, _lib.HF_F32,
                 _lib.current_stream_ptr(self.dev)), "hf_chan_affine_bwd_ex")
-        if not u.im2col and not u.first:
+        if not u.im2col and not u.first and u.sD:  # (u.sD == 0: a tangent-free input -- both terms vanish)
             c = u.x.shape[1]
             if self._extras_mode == 2:  # (conv_D(g_a, V) rides in the chain's launch: only the weight term here)
                 self._conv_slabs(2, u.wbuf[u.sW:], u.xcat, u.ga1, u.geo, u.sW, act_ld=2 * c)

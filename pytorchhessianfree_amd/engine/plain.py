@@ -88,11 +88,21 @@ class PlainStackEngine(FusedGGNEngine):
         self.units, self.tail, self.blocks = units, units[-1], []
         self.stem, self.pool_args, self.fc, self.pfw, self.pfb = None, None, None, None, None
         self.model_ref, self._in_shape = model, tuple(x_in.shape)
-        if self.frozen_any:
-            raise _Unsupported("frozen layer parameters: the plain-stack engine covers fully trainable stacks")
         used = {i for u in units for i in (u.pw, u.pb) if i is not None}
         if used != set(range(len(self.params))):
             raise _Unsupported("the parameter list has entries the engine's layers do not cover")
+        # frozen layers at the input end (round 6, as FusedGGNEngine._mark_dead_prefix): dead for both sweeps; the first
+        # layer with a trainable parameter reads a tangent-free input and needs no data gradient
+        self.dead_units = 0
+        for u in units:
+            if u.pw is not None or u.pb is not None:
+                break
+            u.dead = True
+            self.dead_units += 1
+        if self.dead_units == len(units):
+            raise _Unsupported("every layer is frozen")
+        if self.dead_units:
+            units[self.dead_units].no_dgrad = True
 
     def _allocate_pool(self):
         pass
@@ -129,14 +139,18 @@ class PlainStackEngine(FusedGGNEngine):
     def _tangent_sweep(self, v):
         first = self.units[0]
         carried = False
-        if first.im2col:  # (the first layer's launch carries the v_W scatter of all the others)
-            vw = v[self._offs[first.pw]: self._offs[first.pw] + first.conv.weight.numel()]
+        if first.im2col and not first.dead:  # (the first layer's launch carries the v_W scatter of all the others)
+            vw = (v[self._offs[first.pw]: self._offs[first.pw] + first.conv.weight.numel()] if first.pw is not None
+                  else self._zeros(first.conv.weight.numel()))
             carried = self._conv_carrying_scatter(first, vw, first.sT, v, 1)
         if self._slot_list and not carried:
             _lib.unpack_tangent(v, self._slot_list)  # v_W halves of all [W | v_W] operands: one launch
         for u in self.units:
+            if u.dead:  # (frozen, behind frozen layers only: no tangent)
+                continue
             if u.im2col:  # no input tangent: conv(x, v_W) as a 1x1 product over the im2col
-                vw = v[self._offs[u.pw]: self._offs[u.pw] + u.conv.weight.numel()]
+                vw = (v[self._offs[u.pw]: self._offs[u.pw] + u.conv.weight.numel()] if u.pw is not None
+                      else self._zeros(u.conv.weight.numel()))
                 if not (carried and u is first):
                     self._conv_slabs(0, u.tbuf, u.cols, vw, u.geo, u.sT)
             else:
@@ -150,9 +164,11 @@ class PlainStackEngine(FusedGGNEngine):
         srcs = [(g_last, 1, 0)]
         self._second = second  # (the chain waits for the side branch's slabs, _extras_wait)
         for u in reversed(self.units):
+            if u.dead:  # (nobody needs a cotangent behind the first trainable layer)
+                break
             ga = u.ga1 if (self.hessian and first_order) else u.ga
             self._bn_adjoint(u, srcs, ga)
-            if second and not u.im2col and not u.first:
+            if second and not u.im2col and not u.first and u.sD:
                 # (two launches of two problems each; four in one grouped launch ran 3x slower -- with four
                 # by-value problem descriptions hipcc spills them to scratch memory.  The second one -- conv_D(g, V),
                 # conv_W(t_x, g): no dependence on this chain -- runs on the side branch, see _extras_fork)

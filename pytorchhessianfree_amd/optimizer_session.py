@@ -132,7 +132,7 @@ class _SessionSteps:
                 or reduction not in ("mean", "sum")):
             return None
         eng = sess.engine
-        if (model is not eng.model_ref or eng.train_bn or eng.loss_spec is None or getattr(eng, "frozen_any", False)
+        if (model is not eng.model_ref or eng.train_bn or eng.loss_spec is None
                 or not isinstance(inputs, torch.Tensor) or tuple(inputs.shape) != tuple(eng.x_in.shape)):
             return None
         from .engine import loss_spec_of

@@ -57,7 +57,7 @@ def next_pool_stream(cur, candidates=8):
     """(experiment) the NEXT pool stream whatever the probe says; the probe's verdict is recorded."""
     cand = torch.cuda.Stream()
     picked.append(bool(hfsession._runs_beside(cand, cur)))
-    return cand
+    return cand, picked[-1]  # (round 6: the probe's verdict is returned and kept on the session)
 
 
 run("single graph + one compact all-reduce", "0")

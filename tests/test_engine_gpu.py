@@ -605,7 +605,7 @@ def test_train_mode_prologue_form_variants_agree_and_state_is_independent_of_the
     assert torch.equal(op.logits, logits)  # (bitwise repeatable)
 
 
-@pytest.mark.parametrize("case", ["allcnnc_l2", "allcnnc_hessian", "resnet18", "resnet18_sum"])
+@pytest.mark.parametrize("case", ["allcnnc_l2", "allcnnc_hessian", "resnet18", "resnet18_sum", "resnet18_frozen"])
 def test_engine_diag_ef_matches_per_sample_autograd(case):
     """The diagonal of the empirical Fisher ``(1/N) sum_i g_i^2`` (reference preconditioners.py:11-105: one backward
     pass per sample, or BackPACK's ``SumGradSquared``) from ONE adjoint sweep of the engine + per-sample weight-gradient
@@ -620,6 +620,9 @@ def test_engine_diag_ef_matches_per_sample_autograd(case):
     else:
         model, (x, t), _ = tp.resnet18_mnist(batch_size=8, device=DEV, data_seed=tp.RESNET18_B32_SEPARATED_SEEDS[0])
         lossf = torch.nn.CrossEntropyLoss(reduction=reduction)
+        if case == "resnet18_frozen":  # (round 6: stem + layer1 frozen -- dead units are skipped, no entries for them)
+            tp.freeze_stem_and_layer1(model)
+            list(model.layers)[4].bn2.weight.requires_grad_(False)  # ... and one frozen scale inside the live region
     modelprep.prepare_model(model, channels_last=True)
     params = [p for p in model.parameters() if p.requires_grad]
     out = model(x)
@@ -1097,3 +1100,150 @@ def test_train_mode_batchnorm_launches_against_float64_formulas(rows, ch, splits
     within(float((r_out.double() * (a64.var(0, unbiased=False) + 1e-5).sqrt() - 1).abs().max()), 2e-6)
     within(float((rm.double() - (0.9 * rm0.double() + 0.1 * a64.mean(0))).abs().max()), 1e-6)
     within(float((rv.double() - (0.9 * rv0.double() + 0.1 * a64.var(0, unbiased=True))).abs().max()), 2e-6 * float(rv.abs().max()))
+
+
+def _freeze(model, pattern):
+    blocks = list(model.layers)
+    if pattern == "stem_conv_only":           # frozen weight under a trainable BatchNorm: conv(x, 0) = 0, not dead
+        model.conv1.weight.requires_grad_(False)
+    elif pattern == "mid_block_conv2":        # a frozen weight INSIDE the live region (tangent flows through it)
+        blocks[3].conv2.weight.requires_grad_(False)
+    elif pattern == "all_batchnorm":          # every scale / shift frozen, every convolution trained
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.requires_grad_(False)
+                m.bias.requires_grad_(False)
+    elif pattern == "stem_and_first_block":   # dead prefix that ends INSIDE layer1: an identity block reads a tangent-free input
+        for mod in (model.conv1, model.bn1, blocks[0]):
+            for p in mod.parameters():
+                p.requires_grad_(False)
+    elif pattern == "up_to_layer3":           # dead prefix of six blocks: the first live block has a downsample branch
+        for mod in (model.conv1, model.bn1, *blocks[:6]):
+            for p in mod.parameters():
+                p.requires_grad_(False)
+    elif pattern == "stem_layer1_train":
+        tp.freeze_stem_and_layer1(model)
+        model.train()
+    else:
+        raise ValueError(pattern)
+    return model
+
+
+@pytest.mark.parametrize("pattern", ["mid_block_conv2", "all_batchnorm", "stem_and_first_block", "up_to_layer3",
+                                     "stem_layer1_train"])
+def test_engine_hessian_products_with_frozen_parameter_patterns_match_float64(pattern):
+    """The same patterns under ``curvature_opt="hessian"`` (optimizer.py:450-455): forward-over-reverse with the
+    second-order terms of dead units skipped, ``V = 0`` for a frozen weight, ``v_gamma = 0`` for a frozen scale.  Against
+    float64 double backward of the stock model with the same tensors frozen, on the engine's ReLU decisions: 2e-6
+    (train mode 1e-5), bitwise repeatable; the one-sweep gradient 2e-6."""
+    def make(device=DEV, **kw):
+        model, data, lossf = tp.resnet18_mnist(device=device, **kw)
+        return _freeze(model, pattern), data, lossf
+
+    model, (x, t), lossf = make(batch_size=16, data_seed=3)
+    modelprep.prepare_model(model, channels_last=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    why = []
+    op = FusedGGNEngine.try_build(lossf(out, t), out, params, hessian=True, why=why)
+    assert isinstance(op, FusedGGNEngine) and op.hessian and op.frozen_any, why
+    v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))
+    got = op(v).clone()
+    assert torch.equal(op(v), got)
+    ref, (rx, rt), rl = make(batch_size=16, data_seed=3)
+    ref, rx = ref.double(), rx.double()
+    _replay_relu_decisions(ref, [(u.y > 0) for u in op.units if u.relu])
+    rp = [p for p in ref.parameters() if p.requires_grad]
+    rloss = rl(ref(rx), rt)
+    want = curvature.HessianOperator(rloss, rp)(v.double())
+    train = pattern == "stem_layer1_train"
+    within(float((got.double() - want).abs().max() / want.abs().max()), 1e-5 if train else 2e-6)
+    grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(rloss, rp)])
+    within(float((op.gradient().double() - grad).abs().max() / grad.abs().max()), 1e-5 if train else 2e-6)
+
+
+@pytest.mark.parametrize("pattern", ["stem_conv_only", "mid_block_conv2", "all_batchnorm", "stem_and_first_block",
+                                     "up_to_layer3", "stem_layer1_train"])
+def test_engine_products_with_frozen_parameter_patterns_match_float64(pattern):
+    """The engine "in the subspace of trainable parameters" (reference optimizer.py:121-123, utils.py:31-32) for frozen
+    patterns beyond the fixture's stem + layer1: frozen tensors inside the live region (no tangent term, no gather
+    entry), dead prefixes that end inside a stage or in front of a downsample block, train-mode BatchNorm behind a
+    frozen prefix.  Each against float64 autograd of the stock model with the same tensors frozen, on the engine's own
+    ReLU decisions: 1e-6 (train mode 1e-5, as the unfrozen nets), bitwise repeatable."""
+    def make(device=DEV, **kw):
+        model, data, lossf = tp.resnet18_mnist(device=device, **kw)
+        return _freeze(model, pattern), data, lossf
+
+    model, (x, t), lossf = make(batch_size=16, data_seed=3)
+    modelprep.prepare_model(model, channels_last=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    why = []
+    op = FusedGGNEngine.try_build(lossf(out, t), out, params, why=why)
+    assert isinstance(op, FusedGGNEngine), why
+    assert op.frozen_any and op.n == sum(p.numel() for p in params)
+    expect_dead = {"stem_and_first_block": 1, "up_to_layer3": 6, "stem_layer1_train": 2}.get(pattern, 0)
+    assert op.dead_blocks == expect_dead and op.stem.dead == (expect_dead > 0)
+    v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    got = op(v).clone()
+    assert torch.equal(op(v), got)
+    if pattern == "stem_layer1_train":
+        ref, (rx, rt), rl = make(batch_size=16, data_seed=3)
+        ref, rx = ref.double(), rx.double()
+        _replay_relu_decisions(ref, [(u.y > 0) for u in op.units if u.relu])
+        rp = [p for p in ref.parameters() if p.requires_grad]
+        ro = ref(rx)
+        want = curvature.GGNOperator(rl(ro, rt), ro, rp)(v.double())
+        within(float((got.double() - want).abs().max() / want.abs().max()), 1e-5)
+    else:
+        want = _float64_product(make, v, masks=[(u.y > 0) for u in op.units if u.relu], batch_size=16, data_seed=3)
+        within(float((got.double() - want).abs().max() / want.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize("hessian", [False, True], ids=["ggn", "hessian"])
+def test_allcnnc_plain_stack_engine_with_frozen_layers_matches_float64(hessian):
+    """The plain-stack engine (All-CNN-C, BASELINE configs[3]'s topology) on a trainable subset: the first two
+    convolution layers frozen (dead for both sweeps: the tangent sweep starts at the third layer with a tangent-free
+    input, the adjoint sweep ends there without a data gradient), plus a frozen bias and a frozen weight inside the live
+    region.  GGN and Hessian products against float64 autograd of the stock model with the same tensors frozen (1e-6 /
+    2e-6; All-CNN-C's ReLU inputs at this seed stay clear of zero: the plain float64 product), bitwise repeatable;
+    gradient 2e-6; the diagonal empirical Fisher against the per-sample autograd loop 1e-5."""
+    from pytorchhessianfree_amd.engine import PlainStackEngine
+
+    def make(device=DEV, **kw):
+        model, data, lossf = tp.allcnnc_cifar100(device=device, **kw)
+        convs = [m for m in model.modules() if isinstance(m, torch.nn.Conv2d)]
+        for m in convs[:2]:
+            for p in m.parameters():
+                p.requires_grad_(False)
+        convs[4].bias.requires_grad_(False)
+        convs[6].weight.requires_grad_(False)
+        return model, data, lossf
+
+    model, (x, t), lossf = make(batch_size=8, data_seed=3)
+    modelprep.prepare_model(model, channels_last=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    why = []
+    op = FusedGGNEngine.try_build(lossf(out, t), out, params, hessian=hessian, why=why)
+    assert isinstance(op, PlainStackEngine) and op.frozen_any and op.dead_units == 2, why
+    v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(8))
+    got = op(v).clone()
+    assert torch.equal(op(v), got)
+    ref, (rx, rt), rl = make(batch_size=8, data_seed=3)
+    ref, rx = ref.double(), rx.double()
+    rp = [p for p in ref.parameters() if p.requires_grad]
+    ro = ref(rx)
+    rloss = rl(ro, rt)
+    want = (curvature.HessianOperator(rloss, rp) if hessian else curvature.GGNOperator(rloss, ro, rp))(v.double())
+    within(float((got.double() - want).abs().max() / want.abs().max()), 2e-6 if hessian else 1e-6)
+    grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(rloss, rp)])
+    within(float((op.gradient().double() - grad).abs().max() / grad.abs().max()), 2e-6)
+    got_d = op.diag_ef("mean").clone()
+    want_d = torch.zeros_like(got_d)
+    for i in range(x.shape[0]):
+        g_i = torch.autograd.grad(lossf(model(x[i:i + 1]), t[i:i + 1]), params)
+        want_d += torch.cat([g.reshape(-1) for g in g_i]) ** 2
+    want_d /= x.shape[0]
+    within(float((got_d - want_d).abs().max() / want_d.abs().max()), 1e-5)
+    assert torch.equal(op(v), got)
