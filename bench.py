@@ -147,6 +147,7 @@ def supervise(args):
     -- after the final barrier of the run -- whatever the teardown does afterwards.  The supervisor never initialises
     the GPU (``device_count`` only)."""
     import datetime
+    import shutil
     import signal
     import subprocess
     import tempfile
@@ -259,9 +260,11 @@ def supervise(args):
                     for ln in open(out_path).read().splitlines():
                         if ln.startswith("{"):
                             print(ln, flush=True)
+            shutil.rmtree(tmp, ignore_errors=True)
             raise SystemExit(0)
         print(f"[bench] rung {k} ({name}) failed: {why}", file=sys.stderr, flush=True)
         failed.append({"rung": k, "name": name, "why": why})
+    shutil.rmtree(tmp, ignore_errors=True)
     raise SystemExit(3)
 
 

@@ -297,3 +297,32 @@ def test_acc_step_train_mode_hessian_session_equals_generic_accumulation(monkeyp
     assert torch.equal(sess(v), got)
     want = a._acc_mvp(model, lossf, chunks, "hessian", "mean", v)
     within(float((got - want).abs().max() / want.abs().max()), 1e-4)  # (9.8e-6 measured)
+
+
+def test_acc_step_with_mse_loss_on_engine_equals_step_on_whole_batch():
+    """``acc_step`` under the loss of the reference's own acc tests (``nn.MSELoss``, tests/test_optimizer_acc.py:47-60)
+    on the engine: chunks [20, 12] of float targets merge into one engine batch and equal ``step`` on the 32-sample
+    batch (the reference's bar for this equivalence: 1e-4, test_optimizer_acc.py:175); reduction ``sum`` likewise."""
+    for reduction in ("mean", "sum"):
+        runs = []
+        for kind in ("acc", "step"):
+            model, (x, t), _ = tp.resnet18_mnist_mse(batch_size=32, device=DEV, data_seed=SEEDS[0])
+            lossf = torch.nn.MSELoss(reduction=reduction)
+            modelprep.prepare_model(model, channels_last=True)
+            opt = hf.HessianFree(model.parameters(), graph_matvec=True, cg_max_iter=10)
+
+            def forward():
+                out = model(x)
+                return lossf(out, t), out
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                if kind == "acc":
+                    final = opt.acc_step(model, lossf, _chunks(x, t, (20, 12)), reduction=reduction)
+                    sess = opt._acc_session
+                    assert sess is not None and sess.merged and sess.engines[0].loss_spec["kind"] == "mse"
+                else:
+                    final = opt.step(forward)
+                    assert opt._session is not None
+            runs.append((opt, [final]))
+        _same_trace(*runs[0], *runs[1])
