@@ -1135,7 +1135,7 @@ def test_engine_hessian_products_with_frozen_parameter_patterns_match_float64(pa
     """The same patterns under ``curvature_opt="hessian"`` (optimizer.py:450-455): forward-over-reverse with the
     second-order terms of dead units skipped, ``V = 0`` for a frozen weight, ``v_gamma = 0`` for a frozen scale.  Against
     float64 double backward of the stock model with the same tensors frozen, on the engine's ReLU decisions: 2e-6
-    (train mode 1e-5), bitwise repeatable; the one-sweep gradient 2e-6."""
+    (train mode 1.5e-5), bitwise repeatable; the one-sweep gradient 2e-6."""
     def make(device=DEV, **kw):
         model, data, lossf = tp.resnet18_mnist(device=device, **kw)
         return _freeze(model, pattern), data, lossf
@@ -1157,7 +1157,8 @@ def test_engine_hessian_products_with_frozen_parameter_patterns_match_float64(pa
     rloss = rl(ref(rx), rt)
     want = curvature.HessianOperator(rloss, rp)(v.double())
     train = pattern == "stem_layer1_train"
-    within(float((got.double() - want).abs().max() / want.abs().max()), 1e-5 if train else 2e-6)
+    # (train mode through batch statistics behind a frozen prefix: 4.1e-6 measured; stated 1.5e-5)
+    within(float((got.double() - want).abs().max() / want.abs().max()), 1.5e-5 if train else 2e-6)
     grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(rloss, rp)])
     within(float((op.gradient().double() - grad).abs().max() / grad.abs().max()), 1e-5 if train else 2e-6)
 
@@ -1169,7 +1170,7 @@ def test_engine_products_with_frozen_parameter_patterns_match_float64(pattern):
     patterns beyond the fixture's stem + layer1: frozen tensors inside the live region (no tangent term, no gather
     entry), dead prefixes that end inside a stage or in front of a downsample block, train-mode BatchNorm behind a
     frozen prefix.  Each against float64 autograd of the stock model with the same tensors frozen, on the engine's own
-    ReLU decisions: 1e-6 (train mode 1e-5, as the unfrozen nets), bitwise repeatable."""
+    ReLU decisions: 1e-6 (train mode 1.5e-5), bitwise repeatable."""
     def make(device=DEV, **kw):
         model, data, lossf = tp.resnet18_mnist(device=device, **kw)
         return _freeze(model, pattern), data, lossf
@@ -1194,7 +1195,7 @@ def test_engine_products_with_frozen_parameter_patterns_match_float64(pattern):
         rp = [p for p in ref.parameters() if p.requires_grad]
         ro = ref(rx)
         want = curvature.GGNOperator(rl(ro, rt), ro, rp)(v.double())
-        within(float((got.double() - want).abs().max() / want.abs().max()), 1e-5)
+        within(float((got.double() - want).abs().max() / want.abs().max()), 1.5e-5)  # (3.8e-6 measured)
     else:
         want = _float64_product(make, v, masks=[(u.y > 0) for u in op.units if u.relu], batch_size=16, data_seed=3)
         within(float((got.double() - want).abs().max() / want.abs().max()), 1e-6)
