@@ -185,7 +185,12 @@ def freeze_stem_and_layer1(model):
     """``requires_grad = False`` on the stem (conv1, bn1) and layer1 of a ResNet: the optimizer then works "in the
     subspace of trainable parameters" (reference optimizer.py:121-123, utils.py:31-32; its own test problem freezes
     its first layer, tests/test_utils.py:39-43).  Returns the model."""
-    layer1 = list(model.layers)[:2] if hasattr(model, "layers") else [model.layer1]  # (torchvision's layer1: 2 blocks)
+    if hasattr(model, "layers"):  # (torchvision's layer1 = the blocks in front of the first STRIDED block)
+        blocks = list(model.layers)
+        n1 = next((i for i, b in enumerate(blocks) if i > 0 and getattr(b, "downsample", None) is not None), len(blocks))
+        layer1 = blocks[:n1]
+    else:
+        layer1 = [model.layer1]
     for mod in (model.conv1, model.bn1, *layer1):
         for p in mod.parameters():
             p.requires_grad_(False)
