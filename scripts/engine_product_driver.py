@@ -226,6 +226,7 @@ def main():
     ap.add_argument("--workload", default="resnet18", choices=["resnet18", "allcnnc", "resnet50"])
     ap.add_argument("--curvature", default="ggn", choices=["ggn", "hessian"])
     ap.add_argument("--bn", default="eval", choices=["eval", "train"])
+    ap.add_argument("--freeze", default="", choices=["", "stem+layer1"])
     args = ap.parse_args()
     hf.configure()
     dev = "cuda"
@@ -237,6 +238,8 @@ def main():
         model, (x, t), lossf = tp.resnet50_small_images(batch_size=32, device=dev)
     if args.bn == "train":
         model.train()
+    if args.freeze:
+        tp.freeze_stem_and_layer1(model)
     modelprep.prepare_model(model, channels_last=True)
     params = [p for p in model.parameters() if p.requires_grad]
     out = model(x)
