@@ -13,6 +13,7 @@ from .common import _Unsupported, _flat_view, _live_taps, _pair, _ptr
 
 
 class _Buffers:
+    ADJ_BYTES_PER_WG = 32768  # the BatchNorm adjoint's row-major kernel: one workgroup per this many bytes of the map
     # ---- buffers -------------------------------------------------------------------------
     def _plan(self, direction, u, forward=False):
         n, c, h, w = u.x.shape
@@ -129,7 +130,7 @@ class _Buffers:
                 rp = 256 // (k // 4)
                 # (64 workgroups suit the <= 1.6 MB maps of ResNet-18; a 12.6 MB map of All-CNN-C needs the
                 # whole chip: one workgroup per 32 KB of the map, 64 ... 1024)
-                tgt = min(1024, max(64, u.a.numel() * 4 // 32768))
+                tgt = min(1024, max(64, u.a.numel() * 4 // self.ADJ_BYTES_PER_WG))
                 per = max(rp, -(-u.rows // tgt))
                 u.rb = -(-u.rows // per)
                 if u.rb < 2:
