@@ -592,3 +592,33 @@ def test_train_mode_batchnorm_hessian_closed_forms():
         got_a = c[0] * g_a + c[1] * g_z + c[2] * dg_z + c[3] * da + c[4] * xh + c[5]
     assert float((got_a - want_a).abs().max()) < 1e-12
     assert float((dgg - want_g).abs().max()) < 1e-12 and float((s_g - want_b).abs().max()) < 1e-12
+
+
+def test_path_report_names_the_path_of_every_call():
+    """``HessianFree.path_report()`` (round 6: no silent performance cliffs): per kind of call the path taken -- here,
+    with the CPU oracle in the solver's place and no GPU, ``eager`` for ``step`` and ``acc_step``, ``user`` when the
+    caller supplies gradient and product (optimizer.py:218-247) -- and nothing before the first call; no warning
+    without ``graph_matvec=True`` on a CUDA model."""
+    g = load_golden("step_mwe.npz")
+    model = mwe_nn(g)
+    lossf = torch.nn.MSELoss()
+    opt = make_opt(model.parameters())
+    assert opt.path_report() == {"step": None, "acc_step": None}
+    inputs, targets = T(g["inputs/0"]), T(g["targets/0"])
+
+    def forward():
+        out = model(inputs)
+        return lossf(out, targets), out
+
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        opt.step(forward=forward)
+        rep = opt.path_report()
+        assert rep["step"]["path"] == "eager" and rep["step"]["what"] == opt.PATHS["eager"] and rep["acc_step"] is None
+        opt.acc_step(model, lossf, [(inputs[:8], targets[:8]), (inputs[8:], targets[8:])], reduction="mean")
+        assert opt.path_report()["acc_step"]["path"] == "eager"
+        params = [p for p in model.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in params)
+        opt.step(forward=forward, grad=torch.ones(n), mvp=lambda v: 2.0 * v)
+        assert opt.path_report()["step"]["path"] == "user"
+    assert not [w for w in rec if "slower path" in str(w.message)]
