@@ -299,6 +299,16 @@ def make_resnet18_frozen():
                                   dict(max_iter=40, martens_conv_crit=True, store_x_at_iters=list(range(41))),
                                   sample_iters=set(range(0, 12)))
     put_product(store, "ggn_product", B, grad.numel(), idx, seed=53, B64=B64)
+    # Hessian curvature on the frozen model: one default step, one product (+ float64 twin)
+    run_steps(store, "hessian_step", tp.resnet18_mnist, SEEDS, 1, curv="hessian", mk=dict(batch_size=32),
+              prep=tp.freeze_stem_and_layer1)
+    params = [p for p in model.parameters() if p.requires_grad]
+    loss = lossf(model(x), t)
+    m64, l64, x64 = double_twin(model, lambda m: lossf, x)
+    p64 = [p for p in m64.parameters() if p.requires_grad]
+    loss64 = l64(m64(x64), t)
+    put_product(store, "hessian_product", lambda v: RefHF._Hv(loss, params, v).detach(), grad.numel(), idx, seed=61,
+                B64=lambda v: RefHF._Hv(loss64, p64, v).detach())
     mg.save("convnet_resnet18_frozen.npz", store)
 
 
@@ -313,6 +323,10 @@ def make_resnet18_mse():
                                   dict(max_iter=30, martens_conv_crit=True, store_x_at_iters=list(range(31))),
                                   sample_iters=set(range(0, 12)))
     put_product(store, "ggn_product", B, grad.numel(), idx, seed=59, B64=B64)
+    # acc_step under the MSE loss on ragged chunks [20, 12] (the loss of the reference's own acc tests,
+    # tests/test_optimizer_acc.py:47-60), cg_max_iter = 6
+    run_steps(store, "acc_20_12", tp.resnet18_mnist_mse, SEEDS, 2, acc=(20, 12), opt_kw=dict(cg_max_iter=6),
+              mk=dict(batch_size=32))
     mg.save("convnet_resnet18_mse.npz", store)
 
 

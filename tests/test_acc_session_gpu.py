@@ -326,3 +326,28 @@ def test_acc_step_with_mse_loss_on_engine_equals_step_on_whole_batch():
                     assert opt._session is not None
             runs.append((opt, [final]))
         _same_trace(*runs[0], *runs[1])
+
+
+def test_acc_step_with_mse_loss_matches_reference_trace_with_ragged_chunks():
+    """``acc_step`` under ``nn.MSELoss`` on ragged chunks [20, 12] against the REAL reference's ``acc_step`` on the
+    stock CPU model (golden ``convnet_resnet18_mse.npz``, ``acc_20_12``, cg_max_iter = 6): the chunks merge into one
+    engine batch; the tolerances of the cross-entropy trace."""
+    from helpers import RefTrace, compare_trace
+
+    ref = RefTrace("resnet18_mse", "acc_20_12")
+    model, _, lossf = tp.resnet18_mnist_mse(batch_size=32, device="cpu", data_seed=SEEDS[0])
+    ref.check_inputs([p for p in model.parameters() if p.requires_grad])
+    model = model.to(DEV)
+    modelprep.prepare_model(model, channels_last=True)
+    opt = hf.HessianFree(model.parameters(), graph_matvec=True, cg_max_iter=6)
+    finals = []
+    for i in range(2):
+        _, (x, t), _ = tp.resnet18_mnist_mse(batch_size=32, device="cpu", data_seed=SEEDS[i])
+        ref.check_inputs(x=x, step=i)
+        x, t = x.to(DEV), t.to(DEV)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            finals.append(opt.acc_step(model, lossf, _chunks(x, t, (20, 12)), reduction="mean"))
+    sess = opt._acc_session
+    assert sess is not None and sess.merged and sess.steps == 2 and sess.engines[0].loss_spec["kind"] == "mse"
+    compare_trace(opt.state, finals, ref, final_tol=(1e-4, 1e-3))

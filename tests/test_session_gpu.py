@@ -608,3 +608,50 @@ def test_mse_loss_engine_product_and_session_steps_match_reference_trace():
         assert not [w for w in rec if "slower path" in str(w.message)], [str(w.message) for w in rec]
     assert opt._session is not None and opt._session.steps == 2 and opt.path_report()["step"]["path"] == "session"
     compare_trace(opt.state, finals, ref_t)
+
+
+def test_frozen_layers_hessian_product_and_step_match_reference_trace():
+    """``curvature_opt="hessian"`` (optimizer.py:450-455) on the model with stem + layer1 frozen, against the REAL
+    reference (golden ``convnet_resnet18_frozen.npz``: ``hessian_product`` with its float64 twin, ``hessian_step``):
+    the product 6e-6 of float64 and inside the reference's fp32 envelope (the bounds of the unfrozen Hessian product);
+    one default step through the persistent session over the Hessian engine -- initial loss 1e-5, damping / learning
+    rate / reason identical, iterations +-2; the Hessian of this random-init ReLU net is indefinite at damping 1.0 and
+    back-tracking picks between stored iterates whose losses differ in the third digit (see the unfrozen test in
+    test_engine_gpu.py): final loss 3e-2, and the run must reduce the loss."""
+    from helpers import RefTrace
+    from pytorchhessianfree_amd.engine import FusedGGNEngine
+
+    ref_p, ref_t = RefTrace("resnet18_frozen", "hessian_product"), RefTrace("resnet18_frozen", "hessian_step")
+    cm, (cx, ct), lossf = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=SEEDS[0])
+    tp.freeze_stem_and_layer1(cm)
+    cp = [p for p in cm.parameters() if p.requires_grad]
+    RefTrace("resnet18_frozen", "solve_martens").check_inputs(cp, cx)
+    ref_t.check_inputs(cp, cx, step=0)
+    model, x, t = cm.to(DEV), cx.to(DEV), ct.to(DEV)
+    modelprep.prepare_model(model, channels_last=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    why = []
+    op = FusedGGNEngine.try_build(lossf(out, t), out, params, hessian=True, why=why)
+    assert isinstance(op, FusedGGNEngine) and op.hessian and op.dead_blocks == 2, why
+    got_p = op(ref_p.probe().to(DEV))
+    within(ref_p.vec_err64("", got_p), 6e-6)
+    within(ref_p.vec_err("", got_p), ref_p.envelope("", 6e-6))
+    del op, out
+    opt = hf.HessianFree(model.parameters(), curvature_opt="hessian", graph_matvec=True)
+
+    def forward():
+        o = model(x)
+        return lossf(o, t), o
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fg = opt.step(forward)
+    assert opt._session is not None and opt._session.engine.hessian and opt._session.engine.frozen_any
+    sg, sc, fc = opt.state, ref_t.state, ref_t.finals[0]
+    within(abs(sg["init_losses"][0] - sc["init_losses"][0]), 1e-5 * abs(sc["init_losses"][0]), strict=False)
+    assert sg["dampings"] == sc["dampings"] and sg["learning_rates"] == sc["learning_rates"]
+    assert sg["cg_reasons"] == sc["cg_reasons"]
+    within(abs(sg["num_cg_iters"][0] - sc["num_cg_iters"][0]), 2, strict=False)
+    within(abs(fg - fc), 3e-2 * abs(fc), strict=False)
+    assert fg < sg["init_losses"][0] and fc < sc["init_losses"][0]
