@@ -193,22 +193,23 @@ class _Topology:
         (the adjoint sweep finishes them first: ResNet-18 on 28x28 inputs, layer3 + layer4 + fc = 14 of
         17 MB after ~60 % of the product), with the flat offset of that suffix; ``None`` if the layout does
         not allow it."""
-        if not self.blocks or self.fc is None or self.frozen_any:
-            return None  # (frozen layers: the single-graph form; the late / early split is laid out for the full net)
+        if not self.blocks or self.fc is None:
+            return None
         live = self._live_counts()
         total = sum(live)
         acc = live[self.pfw] + (live[self.pfb] if self.pfb is not None else 0)
         cut = None
         for bi in range(len(self.blocks) - 1, 0, -1):
             chain, ds, _ = self.blocks[bi]
-            acc += sum(live[i] for u in chain + ([ds] if ds is not None else []) for i in (u.pw, u.pg, u.pb))
+            acc += sum(live[i] for u in chain + ([ds] if ds is not None else []) for i in (u.pw, u.pg, u.pb)
+                       if i is not None)  # (frozen tensors: no entry)
             if acc >= tail_fraction * total:
                 cut = bi
                 break
-        if cut is None:
-            return None
+        if cut is None or cut <= self.dead_blocks:
+            return None  # (a frozen prefix that reaches the cut: nothing is left for the second phase to overlap with)
         late = {i for bi in range(cut, len(self.blocks)) for u in self.blocks[bi][0] + ([self.blocks[bi][1]] if self.blocks[bi][1] is not None else [])
-                for i in (u.pw, u.pg, u.pb)} | {self.pfw} | ({self.pfb} if self.pfb is not None else set())
+                for i in (u.pw, u.pg, u.pb) if i is not None} | {self.pfw} | ({self.pfb} if self.pfb is not None else set())
         first = min(late)
         if late != set(range(first, len(self.params))):
             return None  # the late layers' parameters are not a suffix of the vector

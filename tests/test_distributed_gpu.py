@@ -289,11 +289,12 @@ def test_acc_step_two_ranks_accumulated_engine_session(tmp_path):
 def test_step_two_ranks_frozen_layers_engine_session_equals_reference_whole_batch(tmp_path):
     """The engine on a trainable subset under data parallelism: stem + layer1 frozen (N = 11 024 138), shards of
     16 + 16, two default steps through the drop-in API against the REAL reference's whole-batch run on the frozen
-    model (golden ``convnet_resnet18_frozen.npz``).  Both ranks take the persistent session (single product graph: the
-    late / early split of the two-phase form is laid out for the full net), stay bitwise identical, only the live
-    trainable entries travel, lockstep call counts."""
+    model (golden ``convnet_resnet18_frozen.npz``).  Both ranks take the persistent session in its two-phase mode (the
+    late layers' share overlapped with what is left of the adjoint sweep in front of the frozen prefix: layer2), stay
+    bitwise identical, only the live trainable entries travel, lockstep call counts."""
     r0, r1 = _launch_session_ranks(tmp_path, 2, mode="frozen")
-    assert r0["session_mode"].tolist() == [1, 1] and r1["session_mode"].tolist() == [1, 1]
+    assert r0["session_mode"].tolist() == [2, 2] and r1["session_mode"].tolist() == [2, 2]
+    assert r0["validation"].tolist() == [1, 1, 1] and bool(r0["product_equals_plain_allreduce"][0])
     assert np.array_equal(r0["params"], r1["params"]) and r0["params"].shape[1] == 11024138
     for r in (r0, r1):
         assert r["session_calls"].tolist() == [n + 1 + 1 for n in r["num_cg_iters"].tolist()]
