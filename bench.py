@@ -965,7 +965,11 @@ def main():
                           + ("; conv tangent fused" if args.fuse_conv else "")
                           + "; convolutions: " + (os.environ.get("HF_CONV") or "auto") + "; " + layout
                           + ("; deterministic (two products bitwise equal)" if check.get("deterministic")
-                             else "; NOT bitwise repeatable (library kernels with atomics)"),
+                             else "; NOT bitwise repeatable (library kernels with atomics)")
+                          + ("; HessianFree.path_report(): "
+                             + json.dumps({k: (v and {"path": v["path"], "declined": v["declined"]})
+                                           for k, v in state["opt"].path_report().items()})
+                             if state["opt"] is not None else ""),
                 "iteration": ("one hipGraph launch per PCG iteration (product -> K1 -> K2 -> K3)" if fused and group is None
                               else "product graph A -> [all-reduce of the late layers' share on a second communicator] "
                                    "|| product graph B -> all-reduce of the rest -> scatter -> K1-K3 graph"
