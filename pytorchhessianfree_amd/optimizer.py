@@ -171,6 +171,13 @@ class HessianFree(_Accumulation, _SessionSteps, torch.optim.Optimizer):
             path = self._paths[kind]
             out[kind] = None if path is None else {
                 "path": path, "what": self.PATHS[path], "declined": self._declines[kind]}
+        sess = self._session
+        if out["step"] is not None and sess is not None and getattr(sess, "group", None) is not None:
+            # data parallel: which form of the product the session validated / measured on the communicator
+            out["step"]["data_parallel"] = {
+                "product": "two-phase (chunked / overlapped all-reduce)" if sess.split is not None
+                           else "single graph + one compact all-reduce",
+                "validation": getattr(sess, "mode_validation", None), "timing_ms": getattr(sess, "mode_timing", None)}
         return out
 
     def _note_path(self, kind, path, decline=None):
