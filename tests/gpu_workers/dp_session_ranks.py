@@ -107,6 +107,8 @@ def main(outdir, mode="steps", backend="gloo"):
         out["session_calls"] = np.array(calls)
         out["session_off"] = np.array([int(opt._session_off)])
         out["params"] = np.stack(params)
+        rep = opt.path_report()["acc_step" if mode == "acc" else "step"] or {}
+        out["path"] = np.array([str(rep.get("path")), str((rep.get("data_parallel") or {}).get("product", ""))])
         sess = opt._acc_session if mode == "acc" else opt._session
         if sess is not None:
             from pytorchhessianfree_amd import distributed as hfdist

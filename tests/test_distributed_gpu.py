@@ -221,6 +221,8 @@ def test_step_two_ranks_engine_session_equals_cpu_whole_batch(session_two_ranks)
     assert r0["session_mode"].tolist() == [2, 2] and r1["session_mode"].tolist() == [2, 2]
     # (choose_product_mode: both forms identical on both ranks, two-phase equal to the single graph to rounding)
     assert r0["validation"].tolist() == [1, 1, 1] and r1["validation"].tolist() == [1, 1, 1]
+    # (HessianFree.path_report(): the path of the step and the data-parallel form the session settled on)
+    assert [str(v) for v in r0["path"]] == ["session", "two-phase (chunked / overlapped all-reduce)"]
     assert np.array_equal(r0["params"], r1["params"])
     assert r0["num_cg_iters"].tolist() == r1["num_cg_iters"].tolist()
     for r in (r0, r1):
