@@ -41,7 +41,7 @@ _FILE_ORDER = ["test_oracle_golden", "test_host_logic_cpu", "test_session_logic_
                "test_acc_session_gpu", "test_conv_gpu", "test_distributed_gpu"]
 _VARIANT = re.compile(r"(_equals?_|_equal_|bitwise|refuse|declin|falls_back|misuse|rejects|lockstep|launcher|ends_siblings|"
                       r"measured_product_mode|reverified|restart|repeatable|variants|is_used_only|stale_graph|"
-                      r"starts_two_ranks|tiny_and_ragged|cpu_tensors)")
+                      r"starts_two_ranks|tiny_and_ragged|cpu_tensors|like_the_generic|ladder|torchrun|frozen_parameter_patterns)")
 
 
 _PARITY = re.compile(r"(reference|golden|oracle|float64|cpu_whole_batch|lockstep_rule_two_ranks)")
