@@ -49,6 +49,10 @@ def parse():
                     help="multi-rank runs: wall-clock bound in seconds of each rung of the data-parallel fallback ladder "
                          "(comma-separated, the last value repeats; see RUNGS): a rung whose ranks have not all reached "
                          "the end by then is ended and the next one starts with fresh rank processes")
+    ap.add_argument("--ladder", type=int, default=-1,
+                    help="1: run the rank process(es) under the fallback ladder's supervisor even for one rank (with "
+                         "--force-dist 1: the rank-process code path of a multi-GPU run -- RCCL process group on the "
+                         "supervisor's store, direct communicators, validation -- on a single GPU); -1: iff N > 1")
     ap.add_argument("--watchdog", type=float, default=900.0,
                     help="multi-rank runs: seconds after which a rank that is still waiting (a peer died, a "
                          "collective hangs) dumps its stack and exits non-zero instead of blocking for good")
@@ -530,7 +534,7 @@ def main():
     if args.channels_last < 0:
         args.channels_last = 1  # NHWC: the fused engine (ResNets) / +10 % (All-CNN-C), DESIGN.md section 6
     child = os.environ.get("HF_BENCH_CHILD") == "1"
-    if not child and (args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1):
+    if not child and (args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.ladder == 1):
         supervise(args)  # does not return: rank processes are its children, rung by rung
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

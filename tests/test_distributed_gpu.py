@@ -440,3 +440,28 @@ def test_bench_under_torchrun_two_ranks_on_one_device():
     assert rec["n_gpus"] == 2 and ar["rung"] == 0 and ar["rungs_failed"] == [] and ar["ranks_seen"] == 2
     assert ar["validation"]["single_graph_identical_on_all_ranks"] is True
     assert "session" in rec["config"]["path_report"]["step"]["path"]
+
+
+def test_bench_ladder_rank_process_over_rccl_on_one_gpu():
+    """The rank-process code path of a multi-GPU run with the REAL backend, as far as one GPU can take it: ``bench.py
+    --gpus 1 --force-dist 1 --ladder 1`` -- a supervisor that never touches the GPU, ONE rank child that joins an
+    ``nccl`` (= RCCL) process group through the supervisor's store under the rung's prefix, creates the package's two
+    direct communicators, validates both product forms on the live communicator, times them, runs the solves and
+    writes its marker.  First rung, validation passed, ``ranks_seen`` = 1, direct RCCL path."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "1", "--ladder", "1", "--steps",
+         "1", "--warmup", "1", "--iters", "20", "--no-cpu-baseline", "--no-step-timing", "--no-train-bn"],
+        env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    ar = rec["config"]["allreduce"]
+    assert ar["rung"] == 0 and ar["rungs_failed"] == [] and ar["backend"] == "nccl" and ar["ranks_seen"] == 1
+    assert "hf_allreduce_sum" in ar["path"]
+    v = ar["validation"]
+    assert v["single_graph_identical_on_all_ranks"] and v["two_phase_identical_on_all_ranks"]
+    assert v["two_phase_kept_as_candidate"] and v["two_phase_vs_single_graph"] <= 1e-6
+    assert ar["product_mode_timing_ms"] and min(ar["product_mode_timing_ms"].values()) > 0
