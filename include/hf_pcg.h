@@ -468,6 +468,10 @@ int hf_conv2d_nhwc_slabs_unpack(void* out, const void* act, const void* mat, int
  * must be zero-initialised once if the geometry has taps that never meet data; `out_c` (0 = c)
  * restricts the output to X's first out_c channels, laid out [k][r][q][out_c] -- X may carry
  * zero-padding channels that make its rows 16-byte multiples (the 49-tap im2col of a stem).
+ * HF_ERR_ARG (not a silently wrong gradient) when out_c < c meets a geometry that was planned
+ * for the 96-row tile configuration whose output columns are enumerated flat over (tap, channel)
+ * AND has more than one live tap: that enumeration needs out_c == c unless there is a single tap
+ * (where the padded columns are simply cut off).
  * `mat_ld` (directions 0 and 1; 0 = c resp. k): floats between consecutive taps of `mat`, when `mat`
  * is the first-channels slice of a wider [rows][r][q][mat_ld] buffer -- the forward pass of the
  * curvature engine reads the W half of the tangent sweep's [W | v_W] operand in place.
