@@ -266,7 +266,12 @@ def _bn_usable(bn, x):
         isinstance(bn, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d))
         and not bn.training and bn.track_running_stats and bn.running_var is not None
         and x.is_cuda and bn.weight is not None and bn.bias is not None
-        and x.dtype in (torch.float32, torch.float64) and x.dim() >= 2
+        and x.dtype in (torch.float32, torch.float64)
+        # (the input ranks the stock layer itself accepts -- anything else goes to its forward, which raises its own
+        # error: an unbatched [C, H, W] sample, as the reference's per-sample loop preconditioners.py:91-99 feeds it,
+        # is a ValueError for nn.BatchNorm2d, not a layer that silently takes dimension 1 for the channels)
+        and x.dim() in {nn.BatchNorm1d: (2, 3), nn.BatchNorm2d: (4,), nn.BatchNorm3d: (5,)}[
+            next(k for k in (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d) if isinstance(bn, k))]
     )
 
 

@@ -672,3 +672,44 @@ def test_frozen_layers_hessian_product_and_step_match_reference_trace():
     within(abs(sg["num_cg_iters"][0] - sc["num_cg_iters"][0]), 2, strict=False)
     within(abs(fg - fc), 3e-2 * abs(fc), strict=False)
     assert fg < sg["init_losses"][0] and fc < sc["init_losses"][0]
+
+
+def test_get_preconditioner_with_frozen_layers_uses_the_sessions_engine(monkeypatch):
+    """``HessianFree.get_preconditioner`` (optimizer.py:928-952; preconditioners.py:11-105) on a model with frozen layers
+    (stem + layer1 of the ResNet-18): with a persistent session the diagonal empirical Fisher of the TRAINABLE subset
+    comes from the engine's sweep (dead units skipped) and equals the per-sample autograd construction to 1e-5; a
+    preconditioned default step on it reduces the loss."""
+    from pytorchhessianfree_amd import optimizer_session as hfopt
+
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=8, device=DEV, data_seed=SEEDS[0])
+    tp.freeze_stem_and_layer1(model)
+    modelprep.prepare_model(model, channels_last=True)
+    opt = hf.HessianFree(model.parameters(), graph_matvec=True, cg_max_iter=6)
+    calls = []
+    real = hfopt.diag_EF_preconditioner
+    monkeypatch.setattr(hfopt, "diag_EF_preconditioner", lambda *a, **k: calls.append(1) or real(*a, **k))
+
+    def forward():
+        o = model(x)
+        return lossf(o, t), o
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        opt.step(forward)
+        assert opt._session is not None and opt._session.engine.frozen_any
+        M = opt.get_preconditioner(model, lossf, x, t, "mean", use_backpack=False)
+        assert not calls  # (the engine's sweep, not the per-sample loop)
+        # (the reference's loop, preconditioners.py:91-99, on batches of ONE sample: BatchNorm2d wants 4-D inputs --
+        # ``diag_EF_autograd`` itself feeds unbatched samples and raises for this model, here as in the reference)
+        params = [p for p in model.parameters() if p.requires_grad]
+        want = torch.zeros(sum(p.numel() for p in params), device=DEV)
+        for i in range(x.shape[0]):
+            g_i = torch.autograd.grad(lossf(model(x[i:i + 1]), t[i:i + 1]), params)
+            want += torch.cat([g.reshape(-1) for g in g_i]) ** 2
+        want /= x.shape[0]
+        with pytest.raises(ValueError, match="expected 4D input"):
+            hf.diag_EF_autograd(model, lossf, x, t, "mean")
+        assert M.diag.numel() == want.numel() == 11024138
+        within(float((M.diag - want).abs().max() / want.abs().max()), 1e-5)
+        final = opt.step(forward, M_func=M)
+        assert final <= opt.state["init_losses"][-1]
