@@ -351,3 +351,31 @@ def test_acc_step_with_mse_loss_matches_reference_trace_with_ragged_chunks():
     sess = opt._acc_session
     assert sess is not None and sess.merged and sess.steps == 2 and sess.engines[0].loss_spec["kind"] == "mse"
     compare_trace(opt.state, finals, ref, final_tol=(1e-4, 1e-3))
+
+
+def test_acc_step_with_frozen_layers_matches_reference_whole_batch_step():
+    """``acc_step`` on a model with frozen layers (stem + layer1): chunks [16, 16] merge into one engine batch on the
+    trainable subset; the accumulated step equals the REAL reference's whole-batch ``step`` on the frozen model (golden
+    ``convnet_resnet18_frozen.npz``, ``steps``; the reference states accumulated == whole batch to 1e-4,
+    tests/test_optimizer_acc.py:116-175) -- two steps, the tolerances of the unfrozen trace."""
+    from helpers import RefTrace, compare_trace
+
+    ref = RefTrace("resnet18_frozen", "steps")
+    model, _, lossf = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=SEEDS[0])
+    tp.freeze_stem_and_layer1(model)
+    ref.check_inputs([p for p in model.parameters() if p.requires_grad])
+    model = model.to(DEV)
+    modelprep.prepare_model(model, channels_last=True)
+    opt = hf.HessianFree(model.parameters(), graph_matvec=True)
+    finals = []
+    for i in range(2):
+        _, (x, t), _ = tp.resnet18_mnist(batch_size=32, device="cpu", data_seed=SEEDS[i])
+        ref.check_inputs(x=x, step=i)
+        x, t = x.to(DEV), t.to(DEV)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            finals.append(opt.acc_step(model, lossf, _chunks(x, t, (16, 16)), reduction="mean"))
+    sess = opt._acc_session
+    assert sess is not None and sess.merged and sess.steps == 2 and sess.engines[0].frozen_any
+    assert sess.engines[0].dead_blocks == 2 and sess.n == 11024138
+    compare_trace(opt.state, finals, ref, steps=2)
