@@ -1249,3 +1249,45 @@ def test_allcnnc_plain_stack_engine_with_frozen_layers_matches_float64(hessian):
     want_d /= x.shape[0]
     within(float((got_d - want_d).abs().max() / want_d.abs().max()), 1e-5)
     assert torch.equal(op(v), got)
+
+
+@pytest.mark.parametrize("case", ["ggn", "hessian", "ggn_train", "hessian_train", "ggn_frozen", "ggn_sum"])
+def test_mse_head_products_match_float64(case):
+    """The mean-squared-error head (``nn.MSELoss``: the loss of the reference's examples and tests, examples/run_mwe.py:19;
+    ``_Gv`` / ``_Hv`` take any loss, optimizer.py:450-462) under the engine's variants: GGN and Hessian products, eval- and
+    train-mode BatchNorm, frozen stem + layer1, reduction ``sum`` -- against float64 autograd of the stock model on the
+    engine's ReLU decisions (eval 1e-6 / Hessian 2e-6, train mode 1.5e-5); gradient 2e-6 / 1.5e-5; bitwise repeatable."""
+    hessian, train = case.startswith("hessian"), case.endswith("_train")
+    reduction = "sum" if case.endswith("_sum") else "mean"
+
+    def make(device=DEV, **kw):
+        model, data, _ = tp.resnet18_mnist_mse(device=device, **kw)
+        if case.endswith("_frozen"):
+            tp.freeze_stem_and_layer1(model)
+        if train:
+            model.train()
+        return model, data, torch.nn.MSELoss(reduction=reduction)
+
+    model, (x, t), lossf = make(batch_size=16, data_seed=3)
+    modelprep.prepare_model(model, channels_last=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    why = []
+    op = FusedGGNEngine.try_build(lossf(out, t), out, params, hessian=hessian, why=why)
+    assert isinstance(op, FusedGGNEngine) and op.hessian == hessian, why
+    assert op.loss_spec is not None and op.loss_spec["kind"] == "mse" and op.loss_spec["reduction"] == reduction
+    v = torch.randn(op.n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
+    got = op(v).clone()
+    assert torch.equal(op(v), got)
+    ref, (rx, rt), rl = make(batch_size=16, data_seed=3)
+    ref, rx, rt = ref.double(), rx.double(), rt.double()
+    _replay_relu_decisions(ref, [(u.y > 0) for u in op.units if u.relu])
+    rp = [p for p in ref.parameters() if p.requires_grad]
+    ro = ref(rx)
+    rloss = rl(ro, rt)
+    want = (curvature.HessianOperator(rloss, rp) if hessian else curvature.GGNOperator(rloss, ro, rp))(v.double())
+    tol = 1.5e-5 if train else (2e-6 if hessian else 1e-6)
+    within(float((got.double() - want).abs().max() / want.abs().max()), tol)
+    grad = torch.cat([g.reshape(-1) for g in torch.autograd.grad(rloss, rp)])
+    within(float((op.gradient().double() - grad).abs().max() / grad.abs().max()), 1.5e-5 if train else 2e-6)
+    within(abs(float(op.loss_buf) - float(rloss)), 2e-6 * abs(float(rloss)), strict=False)
