@@ -713,3 +713,36 @@ def test_get_preconditioner_with_frozen_layers_uses_the_sessions_engine(monkeypa
         within(float((M.diag - want).abs().max() / want.abs().max()), 1e-5)
         final = opt.step(forward, M_func=M)
         assert final <= opt.state["init_losses"][-1]
+
+
+def test_session_follows_a_frozen_weight_that_is_changed_between_steps(monkeypatch):
+    """Frozen convolution weights are constants of the captured graphs only until somebody writes to them: the engine
+    copies a frozen ``W`` half / ``W^T`` again when the parameter's version or storage changed (``refresh_frozen``,
+    eager, once per batch).  With ``HF_SESSION_VERIFY=1`` every step re-runs the model's OWN forward pass and the
+    session must reproduce its logits (1e-4): a stale frozen weight would end the session with a warning."""
+    monkeypatch.setenv("HF_SESSION_VERIFY", "1")
+    model, (x, t), lossf = tp.resnet18_mnist(batch_size=8, device=DEV, data_seed=SEEDS[0])
+    tp.freeze_stem_and_layer1(model)
+    modelprep.prepare_model(model, channels_last=True)
+    opt = hf.HessianFree(model.parameters(), graph_matvec=True, cg_max_iter=4)
+
+    def forward():
+        o = model(x)
+        return lossf(o, t), o
+
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        opt.step(forward)
+        sess = opt._session
+        assert sess is not None
+        with torch.no_grad():
+            list(model.layers)[0].conv1.weight.mul_(1.25)   # a frozen, dead layer
+            model.conv1.weight.add_(0.01)                   # the frozen stem (im2col'd: read from the parameter)
+        want = float(lossf(model._hf_stock_model_forward(x), t)) if hasattr(model, "_hf_stock_model_forward") else None
+        opt.step(forward)
+        assert opt._session is sess and sess.steps == 2
+        if want is not None:
+            within(abs(opt.state["init_losses"][-1] - want), 1e-5 * abs(want), strict=False)
+        opt.step(forward)
+        assert opt._session is sess and sess.steps == 3
+    assert not [w for w in rec if "persistent engine session" in str(w.message)], [str(w.message) for w in rec]
