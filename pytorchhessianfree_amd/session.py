@@ -247,7 +247,7 @@ class EngineSession(_TwoPhaseProduct):
                 cur.wait_stream(self.stream)
                 raise _NoEngine("the fused engine does not cover this model" if eng is None else
                                 "the engine's own forward pass does not reproduce this train-mode model, or the loss "
-                                "is not a plain softmax cross-entropy")
+                                "is neither a plain softmax cross-entropy nor a mean-squared error")
             self.op = self.engine = eng
             self.n, self.group, self.params = eng.n, eng.group, eng.params
             self.weight = eng.weight
